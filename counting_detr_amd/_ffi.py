@@ -1,0 +1,103 @@
+"""ctypes binding of libcdetr_hip.so (include/cdetr_hip.h).  No torch types cross the boundary: raw device
+pointers (tensor.data_ptr()), sizes and the current hipStream_t.
+
+The product path has NO fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcdetr_hip.so")
+
+ROWS_DENSE, ROWS_CONV_FWD, ROWS_CONV_DGRAD = 0, 1, 2
+_p = C.c_void_p
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("Ha", C.c_int32), ("Wa", C.c_int32), ("Hc", C.c_int32), ("Wc", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("dil", C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("taps", C.c_int32), ("batch", C.c_int32),
+                ("b_layout", C.c_int32), ("relu", C.c_int32), ("out_scale", C.c_float),
+                ("A", _p), ("lda", C.c_int64), ("sA", C.c_int64),
+                ("B", _p), ("ldb", C.c_int64), ("sB", C.c_int64),
+                ("C", _p), ("ldc", C.c_int64), ("sC", C.c_int64),
+                ("w_scale", _p), ("bias", _p), ("resid", _p), ("ldr", C.c_int64), ("gate", _p), ("ldg", C.c_int64),
+                ("g", ConvGeom)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("P", C.c_int32), ("Nout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("batch", C.c_int32),
+                ("dY", _p), ("ldy", C.c_int64), ("sY", C.c_int64),
+                ("X", _p), ("ldx", C.c_int64), ("sX", C.c_int64),
+                ("dW", _p), ("ldw", C.c_int64), ("sW", C.c_int64),
+                ("w_scale", _p), ("g", ConvGeom)]
+
+
+class RcdaFwdDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("nh", C.c_int32),
+                ("scale", C.c_float), ("q_row", _p), ("q_col", _p), ("k_row", _p), ("k_col", _p), ("v", _p),
+                ("mask_row", _p), ("mask_col", _p), ("out", _p), ("a_row", _p), ("a_col", _p)]
+
+
+class RcdaBwdDesc(C.Structure):
+    _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("nh", C.c_int32),
+                ("scale", C.c_float), ("d_out", _p), ("a_row", _p), ("a_col", _p), ("v", _p),
+                ("ds_row", _p), ("ds_col", _p), ("d_v", _p)]
+
+
+EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_maxpool3x3s2", "cdetr_rcda_fwd", "cdetr_rcda_bwd",
+           "cdetr_match_cost", "cdetr_lsap", "cdetr_last_error", "cdetr_abi_version"]
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the library; raises if it is missing -- there is no CPU/eager fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m counting_detr_amd.build` "
+                               "(the Counting-DETR MI355X path has no fallback implementation)")
+        L = C.CDLL(LIB_PATH)
+        L.cdetr_last_error.restype = C.c_char_p
+        L.cdetr_abi_version.restype = C.c_int
+        for name in ("cdetr_gemm", "cdetr_wgrad", "cdetr_rcda_fwd", "cdetr_rcda_bwd"):
+            getattr(L, name).restype = C.c_int
+            getattr(L, name).argtypes = [_p, _p]
+        L.cdetr_colsum.restype = C.c_int
+        L.cdetr_colsum.argtypes = [_p, C.c_int64, C.c_int32, C.c_int32, _p, _p]
+        L.cdetr_maxpool3x3s2.restype = C.c_int
+        L.cdetr_maxpool3x3s2.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
+        L.cdetr_match_cost.restype = C.c_int
+        L.cdetr_match_cost.argtypes = [_p, C.c_int32, _p, _p, _p, _p, C.c_int32, C.c_int32, C.c_float, C.c_float,
+                                       C.c_float, _p, _p]
+        L.cdetr_lsap.restype = C.c_int
+        L.cdetr_lsap.argtypes = [_p, _p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p, _p]
+        if L.cdetr_abi_version() != 1:
+            raise RuntimeError("libcdetr_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().cdetr_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The product path only ever runs on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("counting_detr_amd kernels need device tensors (no CPU fallback exists)")
+    return t.data_ptr()

@@ -1,0 +1,215 @@
+"""AnchorDETR model, SetCriterion, PostProcess and build() -- the API surface of A2/models/anchor_detr.py
+(AnchorDETR :34-140, SetCriterion :143-367, PostProcess :370-402, build :405-445) on the MI355X kernels.
+
+`build(args)` returns `(model, criterion, postprocessors)` exactly like the reference; `model(samples, points=None,
+rects=rects)` returns `({"pred_logits","pred_boxes","pred_vars"}, reference_points)`; `criterion(outputs, targets)`
+returns the dict of 0-dim losses and exposes `.weight_dict` / `.matcher`.  The criterion is sync-free: the matcher
+runs on the device and matched pairs are consumed as device index tensors.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import box_ops, ops
+from .backbone import build_backbone
+from .matcher import build_matcher
+from .misc import NestedTensor, get_world_size, is_dist_avail_and_initialized, nested_tensor_from_tensor_list
+from .transformer import build_transformer
+
+
+class _Conv1x1(nn.Module):
+    """nn.Conv2d(cin, cout, 1) parameters (`weight` [cout,cin,1,1], `bias`); runs as an MFMA GEMM on NHWC rows."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(cout, cin, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(cout))
+        nn.init.xavier_uniform_(self.weight, gain=1)                  # A2/models/anchor_detr.py:86-92
+
+    def forward(self, x_nhwc):
+        return ops.linear(x_nhwc, self.weight, self.bias)
+
+
+class _ProjGN(nn.Sequential):
+    """nn.Sequential(Conv2d 1x1, GroupNorm(32, d)) with state-dict keys `0.*`, `1.*`."""
+
+    def __init__(self, cin, d):
+        super().__init__(_Conv1x1(cin, d), nn.GroupNorm(32, d))
+
+    def forward(self, x_nhwc):
+        y = self[0](x_nhwc)                                           # [B,h,w,d]
+        gn = self[1]
+        # GroupNorm statistics over (8 channels x h x w); evaluated on the NHWC tensor through a channels-first view
+        y = F.group_norm(y.permute(0, 3, 1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)
+        return y.permute(0, 2, 3, 1).contiguous()
+
+
+class AnchorDETR(nn.Module):
+    """A2/models/anchor_detr.py:34-140."""
+
+    def __init__(self, backbone, transformer, num_feature_levels, aux_loss=True):
+        super().__init__()
+        assert num_feature_levels == 1
+        self.transformer = transformer
+        hidden_dim = transformer.d_model
+        self.num_feature_levels = num_feature_levels
+        # built but never used on the stage-2 path (:68-74 vs :119): parameters with no gradient
+        self.input_proj = nn.ModuleList([_ProjGN(backbone.num_channels[0], hidden_dim)])
+        self.backbone = backbone
+        self.aux_loss = aux_loss
+        self.aggr_input_proj = nn.ModuleList([_ProjGN(backbone.num_channels[0] * 2, hidden_dim)])
+
+    def forward(self, samples, points=None, rects=None):
+        if not isinstance(samples, NestedTensor):
+            samples = nested_tensor_from_tensor_list(samples)
+        images, mask = samples.decompose()
+        feat, m = self.backbone.extract_feature(images, mask, rects)         # NHWC [B,h,w,4096]
+        src = self.aggr_input_proj[0](feat)                                   # NHWC [B,h,w,256]
+        (outputs_class, outputs_coord, outputs_var), reference_points = self.transformer(src, m, points)
+        out = {"pred_logits": outputs_class[-1], "pred_boxes": outputs_coord[-1], "pred_vars": outputs_var[-1]}
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
+        return out, reference_points
+
+
+def sigmoid_focal_loss(inputs, targets, num_boxes, alpha: float = 0.25, gamma: float = 2):
+    """A2/models/segmentation.py:198-223."""
+    prob = inputs.sigmoid()
+    ce_loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = prob * targets + (1 - prob) * (1 - targets)
+    loss = ce_loss * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    return loss.mean(1).sum() / num_boxes
+
+
+class SetCriterion(nn.Module):
+    """A2/models/anchor_detr.py:143-367 with losses [labels, boxes, cardinality, vars].  Matching happens on the
+    device (`matcher.match_device`); `indices` are device tensors, so the whole criterion issues no host sync."""
+
+    def __init__(self, num_classes, matcher, weight_dict, losses, focal_alpha=0.25):
+        super().__init__()
+        self.num_classes, self.matcher, self.weight_dict, self.losses, self.focal_alpha = \
+            num_classes, matcher, weight_dict, losses, focal_alpha
+        self.check_status = False   # set True to raise (with a host sync) on an invalid / infeasible cost matrix
+        self._plans = {}            # (target counts, Q, device) -> MatchPlan (device offset tables built once: graph-safe)
+
+    # -- matched (batch, query, target-row) index tensors on the device
+    def _matched(self, idx_i, idx_j, plan):
+        dev = idx_i.device
+        bidx = torch.cat([torch.full((m,), b, dtype=torch.int64, device=dev) for b, m in enumerate(plan.M)])
+        sidx = torch.cat([idx_i[b, :m] for b, m in enumerate(plan.M)])
+        tidx = torch.cat([idx_j[b, :m] + plan.tgt_off_host[b] for b, m in enumerate(plan.M)])
+        return bidx, sidx, tidx
+
+    def forward(self, outputs, targets):
+        out = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "enc_outputs")}
+        logits = out["pred_logits"]
+        B, Q = logits.shape[:2]
+        key = (tuple(len(t["boxes"]) for t in targets), Q, str(logits.device))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = ops.MatchPlan(key[0], Q, logits.device)
+        idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan)
+        if self.check_status and bool((status != 0).any()):
+            raise ValueError("invalid or infeasible matching cost matrix")
+        num_boxes = sum(plan.sizes)
+        if is_dist_avail_and_initialized():
+            nb = torch.as_tensor([num_boxes], dtype=torch.float, device=logits.device)
+            torch.distributed.all_reduce(nb)
+            num_boxes = nb / get_world_size()
+            num_boxes = torch.clamp(num_boxes, min=1)[0]                      # stays on the device (no .item())
+        else:
+            num_boxes = max(float(num_boxes), 1.0)                            # :321-325
+        bidx, sidx, tidx = self._matched(idx_i, idx_j, plan)
+        tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
+        tgt_labels_all = torch.cat([t["labels"] for t in targets])
+        losses = {}
+        for loss in self.losses:
+            losses.update(getattr(self, "loss_" + loss)(out, plan, bidx, sidx, tidx, tgt_boxes_all, tgt_labels_all, num_boxes))
+        if "aux_outputs" in outputs:
+            raise NotImplementedError("aux losses need pred_vars in aux outputs (a reference bug: the shipped configs "
+                                      "run --no_aux_loss, A2/models/anchor_detr.py:136-140,268)")
+        return losses
+
+    def loss_labels(self, out, plan, bidx, sidx, tidx, tb, tl, num_boxes):
+        src_logits = out["pred_logits"]                                       # :166-197
+        target_classes = torch.full(src_logits.shape[:2], self.num_classes, dtype=torch.int64, device=src_logits.device)
+        tco = tl[tidx]
+        target_classes[bidx, sidx] = tco
+        onehot = torch.zeros([src_logits.shape[0], src_logits.shape[1], src_logits.shape[2] + 1], dtype=src_logits.dtype,
+                             device=src_logits.device)
+        onehot.scatter_(2, target_classes.unsqueeze(-1), 1)
+        onehot = onehot[:, :, :-1]
+        loss_ce = sigmoid_focal_loss(src_logits, onehot, num_boxes, alpha=self.focal_alpha, gamma=2) * src_logits.shape[1]
+        with torch.no_grad():
+            if tco.numel() == 0:
+                err = torch.full((), 100.0, device=src_logits.device)
+            else:
+                err = 100 - (src_logits[bidx, sidx].argmax(-1) == tco).float().sum() * (100.0 / tco.numel())
+        return {"loss_ce": loss_ce, "class_error": err}
+
+    @torch.no_grad()
+    def loss_cardinality(self, out, plan, bidx, sidx, tidx, tb, tl, num_boxes):
+        pred_logits = out["pred_logits"]                                      # :199-211
+        tgt_lengths = plan.sizes_f
+        card_pred = (pred_logits.argmax(-1) != pred_logits.shape[-1] - 1).sum(1)
+        return {"cardinality_error": F.l1_loss(card_pred.float(), tgt_lengths)}
+
+    def loss_boxes(self, out, plan, bidx, sidx, tidx, tb, tl, num_boxes):
+        src_boxes = out["pred_boxes"][bidx, sidx]                             # :213-234
+        target_boxes = tb[tidx]
+        loss_bbox = (src_boxes - target_boxes).abs().sum() / num_boxes
+        giou = box_ops.generalized_box_iou_pairs(box_ops.box_cxcywh_to_xyxy(src_boxes),
+                                                 box_ops.box_cxcywh_to_xyxy(target_boxes))
+        return {"loss_bbox": loss_bbox, "loss_giou": (1 - giou).sum() / num_boxes}
+
+    def loss_vars(self, out, plan, bidx, sidx, tidx, tb, tl, num_boxes):
+        src_boxes = out["pred_boxes"][bidx, sidx]                             # :264-289
+        target_boxes = tb[tidx]
+        pv = out["pred_vars"][bidx, sidx]
+        lw = (src_boxes[:, 2] - target_boxes[:, 2]).abs().mean() / pv[:, 0].abs() + pv[:, 0].log().abs()
+        lh = (src_boxes[:, 3] - target_boxes[:, 3]).abs().mean() / pv[:, 1].abs() + pv[:, 1].log().abs()
+        return {"loss_variance": ((lw + lh) / num_boxes).sum()}
+
+
+class PostProcess(nn.Module):
+    """A2/models/anchor_detr.py:370-402 (returned by build() for API parity; unused by the 2nd-stage engine)."""
+
+    @torch.no_grad()
+    def forward(self, outputs, target_sizes):
+        out_logits, out_bbox = outputs["pred_logits"], outputs["pred_boxes"]
+        prob = out_logits.sigmoid()
+        k = min(100, prob[0].numel())
+        topk_values, topk_indexes = torch.topk(prob.view(out_logits.shape[0], -1), k, dim=1)
+        topk_boxes = topk_indexes // out_logits.shape[2]
+        labels = topk_indexes % out_logits.shape[2]
+        boxes = box_ops.box_cxcywh_to_xyxy(out_bbox)
+        boxes = torch.gather(boxes, 1, topk_boxes.unsqueeze(-1).repeat(1, 1, 4))
+        img_h, img_w = target_sizes.unbind(1)
+        boxes = boxes * torch.stack([img_w, img_h, img_w, img_h], dim=1)[:, None, :]
+        return [{"scores": s, "labels": l, "boxes": b} for s, l, b in zip(topk_values, labels, boxes)]
+
+
+def build(args):
+    """A2/models/anchor_detr.py:405-445."""
+    from . import _ffi
+    _ffi.lib()                                # fail loudly now if the HIP library is missing -- there is no fallback
+    num_classes = 1
+    device = torch.device(args.device)
+    backbone = build_backbone(args)
+    transformer = build_transformer(args)
+    model = AnchorDETR(backbone, transformer, num_feature_levels=args.num_feature_levels, aux_loss=args.aux_loss)
+    matcher = build_matcher(args)
+    weight_dict = {"loss_ce": args.cls_loss_coef, "loss_bbox": args.bbox_loss_coef, "loss_giou": args.giou_loss_coef,
+                   "loss_variance": args.variance_loss_coef}
+    if args.aux_loss:
+        aux = {}
+        for i in range(args.dec_layers - 1):
+            aux.update({k + f"_{i}": v for k, v in weight_dict.items()})
+        aux.update({k + "_enc": v for k, v in weight_dict.items()})
+        weight_dict.update(aux)
+    losses = ["labels", "boxes", "cardinality", "vars"]
+    criterion = SetCriterion(num_classes, matcher, weight_dict, losses, focal_alpha=args.focal_alpha)
+    criterion.to(device)
+    return model, criterion, {"bbox": PostProcess()}

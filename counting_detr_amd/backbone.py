@@ -1,0 +1,249 @@
+"""ResNet-50-DC5 backbone with frozen BN and exemplar feature aggregation on the HIP implicit-GEMM kernels.
+
+API mirror of the reference's A2/models/backbone.py (FrozenBatchNorm2d :22-60, BackboneAgg.extract_feature :116-145,
+build_backbone :174-179) and A2/models/resnet.py (Bottleneck :105-160, ResNet :163-280): same parameter/buffer names
+and shapes (state-dict compatible), same math.  Differences are in HOW it runs:
+  * activations are NHWC fp32; every conv is one implicit-GEMM launch with FrozenBN folded into the weight load and
+    bias / residual / ReLU fused in the epilogue (no im2col buffer, no separate BN / ReLU / add passes);
+  * stem + layer1 are frozen and run without autograd; layer2-4 are ONE autograd node whose hand-scheduled backward
+    fuses each ReLU mask, BN scale and residual add into the data-gradient epilogues;
+  * the exemplar centres are computed on the device (the reference does 6 host syncs via int() on device scalars).
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+RESNET50_LAYERS = (3, 4, 6, 3)
+
+
+class ConvW(nn.Module):
+    """Holds a conv weight with the reference's logical shape in channels_last memory ([Cout][kh][kw][Cin])."""
+
+    def __init__(self, cin, cout, k):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k).contiguous(memory_format=torch.channels_last)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")     # A2/models/resnet.py:231-233
+        self.weight = nn.Parameter(w)
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """A2/models/backbone.py:22-60 -- buffers only; `affine()` returns the folded (scale, bias)."""
+
+    def __init__(self, n, eps=1e-5):
+        super().__init__()
+        self.register_buffer("weight", torch.ones(n))
+        self.register_buffer("bias", torch.zeros(n))
+        self.register_buffer("running_mean", torch.zeros(n))
+        self.register_buffer("running_var", torch.ones(n))
+        self.eps = eps
+        self._cache = None
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        state_dict.pop(prefix + "num_batches_tracked", None)
+        self._cache = None
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs)
+
+    def affine(self):
+        key = (self.weight._version, self.bias._version, self.running_mean._version, self.running_var._version,
+               self.weight.data_ptr())
+        if self._cache is None or self._cache[0] != key:
+            with torch.no_grad():
+                scale = self.weight * (self.running_var + self.eps).rsqrt()
+                bias = self.bias - self.running_mean * scale
+            self._cache = (key, scale.contiguous(), bias.contiguous())
+        return self._cache[1], self._cache[2]
+
+    def forward(self, x):   # NCHW reference semantics (not used by the fused path; kept for API parity)
+        s, b = self.affine()
+        return x * s.reshape(1, -1, 1, 1) + b.reshape(1, -1, 1, 1)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride, dilation, has_down):
+        super().__init__()
+        self.conv1, self.bn1 = ConvW(inplanes, planes, 1), FrozenBatchNorm2d(planes)
+        self.conv2, self.bn2 = ConvW(planes, planes, 3), FrozenBatchNorm2d(planes)
+        self.conv3, self.bn3 = ConvW(planes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)
+        self.downsample = nn.Sequential(ConvW(inplanes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)) if has_down else None
+        self.stride, self.dilation = stride, dilation
+
+    def forward_fused(self, x, save=None):
+        s1, b1 = self.bn1.affine()
+        s2, b2 = self.bn2.affine()
+        s3, b3 = self.bn3.affine()
+        a1 = ops.conv_fwd(x, self.conv1.weight, s1, b1, relu=True)
+        a2 = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True)
+        if self.downsample is not None:
+            sd, bd = self.downsample[1].affine()
+            idn = ops.conv_fwd(x, self.downsample[0].weight, sd, bd, stride=self.stride)
+        else:
+            idn = x
+        out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn)
+        if save is not None:
+            save.append((x, a1, a2, out))
+        return out
+
+    def backward_fused(self, saved, dz, need_dx):
+        """dz = gradient w.r.t. the pre-ReLU output of this block (already masked by out > 0).
+        Returns the gradient w.r.t. the pre-ReLU output of the PREVIOUS block (masked by x > 0)."""
+        x, a1, a2, out = saved
+        s1, _ = self.bn1.affine()
+        s2, _ = self.bn2.affine()
+        s3, _ = self.bn3.affine()
+        w1, w2, w3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
+        st, dl = self.stride, self.dilation
+        if w3.requires_grad:
+            ops.conv_wgrad_(dz, a2, w3, s3)
+        dz2 = ops.conv_dgrad(dz, w3, s3, a2.shape[1:3], gate=a2)                 # masked by relu(a2)
+        if w2.requires_grad:
+            ops.conv_wgrad_(dz2, a1, w2, s2, stride=st, pad=dl, dil=dl)
+        dz1 = ops.conv_dgrad(dz2, w2, s2, a1.shape[1:3], stride=st, pad=dl, dil=dl, gate=a1)
+        if w1.requires_grad:
+            ops.conv_wgrad_(dz1, x, w1, s1)
+        if self.downsample is not None:
+            wd = self.downsample[0].weight
+            sd, _ = self.downsample[1].affine()
+            if wd.requires_grad:
+                ops.conv_wgrad_(dz, x, wd, sd, stride=st)
+            if not need_dx:
+                return None
+            d_idn = ops.conv_dgrad(dz, wd, sd, x.shape[1:3], stride=st)
+        else:
+            if not need_dx:
+                return None
+            d_idn = dz
+        # x = relu(previous pre-activation): the gate applies the previous block's ReLU mask in the same epilogue
+        return ops.conv_dgrad(dz1, w1, s1, x.shape[1:3], gate=x, resid=d_idn)
+
+
+_BACKWARD_HOOK = None
+
+
+def set_backward_hook(fn):
+    """fn(segment) is called from the trunk's backward when a gradient segment is final: 0 = every parameter above the
+    backbone, 1 / 2 / 3 = layer4 / layer3 / layer2 (used by the trainer to launch bucketed all-reduces early)."""
+    global _BACKWARD_HOOK
+    _BACKWARD_HOOK = fn
+
+
+class _TrunkFn(torch.autograd.Function):
+    """layer2..layer4 as one autograd node (explicit backward schedule instead of ~100 tiny autograd nodes)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, blocks):
+        saved = []
+        with torch.no_grad():
+            for blk in blocks:
+                x = blk.forward_fused(x, saved)
+        ctx.blocks, ctx.saved_acts = blocks, saved
+        return x
+
+    @staticmethod
+    def backward(ctx, d_out):
+        blocks, saved = ctx.blocks, ctx.saved_acts
+        out_last = saved[-1][3]
+        dz = torch.where(out_last > 0, d_out.contiguous(), torch.zeros((), device=d_out.device))
+        hook = _BACKWARD_HOOK
+        if hook is not None:
+            hook(0)          # autograd runs this node last: every gradient above the backbone is final
+        n2, n3 = RESNET50_LAYERS[1], RESNET50_LAYERS[2]
+        for k in range(len(blocks) - 1, -1, -1):
+            dz = blocks[k].backward_fused(saved[k], dz, need_dx=(k > 0))
+            saved[k] = None
+            if hook is not None:
+                if k == n2 + n3:
+                    hook(1)  # layer4 done
+                elif k == n2:
+                    hook(2)  # layer3 done
+                elif k == 0:
+                    hook(3)  # layer2 done
+        ctx.saved_acts = None
+        return None, None, None
+
+
+class ResNetBody(nn.Module):
+    """Children named as torchvision's resnet50 up to layer4 (state-dict keys `conv1.weight`, `layer3.2.bn1.bias`...)."""
+
+    def __init__(self, dilation=True):
+        super().__init__()
+        self.conv1, self.bn1 = ConvW(3, 64, 7), FrozenBatchNorm2d(64)
+        inplanes, cur_dil = 64, 1
+        for li, (planes, nblocks) in enumerate(zip((64, 128, 256, 512), RESNET50_LAYERS), start=1):
+            stride = 1 if li == 1 else 2
+            prev_dil = cur_dil
+            if li == 4 and dilation:            # DC5: A2/models/backbone.py:153-155, resnet.py:217-224
+                cur_dil *= stride
+                stride = 1
+            blocks = []
+            for b in range(nblocks):
+                blocks.append(Bottleneck(inplanes, planes, stride if b == 0 else 1, prev_dil if b == 0 else cur_dil, b == 0))
+                inplanes = planes * 4
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        self._stem_w4 = None
+
+    def stem_weight4(self):
+        """conv1 weight padded to 4 input channels ([64][7][7][4]) so a tap is one aligned 16-byte K-run."""
+        w = self.conv1.weight
+        key = (w._version, w.data_ptr())
+        if self._stem_w4 is None or self._stem_w4[0] != key:
+            with torch.no_grad():
+                w4 = torch.zeros(64, 4, 7, 7, device=w.device).contiguous(memory_format=torch.channels_last)
+                w4[:, :3] = w
+            self._stem_w4 = (key, w4)
+        return self._stem_w4[1]
+
+    def forward_nhwc(self, images):
+        """images [B,3,H,W] (NCHW, as the reference API) -> layer4 features NHWC [B,H/16,W/16,2048]."""
+        B, _, H, W = images.shape
+        with torch.no_grad():
+            x = torch.zeros((B, H, W, 4), device=images.device, dtype=torch.float32)
+            x[..., :3] = images.permute(0, 2, 3, 1)
+            s, b = self.bn1.affine()
+            x = ops.conv_fwd(x, self.stem_weight4(), s, b, stride=2, pad=3, relu=True)
+            x = ops.maxpool3x3s2(x)
+            for blk in self.layer1:
+                x = blk.forward_fused(x)
+        blocks = list(self.layer2) + list(self.layer3) + list(self.layer4)
+        anchor = self.layer4[-1].conv3.weight
+        if torch.is_grad_enabled() and any(p.requires_grad for blk in blocks for p in blk.parameters()):
+            return _TrunkFn.apply(x, anchor, blocks)
+        with torch.no_grad():
+            for blk in blocks:
+                x = blk.forward_fused(x)
+        return x
+
+
+class BackboneAgg(nn.Module):
+    """A2/models/backbone.py:90-159 (single feature level): body + exemplar aggregation."""
+
+    def __init__(self, train_backbone=True, dilation=True):
+        super().__init__()
+        self.body = ResNetBody(dilation)
+        for name, p in self.body.named_parameters():
+            if not train_backbone or ("layer2" not in name and "layer3" not in name and "layer4" not in name):
+                p.requires_grad_(False)                                   # :93-95
+        self.strides = [16 if dilation else 32]
+        self.num_channels = [2048]
+
+    def extract_feature(self, images, mask, rects):
+        """images [B,3,H,W], mask bool [B,H,W], rects [B,K,4] normalised xyxy (device) ->
+        (features NHWC [B,h,w,4096], mask [B,h,w])."""
+        x = self.body.forward_nhwc(images)
+        B, h, w, Cc = x.shape
+        r = rects[0].to(torch.float32)                                    # only image 0's exemplars (:122)
+        xc = ((r[:, 0] * w + r[:, 2] * w) / 2).to(torch.int64)            # int() truncation (:126-127)
+        yc = ((r[:, 1] * h + r[:, 3] * h) / 2).to(torch.int64)
+        pf = x[:, yc, xc, :].mean(1)                                      # [B, 2048]
+        feat = torch.cat([x, x * pf[:, None, None, :]], dim=-1)
+        m = nn.functional.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]   # nearest (:143)
+        return feat, m
+
+
+def build_backbone(args):
+    train_backbone = args.lr_backbone > 0
+    assert not (args.masks or args.num_feature_levels > 1), "only the single-level 2nd-stage path is built"
+    assert args.backbone == "resnet50"
+    return BackboneAgg(train_backbone, args.dilation)

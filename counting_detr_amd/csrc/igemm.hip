@@ -1,0 +1,578 @@
+// igemm.hip -- implicit-GEMM convolution / linear kernels on the fp32 matrix cores of gfx950.
+//
+// One kernel family serves every dense contraction of the Counting-DETR step:
+//   cdetr_gemm  : C = epi( sum_tap A[row(m,tap)] . W_tap )  -- conv forward (NHWC gather, no im2col buffer),
+//                 conv data-gradient (transposed gather), linear forward / data-gradient, small batched GEMMs;
+//   cdetr_wgrad : dW += dY^T . X[row(p,tap)]                  -- weight gradients, split-K with fp32 atomics.
+// Arithmetic: v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate) -- 64 FLOP/clk/SIMD, 157 TFLOP/s peak.
+// Tiling: 256 threads = 4 waves (2x2), wave tile (BM/2)x(BN/2) of 32x32 fragments, BK = 16, double-buffered LDS with
+// register prefetch (one barrier per k-tile).  LDS rows are padded to 20 floats: the 16-lane groups of ds_read_b128
+// then hit 16 distinct 16-byte slots (conflict-free, see MI355X_MICROARCH.md LDS table).
+// Within a 16-wide k-tile the reduction order is permuted (lane group g supplies k = 8h + 4g + s at step s) so that one
+// ds_read_b128 feeds four MFMAs; A and B use the same permutation, so the sum is unchanged up to fp32 reassociation.
+#include "../../include/cdetr_hip.h"
+#include "common.h"
+#include <type_traits>
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int LDS_K = BK + 4;  // padded k-contiguous row
+
+struct RowCoord {
+    int ybase, xbase, nbase, m;
+    bool valid;
+};
+
+__device__ __forceinline__ RowCoord decode_row(const cdetr_conv_geom& g, int m, int M) {
+    RowCoord r;
+    r.m = m;
+    r.valid = m < M;
+    r.ybase = r.xbase = r.nbase = 0;
+    if (g.mode != CDETR_ROWS_DENSE && r.valid) {
+        const int hw = g.Hc * g.Wc;
+        const int n = m / hw;
+        const int rem = m - n * hw;
+        const int y = rem / g.Wc;
+        const int x = rem - y * g.Wc;
+        r.nbase = n * g.Ha * g.Wa;
+        if (g.mode == CDETR_ROWS_CONV_FWD) {
+            r.ybase = y * g.stride - g.pad;
+            r.xbase = x * g.stride - g.pad;
+        } else {
+            r.ybase = y + g.pad;
+            r.xbase = x + g.pad;
+        }
+    }
+    return r;
+}
+
+// row index into the gathered tensor for (row coord, tap); -1 when the tap falls outside (zero contribution)
+__device__ __forceinline__ long gather_row(const cdetr_conv_geom& g, const RowCoord& r, int tap) {
+    if (!r.valid) return -1;
+    if (g.mode == CDETR_ROWS_DENSE) return r.m;
+    const int ky = tap / g.kw;
+    const int kx = tap - ky * g.kw;
+    if (g.mode == CDETR_ROWS_CONV_FWD) {
+        const int iy = r.ybase + ky * g.dil;
+        const int ix = r.xbase + kx * g.dil;
+        if (iy < 0 || iy >= g.Ha || ix < 0 || ix >= g.Wa) return -1;
+        return (long)r.nbase + (long)iy * g.Wa + ix;
+    }
+    int ty = r.ybase - ky * g.dil;
+    int tx = r.xbase - kx * g.dil;
+    if (ty < 0 || tx < 0) return -1;
+    if (g.stride > 1) {
+        if ((ty % g.stride) != 0 || (tx % g.stride) != 0) return -1;
+        ty /= g.stride;
+        tx /= g.stride;
+    }
+    if (ty >= g.Ha || tx >= g.Wa) return -1;
+    return (long)r.nbase + (long)ty * g.Wa + tx;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+template <int BM, int BN, int BL>
+__global__ __launch_bounds__(256) void igemm_kernel(const cdetr_gemm_desc d, const int tilesM, const int vecA,
+                                                    const int vecB) {
+    constexpr int FM = BM / 64, FN = BN / 64;
+    constexpr int A_SLOTS = BM / 64, B_SLOTS = BN / 64;
+    constexpr int LDS_N = BN + 4;
+    constexpr int B_TILE = (BL == 0) ? BN * LDS_K : BK * LDS_N;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDS_K + 2 * B_TILE];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LDS_K;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int tm = blockIdx.x % tilesM, tn = blockIdx.x / tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = d.A + (long)z * d.sA;
+    const float* __restrict__ B = d.B + (long)z * d.sB;
+    float* __restrict__ C = d.C + (long)z * d.sC;
+    const int K = d.K, taps = d.taps, Ktot = d.K * d.taps;
+    const int nkt = (Ktot + BK - 1) / BK;
+
+    // ---- per-thread loader state
+    const int kq = tid & 3;
+    RowCoord arow[A_SLOTS];
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) arow[i] = decode_row(d.g, m0 + (tid >> 2) + 64 * i, d.M);
+    float bscale0[B_SLOTS];
+    if (BL == 0) {
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+            const int n = n0 + (tid >> 2) + 64 * i;
+            bscale0[i] = (d.w_scale && n < d.N) ? d.w_scale[n] : 1.f;
+        }
+    }
+
+    float4 ra[A_SLOTS], rb[B_SLOTS];
+
+    auto fetch = [&](int kt) {
+        // A: rows gathered, k contiguous
+        const int kk = kt * BK + kq * 4;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            float4 v = zero4();
+            if (vecA) {
+                if (kk < Ktot) {
+                    const int tap = (taps == 1) ? 0 : kk / K;
+                    const int c = kk - tap * K;
+                    const long row = gather_row(d.g, arow[i], tap);
+                    if (row >= 0) v = ld4(A + row * d.lda + c);
+                }
+            } else if (arow[i].valid) {  // scalar path: dense rows only (checked on the host)
+                const float* p = A + (long)arow[i].m * d.lda;
+                if (kk + 0 < Ktot) v.x = p[kk + 0];
+                if (kk + 1 < Ktot) v.y = p[kk + 1];
+                if (kk + 2 < Ktot) v.z = p[kk + 2];
+                if (kk + 3 < Ktot) v.w = p[kk + 3];
+            }
+            ra[i] = v;
+        }
+        if (BL == 0) {
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i) {
+                const int n = n0 + (tid >> 2) + 64 * i;
+                float4 v = zero4();
+                if (n < d.N) {
+                    const float* p = B + (long)n * d.ldb;
+                    if (vecB) {
+                        if (kk < Ktot) v = ld4(p + kk);
+                    } else {
+                        if (kk + 0 < Ktot) v.x = p[kk + 0];
+                        if (kk + 1 < Ktot) v.y = p[kk + 1];
+                        if (kk + 2 < Ktot) v.z = p[kk + 2];
+                        if (kk + 3 < Ktot) v.w = p[kk + 3];
+                    }
+                    const float s = bscale0[i];
+                    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+                }
+                rb[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i) {
+                const int idx = tid + 256 * i;
+                const int kr = idx / (BN / 4);
+                const int nq = idx - kr * (BN / 4);
+                const int kb = kt * BK + kr;
+                const int n = n0 + nq * 4;
+                float4 v = zero4();
+                if (kb < Ktot && n < d.N) {
+                    const int tap = (taps == 1) ? 0 : kb / K;
+                    const int k = kb - tap * K;
+                    const float* p = B + ((long)k * taps + tap) * d.ldb + n;
+                    if (vecB) {
+                        v = ld4(p);
+                    } else {
+                        v.x = p[0];
+                        if (n + 1 < d.N) v.y = p[1];
+                        if (n + 2 < d.N) v.z = p[2];
+                        if (n + 3 < d.N) v.w = p[3];
+                    }
+                    if (d.w_scale) {
+                        const float s = d.w_scale[k];
+                        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+
+    auto stash = [&](int buf) {
+        float* as = As + buf * BM * LDS_K;
+        float* bs = Bs + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i)
+            *reinterpret_cast<float4*>(as + ((tid >> 2) + 64 * i) * LDS_K + kq * 4) = ra[i];
+        if (BL == 0) {
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i)
+                *reinterpret_cast<float4*>(bs + ((tid >> 2) + 64 * i) * LDS_K + kq * 4) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i) {
+                const int idx = tid + 256 * i;
+                const int kr = idx / (BN / 4);
+                const int nq = idx - kr * (BN / 4);
+                *reinterpret_cast<float4*>(bs + kr * LDS_N + nq * 4) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) fetch(kt + 1);
+        const float* as = As + buf * BM * LDS_K + (wm * (BM / 2) + i32) * LDS_K + g * 4;
+        const float* bs = (BL == 0) ? Bs + buf * B_TILE + (wn * (BN / 2) + i32) * LDS_K + g * 4
+                                    : Bs + buf * B_TILE + (g * 4) * LDS_N + wn * (BN / 2) + i32;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float a4[FM][4], b4[FN][4];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+                const float4 t = *reinterpret_cast<const float4*>(as + a * 32 * LDS_K + h * 8);
+                a4[a][0] = t.x; a4[a][1] = t.y; a4[a][2] = t.z; a4[a][3] = t.w;
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                if (BL == 0) {
+                    const float4 t = *reinterpret_cast<const float4*>(bs + b * 32 * LDS_K + h * 8);
+                    b4[b][0] = t.x; b4[b][1] = t.y; b4[b][2] = t.z; b4[b][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b4[b][s] = bs[(h * 8 + s) * LDS_N + b * 32];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[a][s], b4[b][s], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int n = n0 + wn * (BN / 2) + b * 32 + i32;
+            if (n >= d.N) continue;
+            const float bias = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (m >= d.M) continue;
+                float v = (acc[a][b][r] + bias) * d.out_scale;
+                if (d.resid) v += d.resid[(long)m * d.ldr + n];
+                if (d.gate) v = d.gate[(long)m * d.ldg + n] > 0.f ? v : 0.f;
+                if (d.relu) v = fmaxf(v, 0.f);
+                C[(long)m * d.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ wgrad
+// dW[i][tap][c] += scale[i] * sum_p dY[p][i] * X[row(p,tap)][c].  Block = (i-tile, (tap, c-tile), k-slice).
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
+                                                    const int kt_per_slice) {
+    constexpr int FM = BI / 64, FN = BJ / 64;
+    constexpr int A_SLOTS = BI / 64, B_SLOTS = BJ / 64;
+    constexpr int LDI = BI + 4, LDJ = BJ + 4;
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDI + 2 * BK * LDJ];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDI;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int ti = blockIdx.x % tilesI;
+    const int tj = blockIdx.x / tilesI;          // over taps * tilesJ
+    const int tap = tj / tilesJ;
+    const int c0 = (tj - tap * tilesJ) * BJ;
+    const int i0 = ti * BI;
+    const int z = blockIdx.z;
+    const float* __restrict__ dY = d.dY + (long)z * d.sY;
+    const float* __restrict__ X = d.X + (long)z * d.sX;
+    float* __restrict__ dW = d.dW + (long)z * d.sW;
+    const int nkt_all = (d.P + BK - 1) / BK;
+    const int kt_begin = blockIdx.y * kt_per_slice;
+    const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
+    if (kt_begin >= kt_end) return;
+
+    float4 ra[A_SLOTS], rb[B_SLOTS];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) {
+            const int idx = tid + 256 * s;
+            const int kr = idx / (BI / 4);
+            const int iq = idx - kr * (BI / 4);
+            const int p = kt * BK + kr;
+            const int i = i0 + iq * 4;
+            float4 v = zero4();
+            if (p < d.P && i < d.Nout) {
+                const float* q = dY + (long)p * d.ldy + i;
+                if (i + 3 < d.Nout && (d.ldy & 3) == 0) {
+                    v = ld4(q);
+                } else {
+                    v.x = q[0];
+                    if (i + 1 < d.Nout) v.y = q[1];
+                    if (i + 2 < d.Nout) v.z = q[2];
+                    if (i + 3 < d.Nout) v.w = q[3];
+                }
+            }
+            ra[s] = v;
+        }
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) {
+            const int idx = tid + 256 * s;
+            const int kr = idx / (BJ / 4);
+            const int jq = idx - kr * (BJ / 4);
+            const int p = kt * BK + kr;
+            const int c = c0 + jq * 4;
+            float4 v = zero4();
+            if (p < d.P && c < d.Cin) {
+                const RowCoord rc = decode_row(d.g, p, d.P);
+                const long row = gather_row(d.g, rc, tap);
+                if (row >= 0) {
+                    const float* q = X + row * d.ldx + c;
+                    if (c + 3 < d.Cin && (d.ldx & 3) == 0) {
+                        v = ld4(q);
+                    } else {
+                        v.x = q[0];
+                        if (c + 1 < d.Cin) v.y = q[1];
+                        if (c + 2 < d.Cin) v.z = q[2];
+                        if (c + 3 < d.Cin) v.w = q[3];
+                    }
+                }
+            }
+            rb[s] = v;
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) {
+            const int idx = tid + 256 * s;
+            const int kr = idx / (BI / 4);
+            const int iq = idx - kr * (BI / 4);
+            *reinterpret_cast<float4*>(As + buf * BK * LDI + kr * LDI + iq * 4) = ra[s];
+        }
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) {
+            const int idx = tid + 256 * s;
+            const int kr = idx / (BJ / 4);
+            const int jq = idx - kr * (BJ / 4);
+            *reinterpret_cast<float4*>(Bs + buf * BK * LDJ + kr * LDJ + jq * 4) = rb[s];
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    fetch(kt_begin);
+    stash(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) fetch(kt + 1);
+        const float* as = As + buf * BK * LDI + (g * 4) * LDI + wm * (BI / 2) + i32;
+        const float* bs = Bs + buf * BK * LDJ + (g * 4) * LDJ + wn * (BJ / 2) + i32;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float av[FM], bv[FN];
+#pragma unroll
+                for (int a = 0; a < FM; ++a) av[a] = as[(h * 8 + s) * LDI + a * 32];
+#pragma unroll
+                for (int b = 0; b < FN; ++b) bv[b] = bs[(h * 8 + s) * LDJ + b * 32];
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < kt_end) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    const bool single = (gridDim.y == 1);
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int c = c0 + wn * (BJ / 2) + b * 32 + i32;
+            if (c >= d.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (i >= d.Nout) continue;
+                float v = acc[a][b][r];
+                if (d.w_scale) v *= d.w_scale[i];
+                float* dst = dW + (long)i * d.ldw + (long)tap * d.Cin + c;
+                (void)single;
+                atomicAdd(dst, v);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ small kernels
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, long ldx, int M, int N,
+                                                     float* __restrict__ out, int rows_per_block) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int r0 = blockIdx.y * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += X[(long)r * ldx + n];
+    atomicAdd(out + n, s);
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ X, float* __restrict__ Y, int Nimg, int H,
+                                                      int W, int C, int Ho, int Wo) {
+    const long total = (long)Nimg * Ho * Wo * (C / 4);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c4 = (int)(idx % (C / 4));
+        long t = idx / (C / 4);
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * 2 - 1 + ky;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * 2 - 1 + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = ld4(X + (((long)n * H + iy) * W + ix) * C + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(Y + (((long)n * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
+    }
+}
+
+template <int BM, int BN>
+int launch_gemm(const cdetr_gemm_desc& d, hipStream_t st, int vecA, int vecB) {
+    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+    dim3 grid(tilesM * tilesN, 1, d.batch), block(256);
+    if (d.b_layout == 0)
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 0>), grid, block, 0, st, d, tilesM, vecA, vecB);
+    else
+        hipLaunchKernelGGL((igemm_kernel<BM, BN, 1>), grid, block, 0, st, d, tilesM, vecA, vecB);
+    return cdetr_launch_status("cdetr_gemm");
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
+    CDETR_CHECK_ARG(dp != nullptr, "cdetr_gemm: null descriptor");
+    cdetr_gemm_desc d = *dp;
+    CDETR_CHECK_ARG(d.M >= 0 && d.N > 0 && d.K > 0 && d.taps > 0 && d.batch > 0, "cdetr_gemm: bad sizes M=%d N=%d K=%d taps=%d batch=%d",
+                    d.M, d.N, d.K, d.taps, d.batch);
+    CDETR_CHECK_ARG(d.A && d.B && d.C, "cdetr_gemm: null A/B/C");
+    CDETR_CHECK_ARG(d.b_layout == 0 || d.b_layout == 1, "cdetr_gemm: b_layout %d", d.b_layout);
+    if (d.M == 0) return CDETR_OK;
+    if (d.g.mode == CDETR_ROWS_DENSE) {
+        CDETR_CHECK_ARG(d.taps == 1, "cdetr_gemm: dense rows need taps == 1");
+    } else {
+        CDETR_CHECK_ARG(d.g.mode == CDETR_ROWS_CONV_FWD || d.g.mode == CDETR_ROWS_CONV_DGRAD, "cdetr_gemm: mode %d", d.g.mode);
+        CDETR_CHECK_ARG(d.taps == d.g.kh * d.g.kw && d.g.stride >= 1 && d.g.dil >= 1, "cdetr_gemm: conv geometry mismatch");
+        CDETR_CHECK_ARG(d.g.Hc > 0 && d.g.Wc > 0 && d.M % (d.g.Hc * d.g.Wc) == 0, "cdetr_gemm: M is not images*Hc*Wc");
+    }
+    if (d.b_layout == 1 && d.taps > 1) CDETR_CHECK_ARG(d.K % BK == 0, "cdetr_gemm: dgrad with taps needs K %% 16 == 0");
+    const int vecA = ((d.K & 3) == 0 && (d.lda & 3) == 0 && (d.sA & 3) == 0 && aligned16(d.A)) ? 1 : 0;
+    if (!vecA) CDETR_CHECK_ARG(d.g.mode == CDETR_ROWS_DENSE, "cdetr_gemm: unaligned A only supported for dense rows");
+    int vecB;
+    if (d.b_layout == 0)
+        vecB = ((((long)d.K * d.taps) & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && aligned16(d.B)) ? 1 : 0;
+    else
+        vecB = ((d.N & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && aligned16(d.B)) ? 1 : 0;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    // tile choice: the largest tile that still yields >= 1.5 waves of workgroups on 256 CUs
+    auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
+    if (d.N > 64 && d.M > 64 && blocks(128, 128) >= 384) return launch_gemm<128, 128>(d, st, vecA, vecB);
+    if (d.M > 64 && blocks(128, 64) >= 384) return launch_gemm<128, 64>(d, st, vecA, vecB);
+    return launch_gemm<64, 64>(d, st, vecA, vecB);
+}
+
+extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
+    CDETR_CHECK_ARG(dp != nullptr, "cdetr_wgrad: null descriptor");
+    cdetr_wgrad_desc d = *dp;
+    CDETR_CHECK_ARG(d.P >= 0 && d.Nout > 0 && d.Cin > 0 && d.taps > 0 && d.batch > 0, "cdetr_wgrad: bad sizes");
+    CDETR_CHECK_ARG(d.dY && d.X && d.dW, "cdetr_wgrad: null pointer");
+    CDETR_CHECK_ARG(aligned16(d.dY) && aligned16(d.X) && (d.sY & 3) == 0 && (d.sX & 3) == 0, "cdetr_wgrad: dY/X must be 16-byte aligned");
+    if (d.P == 0) return CDETR_OK;
+    if (d.g.mode == CDETR_ROWS_DENSE) {
+        CDETR_CHECK_ARG(d.taps == 1, "cdetr_wgrad: dense rows need taps == 1");
+    } else {
+        CDETR_CHECK_ARG(d.g.mode == CDETR_ROWS_CONV_FWD && d.taps == d.g.kh * d.g.kw, "cdetr_wgrad: geometry");
+        CDETR_CHECK_ARG(d.P % (d.g.Hc * d.g.Wc) == 0, "cdetr_wgrad: P is not images*Hc*Wc");
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int nkt = (d.P + BK - 1) / BK;
+    auto launch = [&](auto bi_c, auto bj_c) {
+        constexpr int BI = decltype(bi_c)::value, BJ = decltype(bj_c)::value;
+        const int tilesI = (d.Nout + BI - 1) / BI, tilesJ = (d.Cin + BJ - 1) / BJ;
+        const long base = (long)tilesI * tilesJ * d.taps * d.batch;
+        long slices = (1024 + base - 1) / base;                 // aim at ~4 workgroups per CU
+        const long max_slices = (nkt + 7) / 8;                  // >= 8 k-tiles (128 pixels) per slice
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        if (slices > 65535) slices = 65535;
+        int per = (int)((nkt + slices - 1) / slices);
+        slices = (nkt + per - 1) / per;
+        dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
+        hipLaunchKernelGGL((wgrad_kernel<BI, BJ>), grid, block, 0, st, d, tilesI, tilesJ, per);
+    };
+    if (d.Nout >= 128 && d.Cin >= 128)
+        launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
+    else if (d.Nout >= 128)
+        launch(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{});
+    else if (d.Cin >= 128)
+        launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 128>{});
+    else
+        launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
+    return cdetr_launch_status("cdetr_wgrad");
+}
+
+extern "C" int cdetr_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, void* stream) {
+    CDETR_CHECK_ARG(X && out && M >= 0 && N > 0, "cdetr_colsum: bad args");
+    if (M == 0) return CDETR_OK;
+    const int rows_per_block = 64;
+    dim3 grid((N + 255) / 256, (M + rows_per_block - 1) / rows_per_block);
+    hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, (long)ldx, M, N, out,
+                       rows_per_block);
+    return cdetr_launch_status("cdetr_colsum");
+}
+
+extern "C" int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream) {
+    CDETR_CHECK_ARG(X && Y && Nimg > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "cdetr_maxpool: bad args");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)Nimg * Ho * Wo * (C / 4);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, Y, Nimg, H, W,
+                       C, Ho, Wo);
+    return cdetr_launch_status("cdetr_maxpool3x3s2");
+}

@@ -1,0 +1,264 @@
+// matcher.hip -- Hungarian matching on the device.
+//
+// cdetr_match_cost : the reference's matching cost (A2/models/matcher.py:222-242) per image only (the reference
+//                    also computes -- and throws away -- the cross-image blocks), fp32, same expression and
+//                    summation order: C = 5*L1 + 2*(pos - neg) + 2*(-GIoU); contraction of mul+add is disabled
+//                    in this file so every product is rounded like the reference's separate torch ops.
+// cdetr_lsap       : exact rectangular linear sum assignment, the algorithm of scipy.optimize.linear_sum_assignment
+//                    (Crouse 2016: shortest augmenting paths, float64 duals, tall matrices transposed, ties broken in
+//                    favour of a not-yet-assigned column, scan order = the `remaining` list with swap-removal) so the
+//                    returned indices are those scipy returns -- including on ties.  One workgroup per image; all solver
+//                    state lives in LDS; the column scan is lane-parallel with a wave-shuffle arg-min whose comparator
+//                    reproduces the sequential tie rule.  Removes the reference's `.cpu()` pipeline drain
+//                    (A2/models/matcher.py:243) so the whole train step stays on the device and is graph-capturable.
+#include "../../include/cdetr_hip.h"
+#include "common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__global__ __launch_bounds__(256) void match_cost_kernel(const float* __restrict__ logits, int ncls,
+                                                         const float* __restrict__ boxes, const float* __restrict__ tgt,
+                                                         const int* __restrict__ tgt_off, const int64_t* __restrict__ cost_off,
+                                                         int Q, float w_class, float w_bbox, float w_giou,
+                                                         float* __restrict__ cost) {
+    const int b = blockIdx.y;
+    const int t0 = tgt_off[b], T = tgt_off[b + 1] - t0;
+    const long total = (long)Q * T;
+    const bool transpose = T < Q;   // solver layout: rows = the shorter side
+    float* out = cost + cost_off[b];
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        // enumerate in OUTPUT order so stores coalesce
+        int q, t;
+        if (transpose) { t = (int)(idx / Q); q = (int)(idx - (long)t * Q); }
+        else { q = (int)(idx / T); t = (int)(idx - (long)q * T); }
+        const float x = logits[((long)b * Q + q) * ncls + 0];   // tgt_ids are all 0 (A2/data/fsc147.py:84)
+        const float p = 1.f / (1.f + expf(-x));
+        const float neg = (0.75f * (p * p)) * (-logf((1.f - p) + 1e-8f));
+        const float pos = (0.25f * ((1.f - p) * (1.f - p))) * (-logf(p + 1e-8f));
+        const float cost_class = pos - neg;
+        const float* ob = boxes + ((long)b * Q + q) * 4;
+        const float* tb = tgt + ((long)t0 + t) * 4;
+        const float ocx = ob[0], ocy = ob[1], ow = ob[2], oh = ob[3];
+        const float tcx = tb[0], tcy = tb[1], tw = tb[2], th = tb[3];
+        const float cost_bbox = ((fabsf(ocx - tcx) + fabsf(ocy - tcy)) + fabsf(ow - tw)) + fabsf(oh - th);
+        const float ox0 = ocx - 0.5f * ow, oy0 = ocy - 0.5f * oh, ox1 = ocx + 0.5f * ow, oy1 = ocy + 0.5f * oh;
+        const float tx0 = tcx - 0.5f * tw, ty0 = tcy - 0.5f * th, tx1 = tcx + 0.5f * tw, ty1 = tcy + 0.5f * th;
+        const float a1 = (ox1 - ox0) * (oy1 - oy0), a2 = (tx1 - tx0) * (ty1 - ty0);
+        const float iw = fmaxf(fminf(ox1, tx1) - fmaxf(ox0, tx0), 0.f), ih = fmaxf(fminf(oy1, ty1) - fmaxf(oy0, ty0), 0.f);
+        const float inter = iw * ih;
+        const float uni = (a1 + a2) - inter;
+        const float iou = inter / uni;
+        const float ew = fmaxf(fmaxf(ox1, tx1) - fminf(ox0, tx0), 0.f), eh = fmaxf(fmaxf(oy1, ty1) - fminf(oy0, ty0), 0.f);
+        const float area = ew * eh;
+        const float giou = iou - (area - uni) / area;
+        const float c = (w_bbox * cost_bbox + w_class * cost_class) + w_giou * (-giou);
+        out[idx] = c;
+    }
+}
+
+struct Cand {          // arg-min candidate with the sequential scan's tie rule
+    double val;
+    int it;            // position in `remaining`
+    int unassigned;    // row4col[j] == -1
+};
+__device__ __forceinline__ Cand better(const Cand& a, const Cand& b) {
+    // sequential rule: strictly smaller value wins; among equal values the LAST unassigned column wins, and if none
+    // is unassigned the FIRST column wins.
+    if (a.it < 0) return b;
+    if (b.it < 0) return a;
+    if (a.val < b.val) return a;
+    if (b.val < a.val) return b;
+    if (a.unassigned != b.unassigned) return a.unassigned ? a : b;
+    if (a.unassigned) return (a.it > b.it) ? a : b;
+    return (a.it < b.it) ? a : b;
+}
+__device__ __forceinline__ Cand shfl_xor_cand(const Cand& c, int m) {
+    Cand r;
+    r.val = __shfl_xor(c.val, m, 64);
+    r.it = __shfl_xor(c.it, m, 64);
+    r.unassigned = __shfl_xor(c.unassigned, m, 64);
+    return r;
+}
+
+// One workgroup (NT threads) per image.
+template <int NT>
+__global__ __launch_bounds__(NT) void lsap_kernel(const float* __restrict__ cost_all, const int64_t* __restrict__ cost_off,
+                                                  const int* __restrict__ tgt_off, int Q, int Mmax, int64_t* __restrict__ idx_i,
+                                                  int64_t* __restrict__ idx_j, int* __restrict__ status, int nc_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int b = blockIdx.x;
+    const int T = tgt_off[b + 1] - tgt_off[b];
+    const bool transpose = T < Q;
+    const int nr = transpose ? T : Q;      // rows of the solver problem (the shorter side)
+    const int nc = transpose ? Q : T;
+    const float* cost = cost_all + cost_off[b];
+    const int tid = threadIdx.x;
+    int64_t* oi = idx_i + (long)b * Mmax;
+    int64_t* oj = idx_j + (long)b * Mmax;
+    if (nr == 0) { if (tid == 0) status[b] = 0; return; }
+
+    // LDS carve (nc_cap >= nc >= nr): v, spc, u f64 | path, row4col, remaining, col4row i32 | SC, SR u8
+    double* v = reinterpret_cast<double*>(lds);
+    double* spc = v + nc_cap;
+    double* u = spc + nc_cap;
+    int* path = reinterpret_cast<int*>(u + nc_cap);
+    int* row4col = path + nc_cap;
+    int* remaining = row4col + nc_cap;
+    int* col4row = remaining + nc_cap;
+    unsigned char* SC = reinterpret_cast<unsigned char*>(col4row + nc_cap);
+    unsigned char* SR = SC + nc_cap;
+    __shared__ Cand wave_best[NT / 64];
+    __shared__ int s_i, s_sink, s_num_remaining, s_bad;
+    __shared__ double s_min;
+
+    if (tid == 0) s_bad = 0;
+    for (int j = tid; j < nc; j += NT) { v[j] = 0.0; path[j] = -1; row4col[j] = -1; }
+    for (int i = tid; i < nr; i += NT) { u[i] = 0.0; col4row[i] = -1; }
+    __syncthreads();
+    // validity scan (scipy raises ValueError on NaN / -inf entries)
+    {
+        int bad = 0;
+        for (long k = tid; k < (long)nr * nc; k += NT) {
+            const float c = cost[k];
+            if (c != c || c == -INFINITY) bad = 1;
+        }
+        if (bad) atomicOr(&s_bad, 1);
+    }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) status[b] = 2; return; }
+
+    for (int cur = 0; cur < nr; ++cur) {
+        // ---- augmenting_path(cur)
+        for (int j = tid; j < nc; j += NT) { spc[j] = INFINITY; SC[j] = 0; remaining[j] = nc - j - 1; }
+        for (int i = tid; i < nr; i += NT) SR[i] = 0;
+        if (tid == 0) { s_i = cur; s_sink = -1; s_num_remaining = nc; s_min = 0.0; }
+        __syncthreads();
+        while (true) {
+            const int i = s_i;
+            const int num_remaining = s_num_remaining;
+            const double min_val = s_min;
+            const double ui = u[i];
+            const float* crow = cost + (long)i * nc;
+            Cand best;
+            best.val = INFINITY; best.it = -1; best.unassigned = 0;
+            for (int it = tid; it < num_remaining; it += NT) {
+                const int j = remaining[it];
+                const double r = ((min_val + (double)crow[j]) - ui) - v[j];
+                double s = spc[j];
+                if (r < s) { path[j] = i; spc[j] = r; s = r; }
+                Cand c;
+                c.val = s; c.it = it; c.unassigned = (row4col[j] == -1);
+                best = better(best, c);
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) best = better(best, shfl_xor_cand(best, m));
+            if (NT > 64) {
+                if ((tid & 63) == 0) wave_best[tid >> 6] = best;
+                __syncthreads();
+                if (tid == 0) {
+                    Cand bb = wave_best[0];
+                    for (int wv = 1; wv < NT / 64; ++wv) bb = better(bb, wave_best[wv]);
+                    wave_best[0] = bb;
+                }
+                __syncthreads();
+                best = wave_best[0];
+            }
+            // every thread now holds the same `best`
+            if (tid == 0) {
+                SR[i] = 1;
+                if (best.it < 0 || best.val == INFINITY) {
+                    s_sink = -2;      // infeasible
+                } else {
+                    const int j = remaining[best.it];
+                    s_min = best.val;
+                    if (row4col[j] == -1) s_sink = j;
+                    else s_i = row4col[j];
+                    SC[j] = 1;
+                    remaining[best.it] = remaining[num_remaining - 1];
+                    s_num_remaining = num_remaining - 1;
+                }
+            }
+            __syncthreads();
+            if (s_sink != -1) break;
+        }
+        const int sink = s_sink;
+        if (sink == -2) { if (tid == 0) status[b] = 1; return; }
+        const double min_val = s_min;
+        // ---- dual update
+        for (int i = tid; i < nr; i += NT) {
+            if (i == cur) u[i] += min_val;
+            else if (SR[i]) u[i] += min_val - spc[col4row[i]];
+        }
+        for (int j = tid; j < nc; j += NT)
+            if (SC[j]) v[j] -= min_val - spc[j];
+        __syncthreads();
+        // ---- augment along the path (sequential, short)
+        if (tid == 0) {
+            int j = sink;
+            while (true) {
+                const int i = path[j];
+                row4col[j] = i;
+                const int t = col4row[i];
+                col4row[i] = j;
+                j = t;
+                if (i == cur) break;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- write (query, target) pairs with ascending query index
+    if (!transpose) {
+        for (int i = tid; i < nr; i += NT) { oi[i] = i; oj[i] = col4row[i]; }
+    } else {
+        // rows are targets, columns are queries: walk the queries in order, emit the assigned ones (stable, ascending)
+        // rank of query j = number of assigned queries with a smaller index
+        for (int j = tid; j < nc; j += NT) remaining[j] = (row4col[j] != -1) ? 1 : 0;
+        __syncthreads();
+        if (tid == 0) {   // nc <= a few thousand: a serial prefix sum is cheap and simple
+            int run = 0;
+            for (int j = 0; j < nc; ++j) { const int f = remaining[j]; remaining[j] = run; run += f; }
+        }
+        __syncthreads();
+        for (int j = tid; j < nc; j += NT)
+            if (row4col[j] != -1) { oi[remaining[j]] = j; oj[remaining[j]] = row4col[j]; }
+    }
+    if (tid == 0) status[b] = 0;
+}
+
+inline size_t lds_bytes(int nc_cap) { return (size_t)nc_cap * (3 * 8 + 4 * 4 + 2) + 16; }
+inline int round_cap(int nc) { return (nc + 15) & ~15; }
+
+}  // namespace
+
+extern "C" int cdetr_match_cost(const float* logits, int32_t ncls, const float* boxes, const float* tgt,
+                                const int32_t* tgt_off, const int64_t* cost_off, int32_t B, int32_t Q, float w_class,
+                                float w_bbox, float w_giou, float* cost, void* stream) {
+    CDETR_CHECK_ARG(logits && boxes && tgt_off && cost_off && cost && B > 0 && Q > 0 && ncls > 0, "cdetr_match_cost: bad args");
+    dim3 grid(64, B);
+    hipLaunchKernelGGL(match_cost_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), logits, ncls, boxes, tgt,
+                       tgt_off, cost_off, Q, w_class, w_bbox, w_giou, cost);
+    return cdetr_launch_status("cdetr_match_cost");
+}
+
+extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int32_t* tgt_off, int32_t B, int32_t Q,
+                          int32_t nc_max, int32_t Mmax, int64_t* idx_i, int64_t* idx_j, int32_t* status, void* stream) {
+    CDETR_CHECK_ARG(cost && cost_off && tgt_off && idx_i && idx_j && status && B > 0 && Q > 0 && Mmax > 0 && nc_max >= Q,
+                    "cdetr_lsap: bad args");
+    const int cap = round_cap(nc_max);
+    const size_t bytes = lds_bytes(cap);
+    if (bytes > 158 * 1024) {
+        cdetr_set_error("cdetr_lsap: max(Q, T) = %d exceeds the LDS-resident solver's capacity (3800)", nc_max);
+        return CDETR_ERR_UNSUPPORTED;
+    }
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (nc_max <= 1024) {
+        if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL(lsap_kernel<64>, dim3(B), dim3(64), bytes, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status, cap);
+    } else {
+        if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        hipLaunchKernelGGL(lsap_kernel<256>, dim3(B), dim3(256), bytes, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status, cap);
+    }
+    return cdetr_launch_status("cdetr_lsap");
+}

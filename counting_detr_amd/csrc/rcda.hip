@@ -1,0 +1,546 @@
+// rcda.hip -- fused Row-Column Decoupled Attention core for gfx950.
+//
+// Reference math (A2/models/row_column_decoupled_attention.py:215-309), per (image n, head):
+//   A_row = softmax_W(scale * q_row k_row^T)   [L,W]        A_col = softmax_H(scale * q_col k_col^T)   [L,H]
+//   out[q,c] = sum_h sum_w A_col[q,h] A_row[q,w] V[h,w,c]
+// The reference materialises T[q,w,c] = sum_h A_col[q,h] V[h,w,c] ([nh,L,W,32] fp32 = 128 MB per encoder call per image
+// at 800x800) plus several permuted copies.  Here nothing but A_row/A_col (2 x 4 MB) ever reaches HBM:
+//   forward : one workgroup = 128 queries (4 waves x 32) of one (n, head).  Phase 1 computes both logit matrices with
+//             VALU FMAs (lanes 0-31 own a full row of S_row, lanes 32-63 a full row of S_col: no cross-lane reduction
+//             in the softmax).  Phase 2 is one long MFMA chain per wave: for every key column w the A operand
+//             P_w[q,h] = A_col[q,h] * A_row[q,w] is formed in registers and multiplied with the LDS-staged V[:,w,:] tile,
+//             accumulating out[32 x 32] in 16 accumulator registers (v_mfma_f32_32x32x2_f32).
+//   backward: G_w^T[h,q] = sum_c V[h,w,c] dOut[q,c] by MFMA (V tile as A operand, dOut^T loop-invariant in registers);
+//             in this transposed layout dA_col accumulates element-wise and dA_row[q,w] = sum_h A_col[q,h] G_w[q,h] is an
+//             in-lane reduction plus one cross-half add; the two softmax backward passes follow in-register.
+//             dV[h,w,c] = sum_q A_col[q,h] A_row[q,w] dOut[q,c] is a second kernel (MFMA over the query axis).
+// Head dim is fixed at 32 (E = 256, 8 heads in every shipped config).
+#include "../../include/cdetr_hip.h"
+#include "common.h"
+
+namespace {
+
+constexpr int D = 32;          // head dim
+constexpr int QW = 32;         // queries per wave
+constexpr int QB = 4 * QW;     // queries per workgroup
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+struct FwdSmem {
+    int sw, sh;          // row strides of the per-wave S_row / S_col tiles
+    int off_srow, off_scol, off_k, off_v;
+    int total;
+};
+__host__ __device__ inline FwdSmem fwd_smem(int H, int W) {
+    FwdSmem s;
+    const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
+    s.sw = Wp + 1;
+    s.sh = Hp + 4;
+    s.off_srow = 0;
+    s.off_scol = s.off_srow + 4 * QW * s.sw;
+    s.off_scol = (s.off_scol + 3) & ~3;
+    s.off_k = s.off_scol + 4 * QW * s.sh;
+    const int kbytes = (W + H) * D;      // k_row + k_col tiles (phase 1)
+    const int vbytes = 2 * Hp * D;       // double-buffered V tile (phase 2), overlays the k tiles
+    s.off_v = s.off_k;
+    s.total = s.off_k + (kbytes > vbytes ? kbytes : vbytes);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NF>   // NF = number of 32-row key fragments along H (H <= 32*NF)
+__global__ __launch_bounds__(256) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KH8 = NF * 4;
+    const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
+    const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
+    const FwdSmem sm = fwd_smem(H, W);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
+    const int qbase = blockIdx.x * QB + wid * QW;
+    const int q = qbase + i32;
+    const bool qvalid = q < L;
+
+    float* Krow = smem + sm.off_k;             // [W][32]
+    float* Kcol = Krow + W * D;                // [H][32]
+    float* Srow = smem + sm.off_srow + wid * QW * sm.sw;
+    float* Scol = smem + sm.off_scol + wid * QW * sm.sh;
+
+    // ---- phase 0: stage the projected keys of this (n, head)
+    for (int idx = tid; idx < (W + H) * 8; idx += 256) {
+        const int key = idx >> 3, c4 = idx & 7;
+        const float* src = (key < W) ? d.k_row + ((long)n * W + key) * E + head * D + c4 * 4
+                                     : d.k_col + ((long)n * H + (key - W)) * E + head * D + c4 * 4;
+        *reinterpret_cast<float4*>(Krow + key * D + c4 * 4) = ld4(src);
+    }
+    // this lane's query vector: half 0 -> q_row, half 1 -> q_col
+    float qv[D];
+    {
+        const float* qp = (g == 0 ? d.q_row : d.q_col) + ((long)n * L + (qvalid ? q : 0)) * E + head * D;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            float4 t = ld4(qp + c4 * 4);
+            if (!qvalid) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            qv[c4 * 4 + 0] = t.x; qv[c4 * 4 + 1] = t.y; qv[c4 * 4 + 2] = t.z; qv[c4 * 4 + 3] = t.w;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 1: logits + softmax; every lane owns one full row (no cross-lane traffic)
+    {
+        const int nkeys = (g == 0) ? W : H;
+        const int npad = (g == 0) ? Wp : Hp;
+        const float* Ks = (g == 0) ? Krow : Kcol;
+        float* S = (g == 0) ? Srow + i32 * sm.sw : Scol + i32 * sm.sh;
+        const uint8_t* mk = (g == 0) ? d.mask_row : d.mask_col;
+        if (mk) mk += (long)n * nkeys;
+        float mx = -INFINITY;
+        for (int k = 0; k < nkeys; ++k) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int c4 = 0; c4 < 8; ++c4) {
+                const float4 kv = *reinterpret_cast<const float4*>(Ks + k * D + c4 * 4);
+                s0 = fmaf(qv[c4 * 4 + 0], kv.x, s0);
+                s1 = fmaf(qv[c4 * 4 + 1], kv.y, s1);
+                s2 = fmaf(qv[c4 * 4 + 2], kv.z, s2);
+                s3 = fmaf(qv[c4 * 4 + 3], kv.w, s3);
+            }
+            float s = ((s0 + s1) + (s2 + s3)) * d.scale;
+            if (mk && mk[k]) s = -INFINITY;
+            S[k] = s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int k = 0; k < nkeys; ++k) {
+            const float e = expf(S[k] - mx);
+            S[k] = e;
+            sum += e;
+        }
+        const float inv = 1.f / sum;
+        for (int k = 0; k < nkeys; ++k) S[k] *= inv;
+        for (int k = nkeys; k < npad; ++k) S[k] = 0.f;
+    }
+    __syncthreads();   // all waves done with Krow/Kcol (the V buffers overlay them)
+
+    // ---- save A_row / A_col for the backward pass (coalesced copy of the wave's contiguous block)
+    {
+        const int nq = min(QW, L - qbase);   // may be <= 0 for tail waves
+        if (nq > 0) {
+            float* gar = d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp;
+            for (int idx = lane; idx < nq * Wp; idx += 64) {
+                const int r = idx / Wp, c = idx - r * Wp;
+                gar[idx] = Srow[r * sm.sw + c];
+            }
+            float* gac = d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp;
+            for (int idx = lane; idx < nq * Hp; idx += 64) {
+                const int r = idx / Hp, c = idx - r * Hp;
+                gac[idx] = Scol[r * sm.sh + c];
+            }
+        }
+    }
+
+    // ---- phase 2: out = sum_w (A_col * A_row[:,w]) . V[:,w,:]
+    float* Vs = smem + sm.off_v;   // [2][Hp][32]
+    // zero the padded key rows of both buffers once
+    for (int idx = tid; idx < 2 * (Hp - H) * D; idx += 256) {
+        const int b = idx / ((Hp - H) * D), r = idx - b * (Hp - H) * D;
+        Vs[b * Hp * D + H * D + r] = 0.f;
+    }
+    float4 acol[KH8];
+#pragma unroll
+    for (int kk = 0; kk < KH8; ++kk)
+        acol[kk] = (kk * 8 < Hp) ? *reinterpret_cast<const float4*>(Scol + i32 * sm.sh + kk * 8 + g * 4)
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const float* vbase = d.v + (long)n * H * W * E + head * D;   // + (h*W + w)*E + c
+    constexpr int VSLOTS = NF;   // float4 per thread per tile: H*8 <= 256*NF
+    float4 rv[VSLOTS];
+    auto vfetch = [&](int w) {
+#pragma unroll
+        for (int s = 0; s < VSLOTS; ++s) {
+            const int idx = tid + 256 * s;
+            const int h = idx >> 3, c4 = idx & 7;
+            rv[s] = (h < H) ? ld4(vbase + ((long)h * W + w) * E + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto vstash = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < VSLOTS; ++s) {
+            const int idx = tid + 256 * s;
+            const int h = idx >> 3, c4 = idx & 7;
+            if (h < H) *reinterpret_cast<float4*>(Vs + buf * Hp * D + h * D + c4 * 4) = rv[s];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    vfetch(0);
+    vstash(0);
+    __syncthreads();
+    for (int w = 0; w < W; ++w) {
+        const int buf = w & 1;
+        if (w + 1 < W) vfetch(w + 1);
+        const float arow = Srow[i32 * sm.sw + w];
+        const float* vb = Vs + buf * Hp * D + (g * 4) * D + i32;
+#pragma unroll
+        for (int kk = 0; kk < KH8; ++kk) {
+            if (kk * 8 < Hp) {
+                const float p0 = acol[kk].x * arow, p1 = acol[kk].y * arow, p2 = acol[kk].z * arow, p3 = acol[kk].w * arow;
+                const float b0 = vb[(kk * 8 + 0) * D], b1 = vb[(kk * 8 + 1) * D], b2 = vb[(kk * 8 + 2) * D],
+                            b3 = vb[(kk * 8 + 3) * D];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p1, b1, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p2, b2, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p3, b3, acc, 0, 0, 0);
+            }
+        }
+        if (w + 1 < W) vstash(buf ^ 1);
+        __syncthreads();
+    }
+    // C layout: col = lane&31 (= channel), row = (r&3) + 8*(r>>2) + 4*g (= query within the wave)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int qq = qbase + (r & 3) + 8 * (r >> 2) + 4 * g;
+        if (qq < L) d.out[((long)n * L + qq) * E + head * D + i32] = acc[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward (dS)
+struct BwdSmem {
+    int sw, sh, off_acol, off_arow, off_darow, off_v, total;
+};
+__host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF) {
+    BwdSmem s;
+    const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
+    s.sw = Wp + 1;
+    s.sh = Hp + 1;
+    s.off_acol = 0;
+    s.off_arow = s.off_acol + 4 * QW * s.sh;
+    s.off_darow = s.off_arow + 4 * QW * s.sw;
+    s.off_v = (s.off_darow + 4 * QW * s.sw + 3) & ~3;
+    s.total = s.off_v + 2 * (32 * NF) * 36;
+    return s;
+}
+
+template <int NF>
+__global__ __launch_bounds__(256) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int VS = 36;                 // V tile row stride (floats): 36/4 odd -> conflict-free ds_read_b128
+    constexpr int HR = 32 * NF;            // V tile rows (zero beyond H)
+    const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
+    const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
+    const BwdSmem sm = bwd_smem(H, W, NF);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
+    const int qbase = blockIdx.x * QB + wid * QW;
+    const int q = qbase + i32;
+    const bool qvalid = q < L;
+    const int nq = min(QW, L - qbase);
+
+    float* Acol = smem + sm.off_acol + wid * QW * sm.sh;     // [32][sh]
+    float* Arow = smem + sm.off_arow + wid * QW * sm.sw;     // [32][sw]
+    float* dArow = smem + sm.off_darow + wid * QW * sm.sw;   // [32][sw]
+    float* Vs = smem + sm.off_v;                             // [2][HR][36]
+
+    // ---- load the saved attention rows of this wave (coalesced), zero for tail queries
+    {
+        const float* gar = d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp;
+        for (int idx = lane; idx < QW * Wp; idx += 64) {
+            const int r = idx / Wp, c = idx - r * Wp;
+            Arow[r * sm.sw + c] = (r < nq) ? gar[idx] : 0.f;
+        }
+        const float* gac = d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp;
+        for (int idx = lane; idx < QW * Hp; idx += 64) {
+            const int r = idx / Hp, c = idx - r * Hp;
+            Acol[r * sm.sh + c] = (r < nq) ? gac[idx] : 0.f;
+        }
+    }
+    // zero V tiles completely once (rows >= H and the 4 pad columns stay zero)
+    for (int idx = tid; idx < 2 * HR * VS; idx += 256) Vs[idx] = 0.f;
+
+    // dOut^T fragment (B operand, loop invariant): lane (j = query, g) holds dOut[q][8kk + 4g + s]
+    float dob[4][4];
+    {
+        const float* dp = d.d_out + ((long)n * L + (qvalid ? q : 0)) * E + head * D;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float4 t = ld4(dp + kk * 8 + g * 4);
+            if (!qvalid) t = make_float4(0.f, 0.f, 0.f, 0.f);
+            dob[kk][0] = t.x; dob[kk][1] = t.y; dob[kk][2] = t.z; dob[kk][3] = t.w;
+        }
+    }
+    __syncthreads();
+    // A_col in the transposed accumulator layout: element (f, r) <-> key row h = 32f + (r&3) + 8(r>>2) + 4g, query i32
+    float acolT[NF][16], dacolT[NF][16];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int h = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+            acolT[f][r] = (h < Hp) ? Acol[i32 * sm.sh + h] : 0.f;
+            dacolT[f][r] = 0.f;
+        }
+
+    const float* vbase = d.v + (long)n * H * W * E + head * D;
+    float4 rv[NF];
+    auto vfetch = [&](int w) {
+#pragma unroll
+        for (int s = 0; s < NF; ++s) {
+            const int idx = tid + 256 * s;
+            const int h = idx >> 3, c4 = idx & 7;
+            rv[s] = (h < H) ? ld4(vbase + ((long)h * W + w) * E + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto vstash = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < NF; ++s) {
+            const int idx = tid + 256 * s;
+            const int h = idx >> 3, c4 = idx & 7;
+            if (h < H) *reinterpret_cast<float4*>(Vs + buf * HR * VS + h * VS + c4 * 4) = rv[s];
+        }
+    };
+    vfetch(0);
+    vstash(0);
+    __syncthreads();
+    for (int w = 0; w < W; ++w) {
+        const int buf = w & 1;
+        if (w + 1 < W) vfetch(w + 1);
+        const float arow = Arow[i32 * sm.sw + w];
+        float part = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            f32x16 gt;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gt[r] = 0.f;
+            const float* va = Vs + buf * HR * VS + (32 * f + i32) * VS + g * 4;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float4 a = *reinterpret_cast<const float4*>(va + kk * 8);
+                gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, dob[kk][0], gt, 0, 0, 0);
+                gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, dob[kk][1], gt, 0, 0, 0);
+                gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, dob[kk][2], gt, 0, 0, 0);
+                gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dob[kk][3], gt, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                part = fmaf(acolT[f][r], gt[r], part);
+                dacolT[f][r] = fmaf(arow, gt[r], dacolT[f][r]);
+            }
+        }
+        part += __shfl_xor(part, 32, 64);
+        if (g == 0) dArow[i32 * sm.sw + w] = part;
+        if (w + 1 < W) vstash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- softmax backward, column attention (registers)
+    {
+        float dot = 0.f;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dot = fmaf(acolT[f][r], dacolT[f][r], dot);
+        dot += __shfl_xor(dot, 32, 64);
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int h = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (h < Hp) Acol[i32 * sm.sh + h] = d.scale * acolT[f][r] * (dacolT[f][r] - dot);
+            }
+    }
+    // ---- softmax backward, row attention (lane (i, g) handles keys w = g, g+2, ...)
+    {
+        float dot = 0.f;
+        for (int w = g; w < W; w += 2) dot = fmaf(Arow[i32 * sm.sw + w], dArow[i32 * sm.sw + w], dot);
+        dot += __shfl_xor(dot, 32, 64);
+        for (int w = g; w < Wp; w += 2)
+            dArow[i32 * sm.sw + w] = (w < W) ? d.scale * Arow[i32 * sm.sw + w] * (dArow[i32 * sm.sw + w] - dot) : 0.f;
+    }
+    // same-wave LDS hand-off: order the writes above before the reads below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    if (nq > 0) {
+        float* gdr = d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp;
+        for (int idx = lane; idx < nq * Wp; idx += 64) {
+            const int r = idx / Wp, c = idx - r * Wp;
+            gdr[idx] = dArow[r * sm.sw + c];
+        }
+        float* gdc = d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp;
+        for (int idx = lane; idx < nq * Hp; idx += 64) {
+            const int r = idx / Hp, c = idx - r * Hp;
+            gdc[idx] = Acol[r * sm.sh + c];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward (dV)
+// dV[h,w,c] += sum_q A_col[q,h] A_row[q,w] dOut[q,c].  Workgroup = (4 consecutive w (one per wave), (n,head), q-slice).
+template <int NF>
+__global__ __launch_bounds__(256) void rcda_dv_kernel(const cdetr_rcda_bwd_desc d, const int q_per_slice) {
+    constexpr int QT = 64;               // queries per LDS tile
+    constexpr int HR = 32 * NF;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
+    const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
+    float* Ac = smem;                    // [QT][HR]   (zero for h >= Hp)
+    float* Ar = Ac + QT * HR;            // [QT][Wp]
+    float* Do = Ar + QT * Wp;            // [QT][32]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
+    const int w = blockIdx.x * 4 + wid;
+    const bool wvalid = w < W;
+    const int qs = blockIdx.z * q_per_slice;
+    const int qe = min(L, qs + q_per_slice);
+    const float* gac = d.a_col + ((long)n * d.nh + head) * L * Hp;
+    const float* gar = d.a_row + ((long)n * d.nh + head) * L * Wp;
+    const float* gdo = d.d_out + (long)n * L * E + head * D;
+
+    f32x16 acc[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    for (int q0 = qs; q0 < qe; q0 += QT) {
+        const int nq = min(QT, qe - q0);
+        __syncthreads();
+        for (int idx = tid; idx < QT * HR; idx += 256) {
+            const int r = idx / HR, c = idx - r * HR;
+            Ac[idx] = (r < nq && c < Hp) ? gac[(long)(q0 + r) * Hp + c] : 0.f;
+        }
+        for (int idx = tid; idx < QT * Wp; idx += 256) {
+            const int r = idx / Wp;
+            Ar[idx] = (r < nq) ? gar[(long)q0 * Wp + idx] : 0.f;
+        }
+        for (int idx = tid; idx < QT * 8; idx += 256) {
+            const int r = idx >> 3, c4 = idx & 7;
+            *reinterpret_cast<float4*>(Do + r * D + c4 * 4) =
+                (r < nq) ? ld4(gdo + (long)(q0 + r) * E + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        if (wvalid) {
+#pragma unroll 2
+            for (int kk = 0; kk < QT / 8; ++kk) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int qq = kk * 8 + g * 4 + s;
+                    const float ar = Ar[qq * Wp + w];
+                    const float b = Do[qq * D + i32];
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        const float a = Ac[qq * HR + 32 * f + i32] * ar;
+                        acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[f], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    if (!wvalid) return;
+#pragma unroll
+    for (int f = 0; f < NF; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int h = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (h < H) atomicAdd(d.d_v + (((long)n * H + h) * W + w) * E + head * D + i32, acc[f][r]);
+        }
+}
+
+template <typename F>
+int set_smem(F func, int bytes, const char* what) {
+    if (bytes > 160 * 1024) {
+        cdetr_set_error("%s: needs %d bytes of LDS (> 160 KiB): feature map too large for this tiling", what, bytes);
+        return CDETR_ERR_UNSUPPORTED;
+    }
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) {
+            cdetr_set_error("%s: hipFuncSetAttribute(%d): %s", what, bytes, hipGetErrorString(e));
+            return CDETR_ERR_LAUNCH;
+        }
+    }
+    return CDETR_OK;
+}
+
+}  // namespace
+
+extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
+    CDETR_CHECK_ARG(dp != nullptr, "cdetr_rcda_fwd: null descriptor");
+    const cdetr_rcda_fwd_desc d = *dp;
+    CDETR_CHECK_ARG(d.N > 0 && d.L > 0 && d.H > 0 && d.W > 0 && d.nh > 0, "cdetr_rcda_fwd: bad sizes");
+    CDETR_CHECK_ARG(d.H <= 128 && d.W <= 1024, "cdetr_rcda_fwd: H must be <= 128 (got %d)", d.H);
+    CDETR_CHECK_ARG(d.q_row && d.q_col && d.k_row && d.k_col && d.v && d.out && d.a_row && d.a_col, "cdetr_rcda_fwd: null pointer");
+    const FwdSmem sm = fwd_smem(d.H, d.W);
+    const int bytes = sm.total * 4;
+    dim3 grid((d.L + QB - 1) / QB, d.N * d.nh), block(256);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    if (d.H <= 32) {
+        if ((rc = set_smem(rcda_fwd_kernel<1>, bytes, "cdetr_rcda_fwd"))) return rc;
+        hipLaunchKernelGGL(rcda_fwd_kernel<1>, grid, block, bytes, st, d);
+    } else if (d.H <= 64) {
+        if ((rc = set_smem(rcda_fwd_kernel<2>, bytes, "cdetr_rcda_fwd"))) return rc;
+        hipLaunchKernelGGL(rcda_fwd_kernel<2>, grid, block, bytes, st, d);
+    } else {
+        if ((rc = set_smem(rcda_fwd_kernel<4>, bytes, "cdetr_rcda_fwd"))) return rc;
+        hipLaunchKernelGGL(rcda_fwd_kernel<4>, grid, block, bytes, st, d);
+    }
+    return cdetr_launch_status("cdetr_rcda_fwd");
+}
+
+extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
+    CDETR_CHECK_ARG(dp != nullptr, "cdetr_rcda_bwd: null descriptor");
+    const cdetr_rcda_bwd_desc d = *dp;
+    CDETR_CHECK_ARG(d.N > 0 && d.L > 0 && d.H > 0 && d.W > 0 && d.nh > 0, "cdetr_rcda_bwd: bad sizes");
+    CDETR_CHECK_ARG(d.H <= 128 && d.W <= 1024, "cdetr_rcda_bwd: H must be <= 128 (got %d)", d.H);
+    CDETR_CHECK_ARG(d.d_out && d.a_row && d.a_col && d.v && d.ds_row && d.ds_col && d.d_v, "cdetr_rcda_bwd: null pointer");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int NF = d.H <= 32 ? 1 : (d.H <= 64 ? 2 : 4);
+    const int Wp = (d.W + 3) & ~3;
+    int rc;
+    {   // dS kernel
+        const BwdSmem sm = bwd_smem(d.H, d.W, NF);
+        const int bytes = sm.total * 4;
+        dim3 grid((d.L + QB - 1) / QB, d.N * d.nh), block(256);
+        if (NF == 1) {
+            if ((rc = set_smem(rcda_bwd_kernel<1>, bytes, "cdetr_rcda_bwd"))) return rc;
+            hipLaunchKernelGGL(rcda_bwd_kernel<1>, grid, block, bytes, st, d);
+        } else if (NF == 2) {
+            if ((rc = set_smem(rcda_bwd_kernel<2>, bytes, "cdetr_rcda_bwd"))) return rc;
+            hipLaunchKernelGGL(rcda_bwd_kernel<2>, grid, block, bytes, st, d);
+        } else {
+            if ((rc = set_smem(rcda_bwd_kernel<4>, bytes, "cdetr_rcda_bwd"))) return rc;
+            hipLaunchKernelGGL(rcda_bwd_kernel<4>, grid, block, bytes, st, d);
+        }
+        if ((rc = cdetr_launch_status("cdetr_rcda_bwd(dS)"))) return rc;
+    }
+    {   // dV kernel
+        const int bytes = (64 * 32 * NF + 64 * Wp + 64 * 32) * 4;
+        const int wgroups = (d.W + 3) / 4;
+        long base = (long)wgroups * d.N * d.nh;
+        int slices = (int)((1024 + base - 1) / base);
+        const int max_slices = (d.L + 127) / 128;
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        int per = (d.L + slices - 1) / slices;
+        per = ((per + 63) / 64) * 64;
+        slices = (d.L + per - 1) / per;
+        dim3 grid(wgroups, d.N * d.nh, slices), block(256);
+        if (NF == 1) {
+            if ((rc = set_smem(rcda_dv_kernel<1>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
+            hipLaunchKernelGGL(rcda_dv_kernel<1>, grid, block, bytes, st, d, per);
+        } else if (NF == 2) {
+            if ((rc = set_smem(rcda_dv_kernel<2>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
+            hipLaunchKernelGGL(rcda_dv_kernel<2>, grid, block, bytes, st, d, per);
+        } else {
+            if ((rc = set_smem(rcda_dv_kernel<4>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
+            hipLaunchKernelGGL(rcda_dv_kernel<4>, grid, block, bytes, st, d, per);
+        }
+        if ((rc = cdetr_launch_status("cdetr_rcda_bwd(dV)"))) return rc;
+    }
+    return CDETR_OK;
+}

@@ -1,0 +1,236 @@
+"""Train step / epoch and counting inference -- counterpart of A2/engine.py:14-67 (train_one_epoch) and
+A2/infer.py:27-122, re-designed for one-process-per-GPU data parallelism on MI355X:
+
+  * all trainable parameters live in ONE flat fp32 arena (views keep the reference's shapes / state-dict keys), their
+    gradients in a second arena that the weight-gradient kernels accumulate into directly; clip_grad_norm_(0.1) and AdamW
+    (A2/main.py:157-189: lr 1e-4, "backbone" 1e-5, wd 1e-4) are a handful of flat ops instead of ~250 per-tensor ones;
+  * the arena is ordered [transformer+proj | layer4 | layer3 | layer2] = the order gradients become final in backward, so
+    the data-parallel all-reduce (RCCL over xGMI) runs as 4 large buckets on a side stream, each launched the moment its
+    segment is final and overlapped with the remaining backbone backward;
+  * the step issues no host sync (device matcher, device loss normaliser), so it can be captured in a HIP graph.
+"""
+import math
+import sys
+
+import torch
+import torch.distributed as dist
+
+from . import backbone as _bb
+from .misc import get_world_size, is_dist_avail_and_initialized, nested_tensor_from_tensor_list, reduce_dict
+
+UNUSED_PREFIXES = ("input_proj.",)   # built but never used on the stage-2 path: grad stays None in the reference
+
+
+def _segment_of(name):
+    if "backbone" in name:
+        for li in (4, 3, 2):
+            if f"layer{li}." in name:
+                return {4: 1, 3: 2, 2: 3}[li]
+        return 3
+    return 0
+
+
+class Trainer:
+    def __init__(self, model, criterion, args, device=None):
+        self.model, self.criterion, self.args = model, criterion, args
+        self.device = torch.device(device or args.device)
+        self.max_norm = args.clip_max_norm
+        self.betas, self.eps, self.wd = (0.9, 0.999), 1e-8, args.weight_decay
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.startswith(UNUSED_PREFIXES)]
+        for n, p in model.named_parameters():
+            if n.startswith(UNUSED_PREFIXES):
+                p.grad = None
+        named.sort(key=lambda np_: _segment_of(np_[0]))            # stable: keeps definition order inside a segment
+        self.names = [n for n, _ in named]
+        sizes = [p.numel() for _, p in named]
+        total = sum(sizes)
+        self.flat_p = torch.zeros(total, device=self.device, dtype=torch.float32)
+        self.flat_g = torch.zeros(total, device=self.device, dtype=torch.float32)
+        self.exp_avg = torch.zeros_like(self.flat_p)
+        self.exp_avg_sq = torch.zeros_like(self.flat_p)
+        self.lr_vec = torch.zeros(total, device=self.device, dtype=torch.float32)   # per-element base lr
+        self.seg_bounds = [0, 0, 0, 0, 0]
+        off = 0
+        for (n, p), sz in zip(named, sizes):
+            pv = self._view_like(self.flat_p[off:off + sz], p)
+            pv.copy_(p.data)
+            p.data = pv
+            p.grad = self._view_like(self.flat_g[off:off + sz], p)
+            lr = args.lr
+            if any(k in n for k in args.lr_backbone_names):
+                lr = args.lr_backbone
+            elif any(k in n for k in args.lr_linear_proj_names):
+                lr = args.lr * args.lr_linear_proj_mult
+            self.lr_vec[off:off + sz] = lr
+            off += sz
+            self.seg_bounds[_segment_of(n) + 1] = off
+        for i in range(1, 5):
+            self.seg_bounds[i] = max(self.seg_bounds[i], self.seg_bounds[i - 1])
+        self.lr_scale = torch.ones((), device=self.device)        # StepLR factor (device scalar: graph-replay safe)
+        self.step_t = torch.zeros((), device=self.device)
+        self.b1_t = torch.tensor(self.betas[0], device=self.device)
+        self.b2_t = torch.tensor(self.betas[1], device=self.device)
+        self.epoch = 0
+        self.comm_stream = None
+        self._graph = None
+        self._static = None
+        if is_dist_avail_and_initialized() and self.device.type == "cuda":
+            self.comm_stream = torch.cuda.Stream()
+        _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
+
+    @staticmethod
+    def _view_like(chunk, p):
+        if p.dim() == 4 and not p.is_contiguous() and p.is_contiguous(memory_format=torch.channels_last):
+            co, ci, kh, kw = p.shape
+            return chunk.view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return chunk.view(p.shape)
+
+    # ------------------------------------------------------------------ data-parallel gradient exchange
+    def _allreduce_segment(self, seg):
+        lo, hi = self.seg_bounds[seg], self.seg_bounds[seg + 1]
+        if hi <= lo:
+            return
+        buf = self.flat_g[lo:hi]
+        if self.comm_stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            with torch.cuda.stream(self.comm_stream):
+                dist.all_reduce(buf)
+        else:
+            dist.all_reduce(buf)
+
+    def _segment_done(self, seg):
+        """Called from the backbone's backward: `seg` (0 = everything above the backbone, 1..3 = layer4..layer2) is final."""
+        self._allreduce_segment(seg)
+
+    def _finish_allreduce(self):
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self.flat_g.div_(get_world_size())
+
+    # ------------------------------------------------------------------ optimizer (flat clip + AdamW)
+    def _optimizer_step(self):
+        g = self.flat_g
+        total_norm = torch.linalg.vector_norm(g)
+        if self.max_norm > 0:                                                        # A2/engine.py:54
+            coef = torch.clamp(self.max_norm / (total_norm + 1e-6), max=1.0)
+            g.mul_(coef)
+        b1, b2 = self.betas
+        self.step_t += 1
+        lr = self.lr_vec * self.lr_scale
+        self.flat_p.mul_(1 - lr * self.wd)
+        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
+        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1 = 1 - torch.pow(self.b1_t, self.step_t)
+        bc2 = 1 - torch.pow(self.b2_t, self.step_t)
+        denom = (self.exp_avg_sq.sqrt() / bc2.sqrt()).add_(self.eps)
+        self.flat_p.addcdiv_(self.exp_avg * (lr / bc1), denom, value=-1.0)
+        return total_norm
+
+    def lr_scheduler_step(self):
+        """StepLR(step=lr_drop, gamma=0.1), stepped once per epoch (A2/main.py:189,219)."""
+        self.epoch += 1
+        self.lr_scale.fill_(0.1 ** (self.epoch // self.args.lr_drop))
+
+    # ------------------------------------------------------------------ one step
+    def _step_impl(self, images, mask, rects, targets):
+        from .misc import NestedTensor
+        self.flat_g.zero_()
+        outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
+        loss_dict = self.criterion(outputs, targets)
+        wd = self.criterion.weight_dict
+        losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)             # A2/engine.py:37
+        losses.backward()
+        if get_world_size() > 1:
+            self._finish_allreduce()
+        gn = self._optimizer_step()
+        out = dict(loss_dict)
+        out["loss"] = losses.detach()
+        out["grad_norm"] = gn
+        return out
+
+    def train_step(self, samples, rects, targets):
+        """samples: [B,3,H,W] tensor, list of [3,h,w] tensors, or NestedTensor.  Returns a dict of device scalars."""
+        nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
+        images, mask = nt.decompose()
+        return self._step_impl(images, mask, rects, targets)
+
+    # ------------------------------------------------------------------ HIP-graph replay of the whole step
+    def capture(self, samples, rects, targets, warmup=3):
+        """Capture fwd + criterion (device matcher) + bwd + clip + AdamW into one HIP graph for fixed shapes / target counts."""
+        assert get_world_size() == 1, "graph capture is used for the single-GPU path"
+        nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
+        images, mask = nt.decompose()
+        st = {"images": images.clone(), "mask": mask.clone(), "rects": rects.clone(),
+              "targets": [{k: v.clone() for k, v in t.items()} for t in targets]}
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                self._step_impl(st["images"], st["mask"], st["rects"], st["targets"])
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self._step_impl(st["images"], st["mask"], st["rects"], st["targets"])
+        self._graph, self._static, self._static_out = graph, st, out
+        return out
+
+    def replay(self, samples=None, rects=None, targets=None):
+        if samples is not None:
+            nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
+            images, mask = nt.decompose()
+            self._static["images"].copy_(images)
+            self._static["mask"].copy_(mask)
+            self._static["rects"].copy_(rects)
+            for st, t in zip(self._static["targets"], targets):
+                for k in st:
+                    st[k].copy_(t[k])
+        self._graph.replay()
+        return self._static_out
+
+
+def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
+    """A2/engine.py:14-67: iterate, step, abort on a non-finite loss.  The loss is read back every `print_freq`
+    iterations only (the reference syncs every step with .item())."""
+    trainer.model.train()
+    trainer.criterion.train()
+    stats = {}
+    n = 0
+    for it, ret in enumerate(data_loader):
+        out = trainer.train_step(ret["image"], ret["ex_rects"], ret["targets"])
+        if it % print_freq == 0:
+            red = reduce_dict({k: v for k, v in out.items() if torch.is_tensor(v)})
+            vals = {k: float(v) for k, v in red.items()}
+            if not math.isfinite(vals["loss"]):
+                log("Loss is {}, stopping training".format(vals["loss"]))
+                log(vals)
+                sys.exit(1)
+            for k, v in vals.items():
+                stats[k] = stats.get(k, 0.0) + v
+            n += 1
+            log(f"Epoch: [{epoch}] it {it} " + "  ".join(f"{k}: {v:.4f}" for k, v in vals.items()))
+    return {k: v / max(n, 1) for k, v in stats.items()}
+
+
+@torch.no_grad()
+def count_objects(model, samples, rects, threshold=0.5):
+    """The counting rule of A2/infer.py:75-81: #queries with sigmoid(logit[...,0]) >= 0.5; also returns the kept boxes."""
+    model.eval()
+    outputs, ref_points = model(samples, rects=rects)
+    prob = outputs["pred_logits"].sigmoid()[..., 0]
+    keep = prob >= threshold
+    return keep.sum(-1), keep, outputs, ref_points
+
+
+def counting_metrics(pred_counts, gt_counts):
+    """MAE / RMSE / NAE / SRE exactly as A2/eval_all.py:252-270."""
+    cnt = len(gt_counts)
+    sae = sse = nae = sre = 0.0
+    for p, g in zip(pred_counts, gt_counts):
+        err = abs(float(g) - float(p))
+        sae += err
+        sse += err ** 2
+        nae += err / g
+        sre += err ** 2 / g
+    return {"MAE": sae / cnt, "RMSE": (sse / cnt) ** 0.5, "NAE": nae / cnt, "SRE": (sre / cnt) ** 0.5}

@@ -1,0 +1,138 @@
+/* cdetr_hip.h -- C-ABI of libcdetr_hip.so: the MI355X (gfx950) kernels of the Counting-DETR hot path.
+ *
+ * The reference (VinAIResearch/Counting-DETR) is pure Python/PyTorch and has NO FFI of its own; each entry
+ * point below replaces the torch-op sequence at the cited reference lines (A2/ = src/CountDETR_147_2nd_stage/).
+ * INTEGRATION.md shows the ctypes stub a reference maintainer would add at each site.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (cdetr_last_error() gives the thread-local message);
+ *     nothing throws across the boundary;
+ *   - every buffer is DEVICE memory allocated by the caller (torch caching allocator); the library never
+ *     allocates, never synchronises, holds no mutable global state (re-entrant: it is called from the Python main
+ *     thread in forward and from the autograd engine thread in backward);
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream); kernels are async;
+ *   - all tensors are fp32 unless stated; activations are NHWC / row-major [rows][channels];
+ *   - arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32) -- exact fp32 products, fp32 accumulation.
+ */
+#ifndef CDETR_HIP_H
+#define CDETR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CDETR_ABI_VERSION 1
+
+/* row-gather modes of cdetr_conv_geom */
+#define CDETR_ROWS_DENSE 0      /* row(m) = m (linear layers, 1x1 stride-1 convs) */
+#define CDETR_ROWS_CONV_FWD 1   /* m = output pixel; tap (ky,kx) -> input pixel (zero outside) */
+#define CDETR_ROWS_CONV_DGRAD 2 /* m = input pixel;  tap (ky,kx) -> output pixel feeding it (transposed conv) */
+
+typedef struct {
+    int32_t mode;
+    int32_t Ha, Wa; /* spatial dims of the GATHERED tensor: its row index is (n*Ha + y)*Wa + x            */
+    int32_t Hc, Wc; /* spatial dims of the enumerated row space (m = (n*Hc + y)*Wc + x)                    */
+    int32_t kh, kw, stride, pad, dil;
+} cdetr_conv_geom;
+
+/* C[m][n] = epilogue( sum_tap sum_k A[row(m,tap)][k] * Wt(n,tap,k) )
+ * b_layout 0 : Wt(n,tap,k) = B[n*ldb + tap*K + k]          (weight [N][taps][K], k contiguous; forward)
+ * b_layout 1 : Wt(n,tap,k) = B[(k*taps + tap)*ldb + n]     (weight [K][taps][N], n contiguous; data-gradient)
+ * epilogue   : v = acc (+ bias[n]); v *= out_scale; v += resid[m][n]; if gate: v = gate[m][n] > 0 ? v : 0;
+ *              if relu: v = max(v, 0)
+ * w_scale    : optional per-output-channel scale of the WEIGHT (frozen-BN fold): index n for b_layout 0,
+ *              index k for b_layout 1.
+ * Replaces: F.conv2d + FrozenBatchNorm2d + ReLU (+residual) A2/models/resnet.py:140-160, backbone.py:50-60;
+ *           F.linear at A2/models/row_column_decoupled_attention.py:165-208,311, transformer.py:412-439; and
+ *           their autograd data-gradients.                                                                    */
+typedef struct {
+    int32_t M, N, K, taps;
+    int32_t batch; /* grid.z; per-batch element strides sA/sB/sC (0 = shared) */
+    int32_t b_layout;
+    int32_t relu;
+    float out_scale;
+    const float* A; int64_t lda, sA;
+    const float* B; int64_t ldb, sB;
+    float* C; int64_t ldc, sC;
+    const float* w_scale;
+    const float* bias;
+    const float* resid; int64_t ldr;
+    const float* gate; int64_t ldg;
+    cdetr_conv_geom g;
+} cdetr_gemm_desc;
+int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
+
+/* dW[i][tap][c] += w_scale[i] * sum_p dY[p][i] * X[row(p,tap)][c]      (weight-gradient, split-K + fp32 atomics)
+ * Replaces: autograd of F.conv2d / F.linear w.r.t. the weight.  dW must hold the value to accumulate onto
+ * (the caller zeroes the gradient arena once per step).                                                       */
+typedef struct {
+    int32_t P, Nout, Cin, taps;
+    int32_t batch;
+    const float* dY; int64_t ldy, sY;
+    const float* X; int64_t ldx, sX;
+    float* dW; int64_t ldw, sW;
+    const float* w_scale;
+    cdetr_conv_geom g; /* mode DENSE or CONV_FWD (p = output pixel) */
+} cdetr_wgrad_desc;
+int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
+
+/* out[n] += sum_m X[m][n]   (bias gradients; atomics) */
+int cdetr_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, void* stream);
+
+/* 3x3 stride-2 pad-1 max pooling, NHWC (A2/models/resnet.py:206,265) */
+int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* ---- Row-Column Decoupled Attention core (A2/models/row_column_decoupled_attention.py:215-309) -------------
+ * Inputs are the PROJECTED tensors: q_row,q_col [N][L][E]; k_row [N][W][E] (already averaged over H);
+ * k_col [N][H][E] (averaged over W); v [N][H][W][E]; E = nh*32.  mask_row [N][W], mask_col [N][H] uint8 (1 = pad)
+ * or NULL.  Computes, per (n, head):  A_row = softmax_W(scale*q_row.k_row^T), A_col = softmax_H(scale*q_col.k_col^T),
+ * out[n][q][head*32+c] = sum_h sum_w A_col[q][h] A_row[q][w] v[n][h][w][head*32+c].
+ * a_row [N][nh][L][Wp], a_col [N][nh][L][Hp] (Wp = W rounded up to 4, Hp = H rounded up to 8; pad = 0) are written
+ * for the backward pass.                                                                                      */
+typedef struct {
+    int32_t N, L, H, W, nh; /* head dim fixed at 32 */
+    float scale;
+    const float* q_row; const float* q_col; const float* k_row; const float* k_col; const float* v;
+    const uint8_t* mask_row; const uint8_t* mask_col;
+    float* out; float* a_row; float* a_col;
+} cdetr_rcda_fwd_desc;
+int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* d, void* stream);
+
+/* Backward of the core: given d_out [N][L][E] and the saved a_row/a_col, writes
+ * ds_row [N][nh][L][Wp], ds_col [N][nh][L][Hp] (gradients of the PRE-softmax logits, already multiplied by
+ * `scale`) and accumulates d_v [N][H][W][E] (must be zeroed by the caller).                                    */
+typedef struct {
+    int32_t N, L, H, W, nh;
+    float scale;
+    const float* d_out; const float* a_row; const float* a_col; const float* v;
+    float* ds_row; float* ds_col; float* d_v;
+} cdetr_rcda_bwd_desc;
+int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* d, void* stream);
+static inline int32_t cdetr_rcda_wp(int32_t W) { return (W + 3) & ~3; }
+static inline int32_t cdetr_rcda_hp(int32_t H) { return (H + 7) & ~7; }
+
+/* ---- Hungarian matcher (A2/models/matcher.py:197-247 + scipy.optimize.linear_sum_assignment) -------------
+ * cdetr_match_cost: per image b, cost[b] = 5*L1 + 2*focal-class + 2*(-GIoU) in fp32 with the reference's expression
+ * order, written in SOLVER layout: [nr][nc] with nr = min(Q,T_b), nc = max(Q,T_b) (transposed when T_b < Q,
+ * exactly like scipy transposes a tall matrix).  cost_off[b] = float offset of image b's block.
+ * logits [B][Q][ncls] (column 0 used: all labels are 0), boxes [B][Q][4] cxcywh, tgt [sum T][4], tgt_off[B+1].    */
+int cdetr_match_cost(const float* logits, int32_t ncls, const float* boxes, const float* tgt, const int32_t* tgt_off,
+                     const int64_t* cost_off, int32_t B, int32_t Q, float w_class, float w_bbox, float w_giou,
+                     float* cost, void* stream);
+/* cdetr_lsap: exact rectangular assignment on the device (float64 duals, shortest augmenting paths, the tie rule of
+ * scipy's solver) -- one workgroup per image.  Writes idx_i/idx_j (int64, [B][Mmax]) = (query, target) pairs with
+ * idx_i ascending -- the (row_ind, col_ind) scipy returns; status[b] = 0 ok / 1 infeasible / 2 invalid cost.
+ * nc_max = max(Q, max_b T_b) (host-known; sizes the LDS-resident solver state, limit 3800);
+ * Mmax = row stride of idx_i / idx_j (>= max_b min(Q, T_b)).                                                    */
+int cdetr_lsap(const float* cost, const int64_t* cost_off, const int32_t* tgt_off, int32_t B, int32_t Q,
+               int32_t nc_max, int32_t Mmax, int64_t* idx_i, int64_t* idx_j, int32_t* status, void* stream);
+
+const char* cdetr_last_error(void);
+int cdetr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,284 @@
+"""Parity of the HIP kernels (through the C-ABI) against the oracle / plain fp64 CPU math.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def close(actual, ref, rtol=2e-4, atol_scale=2e-5, msg=""):
+    """fp32-MFMA tolerance: relative to the reference's magnitude (sums of K products)."""
+    a = actual.detach().double().cpu()
+    r = ref.detach().double().cpu()
+    assert a.shape == r.shape, (a.shape, r.shape)
+    scale = r.abs().max().item() + 1e-30
+    err = (a - r).abs().max().item()
+    assert torch.isfinite(a).all(), msg + " non-finite output"
+    assert err <= rtol * scale + atol_scale * scale, f"{msg} max err {err:.3e} vs scale {scale:.3e}"
+
+
+# ----------------------------------------------------------------------------------------------------- GEMM / linear
+@pytest.mark.parametrize("M,N,K", [(600, 256, 256), (5000, 1024, 256), (5000, 256, 1024), (77, 70, 36), (600, 2, 256),
+                                   (600, 4, 256), (1, 256, 256), (130, 64, 20), (300, 512, 256)])
+@pytest.mark.parametrize("relu,use_resid", [(False, False), (True, True)])
+def test_linear_forward_backward(M, N, K, relu, use_resid):
+    from counting_detr_amd import ops
+    x = torch.randn(M, K, generator=g(1))
+    w = torch.randn(N, K, generator=g(2)) / K ** 0.5
+    b = torch.randn(N, generator=g(3))
+    r = torch.randn(M, N, generator=g(4)) if use_resid else None
+    gy = torch.randn(M, N, generator=g(5))
+    xd = x.to(DEV).requires_grad_(True)
+    wd = torch.nn.Parameter(w.to(DEV))
+    bd = torch.nn.Parameter(b.to(DEV))
+    rd = r.to(DEV).requires_grad_(True) if use_resid else None
+    y = ops.linear(xd, wd, bd, relu=relu, resid=rd)
+    y.backward(gy.to(DEV))
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True)
+    r64 = r.double().requires_grad_(True) if use_resid else None
+    y64 = F.linear(x64, w64, b64)
+    if relu:
+        y64 = F.relu(y64)
+    if use_resid:
+        y64 = y64 + r64
+    y64.backward(gy.double())
+    close(y, y64, msg="y")
+    close(xd.grad, x64.grad, msg="dx")
+    close(wd.grad, w64.grad, msg="dW")
+    close(bd.grad, b64.grad, msg="db")
+    if use_resid:
+        close(rd.grad, r64.grad, msg="dresid")
+
+
+def test_linear_row_slices_accumulate():
+    """in_proj style: rows [lo:hi) of one parameter; gradients accumulate in place into .grad rows."""
+    from counting_detr_amd import ops
+    E = 256
+    w = torch.randn(5 * E, E, generator=g(1)) / 16
+    b = torch.randn(5 * E, generator=g(2))
+    x = torch.randn(2, 37, E, generator=g(3))
+    wd, bd = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    xd = x.to(DEV).requires_grad_(True)
+    y = ops.linear(xd, wd, bd, rows=(2 * E, 3 * E)) + ops.linear(xd, wd, bd, rows=(2 * E, 3 * E)) * 2
+    y.sum().backward()
+    w64, b64, x64 = w.double().requires_grad_(True), b.double().requires_grad_(True), x.double().requires_grad_(True)
+    y64 = 3 * F.linear(x64, w64[2 * E:3 * E], b64[2 * E:3 * E])
+    y64.sum().backward()
+    close(y, y64)
+    close(wd.grad, w64.grad, msg="dW")
+    close(bd.grad, b64.grad, msg="db")
+    close(xd.grad, x64.grad, msg="dx")
+
+
+# ----------------------------------------------------------------------------------------------------- conv
+CONV_CASES = [
+    # Cin, Cout, k, stride, pad, dil, H, W
+    (64, 64, 1, 1, 0, 1, 20, 24),
+    (64, 128, 3, 1, 1, 1, 20, 24),
+    (128, 128, 3, 2, 1, 1, 21, 25),
+    (128, 64, 3, 1, 2, 2, 13, 17),
+    (256, 512, 1, 2, 0, 1, 20, 24),
+    (4, 64, 7, 2, 3, 1, 64, 96),
+    (512, 2048, 1, 1, 0, 1, 10, 12),
+]
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,dil,H,W", CONV_CASES)
+def test_conv_forward_dgrad_wgrad(Cin, Cout, k, stride, pad, dil, H, W):
+    from counting_detr_amd import ops
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g(1))
+    w = torch.randn(Cout, Cin, k, k, generator=g(2)) / (Cin * k * k) ** 0.5
+    scale = 1 + 0.1 * torch.randn(Cout, generator=g(3))
+    bias = 0.1 * torch.randn(Cout, generator=g(4))
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    conv64 = F.conv2d(x64, w64, stride=stride, padding=pad, dilation=dil)
+    Ho, Wo = conv64.shape[-2:]
+    resid = torch.randn(B, Cout, Ho, Wo, generator=g(5))
+    y64 = F.relu(conv64 * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1) + resid.double())
+    gy = torch.randn(B, Cout, Ho, Wo, generator=g(6))
+    dz64 = gy.double() * (y64 > 0)                       # gradient w.r.t. the pre-ReLU value
+    y64.backward(gy.double())
+
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last).to(DEV))
+    assert wd.stride() == w.contiguous(memory_format=torch.channels_last).stride()
+    sd, bd = scale.to(DEV), bias.to(DEV)
+    rd = resid.permute(0, 2, 3, 1).contiguous().to(DEV)
+    y = ops.conv_fwd(xd, wd, sd, bd, stride=stride, pad=pad, dil=dil, relu=True, resid=rd)
+    close(y.permute(0, 3, 1, 2), y64, msg="conv fwd")
+    dz = dz64.float().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = ops.conv_dgrad(dz, wd, sd, (H, W), stride=stride, pad=pad, dil=dil)
+    close(dx.permute(0, 3, 1, 2), x64.grad, msg="conv dgrad")
+    # gate + resid epilogue of the data-gradient
+    gate = torch.randn(B, H, W, Cin, generator=g(7)).to(DEV)
+    extra = torch.randn(B, H, W, Cin, generator=g(8)).to(DEV)
+    dx2 = ops.conv_dgrad(dz, wd, sd, (H, W), stride=stride, pad=pad, dil=dil, gate=gate, resid=extra)
+    ref2 = (x64.grad.permute(0, 2, 3, 1) + extra.double().cpu()) * (gate.cpu() > 0)
+    close(dx2, ref2, msg="conv dgrad gate+resid")
+    ops.conv_wgrad_(dz, xd, wd, sd, stride=stride, pad=pad, dil=dil)
+    ops.conv_wgrad_(dz, xd, wd, sd, stride=stride, pad=pad, dil=dil)    # accumulates
+    close(wd.grad, 2 * w64.grad, msg="conv wgrad", rtol=5e-4)
+
+
+def test_maxpool():
+    from counting_detr_amd import ops
+    x = torch.randn(2, 64, 37, 41, generator=g(1))
+    y = ops.maxpool3x3s2(x.permute(0, 2, 3, 1).contiguous().to(DEV))
+    ref = F.max_pool2d(x, 3, 2, 1)
+    assert torch.equal(y.permute(0, 3, 1, 2).cpu(), ref)
+
+
+# ----------------------------------------------------------------------------------------------------- RCDA core
+def rcda_core_ref(qr, qc, kr, kc, v, mr, mc, nh):
+    """fp64 restatement of A2/models/row_column_decoupled_attention.py:215-309 on projected inputs."""
+    N, L, E = qr.shape
+    H, W = v.shape[1:3]
+    d = E // nh
+    hs = lambda t: t.reshape(N, -1, nh, d).permute(0, 2, 1, 3)   # noqa: E731
+    s_row = (hs(qr) * d ** -0.5) @ hs(kr).transpose(-1, -2)
+    s_col = (hs(qc) * d ** -0.5) @ hs(kc).transpose(-1, -2)
+    if mr is not None:
+        s_row = s_row.masked_fill(mr.bool()[:, None, None, :], float("-inf"))
+        s_col = s_col.masked_fill(mc.bool()[:, None, None, :], float("-inf"))
+    a_row, a_col = s_row.softmax(-1), s_col.softmax(-1)
+    vv = v.reshape(N, H, W, nh, d).permute(0, 3, 1, 2, 4)
+    o = torch.einsum("bnqh,bnqw,bnhwc->bnqc", a_col, a_row, vv)
+    return o.permute(0, 2, 1, 3).reshape(N, L, E)
+
+
+@pytest.mark.parametrize("N,L,H,W,masked", [(2, 300, 50, 50, False), (1, 600, 20, 30, True), (2, 77, 7, 5, True),
+                                            (1, 130, 70, 40, True), (2, 2500, 50, 50, True), (1, 33, 24, 36, False)])
+def test_rcda_core(N, L, H, W, masked):
+    from counting_detr_amd import ops
+    nh, E = 8, 256
+    qr, qc = torch.randn(N, L, E, generator=g(1)), torch.randn(N, L, E, generator=g(2))
+    kr, kc = torch.randn(N, W, E, generator=g(3)), torch.randn(N, H, E, generator=g(4))
+    v = torch.randn(N, H, W, E, generator=g(5))
+    gout = torch.randn(N, L, E, generator=g(6))
+    mr = mc = None
+    if masked:
+        mr = torch.zeros(N, W, dtype=torch.uint8)
+        mc = torch.zeros(N, H, dtype=torch.uint8)
+        mr[0, W - 2:] = 1
+        mc[0, H - 3:] = 1
+    ins = [t.to(DEV).requires_grad_(True) for t in (qr, qc, kr, kc, v)]
+    out = ops.rcda_core(*ins, mr.to(DEV) if masked else None, mc.to(DEV) if masked else None, nh)
+    out.backward(gout.to(DEV))
+    ins64 = [t.double().requires_grad_(True) for t in (qr, qc, kr, kc, v)]
+    ref = rcda_core_ref(*ins64, mr, mc, nh)
+    ref.backward(gout.double())
+    close(out, ref, msg="rcda out")
+    for name, a, b in zip(("dq_row", "dq_col", "dk_row", "dk_col", "dv"), ins, ins64):
+        close(a.grad, b.grad, msg=name, rtol=5e-4)
+
+
+def test_multihead_rcda_module_vs_oracle():
+    """Full module (projections + core + out_proj) against the oracle restatement, both mask branches."""
+    from counting_detr_amd.transformer import MultiheadRCDA
+    from oracle import model as OM
+    E, nh, N, H, W, L = 256, 8, 2, 9, 14, 40
+    m = MultiheadRCDA(E, nh).to(DEV)
+    sd = {"a." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    v = torch.randn(N, H, W, E, generator=g(1))
+    kr = v + torch.randn(N, 1, W, E, generator=g(2))
+    kc = v + torch.randn(N, H, 1, E, generator=g(3))
+    qr, qc = torch.randn(N, L, E, generator=g(4)), torch.randn(N, L, E, generator=g(5))
+    mask = torch.zeros(N, H, W, dtype=torch.bool)
+    mask[1, :, W - 3:] = True
+    mask[1, H - 2:, :] = True
+    ins = [t.to(DEV).requires_grad_(True) for t in (qr, qc, kr, kc, v)]
+    out, _ = m(*ins, key_padding_mask=mask.to(DEV))
+    ins_o = [t.clone().requires_grad_(True) for t in (qr, qc, kr, kc, v)]
+    ref = OM.rcda(*ins_o, sd, "a", mask=mask, nh=nh)
+    gout = torch.randn(ref.shape, generator=g(6))
+    out.backward(gout.to(DEV))
+    ref.backward(gout)
+    close(out, ref, rtol=1e-3, msg="module out")          # north_star: within 1e-3 rel of the fp32 reference
+    for a, b, nm in zip(ins, ins_o, ("qr", "qc", "kr", "kc", "v")):
+        close(a.grad, b.grad, rtol=1e-3, msg="d" + nm)
+    for k, p in m.named_parameters():
+        close(p.grad, sd["a." + k].grad, rtol=1e-3, msg="d" + k)
+
+
+# ----------------------------------------------------------------------------------------------------- matcher
+G45 = ["q300_t37", "q576_t200", "q900_t56", "q300_t450", "q900_t900", "b2_q40", "b2_q300", "t0"]
+
+
+@pytest.mark.parametrize("name", G45)
+def test_matcher_golden(golden, name):
+    """Device cost + device LSAP reproduce the REFERENCE's Hungarian indices bit-exactly (golden vectors)."""
+    from counting_detr_amd.matcher import OriginalHungarianMatcher
+    z = golden("g45_matcher_criterion.npz")
+    B = int(z[f"{name}/B"])
+    outs = {k: torch.from_numpy(z[f"{name}/{k}"]).to(DEV) for k in ("pred_logits", "pred_boxes")}
+    tg = []
+    for b in range(B):
+        bx = torch.from_numpy(z[f"{name}/tgt{b}"]).reshape(-1, 4).to(DEV)
+        tg.append({"boxes": bx, "labels": torch.zeros(bx.shape[0], dtype=torch.int64, device=DEV)})
+    idx = OriginalHungarianMatcher(2, 5, 2)(outs, tg)
+    for b in range(B):
+        assert idx[b][0].dtype == torch.int64 and not idx[b][0].is_cuda
+        assert np.array_equal(idx[b][0].numpy(), z[f"{name}/idx_i{b}"]), f"idx_i image {b}"
+        assert np.array_equal(idx[b][1].numpy(), z[f"{name}/idx_j{b}"]), f"idx_j image {b}"
+
+
+def test_match_cost_values(golden):
+    from counting_detr_amd import ops
+    from oracle import criterion as OC
+    z = golden("g45_matcher_criterion.npz")
+    name = "b2_q40"
+    logits = torch.from_numpy(z[f"{name}/pred_logits"])
+    boxes = torch.from_numpy(z[f"{name}/pred_boxes"])
+    tgs = [torch.from_numpy(z[f"{name}/tgt{b}"]).reshape(-1, 4) for b in range(2)]
+    plan = ops.MatchPlan([t.shape[0] for t in tgs], 40, DEV)
+    cost = ops.match_cost(logits.to(DEV), boxes.to(DEV), torch.cat(tgs).to(DEV), plan).cpu()
+    for b in range(2):
+        T = tgs[b].shape[0]
+        blk = cost[plan.cost_off_host[b]: plan.cost_off_host[b] + 40 * T]
+        blk = blk.view(T, 40).t() if T < 40 else blk.view(40, T)
+        ref = OC.match_cost(logits[b], boxes[b], tgs[b])
+        np.testing.assert_allclose(blk.numpy(), ref.numpy(), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("Q,T,kind", [(300, 37, "float"), (64, 64, "ties"), (50, 120, "ties"), (120, 50, "ints"),
+                                      (900, 900, "float"), (300, 1500, "float"), (7, 1, "float")])
+def test_lsap_vs_scipy(Q, T, kind):
+    """The device solver returns scipy's (row_ind, col_ind), ties included, when fed the same matrix."""
+    from scipy.optimize import linear_sum_assignment
+    from counting_detr_amd import ops
+    rng = np.random.default_rng(Q * 7 + T)
+    if kind == "float":
+        c = rng.standard_normal((Q, T)).astype(np.float32)
+    elif kind == "ties":
+        c = rng.integers(0, 2, (Q, T)).astype(np.float32)
+    else:
+        c = rng.integers(0, 10, (Q, T)).astype(np.float32)
+    plan = ops.MatchPlan([T], Q, DEV)
+    solver_layout = c.T.copy() if T < Q else c
+    cost = torch.from_numpy(np.ascontiguousarray(solver_layout).reshape(-1)).to(DEV)
+    idx_i, idx_j, status = ops.lsap(cost, plan)
+    assert int(status[0]) == 0
+    ri, ci = linear_sum_assignment(c)
+    m = min(Q, T)
+    assert np.array_equal(idx_i[0, :m].cpu().numpy(), ri)
+    assert np.array_equal(idx_j[0, :m].cpu().numpy(), ci)
+
+
+def test_lsap_invalid_cost_raises():
+    from counting_detr_amd import ops
+    plan = ops.MatchPlan([3], 4, DEV)
+    c = torch.zeros(12)
+    c[5] = float("nan")
+    _, _, status = ops.lsap(c.to(DEV), plan)
+    assert int(status[0]) == 2
