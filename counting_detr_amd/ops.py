@@ -78,7 +78,7 @@ def linear_dgrad(dy2d, weight, gate=None, resid=None):
 
 
 class LinearFn(torch.autograd.Function):
-    """y = act(x W[lo:hi]^T + b[lo:hi]) * out_scale (+ resid) -- the F.linear sites of the reference
+    """y = act((x W[lo:hi]^T + b[lo:hi]) * out_scale + resid) -- the F.linear sites of the reference
     (A2/models/transformer.py:412-439, row_column_decoupled_attention.py:165-208,311).
     `wparam` / `bparam` are the leaf parameters (rows lo:hi are used: the 5-way in_proj of RCDA is one parameter);
     their gradients are accumulated IN PLACE into `.grad` rows lo:hi by the weight-gradient kernel."""
@@ -111,9 +111,9 @@ class LinearFn(torch.autograd.Function):
         dy2d = dy.reshape(-1, w.shape[0])
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
-        d_resid = dy if ctx.has_resid else None
-        if ctx.relu:
+        if ctx.relu:   # y = relu((x W^T + b) * out_scale + resid): the mask applies to the residual branch too
             dy2d = torch.where(y > 0, dy2d, torch.zeros((), device=dy.device))
+        d_resid = dy2d.reshape(dy.shape) if ctx.has_resid else None
         if ctx.out_scale != 1.0:
             dy2d = dy2d * ctx.out_scale
         dx = None

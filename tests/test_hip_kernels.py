@@ -46,10 +46,10 @@ def test_linear_forward_backward(M, N, K, relu, use_resid):
     b64 = b.double().requires_grad_(True)
     r64 = r.double().requires_grad_(True) if use_resid else None
     y64 = F.linear(x64, w64, b64)
-    if relu:
-        y64 = F.relu(y64)
     if use_resid:
         y64 = y64 + r64
+    if relu:
+        y64 = F.relu(y64)
     y64.backward(gy.double())
     close(y, y64, msg="y")
     close(xd.grad, x64.grad, msg="dx")
