@@ -1,0 +1,181 @@
+"""bench.py -- images/sec of one FSCD-147 2nd-stage Counting-DETR training step on N MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = forward + device Hungarian matcher + SetCriterion + backward + clip_grad_norm(0.1) + AdamW on a synthetic
+batch of 2 images 800x800 per GPU (Q=300 learned anchors, T=(37,120) targets -- BASELINE.json configs[1]),
+inputs resident in HBM, random-init (name-seeded) weights.  Weak scaling: per-GPU batch fixed, gradients averaged over
+ranks by RCCL.  The step is replayed from a HIP graph (N=1: one graph; N>1: graph / flat all-reduce / graph).
+Prints ONE JSON line on rank 0 with the extra objects `roofline` (fp32-MFMA family of implicit-GEMM kernels, timed with
+HIP events on the launch stream in an instrumented eager pass of the same step) and, at N=1, `cpu_baseline` (the oracle's
+CPU restatement of the same step on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+STEP_GFLOP_PER_IMAGE = 616.0         # 800x800, Q=300, reduced form (mean-before-project keys)
+
+
+def synthetic_batch(B, H, W, Ts, seed, device):
+    g0 = torch.Generator().manual_seed(seed)
+    images = torch.randn(B, 3, H, W, generator=g0)
+    rects = torch.tensor([[.10, .10, .20, .20], [.40, .40, .50, .55], [.70, .20, .80, .30]])[None].repeat(B, 1, 1)
+    g1 = torch.Generator().manual_seed(seed + 1)
+    targets = []
+    for b in range(B):
+        T = Ts[b % len(Ts)]
+        cxcy = torch.rand(T, 2, generator=g1) * 0.8 + 0.1
+        wh = torch.rand(T, 2, generator=g1) * 0.10 + 0.02
+        targets.append({"boxes": torch.cat([cxcy, wh], 1).to(device), "labels": torch.zeros(T, dtype=torch.int64, device=device)})
+    return images.to(device), rects.to(device), targets
+
+
+def cpu_baseline(B, H, W, Ts, steps=2, warmup=1):
+    """The oracle (CPU restatement of the reference step, parity-pinned against the real reference) on the host cores."""
+    from oracle.step import OracleTrainer, synthetic_batch as sb
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or cores
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    tr = OracleTrainer(num_position=300)
+    images, rects, targets = sb(B=B, H=H, W=W, Ts=Ts)
+    for _ in range(warmup):
+        tr.step(images, rects, targets)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step(images, rects, targets)
+    dt = (time.perf_counter() - t0) / steps
+    return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed steps (+{warmup} warm-up) of the same B={B} {H}x{W} Q=300 T={list(Ts)} step, oracle fp32 on CPU",
+            "ms_per_step": dt * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, nargs=2, default=[800, 800])
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU")
+    ap.add_argument("--queries", type=int, default=300)
+    ap.add_argument("--no-graph", action="store_true", help="eager step (bucketed all-reduce overlapped with backward)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the Counting-DETR HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)   # RCCL over xGMI
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+
+    import counting_detr_amd
+    from counting_detr_amd import ops
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.engine import Trainer
+    from oracle.weights import model_schema, seeded_state_dict   # name-seeded random init (test infra used as an initialiser only)
+
+    H, W = a.size
+    Ts = (37, 120)
+    args = default_args(device=str(dev), num_query_position=a.queries)
+    model, crit, _ = counting_detr_amd.build_model(args)
+    model.load_state_dict(seeded_state_dict(model_schema(num_position=a.queries)), strict=True)
+    model.to(dev).train()
+    crit.train()
+    trainer = Trainer(model, crit, args, device=dev)
+    images, rects, targets = synthetic_batch(a.batch, H, W, Ts, seed=1000 * rank, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.no_graph:
+        step = lambda: trainer.train_step(images, rects, targets)      # noqa: E731
+    else:
+        trainer.capture(images, rects, targets, warmup=1)
+        step = trainer.replay
+    for _ in range(a.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    loss = float(out["loss"])
+    ms_per_step = dt / a.steps * 1e3
+    value = a.batch * world * a.steps / dt
+
+    # ---- roofline leg: same fwd+bwd, eager, every matrix-core launch bracketed by HIP events on its own stream
+    import counting_detr_amd.backbone as bb
+    hook = bb._BACKWARD_HOOK
+    bb.set_backward_hook(None)
+    ops.PROFILE = []
+    nb = float(sum(len(t_["boxes"]) for t_ in targets))
+    from counting_detr_amd.misc import nested_tensor_from_tensor_list
+    im, mk = nested_tensor_from_tensor_list(images).decompose()
+    reps = 2
+    for _ in range(reps):
+        trainer._fwd_bwd(im, mk, rects, targets, nb)
+    torch.cuda.synchronize()
+    fam = {}
+    for family, flops, e0, e1 in ops.PROFILE:
+        f = fam.setdefault(family, [0.0, 0.0, 0])
+        f[0] += flops
+        f[1] += e0.elapsed_time(e1) * 1e-3
+        f[2] += 1
+    ops.PROFILE = None
+    bb.set_backward_hook(hook)
+    kern = {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / reps * 1e3, "launches_per_step": v[2] // reps,
+                "gflop_per_step": v[0] / reps / 1e9} for k, v in fam.items() if v[1] > 0}
+    ig = fam.get("igemm", [0.0, 1.0, 1])
+    achieved = ig[0] / ig[1] / 1e12
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "igemm_kernel<BM,BN,BL> (conv fwd / dgrad / linear; fp32 MFMA 32x32x2)",
+                "avg_launch_us": ig[1] / max(ig[2], 1) * 1e6, "families": kern,
+                "whole_step_tflops": STEP_GFLOP_PER_IMAGE * a.batch / ms_per_step if (H, W, a.queries) == (800, 800, 300) else None}
+
+    res = {"metric": "images/sec FSCD-147 2nd-stage train step", "value": value, "unit": "images/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+           "config": {"workload": f"FSCD-147 2nd-stage train step (ResNet-50-DC5 + RCDA enc6/dec6, Q={a.queries} learned, "
+                                  f"{H}x{W}, T={list(Ts)}), fwd+matcher+loss+bwd+clip+AdamW",
+                      "images_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
+                      "graph": not a.no_graph, "final_loss": loss},
+           "roofline": roofline}
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a.batch, H, W, Ts)
+    if rank == 0:
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,7 +102,9 @@ class SetCriterion(nn.Module):
         tidx = torch.cat([idx_j[b, :m] + plan.tgt_off_host[b] for b, m in enumerate(plan.M)])
         return bidx, sidx, tidx
 
-    def forward(self, outputs, targets):
+    def forward(self, outputs, targets, num_boxes=None):
+        """`num_boxes`: optional precomputed normaliser (device scalar) -- the data-parallel trainer all-reduces the target
+        count BEFORE the (graph-captured) step; otherwise it is computed here as in the reference (:321-325)."""
         out = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "enc_outputs")}
         logits = out["pred_logits"]
         B, Q = logits.shape[:2]
@@ -113,14 +115,16 @@ class SetCriterion(nn.Module):
         idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan)
         if self.check_status and bool((status != 0).any()):
             raise ValueError("invalid or infeasible matching cost matrix")
-        num_boxes = sum(plan.sizes)
-        if is_dist_avail_and_initialized():
+        if num_boxes is not None:
+            pass
+        elif is_dist_avail_and_initialized():
+            num_boxes = sum(plan.sizes)
             nb = torch.as_tensor([num_boxes], dtype=torch.float, device=logits.device)
             torch.distributed.all_reduce(nb)
             num_boxes = nb / get_world_size()
             num_boxes = torch.clamp(num_boxes, min=1)[0]                      # stays on the device (no .item())
         else:
-            num_boxes = max(float(num_boxes), 1.0)                            # :321-325
+            num_boxes = max(float(sum(plan.sizes)), 1.0)                      # :321-325
         bidx, sidx, tidx = self._matched(idx_i, idx_j, plan)
         tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
         tgt_labels_all = torch.cat([t["labels"] for t in targets])

@@ -134,59 +134,111 @@ class Trainer:
         self.lr_scale.fill_(0.1 ** (self.epoch // self.args.lr_drop))
 
     # ------------------------------------------------------------------ one step
-    def _step_impl(self, images, mask, rects, targets):
+    def _num_boxes(self, targets):
+        """Loss normaliser: sum of target counts over all ranks / world, clamped at 1 (A2/models/anchor_detr.py:321-325).
+        Issued before the forward: it scales the loss, so it must be known before the loss is formed."""
+        nb = float(sum(len(t["boxes"]) for t in targets))
+        if get_world_size() > 1:
+            t = torch.tensor([nb], dtype=torch.float32, device=self.device)
+            dist.all_reduce(t)
+            return torch.clamp(t / get_world_size(), min=1)[0]
+        return max(nb, 1.0)
+
+    def _fwd_bwd(self, images, mask, rects, targets, num_boxes):
         from .misc import NestedTensor
         self.flat_g.zero_()
         outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
-        loss_dict = self.criterion(outputs, targets)
+        loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
         wd = self.criterion.weight_dict
         losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)             # A2/engine.py:37
         losses.backward()
-        if get_world_size() > 1:
-            self._finish_allreduce()
-        gn = self._optimizer_step()
         out = dict(loss_dict)
         out["loss"] = losses.detach()
-        out["grad_norm"] = gn
+        return out
+
+    def _step_impl(self, images, mask, rects, targets, num_boxes):
+        out = self._fwd_bwd(images, mask, rects, targets, num_boxes)
+        if get_world_size() > 1:
+            self._finish_allreduce()
+        out["grad_norm"] = self._optimizer_step()
         return out
 
     def train_step(self, samples, rects, targets):
-        """samples: [B,3,H,W] tensor, list of [3,h,w] tensors, or NestedTensor.  Returns a dict of device scalars."""
+        """Eager step.  samples: [B,3,H,W] tensor, list of [3,h,w] tensors, or NestedTensor.  Returns device scalars.
+        With world_size > 1 the gradient all-reduce runs as 4 buckets on a side stream, overlapped with backward."""
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
         images, mask = nt.decompose()
-        return self._step_impl(images, mask, rects, targets)
+        return self._step_impl(images, mask, rects, targets, self._num_boxes(targets))
 
-    # ------------------------------------------------------------------ HIP-graph replay of the whole step
-    def capture(self, samples, rects, targets, warmup=3):
-        """Capture fwd + criterion (device matcher) + bwd + clip + AdamW into one HIP graph for fixed shapes / target counts."""
-        assert get_world_size() == 1, "graph capture is used for the single-GPU path"
+    # ------------------------------------------------------------------ HIP-graph replay of the step
+    def _dry_run(self, st):
+        """Forward + criterion without autograd: builds every lazily cached device table (frozen-BN folds, padded stem
+        weight, match plans, LDS attributes) OUTSIDE the capture; parameters are untouched."""
+        from .misc import NestedTensor
+        with torch.no_grad():
+            outputs, _ = self.model(NestedTensor(st["images"], st["mask"]), rects=st["rects"])
+            self.criterion(outputs, st["targets"], num_boxes=1.0)
+
+    def capture(self, samples, rects, targets, warmup=0):
+        """Capture (record, not run) the step for fixed shapes / target counts; `replay()` executes it.
+        world_size == 1: ONE graph = zero-grad + forward + device matcher + losses + backward + clip + AdamW.
+        world_size  > 1: graph A = everything up to the gradients, then ONE eager flat all-reduce (RCCL) on the compute
+        stream, then graph B = clip + AdamW (no collective inside a capture)."""
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
         images, mask = nt.decompose()
         st = {"images": images.clone(), "mask": mask.clone(), "rects": rects.clone(),
               "targets": [{k: v.clone() for k, v in t.items()} for t in targets]}
+        world = get_world_size()
+        nb0 = self._num_boxes(targets)
+        st["num_boxes"] = nb0.clone() if torch.is_tensor(nb0) else nb0
+        hook = _bb._BACKWARD_HOOK
+        _bb.set_backward_hook(None)                # no collectives inside the capture
+        self._dry_run(st)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                self._step_impl(st["images"], st["mask"], st["rects"], st["targets"])
+                self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
+                if world > 1:
+                    dist.all_reduce(self.flat_g)
+                    self.flat_g.div_(world)
+                self._optimizer_step()
         torch.cuda.current_stream().wait_stream(s)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self._step_impl(st["images"], st["mask"], st["rects"], st["targets"])
-        self._graph, self._static, self._static_out = graph, st, out
+        torch.cuda.synchronize()
+        g_a = torch.cuda.CUDAGraph()
+        if world == 1:
+            with torch.cuda.graph(g_a):
+                out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
+                out["grad_norm"] = self._optimizer_step()
+            g_b = None
+        else:
+            with torch.cuda.graph(g_a):
+                out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
+            g_b = torch.cuda.CUDAGraph()           # (capturing records work, it does not run it)
+            with torch.cuda.graph(g_b, pool=g_a.pool()):
+                self.flat_g.div_(world)
+                out["grad_norm"] = self._optimizer_step()
+        _bb.set_backward_hook(hook)
+        self._graph, self._graph_b, self._static, self._static_out = g_a, g_b, st, out
         return out
 
     def replay(self, samples=None, rects=None, targets=None):
+        st = self._static
         if samples is not None:
             nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
             images, mask = nt.decompose()
-            self._static["images"].copy_(images)
-            self._static["mask"].copy_(mask)
-            self._static["rects"].copy_(rects)
-            for st, t in zip(self._static["targets"], targets):
-                for k in st:
-                    st[k].copy_(t[k])
+            st["images"].copy_(images)
+            st["mask"].copy_(mask)
+            st["rects"].copy_(rects)
+            for s_t, t in zip(st["targets"], targets):
+                for k in s_t:
+                    s_t[k].copy_(t[k])
+            if torch.is_tensor(st["num_boxes"]):
+                st["num_boxes"].copy_(self._num_boxes(targets))
         self._graph.replay()
+        if self._graph_b is not None:
+            dist.all_reduce(self.flat_g)
+            self._graph_b.replay()
         return self._static_out
 
 

@@ -14,6 +14,29 @@ from ._ffi import ConvGeom, GemmDesc, RcdaBwdDesc, RcdaFwdDesc, WgradDesc, check
 import ctypes as C
 
 
+# Optional per-launch instrumentation (bench.py's roofline leg): a list collecting (family, algorithmic FLOPs,
+# start event, end event) for every matrix-core launch; HIP events are recorded on the launch stream itself.
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, family, flops):
+        self.family, self.flops = family, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.t0 = torch.cuda.Event(enable_timing=True)
+            self.t0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            t1 = torch.cuda.Event(enable_timing=True)
+            t1.record()
+            PROFILE.append((self.family, self.flops, self.t0, t1))
+        return False
+
+
 def _geom(mode=_ffi.ROWS_DENSE, Ha=0, Wa=0, Hc=0, Wc=0, kh=1, kw=1, stride=1, pad=0, dil=1):
     return ConvGeom(mode, Ha, Wa, Hc, Wc, kh, kw, stride, pad, dil)
 
@@ -29,7 +52,8 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
     d.resid, d.ldr = ptr(resid), ldr
     d.gate, d.ldg = ptr(gate), ldg
     d.g = geom if geom is not None else _geom()
-    check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
+    with _Timed("igemm", 2.0 * M * N * K * taps * batch):
+        check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
 
 
 def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0):
@@ -40,7 +64,8 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
     d.dW, d.ldw, d.sW = ptr(dW), ldw, sW
     d.w_scale = ptr(w_scale)
     d.g = geom if geom is not None else _geom()
-    check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
+    with _Timed("wgrad", 2.0 * P * Nout * Cin * taps * batch):
+        check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
 
 
 def colsum_(X2d, out):
@@ -210,7 +235,8 @@ class RcdaCoreFn(torch.autograd.Function):
         d.q_row, d.q_col, d.k_row, d.k_col, d.v = ptr(q_row), ptr(q_col), ptr(k_row), ptr(k_col), ptr(v)
         d.mask_row, d.mask_col = ptr(mask_row), ptr(mask_col)
         d.out, d.a_row, d.a_col = ptr(out), ptr(a_row), ptr(a_col)
-        check(lib().cdetr_rcda_fwd(C.byref(d), stream_ptr()), "cdetr_rcda_fwd")
+        with _Timed("rcda_fwd", 2.0 * N * nh * L * (H * W * 32 + (H + W) * 32)):
+            check(lib().cdetr_rcda_fwd(C.byref(d), stream_ptr()), "cdetr_rcda_fwd")
         ctx.save_for_backward(q_row, q_col, k_row, k_col, v, a_row, a_col)
         ctx.nh = nh
         return out
@@ -230,7 +256,8 @@ class RcdaCoreFn(torch.autograd.Function):
         d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
         d.d_out, d.a_row, d.a_col, d.v = ptr(d_out), ptr(a_row), ptr(a_col), ptr(v)
         d.ds_row, d.ds_col, d.d_v = ptr(ds_row), ptr(ds_col), ptr(d_v)
-        check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
+        with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32)):
+            check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
         # logits -> projected q/k gradients: four small batched GEMMs per (n, head) on the same MFMA kernels
         dq_row = torch.empty_like(q_row)
         dq_col = torch.empty_like(q_col)

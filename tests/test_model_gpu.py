@@ -98,8 +98,8 @@ def test_graph_replay_equals_eager():
         model.train()
         tr = Trainer(model, crit, args, device=DEV)
         if use_graph:
-            tr.capture(images, rects, targets, warmup=0)      # capture performs ONE step
-            out = tr._static_out
+            tr.capture(images, rects, targets, warmup=0)            # records the step (weights untouched) ...
+            out = tr.replay()                                       # ... and this executes it once
         else:
             out = tr.train_step(images, rects, targets)
         res.append({k: float(v) for k, v in out.items()})
