@@ -143,12 +143,22 @@ def main():
         trainer._fwd_bwd(im, mk, rects, targets, nb)
     torch.cuda.synchronize()
     fam = {}
-    for family, flops, e0, e1 in ops.PROFILE:
+    shapes = {}
+    for family, flops, e0, e1, tag in ops.PROFILE:
+        if tag is not None:
+            sh = shapes.setdefault((family,) + tuple(tag), [0.0, 0.0, 0])
+            sh[0] += flops; sh[1] += e0.elapsed_time(e1) * 1e-3; sh[2] += 1
         f = fam.setdefault(family, [0.0, 0.0, 0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 1
     ops.PROFILE = None
+    if os.environ.get("CDETR_BENCH_SHAPES") and rank == 0:
+        rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
+        with open(os.environ["CDETR_BENCH_SHAPES"], "w") as f:
+            f.write("family,M,N,K,taps,layout,batch,calls_per_step,us_per_call,ms_per_step,tflops\n")
+            for k, v in rows:
+                f.write(",".join(str(x) for x in k) + f",{v[2] // reps},{v[1] / v[2] * 1e6:.1f},{v[1] / reps * 1e3:.3f},{v[0] / v[1] / 1e12:.1f}\n")
     bb.set_backward_hook(hook)
     kern = {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / reps * 1e3, "launches_per_step": v[2] // reps,
                 "gflop_per_step": v[0] / reps / 1e9} for k, v in fam.items() if v[1] > 0}

@@ -35,7 +35,7 @@ class WgradDesc(C.Structure):
                 ("dY", _p), ("ldy", C.c_int64), ("sY", C.c_int64),
                 ("X", _p), ("ldx", C.c_int64), ("sX", C.c_int64),
                 ("dW", _p), ("ldw", C.c_int64), ("sW", C.c_int64),
-                ("w_scale", _p), ("g", ConvGeom)]
+                ("w_scale", _p), ("dbias", _p), ("g", ConvGeom)]
 
 
 class RcdaFwdDesc(C.Structure):

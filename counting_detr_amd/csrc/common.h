@@ -31,6 +31,26 @@ static inline int cdetr_launch_status(const char* what) {
     return CDETR_OK;
 }
 
+// hipcc (ROCm 7.2) does not pad the MFMA -> accumulator-read hazard across a loop-exit edge: the register copies
+// (v_accvgpr_read) that follow a k-loop can issue before the last 16-pass MFMA has written its final rows (seen on
+// wgrad_fast_kernel<64,64>: accumulator row r = 15 stale).  Scheduling barriers / inline nops do not help (the copies are
+// placed by the register allocator ahead of them).  Fix: issue one more MFMA with zero operands on every accumulator in
+// the epilogue's own basic block -- an exact +0 -- so the in-block hazard recognizer pads the following reads correctly.
+__device__ __forceinline__ void mfma_drain(f32x16& acc) { acc = __builtin_amdgcn_mfma_f32_32x32x2f32(0.f, 0.f, acc, 0, 0, 0); }
+__device__ __forceinline__ void mfma_drain(f32x4& acc) { acc = __builtin_amdgcn_mfma_f32_16x16x4f32(0.f, 0.f, acc, 0, 0, 0); }
+template <int FM, int FN>
+__device__ __forceinline__ void mfma_drain(f32x16 (&acc)[FM][FN]) {
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b) mfma_drain(acc[a][b]);
+}
+template <int NF>
+__device__ __forceinline__ void mfma_drain(f32x16 (&acc)[NF]) {
+#pragma unroll
+    for (int a = 0; a < NF; ++a) mfma_drain(acc[a]);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

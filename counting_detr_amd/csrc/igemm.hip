@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const cdetr_gemm_desc d, con
         __syncthreads();
     }
 
+    mfma_drain(acc);
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
         __syncthreads();
     }
 
+    mfma_drain(acc);
     const bool single = (gridDim.y == 1);
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
@@ -429,6 +431,503 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
                 atomicAdd(dst, v);
             }
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ fast forward / dgrad
+// Same math as igemm_kernel, for the common case K % 32 == 0 with 16-byte aligned operands (every heavy layer):
+//   * BK = 32, so a k-tile never straddles a filter tap: the tap is wave-uniform, its gather is resolved once per tap
+//     into per-thread row pointers and the steady-state loop has no integer division at all;
+//   * twice the MFMA work per barrier (16 / 32 / 64 MFMAs per wave per tile for 64x64 / 128x64 / 128x128).
+template <int BM, int BN, int BL, int BKF>
+__global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
+    constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
+    constexpr int F4R = BKF / 4;             // float4 per k-row (8 or 16)
+    constexpr int RPP = 256 / F4R;           // rows covered by one pass of the 256 threads (32 or 16)
+    constexpr int FM = BM / 64, FN = BN / 64;
+    constexpr int A_SLOTS = BM / RPP, B_SLOTS = (BL == 0) ? BN / RPP : BKF * BN / 1024;
+    constexpr int LDN = BN + 4;
+    constexpr int A_TILE = BM * LDK;
+    constexpr int B_TILE = (BL == 0) ? BN * LDK : BKF * LDN;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * A_TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int tm = blockIdx.x % tilesM, tn = blockIdx.x / tilesM;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = d.A + (long)z * d.sA;
+    const float* __restrict__ B = d.B + (long)z * d.sB;
+    float* __restrict__ C = d.C + (long)z * d.sC;
+    const int K = d.K, taps = d.taps;
+    const int nkt = (K / BKF) * taps;
+
+    const int kq = tid % F4R, r8 = tid / F4R;
+    RowCoord arow[A_SLOTS];
+    const float* ap[A_SLOTS];
+#pragma unroll
+    for (int i = 0; i < A_SLOTS; ++i) arow[i] = decode_row(d.g, m0 + r8 + RPP * i, d.M);
+    auto set_tap = [&](int tap) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) {
+            const long row = gather_row(d.g, arow[i], tap);
+            ap[i] = (row >= 0) ? A + row * d.lda + kq * 4 : nullptr;
+        }
+    };
+    // B operand pointers
+    const float* bp[B_SLOTS];
+    float bscale0[B_SLOTS];
+    if (BL == 0) {
+#pragma unroll
+        for (int i = 0; i < B_SLOTS; ++i) {
+            const int n = n0 + r8 + RPP * i;
+            bp[i] = (n < d.N) ? B + (long)n * d.ldb + kq * 4 : nullptr;
+            bscale0[i] = (d.w_scale && n < d.N) ? d.w_scale[n] : 1.f;
+        }
+    }
+    float4 ra[A_SLOTS], rb[B_SLOTS];
+    auto fetch = [&](int tap, int kc) {
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) ra[i] = ap[i] ? ld4(ap[i] + kc) : zero4();
+        if (BL == 0) {
+            const int koff = tap * K + kc;
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i) {
+                float4 v = bp[i] ? ld4(bp[i] + koff) : zero4();
+                const float s = bscale0[i];
+                v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+                rb[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i) {
+                const int idx = tid + 256 * i;
+                const int kr = idx / (BN / 4);
+                const int nq = idx - kr * (BN / 4);
+                const int n = n0 + nq * 4;
+                const int k = kc + kr;
+                float4 v = zero4();
+                if (n < d.N) {
+                    v = ld4(B + ((long)k * taps + tap) * d.ldb + n);
+                    if (d.w_scale) {
+                        const float s = d.w_scale[k];
+                        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+                    }
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        float* as = As + buf * A_TILE;
+        float* bs = Bs + buf * B_TILE;
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = ra[i];
+        if (BL == 0) {
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i) *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = rb[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; ++i) {
+                const int idx = tid + 256 * i;
+                const int kr = idx / (BN / 4);
+                const int nq = idx - kr * (BN / 4);
+                *reinterpret_cast<float4*>(bs + kr * LDN + nq * 4) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    int f_tap = 0, f_kc = 0;
+    set_tap(0);
+    fetch(0, 0);
+    stash(0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) {
+            f_kc += BKF;
+            if (f_kc == K) { f_kc = 0; ++f_tap; set_tap(f_tap); }
+            fetch(f_tap, f_kc);
+        }
+        const float* as = As + buf * A_TILE + (wm * (BM / 2) + i32) * LDK + g * 4;
+        const float* bs = (BL == 0) ? Bs + buf * B_TILE + (wn * (BN / 2) + i32) * LDK + g * 4
+                                    : Bs + buf * B_TILE + (g * 4) * LDN + wn * (BN / 2) + i32;
+#pragma unroll
+        for (int h = 0; h < BKF / 8; ++h) {
+            float a4[FM][4], b4[FN][4];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+                const float4 t = *reinterpret_cast<const float4*>(as + a * 32 * LDK + h * 8);
+                a4[a][0] = t.x; a4[a][1] = t.y; a4[a][2] = t.z; a4[a][3] = t.w;
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                if (BL == 0) {
+                    const float4 t = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + h * 8);
+                    b4[b][0] = t.x; b4[b][1] = t.y; b4[b][2] = t.z; b4[b][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b4[b][s] = bs[(h * 8 + s) * LDN + b * 32];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[a][s], b4[b][s], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) stash(buf ^ 1);
+        __syncthreads();
+    }
+    mfma_drain(acc);
+
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int n = n0 + wn * (BN / 2) + b * 32 + i32;
+            if (n >= d.N) continue;
+            const float bias = d.bias ? d.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (m >= d.M) continue;
+                float v = (acc[a][b][r] + bias) * d.out_scale;
+                if (d.resid) v += d.resid[(long)m * d.ldr + n];
+                if (d.gate) v = d.gate[(long)m * d.ldg + n] > 0.f ? v : 0.f;
+                if (d.relu) v = fmaxf(v, 0.f);
+                C[(long)m * d.ldc + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fast wgrad
+// dW[i][tap][c] += scale[i] * sum_p dY[p][i] * X[row(p,tap)][c]  (+ optional dbias[i] += sum_p dY[p][i]).
+// BK = 32 pixels per tile; every thread owns ONE pixel row of the tile (8 threads x 16 B per 128-byte run), so the
+// pixel -> (n, y, x) coordinates are advanced incrementally (no division) and the tap gather costs a few integer ops.
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
+                                                         const int kt_per_slice, float* __restrict__ dbias) {
+    constexpr int BKF = 32;
+    constexpr int FM = BI / 64, FN = BJ / 64;
+    constexpr int A_SLOTS = BI / 32, B_SLOTS = BJ / 32;
+    constexpr int LDI = BI + 4, LDJ = BJ + 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                      // [2][32][LDI]
+    float* Bs = smem + 2 * BKF * LDI;      // [2][32][LDJ]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int ti = blockIdx.x % tilesI;
+    const int tj = blockIdx.x / tilesI;
+    const int tap = tj / tilesJ;
+    const int c0 = (tj - tap * tilesJ) * BJ;
+    const int i0 = ti * BI;
+    const int z = blockIdx.z;
+    const float* __restrict__ dY = d.dY + (long)z * d.sY;
+    const float* __restrict__ X = d.X + (long)z * d.sX;
+    float* __restrict__ dW = d.dW + (long)z * d.sW;
+    const int nkt_all = (d.P + BKF - 1) / BKF;
+    const int kt_begin = blockIdx.y * kt_per_slice;
+    const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
+    if (kt_begin >= kt_end) return;
+
+    const int kr = tid >> 3, cq = (tid & 7) * 4;
+    const bool dense = d.g.mode == CDETR_ROWS_DENSE;
+    const int ky = dense ? 0 : tap / d.g.kw, kx = dense ? 0 : tap - (tap / d.g.kw) * d.g.kw;
+    // this thread's pixel for the first tile
+    int p = kt_begin * BKF + kr;
+    int pn = 0, py = 0, px = 0;
+    if (!dense) {
+        const int hw = d.g.Hc * d.g.Wc;
+        pn = p / hw;
+        const int rem = p - pn * hw;
+        py = rem / d.g.Wc;
+        px = rem - py * d.g.Wc;
+    }
+    const bool do_bias = (dbias != nullptr) && tj == 0;
+    float4 bsum[A_SLOTS];
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) bsum[s] = zero4();
+
+    float4 ra[A_SLOTS], rb[B_SLOTS];
+    auto fetch = [&]() {   // loads the tile whose pixel row for this thread is (p; pn, py, px), then advances by 32 pixels
+        const bool pv = p < d.P;
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) {
+            const int i = i0 + cq + 32 * s;
+            float4 v = zero4();
+            if (pv && i < d.Nout) v = ld4(dY + (long)p * d.ldy + i);
+            ra[s] = v;
+        }
+        long row = -1;
+        if (pv) {
+            if (dense) row = p;
+            else {
+                const int iy = py * d.g.stride - d.g.pad + ky * d.g.dil;
+                const int ix = px * d.g.stride - d.g.pad + kx * d.g.dil;
+                if (iy >= 0 && iy < d.g.Ha && ix >= 0 && ix < d.g.Wa) row = ((long)pn * d.g.Ha + iy) * d.g.Wa + ix;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) {
+            const int c = c0 + cq + 32 * s;
+            rb[s] = (row >= 0 && c < d.Cin) ? ld4(X + row * d.ldx + c) : zero4();
+        }
+        p += BKF;
+        if (!dense) {
+            px += BKF;
+            while (px >= d.g.Wc) { px -= d.g.Wc; ++py; }
+            while (py >= d.g.Hc) { py -= d.g.Hc; ++pn; }
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) {
+            *reinterpret_cast<float4*>(As + buf * BKF * LDI + kr * LDI + cq + 32 * s) = ra[s];
+            if (do_bias) { bsum[s].x += ra[s].x; bsum[s].y += ra[s].y; bsum[s].z += ra[s].z; bsum[s].w += ra[s].w; }
+        }
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) *reinterpret_cast<float4*>(Bs + buf * BKF * LDJ + kr * LDJ + cq + 32 * s) = rb[s];
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    fetch();
+    stash(0);
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        if (kt + 1 < kt_end) fetch();
+        const float* as = As + buf * BKF * LDI + (g * 4) * LDI + wm * (BI / 2) + i32;
+        const float* bs = Bs + buf * BKF * LDJ + (g * 4) * LDJ + wn * (BJ / 2) + i32;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                float av[FM], bv[FN];
+#pragma unroll
+                for (int a = 0; a < FM; ++a) av[a] = as[(h * 8 + s) * LDI + a * 32];
+#pragma unroll
+                for (int b = 0; b < FN; ++b) bv[b] = bs[(h * 8 + s) * LDJ + b * 32];
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < kt_end) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    mfma_drain(acc);
+    const bool single = (gridDim.y == 1);
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int c = c0 + wn * (BJ / 2) + b * 32 + i32;
+            if (c >= d.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (i >= d.Nout) continue;
+                float v = acc[a][b][r];
+                if (d.w_scale) v *= d.w_scale[i];
+                float* dst = dW + (long)i * d.ldw + (long)tap * d.Cin + c;
+                if (single) *dst += v;          // this launch owns the element: plain read-modify-write
+                else atomicAdd(dst, v);
+            }
+        }
+    }
+    if (do_bias) {   // column sums of dY: reduce the 32 pixel rows of the block through LDS, one atomic per column
+        __syncthreads();
+        float* red = smem;   // [32][BI]
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) *reinterpret_cast<float4*>(red + kr * BI + cq + 32 * s) = bsum[s];
+        __syncthreads();
+        for (int i = tid; i < BI; i += 256) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) t += red[r * BI + i];
+            if (i0 + i < d.Nout) atomicAdd(dbias + i0 + i, t);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ direct small GEMMs
+// Latency-optimised path for the ~450 small contractions per step (decoder M = B*Q = 600 rows, positional MLPs,
+// per-head dq/dk of RCDA): one wave = one 16x16 output tile on v_mfma_f32_16x16x4_f32, operands loaded straight from
+// global/L2 in the MFMA register layout -- no LDS, no barrier, every wave independent, so a 600x256x256 GEMM runs as
+// 608 concurrent waves of 64 MFMAs instead of 40 workgroups stepping through 8 barrier-separated k-tiles.
+template <int BL>
+__global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN,
+                                                           const int vecA, const int vecB) {
+    constexpr int UB = 8;   // 16-wide k-chunks whose loads are issued back-to-back before the first MFMA consumes one
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wid;
+    if (tile >= tilesM * tilesN) return;
+    const int tm = tile % tilesM, tn = tile / tilesM;
+    const int i = lane & 15, g4 = lane >> 4;
+    const int m = tm * 16 + i, n = tn * 16 + i;
+    const int z = blockIdx.z;
+    const float* __restrict__ A = d.A + (long)z * d.sA;
+    const float* __restrict__ B = d.B + (long)z * d.sB;
+    float* __restrict__ C = d.C + (long)z * d.sC;
+    const int K = d.K;
+    const bool mv = m < d.M, nv = n < d.N;
+    const float* arow = A + (long)(mv ? m : 0) * d.lda;
+    const float* brow = B + (BL == 0 ? (long)(nv ? n : 0) * d.ldb : (long)(nv ? n : 0));
+    const float s0 = (BL == 0 && d.w_scale && nv) ? d.w_scale[n] : 1.f;
+    const float am = mv ? 1.f : 0.f;
+    const float bm = nv ? s0 : 0.f;
+    const float* wsc = d.w_scale;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < K; k0 += 16 * UB) {
+        float a[UB][4], b[UB][4];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {       // branch-free, clamped addresses: all loads of the batch are in flight together
+            const int k = k0 + u * 16 + g4 * 4;
+            if (vecA) {
+                const bool ok = k < K;
+                const float4 t = ld4(arow + (ok ? k : 0));
+                const float f = ok ? am : 0.f;
+                a[u][0] = t.x * f; a[u][1] = t.y * f; a[u][2] = t.z * f; a[u][3] = t.w * f;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bool ok = k + s < K;
+                    a[u][s] = arow[ok ? k + s : 0] * (ok ? am : 0.f);
+                }
+            }
+            if (BL == 0) {
+                if (vecB) {
+                    const bool ok = k < K;
+                    const float4 t = ld4(brow + (ok ? k : 0));
+                    const float f = ok ? bm : 0.f;
+                    b[u][0] = t.x * f; b[u][1] = t.y * f; b[u][2] = t.z * f; b[u][3] = t.w * f;
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const bool ok = k + s < K;
+                        b[u][s] = brow[ok ? k + s : 0] * (ok ? bm : 0.f);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const bool ok = k + s < K;
+                    const int kk = ok ? k + s : 0;
+                    float v = brow[(long)kk * d.ldb];
+                    if (wsc) v *= wsc[kk];
+                    b[u][s] = (ok && nv) ? v : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][s], acc, 0, 0, 0);
+    }
+    mfma_drain(acc);
+    // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
+    const int no = tn * 16 + i;
+    if (no >= d.N) return;
+    const float bias = d.bias ? d.bias[no] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int mo = tm * 16 + g4 * 4 + r;
+        if (mo >= d.M) continue;
+        float v = (acc[r] + bias) * d.out_scale;
+        if (d.resid) v += d.resid[(long)mo * d.ldr + no];
+        if (d.gate) v = d.gate[(long)mo * d.ldg + no] > 0.f ? v : 0.f;
+        if (d.relu) v = fmaxf(v, 0.f);
+        C[(long)mo * d.ldc + no] = v;
+    }
+}
+
+// dW[i][c] += scale[i] * sum_p dY[p][i] X[p][c] (+ dbias[i] += sum_p dY[p][i]) for short reductions (P <= 1024).
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
+                                                           float* __restrict__ dbias) {
+    constexpr int UB = 4;
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wid;
+    if (tile >= tilesI * tilesJ) return;
+    const int ti = tile % tilesI, tj = tile / tilesI;
+    const int i = lane & 15, g4 = lane >> 4;
+    const int z = blockIdx.z;
+    const float* __restrict__ dY = d.dY + (long)z * d.sY;
+    const float* __restrict__ X = d.X + (long)z * d.sX;
+    float* __restrict__ dW = d.dW + (long)z * d.sW;
+    const int ci = ti * 16 + i, cc = tj * 16 + i;
+    const bool iv = ci < d.Nout, cv = cc < d.Cin;
+    const float* ya = dY + (iv ? ci : 0);
+    const float* xb = X + (cv ? cc : 0);
+    const float fa = iv ? 1.f : 0.f, fb = cv ? 1.f : 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+    for (int p0 = 0; p0 < d.P; p0 += 16 * UB) {
+        float a[UB][4], b[UB][4];
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int p = p0 + u * 16 + g4 * 4 + s;
+                const bool pv = p < d.P;
+                const long pc = pv ? p : 0;
+                a[u][s] = ya[pc * d.ldy] * (pv ? fa : 0.f);
+                b[u][s] = xb[pc * d.ldx] * (pv ? fb : 0.f);
+            }
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][s], acc, 0, 0, 0);
+                bsum += a[u][s];
+            }
+    }
+    mfma_drain(acc);
+    const int co = tj * 16 + i;
+    if (co < d.Cin) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int io = ti * 16 + g4 * 4 + r;
+            if (io >= d.Nout) continue;
+            float v = acc[r];
+            if (d.w_scale) v *= d.w_scale[io];
+            dW[(long)io * d.ldw + co] += v;      // one owner per element within a launch
+        }
+    }
+    if (dbias != nullptr && tj == 0) {
+        bsum += __shfl_xor(bsum, 16, 64);
+        bsum += __shfl_xor(bsum, 32, 64);
+        if (g4 == 0 && iv) atomicAdd(dbias + ci, bsum);
     }
 }
 
@@ -483,6 +982,35 @@ int launch_gemm(const cdetr_gemm_desc& d, hipStream_t st, int vecA, int vecB) {
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <typename F>
+int raise_lds(F func, int bytes, const char* what) {
+    if (bytes > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(func), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e != hipSuccess) {
+            cdetr_set_error("%s: hipFuncSetAttribute(%d): %s", what, bytes, hipGetErrorString(e));
+            return CDETR_ERR_LAUNCH;
+        }
+    }
+    return CDETR_OK;
+}
+
+template <int BM, int BN, int BKF>
+int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
+    const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
+    dim3 grid(tilesM * tilesN, 1, d.batch), block(256);
+    int rc;
+    if (d.b_layout == 0) {
+        const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
+        if ((rc = raise_lds(igemm_fast_kernel<BM, BN, 0, BKF>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<BM, BN, 0, BKF>), grid, block, bytes, st, d, tilesM);
+    } else {
+        const int bytes = (2 * BM * (BKF + 4) + 2 * BKF * (BN + 4)) * 4;
+        if ((rc = raise_lds(igemm_fast_kernel<BM, BN, 1, BKF>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<BM, BN, 1, BKF>), grid, block, bytes, st, d, tilesM);
+    }
+    return cdetr_launch_status("cdetr_gemm");
+}
+
 }  // namespace
 
 extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
@@ -511,6 +1039,26 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile choice: the largest tile that still yields >= 1.5 waves of workgroups on 256 CUs
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
+    if (d.g.mode == CDETR_ROWS_DENSE && (blocks(64, 64) < 24 || !(vecA && vecB && (d.K % 32) == 0)) && blocks(64, 64) < 192) {   // latency-bound: one wave per 16x16 tile
+        const int tilesM = (d.M + 15) / 16, tilesN = (d.N + 15) / 16;
+        dim3 grid((tilesM * tilesN + 3) / 4, 1, d.batch);
+        if (d.b_layout == 0)
+            hipLaunchKernelGGL(igemm_direct_kernel<0>, grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+        else
+            hipLaunchKernelGGL(igemm_direct_kernel<1>, grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+        return cdetr_launch_status("cdetr_gemm");
+    }
+    if (vecA && vecB && (d.K % 32) == 0) {   // fast path: tap-uniform k-tiles, no integer division in the loop
+        // cost model: CUs run ceil(blocks / 256) "rounds" of a workgroup whose matrix-pipe time is ~ BM*BN; take the
+        // cheapest tile, preferring the finer one on ties (better tail / latency hiding)
+        auto cost = [&](int bm, int bn) { return ((blocks(bm, bn) + 255) / 256) * (long)bm * bn; };
+        const long c128 = cost(128, 128), c12864 = cost(128, 64), c64 = cost(64, 64);
+        const bool k64 = (d.K % 64) == 0;
+        if (c64 <= c12864 && c64 <= c128)
+            return k64 ? launch_gemm_fast<64, 64, 64>(d, st) : launch_gemm_fast<64, 64, 32>(d, st);
+        if (c12864 <= c128) return launch_gemm_fast<128, 64, 32>(d, st);
+        return launch_gemm_fast<128, 128, 32>(d, st);
+    }
     if (d.N > 64 && d.M > 64 && blocks(128, 128) >= 384) return launch_gemm<128, 128>(d, st, vecA, vecB);
     if (d.M > 64 && blocks(128, 64) >= 384) return launch_gemm<128, 64>(d, st, vecA, vecB);
     return launch_gemm<64, 64>(d, st, vecA, vecB);
@@ -530,7 +1078,53 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
         CDETR_CHECK_ARG(d.P % (d.g.Hc * d.g.Wc) == 0, "cdetr_wgrad: P is not images*Hc*Wc");
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (d.g.mode == CDETR_ROWS_DENSE && d.P <= 1024) {
+        const int tilesI = (d.Nout + 15) / 16, tilesJ = (d.Cin + 15) / 16;
+        dim3 grid((tilesI * tilesJ + 3) / 4, 1, d.batch);
+        hipLaunchKernelGGL(wgrad_direct_kernel, grid, dim3(256), 0, st, d, tilesI, tilesJ, d.dbias);
+        return cdetr_launch_status("cdetr_wgrad");
+    }
+    const bool fast = (d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0;
+    if (fast) {
+        const int nktf = (d.P + 31) / 32;
+        int rcf = CDETR_OK;
+        auto launchf = [&](auto bi_c, auto bj_c) {
+            constexpr int BI = decltype(bi_c)::value, BJ = decltype(bj_c)::value;
+            const int tilesI = (d.Nout + BI - 1) / BI, tilesJ = (d.Cin + BJ - 1) / BJ;
+            const long base = (long)tilesI * tilesJ * d.taps * d.batch;
+            long slices = (768 + base - 1) / base;                  // ~3 workgroups per CU
+            const long max_slices = (nktf + 3) / 4;                 // >= 4 k-tiles (128 pixels) per slice
+            if (slices > max_slices) slices = max_slices;
+            if (slices < 1) slices = 1;
+            if (slices > 65535) slices = 65535;
+            const int per = (int)((nktf + slices - 1) / slices);
+            slices = (nktf + per - 1) / per;
+            const int bytes = (2 * 32 * (BI + 4) + 2 * 32 * (BJ + 4)) * 4;
+            if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ>, bytes, "cdetr_wgrad"))) return;
+            dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
+            hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
+        };
+        // small outputs (few 128x128 tiles) cannot fill 256 CUs even with every allowed k-slice: use 64x64 tiles there
+        const long big_blocks = (long)((d.Nout + 127) / 128) * ((d.Cin + 127) / 128) * d.taps * d.batch * ((nktf + 3) / 4);
+        if (d.Nout >= 128 && d.Cin >= 128 && big_blocks >= 512)
+            launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
+        else if (d.Nout >= 128 && d.Cin < 128)
+            launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{});
+        else if (d.Cin >= 128 && d.Nout < 128)
+            launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 128>{});
+        else
+            launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
+        if (rcf) return rcf;
+        return cdetr_launch_status("cdetr_wgrad");
+    }
     const int nkt = (d.P + BK - 1) / BK;
+    if (d.dbias) {   // generic path: separate column-sum launch
+        const int rows_per_block = 64;
+        dim3 cg((d.Nout + 255) / 256, (d.P + rows_per_block - 1) / rows_per_block, 1);
+        for (int zb = 0; zb < d.batch; ++zb)
+            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, st, d.dY + (long)zb * d.sY, (long)d.ldy, d.P, d.Nout, d.dbias,
+                               rows_per_block);
+    }
     auto launch = [&](auto bi_c, auto bj_c) {
         constexpr int BI = decltype(bi_c)::value, BJ = decltype(bj_c)::value;
         const int tilesI = (d.Nout + BI - 1) / BI, tilesJ = (d.Cin + BJ - 1) / BJ;

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(256) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc
         if (w + 1 < W) vstash(buf ^ 1);
         __syncthreads();
     }
+    mfma_drain(acc);
     // C layout: col = lane&31 (= channel), row = (r&3) + 8*(r>>2) + 4*g (= query within the wave)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -440,6 +441,7 @@ __global__ __launch_bounds__(256) void rcda_dv_kernel(const cdetr_rcda_bwd_desc 
             }
         }
     }
+    mfma_drain(acc);
     if (!wvalid) return;
 #pragma unroll
     for (int f = 0; f < NF; ++f)

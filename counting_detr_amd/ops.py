@@ -20,8 +20,8 @@ PROFILE = None
 
 
 class _Timed:
-    def __init__(self, family, flops):
-        self.family, self.flops = family, flops
+    def __init__(self, family, flops, tag=None):
+        self.family, self.flops, self.tag = family, flops, tag
 
     def __enter__(self):
         if PROFILE is not None:
@@ -33,7 +33,7 @@ class _Timed:
         if PROFILE is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
-            PROFILE.append((self.family, self.flops, self.t0, t1))
+            PROFILE.append((self.family, self.flops, self.t0, t1, self.tag))
         return False
 
 
@@ -52,19 +52,21 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
     d.resid, d.ldr = ptr(resid), ldr
     d.gate, d.ldg = ptr(gate), ldg
     d.g = geom if geom is not None else _geom()
-    with _Timed("igemm", 2.0 * M * N * K * taps * batch):
+    with _Timed("igemm", 2.0 * M * N * K * taps * batch, (M, N, K, taps, b_layout, batch)):
         check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
 
 
-def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0):
+def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0,
+              dbias=None):
     d = WgradDesc()
     d.P, d.Nout, d.Cin, d.taps, d.batch = P, Nout, Cin, taps, batch
     d.dY, d.ldy, d.sY = ptr(dY), ldy, sY
     d.X, d.ldx, d.sX = ptr(X), ldx, sX
     d.dW, d.ldw, d.sW = ptr(dW), ldw, sW
     d.w_scale = ptr(w_scale)
+    d.dbias = ptr(dbias)
     d.g = geom if geom is not None else _geom()
-    with _Timed("wgrad", 2.0 * P * Nout * Cin * taps * batch):
+    with _Timed("wgrad", 2.0 * P * Nout * Cin * taps * batch, (P, Nout, Cin, taps, -1, batch)):
         check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
 
 
@@ -146,9 +148,9 @@ class LinearFn(torch.autograd.Function):
             dx = linear_dgrad(dy2d, w).reshape(ctx.xshape)
         if wparam.requires_grad:
             gw = grad_buffer(wparam)[lo:hi]
-            wgrad_raw(dy2d, dy2d.stride(0), x2d, x2d.stride(0), gw, gw.stride(0), dy2d.shape[0], w.shape[0], x2d.shape[1])
-            if bparam is not None and bparam.requires_grad:
-                colsum_(dy2d, grad_buffer(bparam)[lo:hi])
+            gb = grad_buffer(bparam)[lo:hi] if (bparam is not None and bparam.requires_grad) else None
+            wgrad_raw(dy2d, dy2d.stride(0), x2d, x2d.stride(0), gw, gw.stride(0), dy2d.shape[0], w.shape[0], x2d.shape[1],
+                      dbias=gb)
         return dx, None, None, None, None, None, d_resid, None
 
 

@@ -65,8 +65,9 @@ typedef struct {
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 
 /* dW[i][tap][c] += w_scale[i] * sum_p dY[p][i] * X[row(p,tap)][c]      (weight-gradient, split-K + fp32 atomics)
- * Replaces: autograd of F.conv2d / F.linear w.r.t. the weight.  dW must hold the value to accumulate onto
- * (the caller zeroes the gradient arena once per step).                                                       */
+ * dbias[i]      += sum_p dY[p][i]                                       (optional, fused: NULL = skip)
+ * Replaces: autograd of F.conv2d / F.linear w.r.t. weight and bias.  dW / dbias must hold the value to accumulate
+ * onto (the caller zeroes the gradient arena once per step).                                                  */
 typedef struct {
     int32_t P, Nout, Cin, taps;
     int32_t batch;
@@ -74,6 +75,7 @@ typedef struct {
     const float* X; int64_t ldx, sX;
     float* dW; int64_t ldw, sW;
     const float* w_scale;
+    float* dbias;
     cdetr_conv_geom g; /* mode DENSE or CONV_FWD (p = output pixel) */
 } cdetr_wgrad_desc;
 int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
