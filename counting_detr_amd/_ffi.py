@@ -50,7 +50,7 @@ class RcdaBwdDesc(C.Structure):
                 ("ds_row", _p), ("ds_col", _p), ("d_v", _p)]
 
 
-EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_maxpool3x3s2", "cdetr_rcda_fwd", "cdetr_rcda_bwd",
+EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_maxpool3x3s2", "cdetr_rcda_fwd", "cdetr_rcda_bwd",
            "cdetr_match_cost", "cdetr_lsap", "cdetr_last_error", "cdetr_abi_version"]
 
 _lib = None
@@ -71,6 +71,12 @@ def lib():
             getattr(L, name).argtypes = [_p, _p]
         L.cdetr_colsum.restype = C.c_int
         L.cdetr_colsum.argtypes = [_p, C.c_int64, C.c_int32, C.c_int32, _p, _p]
+        L.cdetr_sumsq.restype = C.c_int
+        L.cdetr_sumsq.argtypes = [_p, C.c_int64, _p, _p]
+        L.cdetr_adamw_step.restype = C.c_int
+        L.cdetr_adamw_step.argtypes = [_p, _p, _p, _p, _p, C.c_int64, _p, _p] + [C.c_float] * 6 + [_p]
+        L.cdetr_relu_mask.restype = C.c_int
+        L.cdetr_relu_mask.argtypes = [_p, _p, _p, C.c_int64, C.c_float, _p]
         L.cdetr_maxpool3x3s2.restype = C.c_int
         L.cdetr_maxpool3x3s2.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
         L.cdetr_match_cost.restype = C.c_int

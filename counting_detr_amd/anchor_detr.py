@@ -57,6 +57,7 @@ class AnchorDETR(nn.Module):
         self.input_proj = nn.ModuleList([_ProjGN(backbone.num_channels[0], hidden_dim)])
         self.backbone = backbone
         self.aux_loss = aux_loss
+        self.transformer.all_layer_heads = bool(aux_loss)
         self.aggr_input_proj = nn.ModuleList([_ProjGN(backbone.num_channels[0] * 2, hidden_dim)])
 
     def forward(self, samples, points=None, rects=None):

@@ -12,6 +12,7 @@
 // ds_read_b128 feeds four MFMAs; A and B use the same permutation, so the sum is unchanged up to fp32 reassociation.
 #include "../../include/cdetr_hip.h"
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -458,7 +459,14 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int i32 = lane & 31, g = lane >> 5;
-    const int tm = blockIdx.x % tilesM, tn = blockIdx.x / tilesM;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (private 4 MiB L2 each).  XCD x owns a contiguous band of
+    // row-tiles and sweeps all column-tiles of a row-tile before moving on, so the A row-panel of a tile is fetched
+    // from HBM/MALL once per XCD and the (small) weight matrix stays L2-resident.  Placement only affects speed.
+    const int tilesN = (d.N + BN - 1) / BN;
+    const int band = (tilesM + 7) >> 3;
+    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3;
+    const int tm = xcd * band + jloc / tilesN, tn = jloc % tilesN;
+    if (tm >= tilesM) return;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const float* __restrict__ A = d.A + (long)z * d.sA;
@@ -997,7 +1005,7 @@ int raise_lds(F func, int bytes, const char* what) {
 template <int BM, int BN, int BKF>
 int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-    dim3 grid(tilesM * tilesN, 1, d.batch), block(256);
+    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN, 1, d.batch), block(256);      // 8 XCD bands (see the kernel)
     int rc;
     if (d.b_layout == 0) {
         const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
@@ -1039,7 +1047,21 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile choice: the largest tile that still yields >= 1.5 waves of workgroups on 256 CUs
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
-    if (d.g.mode == CDETR_ROWS_DENSE && (blocks(64, 64) < 24 || !(vecA && vecB && (d.K % 32) == 0)) && blocks(64, 64) < 192) {   // latency-bound: one wave per 16x16 tile
+    // tuning knob (tools/gemm_sweep.py): CDETR_GEMM_VARIANT = 1..4 forces a fast tile, 5 the direct kernel, 6 the generic one
+    const char* force_s = getenv("CDETR_GEMM_VARIANT");
+    const int force = force_s ? atoi(force_s) : 0;
+    const bool fast_ok = vecA && vecB && (d.K % 32) == 0;
+    if (force >= 1 && force <= 4 && fast_ok) {
+        if (force == 1) return launch_gemm_fast<128, 128, 32>(d, st);
+        if (force == 2) return launch_gemm_fast<128, 64, 32>(d, st);
+        if (force == 3 && (d.K % 64) == 0) return launch_gemm_fast<64, 64, 64>(d, st);
+        return launch_gemm_fast<64, 64, 32>(d, st);
+    }
+    if (force == 6) {
+        if (d.N > 64 && d.M > 64) return launch_gemm<128, 128>(d, st, vecA, vecB);
+        return launch_gemm<64, 64>(d, st, vecA, vecB);
+    }
+    if ((force == 5 && d.g.mode == CDETR_ROWS_DENSE) || (d.g.mode == CDETR_ROWS_DENSE && (blocks(64, 64) <= 48 || !(vecA && vecB && (d.K % 32) == 0)) && blocks(64, 64) < 192)) {   // latency-bound: one wave per 16x16 tile
         const int tilesM = (d.M + 15) / 16, tilesN = (d.N + 15) / 16;
         dim3 grid((tilesM * tilesN + 3) / 4, 1, d.batch);
         if (d.b_layout == 0)
@@ -1051,13 +1073,11 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     if (vecA && vecB && (d.K % 32) == 0) {   // fast path: tap-uniform k-tiles, no integer division in the loop
         // cost model: CUs run ceil(blocks / 256) "rounds" of a workgroup whose matrix-pipe time is ~ BM*BN; take the
         // cheapest tile, preferring the finer one on ties (better tail / latency hiding)
-        auto cost = [&](int bm, int bn) { return ((blocks(bm, bn) + 255) / 256) * (long)bm * bn; };
-        const long c128 = cost(128, 128), c12864 = cost(128, 64), c64 = cost(64, 64);
-        const bool k64 = (d.K % 64) == 0;
-        if (c64 <= c12864 && c64 <= c128)
-            return k64 ? launch_gemm_fast<64, 64, 64>(d, st) : launch_gemm_fast<64, 64, 32>(d, st);
-        if (c12864 <= c128) return launch_gemm_fast<128, 64, 32>(d, st);
-        return launch_gemm_fast<128, 128, 32>(d, st);
+        // measured on MI355X (tools/gemm_sweep.py, profiles/r1_gemm_sweep.txt): 64x64 tiles at 4 workgroups/CU beat the
+        // 128-wide tiles on every shape of this model (latency hiding by occupancy matters more than operand reuse at
+        // the fp32-MFMA rate); BK = 64 only pays when the grid is too small to give every CU two workgroups.
+        if ((d.K % 64) == 0 && blocks(64, 64) < 512) return launch_gemm_fast<64, 64, 64>(d, st);
+        return launch_gemm_fast<64, 64, 32>(d, st);
     }
     if (d.N > 64 && d.M > 64 && blocks(128, 128) >= 384) return launch_gemm<128, 128>(d, st, vecA, vecB);
     if (d.M > 64 && blocks(128, 64) >= 384) return launch_gemm<128, 64>(d, st, vecA, vecB);
@@ -1104,14 +1124,19 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
             hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
         };
-        // small outputs (few 128x128 tiles) cannot fill 256 CUs even with every allowed k-slice: use 64x64 tiles there
-        const long big_blocks = (long)((d.Nout + 127) / 128) * ((d.Cin + 127) / 128) * d.taps * d.batch * ((nktf + 3) / 4);
-        if (d.Nout >= 128 && d.Cin >= 128 && big_blocks >= 512)
+        const char* wf = getenv("CDETR_WGRAD_VARIANT");   // tuning knob: 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64
+        const int wforce = wf ? atoi(wf) : 0;
+        if (wforce == 1) launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
+        else if (wforce == 2) launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{});
+        else if (wforce == 3) launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 128>{});
+        else if (wforce == 4) launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
+        if (wforce) { if (rcf) return rcf; return cdetr_launch_status("cdetr_wgrad"); }
+        // measured (tools/gemm_sweep.py wgrad, profiles/r1_gemm_sweep.txt): 64x64 tiles win for 1x1 / linear layers,
+        // 128-wide tiles only for the 3x3 convolutions (9 taps = 9x more output tiles per k-slice)
+        if (d.taps > 1 && d.Nout >= 512 && d.Cin >= 512)
             launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
-        else if (d.Nout >= 128 && d.Cin < 128)
+        else if (d.taps > 1 && d.Nout >= 128)
             launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{});
-        else if (d.Cin >= 128 && d.Nout < 128)
-            launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 128>{});
         else
             launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
         if (rcf) return rcf;

@@ -30,6 +30,44 @@ def _segment_of(name):
     return 0
 
 
+class FlatGradExchange:
+    """Bucketed SUM all-reduce of a flat gradient arena whose segments become final in order 0, 1, 2, ... during backward.
+    Each bucket is launched on a side stream the moment its segment is final (event dependency on the compute stream) and
+    overlaps with the rest of backward; `finish()` joins the side stream.  On CPU tensors (gloo, tests) it runs inline.
+    Four large buckets (58 / 60 / 28 / 5 MB) instead of torch-DDP's 25 MB default: xGMI ring collectives are per-link
+    latency/bandwidth bound, fewer and larger is better."""
+
+    def __init__(self, flat_g, seg_bounds):
+        self.flat_g, self.seg_bounds = flat_g, list(seg_bounds)
+        self.stream = torch.cuda.Stream() if (flat_g.is_cuda and is_dist_avail_and_initialized()) else None
+        self.launched = []
+
+    def segment_done(self, seg):
+        lo, hi = self.seg_bounds[seg], self.seg_bounds[seg + 1]
+        self.launched.append(seg)
+        if hi <= lo or get_world_size() < 2:
+            return
+        buf = self.flat_g[lo:hi]
+        if self.stream is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                dist.all_reduce(buf)
+        else:
+            dist.all_reduce(buf)
+
+    def finish(self):
+        """Reduce whatever segment was not announced (e.g. a model without the backbone hook), then join."""
+        nseg = len(self.seg_bounds) - 1
+        for seg in range(nseg):
+            if seg not in self.launched:
+                self.segment_done(seg)
+        self.launched = []
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
 class Trainer:
     def __init__(self, model, criterion, args, device=None):
         self.model, self.criterion, self.args = model, criterion, args
@@ -66,16 +104,13 @@ class Trainer:
             self.seg_bounds[_segment_of(n) + 1] = off
         for i in range(1, 5):
             self.seg_bounds[i] = max(self.seg_bounds[i], self.seg_bounds[i - 1])
-        self.lr_scale = torch.ones((), device=self.device)        # StepLR factor (device scalar: graph-replay safe)
-        self.step_t = torch.zeros((), device=self.device)
-        self.b1_t = torch.tensor(self.betas[0], device=self.device)
-        self.b2_t = torch.tensor(self.betas[1], device=self.device)
+        # device-resident optimizer scalars (graph-replay safe): [step count, StepLR factor, last grad norm, spare]
+        self.opt_state = torch.tensor([0.0, 1.0, 0.0, 0.0], device=self.device)
+        self.sumsq = torch.zeros(1, device=self.device)
         self.epoch = 0
-        self.comm_stream = None
         self._graph = None
         self._static = None
-        if is_dist_avail_and_initialized() and self.device.type == "cuda":
-            self.comm_stream = torch.cuda.Stream()
+        self.exchange = FlatGradExchange(self.flat_g, self.seg_bounds)
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
 
     @staticmethod
@@ -86,52 +121,32 @@ class Trainer:
         return chunk.view(p.shape)
 
     # ------------------------------------------------------------------ data-parallel gradient exchange
-    def _allreduce_segment(self, seg):
-        lo, hi = self.seg_bounds[seg], self.seg_bounds[seg + 1]
-        if hi <= lo:
-            return
-        buf = self.flat_g[lo:hi]
-        if self.comm_stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
-                dist.all_reduce(buf)
-        else:
-            dist.all_reduce(buf)
-
     def _segment_done(self, seg):
         """Called from the backbone's backward: `seg` (0 = everything above the backbone, 1..3 = layer4..layer2) is final."""
-        self._allreduce_segment(seg)
+        self.exchange.segment_done(seg)
 
     def _finish_allreduce(self):
-        if self.comm_stream is not None:
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
-        self.flat_g.div_(get_world_size())
+        self.exchange.finish()      # the 1/world average is folded into cdetr_adamw_step (grad_div)
 
     # ------------------------------------------------------------------ optimizer (flat clip + AdamW)
     def _optimizer_step(self):
-        g = self.flat_g
-        total_norm = torch.linalg.vector_norm(g)
-        if self.max_norm > 0:                                                        # A2/engine.py:54
-            coef = torch.clamp(self.max_norm / (total_norm + 1e-6), max=1.0)
-            g.mul_(coef)
+        """clip_grad_norm_(max_norm) + AdamW over the flat arenas: one reduction pass + one fused update pass
+        (cdetr_sumsq / cdetr_adamw_step); step count, StepLR factor and the norm stay on the device."""
+        from . import _ffi
+        n = self.flat_p.numel()
         b1, b2 = self.betas
-        self.step_t += 1
-        lr = self.lr_vec * self.lr_scale
-        self.flat_p.mul_(1 - lr * self.wd)
-        self.exp_avg.mul_(b1).add_(g, alpha=1 - b1)
-        self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
-        bc1 = 1 - torch.pow(self.b1_t, self.step_t)
-        bc2 = 1 - torch.pow(self.b2_t, self.step_t)
-        denom = (self.exp_avg_sq.sqrt() / bc2.sqrt()).add_(self.eps)
-        self.flat_p.addcdiv_(self.exp_avg * (lr / bc1), denom, value=-1.0)
-        return total_norm
+        st = _ffi.stream_ptr()
+        _ffi.check(_ffi.lib().cdetr_sumsq(self.flat_g.data_ptr(), n, self.sumsq.data_ptr(), st), "cdetr_sumsq")
+        _ffi.check(_ffi.lib().cdetr_adamw_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                               self.exp_avg_sq.data_ptr(), self.lr_vec.data_ptr(), n, self.sumsq.data_ptr(),
+                                               self.opt_state.data_ptr(), float(self.max_norm), b1, b2, self.eps, self.wd,
+                                               1.0 / get_world_size(), st), "cdetr_adamw_step")
+        return self.opt_state[2]
 
     def lr_scheduler_step(self):
         """StepLR(step=lr_drop, gamma=0.1), stepped once per epoch (A2/main.py:189,219)."""
         self.epoch += 1
-        self.lr_scale.fill_(0.1 ** (self.epoch // self.args.lr_drop))
+        self.opt_state[1] = 0.1 ** (self.epoch // self.args.lr_drop)
 
     # ------------------------------------------------------------------ one step
     def _num_boxes(self, targets):
@@ -201,7 +216,6 @@ class Trainer:
                 self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
                 if world > 1:
                     dist.all_reduce(self.flat_g)
-                    self.flat_g.div_(world)
                 self._optimizer_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
@@ -216,7 +230,6 @@ class Trainer:
                 out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
             g_b = torch.cuda.CUDAGraph()           # (capturing records work, it does not run it)
             with torch.cuda.graph(g_b, pool=g_a.pool()):
-                self.flat_g.div_(world)
                 out["grad_norm"] = self._optimizer_step()
         _bb.set_backward_hook(hook)
         self._graph, self._graph_b, self._static, self._static_out = g_a, g_b, st, out

@@ -76,6 +76,14 @@ def colsum_(X2d, out):
     check(lib().cdetr_colsum(ptr(X2d), X2d.stride(0), M, N, ptr(out), stream_ptr()), "cdetr_colsum")
 
 
+def relu_mask(y, dy, scale=1.0):
+    """dz = (y > 0) ? dy * scale : 0 in one pass."""
+    dy = dy.contiguous()
+    dz = torch.empty_like(dy)
+    check(lib().cdetr_relu_mask(ptr(y), ptr(dy), ptr(dz), dy.numel(), scale, stream_ptr()), "cdetr_relu_mask")
+    return dz
+
+
 def grad_buffer(p):
     """The in-place gradient accumulator of a parameter (the trainer pre-binds views of its flat arena)."""
     if p.grad is None:
@@ -139,10 +147,18 @@ class LinearFn(torch.autograd.Function):
         if not dy2d.is_contiguous():
             dy2d = dy2d.contiguous()
         if ctx.relu:   # y = relu((x W^T + b) * out_scale + resid): the mask applies to the residual branch too
-            dy2d = torch.where(y > 0, dy2d, torch.zeros((), device=dy.device))
-        d_resid = dy2d.reshape(dy.shape) if ctx.has_resid else None
-        if ctx.out_scale != 1.0:
-            dy2d = dy2d * ctx.out_scale
+            if ctx.has_resid:
+                dy2d = relu_mask(y, dy2d)
+                d_resid = dy2d.reshape(dy.shape)
+                if ctx.out_scale != 1.0:
+                    dy2d = dy2d * ctx.out_scale
+            else:
+                dy2d = relu_mask(y, dy2d, ctx.out_scale)
+                d_resid = None
+        else:
+            d_resid = dy2d.reshape(dy.shape) if ctx.has_resid else None
+            if ctx.out_scale != 1.0:
+                dy2d = dy2d * ctx.out_scale
         dx = None
         if ctx.needs_input_grad[0]:
             dx = linear_dgrad(dy2d, w).reshape(ctx.xshape)

@@ -205,6 +205,7 @@ class Transformer(nn.Module):
         super().__init__()
         assert num_feature_levels == 1 and attention_type == "RCDA" and dropout == 0.0 and activation == "relu"
         self.d_model, self.nhead, self.stage = d_model, nhead, stage
+        self.all_layer_heads = True     # AnchorDETR sets this to its aux_loss flag
         self.encoder_layers = nn.ModuleList(
             TransformerEncoderLayerSpatial(d_model, dim_feedforward, nhead) for _ in range(num_encoder_layers))
         self.decoder_layers = nn.ModuleList(
@@ -284,8 +285,11 @@ class Transformer(nn.Module):
 
         output = tgt
         outputs_classes, outputs_coords, outputs_vars = [], [], []
+        last = len(self.decoder_layers) - 1
         for lid, layer in enumerate(self.decoder_layers):
             output = layer(output, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean, mask_row, mask_col)
+            if not (self.all_layer_heads or lid == last):
+                continue     # the heads of layers 0..4 only feed the aux losses (the reference computes and drops them)
             outputs_class = self.cls_embed[lid](output)
             tmp = self.bbox_embed[lid](output)
             tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], dim=-1)                     # :200

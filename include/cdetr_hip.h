@@ -83,6 +83,19 @@ int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
 /* out[n] += sum_m X[m][n]   (bias gradients; atomics) */
 int cdetr_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, void* stream);
 
+/* ---- fused optimizer tail over the flat arenas (A2/engine.py:54-57 clip_grad_norm_(0.1) + torch.optim.AdamW) ------
+ * cdetr_sumsq:      out[0] = sum_i g[i]^2
+ * cdetr_adamw_step: g' = g * grad_div; coef = min(max_norm / (||g'|| + 1e-6), 1) (max_norm <= 0: no clip);
+ *                   p *= 1 - lr*wd; m = b1 m + (1-b1) g'coef; v = b2 v + (1-b2)(g'coef)^2;
+ *                   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  lr = lr[i] * state[1], t = state[0] + 1.
+ *                   state (device float[4]): [0] step count (incremented), [1] lr scale (StepLR), [2] <- ||g'|| (logging).   */
+int cdetr_sumsq(const float* g, int64_t n, float* out, void* stream);
+int cdetr_adamw_step(float* p, const float* g, float* m, float* v, const float* lr, int64_t n, const float* sumsq,
+                     float* state, float max_norm, float beta1, float beta2, float eps, float weight_decay, float grad_div,
+                     void* stream);
+/* dz[i] = y[i] > 0 ? dy[i] * scale : 0      (ReLU backward of the fused linear+ReLU layers) */
+int cdetr_relu_mask(const float* y, const float* dy, float* dz, int64_t n, float scale, void* stream);
+
 /* 3x3 stride-2 pad-1 max pooling, NHWC (A2/models/resnet.py:206,265) */
 int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream);
 
