@@ -13,6 +13,7 @@
 //                    (A2/models/matcher.py:243) so the whole train step stays on the device and is graph-capturable.
 #include "../../include/cdetr_hip.h"
 #include "common.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -227,6 +228,154 @@ __global__ __launch_bounds__(NT) void lsap_kernel(const float* __restrict__ cost
     if (tid == 0) status[b] = 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ single-wave solver
+// Same algorithm, tie rule and scan order as lsap_kernel, organised for latency: ONE wavefront per image, no barriers.
+// Lane l owns columns l, l+64, ... (<= CPL per lane): their dual v, shortest-path cost, predecessor and position in
+// scipy's `remaining` list live in REGISTERS; rows' duals / assignments, row4col, `remaining` and -- when it fits -- the
+// whole fp32 cost matrix live in LDS.  One inner iteration = CPL fused updates per lane + a 6-step shuffle arg-min.
+// The SR/SC bookkeeping of the reference algorithm collapses to a per-lane bit mask: the visited rows (other than the
+// current one) are exactly row4col[j] of the visited non-sink columns.
+template <int CPL, bool COST_LDS>
+__global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__ cost_all, const int64_t* __restrict__ cost_off,
+                                                       const int* __restrict__ tgt_off, int Q, int Mmax,
+                                                       int64_t* __restrict__ idx_i, int64_t* __restrict__ idx_j,
+                                                       int* __restrict__ status) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int b = blockIdx.x;
+    const int T = tgt_off[b + 1] - tgt_off[b];
+    const bool transpose = T < Q;
+    const int nr = transpose ? T : Q;
+    const int nc = transpose ? Q : T;
+    const float* cost_g = cost_all + cost_off[b];
+    const int lane = threadIdx.x;
+    int64_t* oi = idx_i + (long)b * Mmax;
+    int64_t* oj = idx_j + (long)b * Mmax;
+    if (nr == 0) { if (lane == 0) status[b] = 0; return; }
+
+    // LDS carve: u[nr] f64 | col4row[nr] | row4col[nc] | remaining[nc] | path[nc] | cost[nr*nc] f32 (optional)
+    double* u = reinterpret_cast<double*>(lds);
+    int* col4row = reinterpret_cast<int*>(u + nr);
+    int* row4col = col4row + nr;
+    int* remaining = row4col + nc;
+    int* pathl = remaining + nc;
+    float* cost_l = reinterpret_cast<float*>(pathl + nc);
+    const float* cost = COST_LDS ? cost_l : cost_g;
+
+    int bad = 0;
+    for (long k = lane; k < (long)nr * nc; k += 64) {
+        const float c = cost_g[k];
+        if (c != c || c == -INFINITY) bad = 1;
+        if (COST_LDS) cost_l[k] = c;
+    }
+    if (__any(bad)) { if (lane == 0) status[b] = 2; return; }
+    for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = lane; j < nc; j += 64) row4col[j] = -1;
+
+    double v[CPL], spc[CPL];
+    int path[CPL], pos[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; path[c] = -1; }
+
+    for (int cur = 0; cur < nr; ++cur) {
+        unsigned sc = 0;                       // visited-column mask of this lane
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) { spc[c] = INFINITY; pos[c] = nc - 1 - (lane + 64 * c); }
+        for (int it = lane; it < nc; it += 64) remaining[it] = nc - 1 - it;
+        int i = cur, num_remaining = nc, sink = -1;
+        double min_val = 0.0;
+        while (true) {
+            const double ui = u[i];
+            const float* crow = cost + (long)i * nc;
+            Cand best;
+            best.val = INFINITY; best.it = -1; best.unassigned = 0;
+            int best_j = -1;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const int j = lane + 64 * c;
+                if (j < nc && !((sc >> c) & 1u)) {
+                    const double r = ((min_val + (double)crow[j]) - ui) - v[c];
+                    if (r < spc[c]) { path[c] = i; spc[c] = r; }
+                    Cand cd;
+                    cd.val = spc[c]; cd.it = pos[c]; cd.unassigned = (row4col[j] == -1);
+                    const Cand nb = better(best, cd);
+                    if (nb.it != best.it) best_j = j;
+                    best = nb;
+                }
+            }
+#pragma unroll
+            for (int m = 32; m > 0; m >>= 1) {
+                const Cand o = shfl_xor_cand(best, m);
+                const int oj2 = __shfl_xor(best_j, m, 64);
+                const Cand nb = better(best, o);
+                if (nb.it != best.it) best_j = oj2;
+                best = nb;
+            }
+            if (best.it < 0 || best.val == INFINITY) { sink = -2; break; }
+            min_val = best.val;
+            const int jstar = best_j;
+            // visited-column bit on the owner lane
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (lane + 64 * c == jstar) sc |= (1u << c);
+            // swap-removal from `remaining` (position best.it), keeping every column's position in registers
+            const int last = num_remaining - 1;
+            const int jlast = remaining[last];
+            if (lane == 0) remaining[best.it] = jlast;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c)
+                if (lane + 64 * c == jlast) pos[c] = best.it;
+            num_remaining = last;
+            const int owner_row = row4col[jstar];
+            if (owner_row == -1) { sink = jstar; break; }
+            i = owner_row;
+        }
+        if (sink == -2) { if (lane == 0) status[b] = 1; return; }
+        // ---- dual update: rows visited (other than cur) = row4col[j] of the visited non-sink columns
+        if (lane == 0) u[cur] += min_val;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = lane + 64 * c;
+            if ((sc >> c) & 1u) {
+                const double delta = min_val - spc[c];
+                v[c] -= delta;
+                if (j != sink) u[row4col[j]] += delta;
+            }
+            if (j < nc) pathl[j] = path[c];
+        }
+        // ---- augment (short sequential walk)
+        if (lane == 0) {
+            int j = sink;
+            while (true) {
+                const int ii = pathl[j];
+                row4col[j] = ii;
+                const int t = col4row[ii];
+                col4row[ii] = j;
+                j = t;
+                if (ii == cur) break;
+            }
+        }
+    }
+    // ---- (query, target) pairs with ascending query index
+    if (!transpose) {
+        for (int i = lane; i < nr; i += 64) { oi[i] = i; oj[i] = col4row[i]; }
+    } else {
+        int base = 0;
+        for (int j0 = 0; j0 < nc; j0 += 64) {
+            const int j = j0 + lane;
+            const int r = (j < nc) ? row4col[j] : -1;
+            const unsigned long long m = __ballot(r != -1);
+            if (r != -1) {
+                const int rank = base + __popcll(m & ((1ull << lane) - 1ull));
+                oi[rank] = j;
+                oj[rank] = r;
+            }
+            base += __popcll(m);
+        }
+    }
+    if (lane == 0) status[b] = 0;
+}
+
 inline size_t lds_bytes(int nc_cap) { return (size_t)nc_cap * (3 * 8 + 4 * 4 + 2) + 16; }
 inline int round_cap(int nc) { return (nc + 15) & ~15; }
 
@@ -253,6 +402,20 @@ extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int3
         return CDETR_ERR_UNSUPPORTED;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (nc_max <= 1024 && getenv("CDETR_LSAP_GENERIC") == nullptr) {
+        // single-wave register-resident solver; nr <= Mmax rows, nc <= nc_max columns
+        const size_t state = (size_t)Mmax * 12 + (size_t)nc_max * 12 + 64;
+        const size_t with_cost = state + (size_t)Mmax * nc_max * 4;
+        const bool cost_lds = with_cost <= 156 * 1024;
+        const size_t wb = cost_lds ? with_cost : state;
+        auto go = [&](auto kern) {
+            if (wb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wb);
+            hipLaunchKernelGGL(kern, dim3(B), dim3(64), wb, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status);
+        };
+        if (nc_max <= 512) { if (cost_lds) go(lsap_wave_kernel<8, true>); else go(lsap_wave_kernel<8, false>); }
+        else { if (cost_lds) go(lsap_wave_kernel<16, true>); else go(lsap_wave_kernel<16, false>); }
+        return cdetr_launch_status("cdetr_lsap");
+    }
     if (nc_max <= 1024) {
         if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         hipLaunchKernelGGL(lsap_kernel<64>, dim3(B), dim3(64), bytes, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status, cap);

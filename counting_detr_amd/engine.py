@@ -143,6 +143,19 @@ class Trainer:
                                                1.0 / get_world_size(), st), "cdetr_adamw_step")
         return self.opt_state[2]
 
+    def state_dict(self):
+        """Optimizer state in a self-describing form (flat moments + names/offsets) for the checkpoint's "optimizer" key."""
+        sizes = [dict(self.model.named_parameters())[n].numel() for n in self.names]
+        return {"names": self.names, "sizes": sizes, "exp_avg": self.exp_avg.detach().cpu(),
+                "exp_avg_sq": self.exp_avg_sq.detach().cpu(), "state": self.opt_state.detach().cpu(), "epoch": self.epoch}
+
+    def load_state_dict(self, sd):
+        assert sd["names"] == self.names, "optimizer state does not match this model's parameter layout"
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.opt_state.copy_(sd["state"])
+        self.epoch = int(sd["epoch"])
+
     def lr_scheduler_step(self):
         """StepLR(step=lr_drop, gamma=0.1), stepped once per epoch (A2/main.py:189,219)."""
         self.epoch += 1

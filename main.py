@@ -1,0 +1,103 @@
+"""main.py -- CLI of the reference's 2nd-stage trainer (A2/main.py:17-258) on the MI355X path.
+
+Same flags, same driver behaviour: build_model -> 3 lr groups / AdamW / StepLR(lr_drop) -> optional --resume (model
+weights only, keys filtered like A2/main.py:195-209) -> per epoch train_one_epoch, scheduler step, checkpoint
+{"model","optimizer","lr_scheduler","epoch","args"} to <output_dir>/detr_retrain.pth (+ numbered copies), JSON log line.
+Differences: any number of images per GPU (--images_per_gpu), data-parallel over the GPUs of a node under torchrun
+(RCCL), and --synthetic (seeded tensors; FSC-147 is not available in this environment -- with a dataset, pass a
+DataLoader yielding the reference's sample dicts to `train_one_epoch`).
+
+  python main.py --synthetic --no_aux_loss --num_query_pattern 1 --epochs 1 -o /tmp/out
+  python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 main.py --synthetic --no_aux_loss ...
+"""
+import json
+import os
+import time
+from pathlib import Path
+
+import torch
+
+import counting_detr_amd
+from counting_detr_amd import misc as utils
+from counting_detr_amd.args import get_args_parser
+from counting_detr_amd.engine import Trainer, count_objects, counting_metrics, train_one_epoch
+
+
+class SyntheticLoader:
+    """Seeded stand-in for FSC147Dataset + DataLoader: yields the step's sample dict (images already on the device)."""
+
+    def __init__(self, args, device, steps, size=(800, 800), targets=(37, 120)):
+        self.args, self.device, self.steps, self.size, self.targets = args, device, steps, size, targets
+
+    def __iter__(self):
+        B = self.args.images_per_gpu
+        H, W = self.size
+        rects = torch.tensor([[.10, .10, .20, .20], [.40, .40, .50, .55], [.70, .20, .80, .30]], device=self.device)
+        for it in range(self.steps):
+            g = torch.Generator().manual_seed(1000003 * utils.get_rank() + it)
+            tg = []
+            for b in range(B):
+                T = self.targets[b % len(self.targets)]
+                box = torch.cat([torch.rand(T, 2, generator=g) * 0.8 + 0.1, torch.rand(T, 2, generator=g) * 0.10 + 0.02], 1)
+                tg.append({"boxes": box.to(self.device), "labels": torch.zeros(T, dtype=torch.int64, device=self.device)})
+            yield {"image": torch.randn(B, 3, H, W, generator=g).to(self.device), "ex_rects": rects[None].repeat(B, 1, 1),
+                   "targets": tg}
+
+    def __len__(self):
+        return self.steps
+
+
+def main(args):
+    utils.init_distributed_mode(args)
+    os.makedirs(args.output_dir, exist_ok=True)
+    device = torch.device(args.device if not getattr(args, "distributed", False) else f"cuda:{args.gpu}")
+    torch.manual_seed(args.seed + utils.get_rank())
+    model, criterion, _ = counting_detr_amd.build_model(args)
+    model.to(device)
+
+    if args.resume:                                                     # A2/main.py:195-209
+        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
+        sd = model.state_dict()
+        pretrained = {k: v for k, v in checkpoint["model"].items() if k in sd and "transformer.pattern." not in k}
+        missing, unexpected = model.load_state_dict(pretrained, strict=False)
+        if missing:
+            print("Missing Keys: {}".format(missing))
+        if unexpected:
+            print("Unexpected Keys: {}".format(unexpected))
+
+    trainer = Trainer(model, criterion, args, device=device)           # 3 lr groups + flat AdamW (A2/main.py:157-189)
+    if not args.synthetic:
+        raise SystemExit("no dataset reader in this build (FSC-147 I/O is out of scope, SURVEY.md 8f): use --synthetic, or "
+                         "drive counting_detr_amd.engine.train_one_epoch with your own DataLoader")
+    loader = SyntheticLoader(args, device, args.steps_per_epoch)
+    print("Start training")
+    start = time.time()
+    output_dir = Path(args.output_dir)
+    for epoch in range(args.start_epoch, args.epochs):
+        stats = train_one_epoch(trainer, loader, epoch, print_freq=10)
+        trainer.lr_scheduler_step()
+        paths = [output_dir / "detr_retrain.pth"]
+        if (epoch + 1) % args.lr_drop == 0 or (epoch + 1) % 10 == 0:
+            paths.append(output_dir / f"detr_retrain_{epoch:04}.pth")
+        for p in paths:
+            utils.save_on_master({"model": model.state_dict(), "optimizer": trainer.state_dict(),
+                                  "lr_scheduler": {"last_epoch": trainer.epoch, "step_size": args.lr_drop, "gamma": 0.1},
+                                  "epoch": epoch, "args": args}, p)
+        if utils.is_main_process():
+            with (output_dir / "detr_retrain.txt").open("a") as f:
+                f.write(json.dumps({**{f"train_{k}": v for k, v in stats.items()}, "epoch": epoch}) + "\n")
+    print("time: ", time.time() - start)
+    if args.eval:                                                       # counting rule + MAE on the synthetic shard
+        pred, gt = [], []
+        for ret in SyntheticLoader(args, device, 2):
+            counts, _, _, _ = count_objects(model, ret["image"], ret["ex_rects"])
+            pred += [int(c) for c in counts]
+            gt += [len(t["boxes"]) for t in ret["targets"]]
+        print("counting metrics (synthetic):", counting_metrics(pred, gt))
+
+
+if __name__ == "__main__":
+    a = get_args_parser().parse_args()
+    if a.output_dir:
+        Path(a.output_dir).mkdir(parents=True, exist_ok=True)
+    main(a)
