@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense bf16 MFMA; the split-bf16 mode spends 3 bf16 MFMAs per algorithmic product
+PRECISIONS = {"bf16x3": 1, "fp32": 0}
 STEP_GFLOP_PER_IMAGE = 616.0         # 800x800, Q=300, reduced form (mean-before-project keys)
 
 
@@ -74,6 +76,9 @@ def main():
     ap.add_argument("--queries", type=int, default=300)
     ap.add_argument("--no-graph", action="store_true", help="eager step (bucketed all-reduce overlapped with backward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=list(PRECISIONS), default="bf16x3",
+                    help="matrix-core arithmetic of the GEMM kernels: split-bf16 x3 (default, ~5e-6 rel) or fp32 MFMA (exact products)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other precision mode")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -94,6 +99,7 @@ def main():
     from counting_detr_amd.engine import Trainer
     from oracle.weights import model_schema, seeded_state_dict   # name-seeded random init (test infra used as an initialiser only)
 
+    ops.PRECISION = PRECISIONS[a.precision]
     H, W = a.size
     Ts = (37, 120)
     args = default_args(device=str(dev), num_query_position=a.queries)
@@ -164,20 +170,39 @@ def main():
                 "gflop_per_step": v[0] / reps / 1e9} for k, v in fam.items() if v[1] > 0}
     ig = fam.get("igemm", [0.0, 1.0, 1])
     achieved = ig[0] / ig[1] / 1e12
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                "kernel": "igemm_kernel<BM,BN,BL> (conv fwd / dgrad / linear; fp32 MFMA 32x32x2)",
+    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None,
+                "peak_note": ("fp32 MFMA v_mfma_f32_32x32x2_f32" if a.precision == "fp32" else
+                              "2500 TF dense bf16 MFMA / 3 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi)"),
+                "kernel": "igemm_fast_kernel (conv fwd / dgrad / linear) -- algorithmic FLOPs 2*M*N*K*taps per launch",
                 "avg_launch_us": ig[1] / max(ig[2], 1) * 1e6, "families": kern,
                 "whole_step_tflops": STEP_GFLOP_PER_IMAGE * a.batch / ms_per_step if (H, W, a.queries) == (800, 800, 300) else None}
 
     res = {"metric": "images/sec FSCD-147 2nd-stage train step", "value": value, "unit": "images/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "fp32", "data": "synthetic",
+           "vs_baseline": None, "dtype": ("fp32" if a.precision == "fp32" else "bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"),
+           "data": "synthetic",
            "config": {"workload": f"FSCD-147 2nd-stage train step (ResNet-50-DC5 + RCDA enc6/dec6, Q={a.queries} learned, "
                                   f"{H}x{W}, T={list(Ts)}), fwd+matcher+loss+bwd+clip+AdamW",
                       "images_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                      "graph": not a.no_graph, "final_loss": loss},
+                      "graph": not a.no_graph, "precision": a.precision, "final_loss": loss},
            "roofline": roofline}
+    if world == 1 and not a.no_alt and not a.no_graph:
+        # the same step in the other arithmetic mode (short run), for transparency
+        alt = "fp32" if a.precision != "fp32" else "bf16x3"
+        ops.PRECISION = PRECISIONS[alt]
+        trainer.capture(images, rects, targets, warmup=1)
+        for _ in range(2):
+            trainer.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            trainer.replay()
+        torch.cuda.synchronize()
+        dta = (time.perf_counter() - t1) / 5
+        res["alt_precision"] = {"precision": alt, "value": a.batch / dta, "unit": "images/s", "ms_per_step": dta * 1e3, "steps": 5}
+        ops.PRECISION = PRECISIONS[a.precision]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.batch, H, W, Ts)
     if rank == 0:

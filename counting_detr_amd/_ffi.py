@@ -22,7 +22,7 @@ class ConvGeom(C.Structure):
 
 class GemmDesc(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("taps", C.c_int32), ("batch", C.c_int32),
-                ("b_layout", C.c_int32), ("relu", C.c_int32), ("out_scale", C.c_float),
+                ("b_layout", C.c_int32), ("relu", C.c_int32), ("precision", C.c_int32), ("out_scale", C.c_float),
                 ("A", _p), ("lda", C.c_int64), ("sA", C.c_int64),
                 ("B", _p), ("ldb", C.c_int64), ("sB", C.c_int64),
                 ("C", _p), ("ldc", C.c_int64), ("sC", C.c_int64),
@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
 
 
 class WgradDesc(C.Structure):
-    _fields_ = [("P", C.c_int32), ("Nout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("batch", C.c_int32),
+    _fields_ = [("P", C.c_int32), ("Nout", C.c_int32), ("Cin", C.c_int32), ("taps", C.c_int32), ("batch", C.c_int32), ("precision", C.c_int32),
                 ("dY", _p), ("ldy", C.c_int64), ("sY", C.c_int64),
                 ("X", _p), ("ldx", C.c_int64), ("sX", C.c_int64),
                 ("dW", _p), ("ldw", C.c_int64), ("sW", C.c_int64),

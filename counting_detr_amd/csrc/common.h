@@ -5,6 +5,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define CDETR_OK 0
 #define CDETR_ERR_ARG (-1)
@@ -49,6 +50,23 @@ template <int NF>
 __device__ __forceinline__ void mfma_drain(f32x16 (&acc)[NF]) {
 #pragma unroll
     for (int a = 0; a < NF; ++a) mfma_drain(acc[a]);
+}
+
+// split-bf16 ("bf16x3") operand preparation: x = hi + lo + O(2^-18 |x|) with hi = bf16(x), lo = bf16(x - hi); a product
+// a*b is then evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (fp32 accumulate), relative error <= ~1e-5.
+__device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const __bf16 h = (__bf16)x[i];
+        hi[i] = h;
+        lo[i] = (__bf16)(x[i] - (float)h);
+    }
+}
+__device__ __forceinline__ f32x16 mfma_bf16x3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    return acc;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -438,26 +438,33 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 
 // ------------------------------------------------------------------------------------------------ fast forward / dgrad
 // Same math as igemm_kernel, for the common case K % 32 == 0 with 16-byte aligned operands (every heavy layer):
-//   * BK = 32, so a k-tile never straddles a filter tap: the tap is wave-uniform, its gather is resolved once per tap
-//     into per-thread row pointers and the steady-state loop has no integer division at all;
-//   * twice the MFMA work per barrier (16 / 32 / 64 MFMAs per wave per tile for 64x64 / 128x64 / 128x128).
-template <int BM, int BN, int BL, int BKF>
-__global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
+//   * a k-tile never straddles a filter tap: the tap is wave-uniform, its gather is resolved once per tap into
+//     per-thread row pointers and the steady-state loop has no integer division at all;
+//   * workgroup = WM x WN waves, each wave FM x FN fragments of 32x32 (tile BM = 32*FM*WM, BN = 32*FN*WN):
+//     64x64 (2x2 waves), 32x64 (1x2 waves, 128 threads: finer granularity against tail quantisation on 256 CUs),
+//     128x64 / 128x128 (2x2 waves, 2x1 / 2x2 fragments);
+//   * TWO k-tiles of global loads in flight: tile t+2 is issued before tile t is computed and is written to LDS one
+//     iteration later, so a load has two tile-times (>= 2048 matrix-pipe cycles) to land (ablation in tools/gemm_sweep.py:
+//     with a single tile in flight ~27 % of the kernel was exposed load latency).
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3; ABL: ablation builds
+__global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
+    constexpr int NT = 64 * WM * WN;
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
     constexpr int F4R = BKF / 4;             // float4 per k-row (8 or 16)
-    constexpr int RPP = 256 / F4R;           // rows covered by one pass of the 256 threads (32 or 16)
-    constexpr int FM = BM / 64, FN = BN / 64;
-    constexpr int A_SLOTS = BM / RPP, B_SLOTS = (BL == 0) ? BN / RPP : BKF * BN / 1024;
+    constexpr int RPP = NT / F4R;            // rows covered by one pass of the workgroup's threads
+    constexpr int A_SLOTS = BM / RPP, B_SLOTS = (BL == 0) ? BN / RPP : BKF * BN / (4 * NT);
     constexpr int LDN = BN + 4;
     constexpr int A_TILE = BM * LDK;
     constexpr int B_TILE = (BL == 0) ? BN * LDK : BKF * LDN;
+    static_assert(BM % RPP == 0 && (BL != 0 || BN % RPP == 0) && (BKF * BN) % (4 * NT) == 0, "tile / thread mapping");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * A_TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;
+    const int wm = wid / WN, wn = wid % WN;
     const int i32 = lane & 31, g = lane >> 5;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (private 4 MiB L2 each).  XCD x owns a contiguous band of
     // row-tiles and sweeps all column-tiles of a row-tile before moving on, so the A row-panel of a tile is fetched
@@ -487,7 +494,6 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d
             ap[i] = (row >= 0) ? A + row * d.lda + kq * 4 : nullptr;
         }
     };
-    // B operand pointers
     const float* bp[B_SLOTS];
     float bscale0[B_SLOTS];
     if (BL == 0) {
@@ -498,10 +504,10 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d
             bscale0[i] = (d.w_scale && n < d.N) ? d.w_scale[n] : 1.f;
         }
     }
-    float4 ra[A_SLOTS], rb[B_SLOTS];
-    auto fetch = [&](int tap, int kc) {
+    float4 ra[2][A_SLOTS], rb[2][B_SLOTS];     // two register sets: tiles t+1 and t+2 in flight
+    auto fetch = [&](float4 (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], int tap, int kc) {
 #pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) ra[i] = ap[i] ? ld4(ap[i] + kc) : zero4();
+        for (int i = 0; i < A_SLOTS; ++i) qa[i] = ap[i] ? ld4(ap[i] + kc) : zero4();
         if (BL == 0) {
             const int koff = tap * K + kc;
 #pragma unroll
@@ -509,12 +515,12 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d
                 float4 v = bp[i] ? ld4(bp[i] + koff) : zero4();
                 const float s = bscale0[i];
                 v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-                rb[i] = v;
+                qb[i] = v;
             }
         } else {
 #pragma unroll
             for (int i = 0; i < B_SLOTS; ++i) {
-                const int idx = tid + 256 * i;
+                const int idx = tid + NT * i;
                 const int kr = idx / (BN / 4);
                 const int nq = idx - kr * (BN / 4);
                 const int n = n0 + nq * 4;
@@ -527,25 +533,25 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d
                         v.x *= s; v.y *= s; v.z *= s; v.w *= s;
                     }
                 }
-                rb[i] = v;
+                qb[i] = v;
             }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](const float4 (&qa)[A_SLOTS], const float4 (&qb)[B_SLOTS], int buf) {
         float* as = As + buf * A_TILE;
         float* bs = Bs + buf * B_TILE;
 #pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = ra[i];
+        for (int i = 0; i < A_SLOTS; ++i) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = qa[i];
         if (BL == 0) {
 #pragma unroll
-            for (int i = 0; i < B_SLOTS; ++i) *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = rb[i];
+            for (int i = 0; i < B_SLOTS; ++i) *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = qb[i];
         } else {
 #pragma unroll
             for (int i = 0; i < B_SLOTS; ++i) {
-                const int idx = tid + 256 * i;
+                const int idx = tid + NT * i;
                 const int kr = idx / (BN / 4);
                 const int nq = idx - kr * (BN / 4);
-                *reinterpret_cast<float4*>(bs + kr * LDN + nq * 4) = rb[i];
+                *reinterpret_cast<float4*>(bs + kr * LDN + nq * 4) = qb[i];
             }
         }
     };
@@ -558,49 +564,97 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    int f_tap = 0, f_kc = 0;
-    set_tap(0);
-    fetch(0, 0);
-    stash(0);
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) {
-            f_kc += BKF;
-            if (f_kc == K) { f_kc = 0; ++f_tap; set_tap(f_tap); }
-            fetch(f_tap, f_kc);
-        }
-        const float* as = As + buf * A_TILE + (wm * (BM / 2) + i32) * LDK + g * 4;
-        const float* bs = (BL == 0) ? Bs + buf * B_TILE + (wn * (BN / 2) + i32) * LDK + g * 4
-                                    : Bs + buf * B_TILE + (g * 4) * LDN + wn * (BN / 2) + i32;
+    auto compute = [&](int buf) {
+        const float* as = As + buf * A_TILE + (wm * (32 * FM) + i32) * LDK + g * 4;
+        const float* bs = (BL == 0) ? Bs + buf * B_TILE + (wn * (32 * FN) + i32) * LDK + g * 4
+                                    : Bs + buf * B_TILE + (g * 4) * LDN + wn * (32 * FN) + i32;
+        if (PREC == 0) {
 #pragma unroll
-        for (int h = 0; h < BKF / 8; ++h) {
-            float a4[FM][4], b4[FN][4];
+            for (int h = 0; h < BKF / 8; ++h) {
+                float a4[FM][4], b4[FN][4];
 #pragma unroll
-            for (int a = 0; a < FM; ++a) {
-                const float4 t = *reinterpret_cast<const float4*>(as + a * 32 * LDK + h * 8);
-                a4[a][0] = t.x; a4[a][1] = t.y; a4[a][2] = t.z; a4[a][3] = t.w;
-            }
-#pragma unroll
-            for (int b = 0; b < FN; ++b) {
-                if (BL == 0) {
-                    const float4 t = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + h * 8);
-                    b4[b][0] = t.x; b4[b][1] = t.y; b4[b][2] = t.z; b4[b][3] = t.w;
-                } else {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) b4[b][s] = bs[(h * 8 + s) * LDN + b * 32];
+                for (int a = 0; a < FM; ++a) {
+                    const float4 t = *reinterpret_cast<const float4*>(as + a * 32 * LDK + h * 8);
+                    a4[a][0] = t.x; a4[a][1] = t.y; a4[a][2] = t.z; a4[a][3] = t.w;
                 }
-            }
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int b = 0; b < FN; ++b) {
+                    if (BL == 0) {
+                        const float4 t = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + h * 8);
+                        b4[b][0] = t.x; b4[b][1] = t.y; b4[b][2] = t.z; b4[b][3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) b4[b][s] = bs[(h * 8 + s) * LDN + b * 32];
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int a = 0; a < FM; ++a)
+#pragma unroll
+                        for (int b = 0; b < FN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[a][s], b4[b][s], acc[a][b], 0, 0, 0);
+            }
+        } else {
+            // split-bf16: 16 k per step; lane group g supplies k = 16hp + {4g..4g+3, 8+4g..8+4g+3} for A and B alike
+#pragma unroll
+            for (int hp = 0; hp < BKF / 16; ++hp) {
+                bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+                for (int a = 0; a < FM; ++a) {
+                    const float4 t0 = *reinterpret_cast<const float4*>(as + a * 32 * LDK + hp * 16);
+                    const float4 t1 = *reinterpret_cast<const float4*>(as + a * 32 * LDK + hp * 16 + 8);
+                    const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                    split_bf16x8(x, ah[a], al[a]);
+                }
+#pragma unroll
+                for (int b = 0; b < FN; ++b) {
+                    float x[8];
+                    if (BL == 0) {
+                        const float4 t0 = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + hp * 16);
+                        const float4 t1 = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + hp * 16 + 8);
+                        x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            x[s] = bs[(hp * 16 + s) * LDN + b * 32];
+                            x[4 + s] = bs[(hp * 16 + 8 + s) * LDN + b * 32];
+                        }
+                    }
+                    split_bf16x8(x, bh[b], bl[b]);
+                }
 #pragma unroll
                 for (int a = 0; a < FM; ++a)
 #pragma unroll
-                    for (int b = 0; b < FN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[a][s], b4[b][s], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+            }
         }
-        if (kt + 1 < nkt) stash(buf ^ 1);
-        __syncthreads();
+    };
+
+    // ---- software pipeline: LDS[t & 1] holds tile t, register set (t+1) & 1 holds tile t+1, tile t+2 is being issued
+    int f_tap = 0, f_kc = 0;       // coordinates of the most recently issued tile
+    auto advance = [&]() {
+        f_kc += BKF;
+        if (f_kc == K) { f_kc = 0; ++f_tap; set_tap(f_tap); }
+    };
+    set_tap(0);
+    fetch(ra[0], rb[0], 0, 0);
+    if (nkt > 1) { advance(); fetch(ra[1], rb[1], f_tap, f_kc); }
+    stash(ra[0], rb[0], 0);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+        // even step: tile kt in LDS[0]; tile kt+1 in set 1; issue tile kt+2 into set 0
+        if (ABL == 0 && kt + 2 < nkt) { advance(); fetch(ra[0], rb[0], f_tap, f_kc); }
+        compute(0);
+        if (kt + 1 < nkt) {
+            if (ABL == 0) stash(ra[1], rb[1], 1);
+            if (ABL != 2) __syncthreads();
+            // odd step: tile kt+1 in LDS[1]; tile kt+2 in set 0; issue tile kt+3 into set 1
+            if (ABL == 0 && kt + 3 < nkt) { advance(); fetch(ra[1], rb[1], f_tap, f_kc); }
+            compute(ABL == 0 ? 1 : 0);
+            if (ABL == 0 && kt + 2 < nkt) stash(ra[0], rb[0], 0);
+        }
+        if (ABL != 2) __syncthreads();
     }
     mfma_drain(acc);
 
@@ -608,12 +662,12 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d
     for (int a = 0; a < FM; ++a) {
 #pragma unroll
         for (int b = 0; b < FN; ++b) {
-            const int n = n0 + wn * (BN / 2) + b * 32 + i32;
+            const int n = n0 + wn * (32 * FN) + b * 32 + i32;
             if (n >= d.N) continue;
             const float bias = d.bias ? d.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                const int m = m0 + wm * (32 * FM) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 if (m >= d.M) continue;
                 float v = (acc[a][b][r] + bias) * d.out_scale;
                 if (d.resid) v += d.resid[(long)m * d.ldr + n];
@@ -629,7 +683,7 @@ __global__ __launch_bounds__(256) void igemm_fast_kernel(const cdetr_gemm_desc d
 // dW[i][tap][c] += scale[i] * sum_p dY[p][i] * X[row(p,tap)][c]  (+ optional dbias[i] += sum_p dY[p][i]).
 // BK = 32 pixels per tile; every thread owns ONE pixel row of the tile (8 threads x 16 B per 128-byte run), so the
 // pixel -> (n, y, x) coordinates are advanced incrementally (no division) and the tap gather costs a few integer ops.
-template <int BI, int BJ>
+template <int BI, int BJ, int PREC>
 __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
                                                          const int kt_per_slice, float* __restrict__ dbias) {
     constexpr int BKF = 32;
@@ -733,20 +787,51 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
         if (kt + 1 < kt_end) fetch();
         const float* as = As + buf * BKF * LDI + (g * 4) * LDI + wm * (BI / 2) + i32;
         const float* bs = Bs + buf * BKF * LDJ + (g * 4) * LDJ + wn * (BJ / 2) + i32;
+        if (PREC == 0) {
 #pragma unroll
-        for (int h = 0; h < 4; ++h) {
+            for (int h = 0; h < 4; ++h) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                float av[FM], bv[FN];
+                for (int s = 0; s < 4; ++s) {
+                    float av[FM], bv[FN];
 #pragma unroll
-                for (int a = 0; a < FM; ++a) av[a] = as[(h * 8 + s) * LDI + a * 32];
+                    for (int a = 0; a < FM; ++a) av[a] = as[(h * 8 + s) * LDI + a * 32];
 #pragma unroll
-                for (int b = 0; b < FN; ++b) bv[b] = bs[(h * 8 + s) * LDJ + b * 32];
+                    for (int b = 0; b < FN; ++b) bv[b] = bs[(h * 8 + s) * LDJ + b * 32];
+#pragma unroll
+                    for (int a = 0; a < FM; ++a)
+#pragma unroll
+                        for (int b = 0; b < FN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+                bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+                for (int a = 0; a < FM; ++a) {
+                    float x[8];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        x[s] = as[(hp * 16 + s) * LDI + a * 32];
+                        x[4 + s] = as[(hp * 16 + 8 + s) * LDI + a * 32];
+                    }
+                    split_bf16x8(x, ah[a], al[a]);
+                }
+#pragma unroll
+                for (int b = 0; b < FN; ++b) {
+                    float x[8];
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        x[s] = bs[(hp * 16 + s) * LDJ + b * 32];
+                        x[4 + s] = bs[(hp * 16 + 8 + s) * LDJ + b * 32];
+                    }
+                    split_bf16x8(x, bh[b], bl[b]);
+                }
 #pragma unroll
                 for (int a = 0; a < FM; ++a)
 #pragma unroll
-                    for (int b = 0; b < FN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
             }
         }
         if (kt + 1 < kt_end) stash(buf ^ 1);
@@ -794,10 +879,9 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
 // per-head dq/dk of RCDA): one wave = one 16x16 output tile on v_mfma_f32_16x16x4_f32, operands loaded straight from
 // global/L2 in the MFMA register layout -- no LDS, no barrier, every wave independent, so a 600x256x256 GEMM runs as
 // 608 concurrent waves of 64 MFMAs instead of 40 workgroups stepping through 8 barrier-separated k-tiles.
-template <int BL>
+template <int BL, int UB>   // UB = 16-wide k-chunks whose loads are issued back-to-back before the first MFMA consumes one
 __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN,
                                                            const int vecA, const int vecB) {
-    constexpr int UB = 8;   // 16-wide k-chunks whose loads are issued back-to-back before the first MFMA consumes one
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + wid;
     if (tile >= tilesM * tilesN) return;
@@ -1002,21 +1086,28 @@ int raise_lds(F func, int bytes, const char* what) {
     return CDETR_OK;
 }
 
-template <int BM, int BN, int BKF>
-int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
+template <int WM, int WN, int FM, int FN, int BKF, int PREC, int ABL = 0>
+int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
+    constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN, 1, d.batch), block(256);      // 8 XCD bands (see the kernel)
+    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN, 1, d.batch), block(64 * WM * WN);      // 8 XCD bands (see the kernel)
     int rc;
     if (d.b_layout == 0) {
         const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
-        if ((rc = raise_lds(igemm_fast_kernel<BM, BN, 0, BKF>, bytes, "cdetr_gemm"))) return rc;
-        hipLaunchKernelGGL((igemm_fast_kernel<BM, BN, 0, BKF>), grid, block, bytes, st, d, tilesM);
+        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>), grid, block, bytes, st, d, tilesM);
     } else {
         const int bytes = (2 * BM * (BKF + 4) + 2 * BKF * (BN + 4)) * 4;
-        if ((rc = raise_lds(igemm_fast_kernel<BM, BN, 1, BKF>, bytes, "cdetr_gemm"))) return rc;
-        hipLaunchKernelGGL((igemm_fast_kernel<BM, BN, 1, BKF>), grid, block, bytes, st, d, tilesM);
+        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC, ABL>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC, ABL>), grid, block, bytes, st, d, tilesM);
     }
     return cdetr_launch_status("cdetr_gemm");
+}
+
+template <int WM, int WN, int FM, int FN, int BKF, int ABL = 0>
+int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
+    if (ABL == 0 && d.precision == 1) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 1, 0>(d, st);
+    return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 0, ABL>(d, st);
 }
 
 }  // namespace
@@ -1051,11 +1142,15 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     const char* force_s = getenv("CDETR_GEMM_VARIANT");
     const int force = force_s ? atoi(force_s) : 0;
     const bool fast_ok = vecA && vecB && (d.K % 32) == 0;
+    if (force == 7 && fast_ok) return launch_gemm_fast<1, 2, 1, 1, 32>(d, st);                 // 32x64, 2 waves
     if (force >= 1 && force <= 4 && fast_ok) {
-        if (force == 1) return launch_gemm_fast<128, 128, 32>(d, st);
-        if (force == 2) return launch_gemm_fast<128, 64, 32>(d, st);
-        if (force == 3 && (d.K % 64) == 0) return launch_gemm_fast<64, 64, 64>(d, st);
-        return launch_gemm_fast<64, 64, 32>(d, st);
+        if (force == 1) return launch_gemm_fast<2, 2, 2, 2, 32>(d, st);                       // 128x128
+        if (force == 2) return launch_gemm_fast<2, 2, 2, 1, 32>(d, st);                       // 128x64
+        if (force == 3 && (d.K % 64) == 0) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);    // 64x64, BK 64
+        const char* abl = getenv("CDETR_GEMM_ABL");
+        if (abl && atoi(abl) == 1) return launch_gemm_fast<2, 2, 1, 1, 32, 1>(d, st);
+        if (abl && atoi(abl) == 2) return launch_gemm_fast<2, 2, 1, 1, 32, 2>(d, st);
+        return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);                                       // 64x64, BK 32
     }
     if (force == 6) {
         if (d.N > 64 && d.M > 64) return launch_gemm<128, 128>(d, st, vecA, vecB);
@@ -1064,10 +1159,15 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     if ((force == 5 && d.g.mode == CDETR_ROWS_DENSE) || (d.g.mode == CDETR_ROWS_DENSE && (blocks(64, 64) <= 48 || !(vecA && vecB && (d.K % 32) == 0)) && blocks(64, 64) < 192)) {   // latency-bound: one wave per 16x16 tile
         const int tilesM = (d.M + 15) / 16, tilesN = (d.N + 15) / 16;
         dim3 grid((tilesM * tilesN + 3) / 4, 1, d.batch);
-        if (d.b_layout == 0)
-            hipLaunchKernelGGL(igemm_direct_kernel<0>, grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
-        else
-            hipLaunchKernelGGL(igemm_direct_kernel<1>, grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+        // K <= 256: every operand load of the wave is in flight at once (one memory round trip per tile)
+        const bool deep = d.K > 128 && vecA && (d.b_layout == 1 || vecB);
+        if (d.b_layout == 0) {
+            if (deep) hipLaunchKernelGGL((igemm_direct_kernel<0, 16>), grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+            else hipLaunchKernelGGL((igemm_direct_kernel<0, 8>), grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+        } else {
+            if (deep) hipLaunchKernelGGL((igemm_direct_kernel<1, 16>), grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+            else hipLaunchKernelGGL((igemm_direct_kernel<1, 8>), grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+        }
         return cdetr_launch_status("cdetr_gemm");
     }
     if (vecA && vecB && (d.K % 32) == 0) {   // fast path: tap-uniform k-tiles, no integer division in the loop
@@ -1076,8 +1176,8 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         // measured on MI355X (tools/gemm_sweep.py, profiles/r1_gemm_sweep.txt): 64x64 tiles at 4 workgroups/CU beat the
         // 128-wide tiles on every shape of this model (latency hiding by occupancy matters more than operand reuse at
         // the fp32-MFMA rate); BK = 64 only pays when the grid is too small to give every CU two workgroups.
-        if ((d.K % 64) == 0 && blocks(64, 64) < 512) return launch_gemm_fast<64, 64, 64>(d, st);
-        return launch_gemm_fast<64, 64, 32>(d, st);
+        if ((d.K % 64) == 0 && blocks(64, 64) < 512) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);
+        return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);
     }
     if (d.N > 64 && d.M > 64 && blocks(128, 128) >= 384) return launch_gemm<128, 128>(d, st, vecA, vecB);
     if (d.M > 64 && blocks(128, 64) >= 384) return launch_gemm<128, 64>(d, st, vecA, vecB);
@@ -1120,9 +1220,14 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             const int per = (int)((nktf + slices - 1) / slices);
             slices = (nktf + per - 1) / per;
             const int bytes = (2 * 32 * (BI + 4) + 2 * 32 * (BJ + 4)) * 4;
-            if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ>, bytes, "cdetr_wgrad"))) return;
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
-            hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
+            if (d.precision == 1) {
+                if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 1>, bytes, "cdetr_wgrad"))) return;
+                hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ, 1>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
+            } else {
+                if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 0>, bytes, "cdetr_wgrad"))) return;
+                hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ, 0>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
+            }
         };
         const char* wf = getenv("CDETR_WGRAD_VARIANT");   // tuning knob: 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64
         const int wforce = wf ? atoi(wf) : 0;

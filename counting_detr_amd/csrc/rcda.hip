@@ -17,12 +17,12 @@
 // Head dim is fixed at 32 (E = 256, 8 heads in every shipped config).
 #include "../../include/cdetr_hip.h"
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int D = 32;          // head dim
 constexpr int QW = 32;         // queries per wave
-constexpr int QB = 4 * QW;     // queries per workgroup
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
@@ -31,15 +31,15 @@ struct FwdSmem {
     int off_srow, off_scol, off_k, off_v;
     int total;
 };
-__host__ __device__ inline FwdSmem fwd_smem(int H, int W) {
+__host__ __device__ inline FwdSmem fwd_smem(int H, int W, int NW) {
     FwdSmem s;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
     s.sw = Wp + 1;
     s.sh = Hp + 4;
     s.off_srow = 0;
-    s.off_scol = s.off_srow + 4 * QW * s.sw;
+    s.off_scol = s.off_srow + NW * QW * s.sw;
     s.off_scol = (s.off_scol + 3) & ~3;
-    s.off_k = s.off_scol + 4 * QW * s.sh;
+    s.off_k = s.off_scol + NW * QW * s.sh;
     const int kbytes = (W + H) * D;      // k_row + k_col tiles (phase 1)
     const int vbytes = 2 * Hp * D;       // double-buffered V tile (phase 2), overlays the k tiles
     s.off_v = s.off_k;
@@ -48,13 +48,14 @@ __host__ __device__ inline FwdSmem fwd_smem(int H, int W) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NF>   // NF = number of 32-row key fragments along H (H <= 32*NF)
-__global__ __launch_bounds__(256) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc d) {
+template <int NF, int NW>   // NF = 32-row key fragments along H (H <= 32*NF); NW = waves (x32 queries) per workgroup
+__global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc d) {
+    constexpr int NT = 64 * NW, QB = QW * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int KH8 = NF * 4;
     const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
-    const FwdSmem sm = fwd_smem(H, W);
+    const FwdSmem sm = fwd_smem(H, W, NW);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, g = lane >> 5;
     const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc
     float* Scol = smem + sm.off_scol + wid * QW * sm.sh;
 
     // ---- phase 0: stage the projected keys of this (n, head)
-    for (int idx = tid; idx < (W + H) * 8; idx += 256) {
+    for (int idx = tid; idx < (W + H) * 8; idx += NT) {
         const int key = idx >> 3, c4 = idx & 7;
         const float* src = (key < W) ? d.k_row + ((long)n * W + key) * E + head * D + c4 * 4
                                      : d.k_col + ((long)n * H + (key - W)) * E + head * D + c4 * 4;
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc
     // ---- phase 2: out = sum_w (A_col * A_row[:,w]) . V[:,w,:]
     float* Vs = smem + sm.off_v;   // [2][Hp][32]
     // zero the padded key rows of both buffers once
-    for (int idx = tid; idx < 2 * (Hp - H) * D; idx += 256) {
+    for (int idx = tid; idx < 2 * (Hp - H) * D; idx += NT) {
         const int b = idx / ((Hp - H) * D), r = idx - b * (Hp - H) * D;
         Vs[b * Hp * D + H * D + r] = 0.f;
     }
@@ -154,12 +155,12 @@ __global__ __launch_bounds__(256) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc
                                  : make_float4(0.f, 0.f, 0.f, 0.f);
 
     const float* vbase = d.v + (long)n * H * W * E + head * D;   // + (h*W + w)*E + c
-    constexpr int VSLOTS = NF;   // float4 per thread per tile: H*8 <= 256*NF
+    constexpr int VSLOTS = (NF * 256 + NT - 1) / NT;   // float4 per thread per tile: H*8 <= 256*NF
     float4 rv[VSLOTS];
     auto vfetch = [&](int w) {
 #pragma unroll
         for (int s = 0; s < VSLOTS; ++s) {
-            const int idx = tid + 256 * s;
+            const int idx = tid + NT * s;
             const int h = idx >> 3, c4 = idx & 7;
             rv[s] = (h < H) ? ld4(vbase + ((long)h * W + w) * E + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc
     auto vstash = [&](int buf) {
 #pragma unroll
         for (int s = 0; s < VSLOTS; ++s) {
-            const int idx = tid + 256 * s;
+            const int idx = tid + NT * s;
             const int h = idx >> 3, c4 = idx & 7;
             if (h < H) *reinterpret_cast<float4*>(Vs + buf * Hp * D + h * D + c4 * 4) = rv[s];
         }
@@ -211,27 +212,28 @@ __global__ __launch_bounds__(256) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc
 struct BwdSmem {
     int sw, sh, off_acol, off_arow, off_darow, off_v, total;
 };
-__host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF) {
+__host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW) {
     BwdSmem s;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
     s.sw = Wp + 1;
     s.sh = Hp + 1;
     s.off_acol = 0;
-    s.off_arow = s.off_acol + 4 * QW * s.sh;
-    s.off_darow = s.off_arow + 4 * QW * s.sw;
-    s.off_v = (s.off_darow + 4 * QW * s.sw + 3) & ~3;
+    s.off_arow = s.off_acol + NW * QW * s.sh;
+    s.off_darow = s.off_arow + NW * QW * s.sw;
+    s.off_v = (s.off_darow + NW * QW * s.sw + 3) & ~3;
     s.total = s.off_v + 2 * (32 * NF) * 36;
     return s;
 }
 
-template <int NF>
-__global__ __launch_bounds__(256) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
+template <int NF, int NW>
+__global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
+    constexpr int NT = 64 * NW, QB = QW * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int VS = 36;                 // V tile row stride (floats): 36/4 odd -> conflict-free ds_read_b128
     constexpr int HR = 32 * NF;            // V tile rows (zero beyond H)
     const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
-    const BwdSmem sm = bwd_smem(H, W, NF);
+    const BwdSmem sm = bwd_smem(H, W, NF, NW);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, g = lane >> 5;
     const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc
         }
     }
     // zero V tiles completely once (rows >= H and the 4 pad columns stay zero)
-    for (int idx = tid; idx < 2 * HR * VS; idx += 256) Vs[idx] = 0.f;
+    for (int idx = tid; idx < 2 * HR * VS; idx += NT) Vs[idx] = 0.f;
 
     // dOut^T fragment (B operand, loop invariant): lane (j = query, g) holds dOut[q][8kk + 4g + s]
     float dob[4][4];
@@ -285,19 +287,20 @@ __global__ __launch_bounds__(256) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc
         }
 
     const float* vbase = d.v + (long)n * H * W * E + head * D;
-    float4 rv[NF];
+    constexpr int VSLOTS = (NF * 256 + NT - 1) / NT;
+    float4 rv[VSLOTS];
     auto vfetch = [&](int w) {
 #pragma unroll
-        for (int s = 0; s < NF; ++s) {
-            const int idx = tid + 256 * s;
+        for (int s = 0; s < VSLOTS; ++s) {
+            const int idx = tid + NT * s;
             const int h = idx >> 3, c4 = idx & 7;
             rv[s] = (h < H) ? ld4(vbase + ((long)h * W + w) * E + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto vstash = [&](int buf) {
 #pragma unroll
-        for (int s = 0; s < NF; ++s) {
-            const int idx = tid + 256 * s;
+        for (int s = 0; s < VSLOTS; ++s) {
+            const int idx = tid + NT * s;
             const int h = idx >> 3, c4 = idx & 7;
             if (h < H) *reinterpret_cast<float4*>(Vs + buf * HR * VS + h * VS + c4 * 4) = rv[s];
         }
@@ -468,6 +471,35 @@ int set_smem(F func, int bytes, const char* what) {
     return CDETR_OK;
 }
 
+template <int NF, int NW>
+int launch_rcda_fwd(const cdetr_rcda_fwd_desc& d, hipStream_t st) {
+    const FwdSmem sm = fwd_smem(d.H, d.W, NW);
+    const int bytes = sm.total * 4;
+    int rc;
+    if ((rc = set_smem(rcda_fwd_kernel<NF, NW>, bytes, "cdetr_rcda_fwd"))) return rc;
+    dim3 grid((d.L + QW * NW - 1) / (QW * NW), d.N * d.nh), block(64 * NW);
+    hipLaunchKernelGGL((rcda_fwd_kernel<NF, NW>), grid, block, bytes, st, d);
+    return cdetr_launch_status("cdetr_rcda_fwd");
+}
+template <int NF, int NW>
+int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st) {
+    const BwdSmem sm = bwd_smem(d.H, d.W, NF, NW);
+    const int bytes = sm.total * 4;
+    int rc;
+    if ((rc = set_smem(rcda_bwd_kernel<NF, NW>, bytes, "cdetr_rcda_bwd"))) return rc;
+    dim3 grid((d.L + QW * NW - 1) / (QW * NW), d.N * d.nh), block(64 * NW);
+    hipLaunchKernelGGL((rcda_bwd_kernel<NF, NW>), grid, block, bytes, st, d);
+    return cdetr_launch_status("cdetr_rcda_bwd(dS)");
+}
+// waves per workgroup: 4 when that already gives >= 4 workgroups per CU, else 2 (finer granularity: less tail
+// quantisation on 256 CUs and 2-3 co-resident workgroups per CU to hide the V-tile latency)
+inline int pick_nw(int L, int NH) {
+    const long b4 = (long)((L + 127) / 128) * NH;
+    const char* f = getenv("CDETR_RCDA_NW");
+    if (f) return atoi(f) == 4 ? 4 : 2;
+    return b4 >= 128 ? 4 : 2;      // measured: 2-wave workgroups only pay for the short decoder query sets
+}
+
 }  // namespace
 
 extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
@@ -476,22 +508,11 @@ extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
     CDETR_CHECK_ARG(d.N > 0 && d.L > 0 && d.H > 0 && d.W > 0 && d.nh > 0, "cdetr_rcda_fwd: bad sizes");
     CDETR_CHECK_ARG(d.H <= 128 && d.W <= 1024, "cdetr_rcda_fwd: H must be <= 128 (got %d)", d.H);
     CDETR_CHECK_ARG(d.q_row && d.q_col && d.k_row && d.k_col && d.v && d.out && d.a_row && d.a_col, "cdetr_rcda_fwd: null pointer");
-    const FwdSmem sm = fwd_smem(d.H, d.W);
-    const int bytes = sm.total * 4;
-    dim3 grid((d.L + QB - 1) / QB, d.N * d.nh), block(256);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    int rc;
-    if (d.H <= 32) {
-        if ((rc = set_smem(rcda_fwd_kernel<1>, bytes, "cdetr_rcda_fwd"))) return rc;
-        hipLaunchKernelGGL(rcda_fwd_kernel<1>, grid, block, bytes, st, d);
-    } else if (d.H <= 64) {
-        if ((rc = set_smem(rcda_fwd_kernel<2>, bytes, "cdetr_rcda_fwd"))) return rc;
-        hipLaunchKernelGGL(rcda_fwd_kernel<2>, grid, block, bytes, st, d);
-    } else {
-        if ((rc = set_smem(rcda_fwd_kernel<4>, bytes, "cdetr_rcda_fwd"))) return rc;
-        hipLaunchKernelGGL(rcda_fwd_kernel<4>, grid, block, bytes, st, d);
-    }
-    return cdetr_launch_status("cdetr_rcda_fwd");
+    const int nw = pick_nw(d.L, d.N * d.nh);
+    if (d.H <= 32) return nw == 4 ? launch_rcda_fwd<1, 4>(d, st) : launch_rcda_fwd<1, 2>(d, st);
+    if (d.H <= 64) return nw == 4 ? launch_rcda_fwd<2, 4>(d, st) : launch_rcda_fwd<2, 2>(d, st);
+    return nw == 4 ? launch_rcda_fwd<4, 4>(d, st) : launch_rcda_fwd<4, 2>(d, st);
 }
 
 extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
@@ -503,23 +524,12 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int NF = d.H <= 32 ? 1 : (d.H <= 64 ? 2 : 4);
     const int Wp = (d.W + 3) & ~3;
+    const int nw = pick_nw(d.L, d.N * d.nh);
     int rc;
-    {   // dS kernel
-        const BwdSmem sm = bwd_smem(d.H, d.W, NF);
-        const int bytes = sm.total * 4;
-        dim3 grid((d.L + QB - 1) / QB, d.N * d.nh), block(256);
-        if (NF == 1) {
-            if ((rc = set_smem(rcda_bwd_kernel<1>, bytes, "cdetr_rcda_bwd"))) return rc;
-            hipLaunchKernelGGL(rcda_bwd_kernel<1>, grid, block, bytes, st, d);
-        } else if (NF == 2) {
-            if ((rc = set_smem(rcda_bwd_kernel<2>, bytes, "cdetr_rcda_bwd"))) return rc;
-            hipLaunchKernelGGL(rcda_bwd_kernel<2>, grid, block, bytes, st, d);
-        } else {
-            if ((rc = set_smem(rcda_bwd_kernel<4>, bytes, "cdetr_rcda_bwd"))) return rc;
-            hipLaunchKernelGGL(rcda_bwd_kernel<4>, grid, block, bytes, st, d);
-        }
-        if ((rc = cdetr_launch_status("cdetr_rcda_bwd(dS)"))) return rc;
-    }
+    if (NF == 1) rc = nw == 4 ? launch_rcda_bwd<1, 4>(d, st) : launch_rcda_bwd<1, 2>(d, st);
+    else if (NF == 2) rc = nw == 4 ? launch_rcda_bwd<2, 4>(d, st) : launch_rcda_bwd<2, 2>(d, st);
+    else rc = nw == 4 ? launch_rcda_bwd<4, 4>(d, st) : launch_rcda_bwd<4, 2>(d, st);
+    if (rc) return rc;
     {   // dV kernel
         const int bytes = (64 * 32 * NF + 64 * Wp + 64 * 32) * 4;
         const int wgroups = (d.W + 3) / 4;

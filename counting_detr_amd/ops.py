@@ -18,6 +18,12 @@ import ctypes as C
 # start event, end event) for every matrix-core launch; HIP events are recorded on the launch stream itself.
 PROFILE = None
 
+# Matrix-core arithmetic of the implicit-GEMM / weight-gradient kernels: 1 (default) = split-bf16 x3: every fp32 operand is
+# split hi+lo and a product costs 3 bf16 MFMAs with fp32 accumulation (~5e-6 relative, ~5x less matrix-pipe time);
+# 0 = fp32 MFMA (exact fp32 products).  Both modes pass the same parity suite (1e-3 rel, bit-exact Hungarian indices).
+import os as _os
+PRECISION = int(_os.environ.get("CDETR_PRECISION", "1"))
+
 
 class _Timed:
     def __init__(self, family, flops, tag=None):
@@ -45,6 +51,7 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0):
     d = GemmDesc()
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
+    d.precision = PRECISION
     d.A, d.lda, d.sA = ptr(A), lda, sA
     d.B, d.ldb, d.sB = ptr(B), ldb, sB
     d.C, d.ldc, d.sC = ptr(Cout), ldc, sC
@@ -60,6 +67,7 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
               dbias=None):
     d = WgradDesc()
     d.P, d.Nout, d.Cin, d.taps, d.batch = P, Nout, Cin, taps, batch
+    d.precision = PRECISION
     d.dY, d.ldy, d.sY = ptr(dY), ldy, sY
     d.X, d.ldx, d.sX = ptr(X), ldx, sX
     d.dW, d.ldw, d.sW = ptr(dW), ldw, sW

@@ -52,6 +52,7 @@ typedef struct {
     int32_t batch; /* grid.z; per-batch element strides sA/sB/sC (0 = shared) */
     int32_t b_layout;
     int32_t relu;
+    int32_t precision; /* 0 = fp32 MFMA (exact fp32 products), 1 = split-bf16 x3 on the bf16 matrix pipe (~1e-5 rel) */
     float out_scale;
     const float* A; int64_t lda, sA;
     const float* B; int64_t ldb, sB;
@@ -71,6 +72,7 @@ int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 typedef struct {
     int32_t P, Nout, Cin, taps;
     int32_t batch;
+    int32_t precision; /* as in cdetr_gemm_desc */
     const float* dY; int64_t ldy, sY;
     const float* X; int64_t ldx, sX;
     float* dW; int64_t ldw, sW;

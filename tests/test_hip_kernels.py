@@ -9,6 +9,20 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=[0, 1], ids=["fp32mfma", "bf16x3"])
+def precision(request):
+    """Both matrix-core arithmetic modes of the GEMM kernels: fp32 MFMA (exact products) and split-bf16 x3."""
+    from counting_detr_amd import ops
+    old = ops.PRECISION
+    ops.PRECISION = request.param
+    yield request.param
+    ops.PRECISION = old
+
+
+def tol(precision):
+    return dict(rtol=2e-4, atol_scale=2e-5) if precision == 0 else dict(rtol=2e-4, atol_scale=6e-5)
+
+
 def g(seed):
     return torch.Generator().manual_seed(seed)
 
@@ -28,7 +42,7 @@ def close(actual, ref, rtol=2e-4, atol_scale=2e-5, msg=""):
 @pytest.mark.parametrize("M,N,K", [(600, 256, 256), (5000, 1024, 256), (5000, 256, 1024), (77, 70, 36), (600, 2, 256),
                                    (600, 4, 256), (1, 256, 256), (130, 64, 20), (300, 512, 256)])
 @pytest.mark.parametrize("relu,use_resid", [(False, False), (True, True)])
-def test_linear_forward_backward(M, N, K, relu, use_resid):
+def test_linear_forward_backward(M, N, K, relu, use_resid, precision):
     from counting_detr_amd import ops
     x = torch.randn(M, K, generator=g(1))
     w = torch.randn(N, K, generator=g(2)) / K ** 0.5
@@ -48,15 +62,16 @@ def test_linear_forward_backward(M, N, K, relu, use_resid):
     y64 = F.linear(x64, w64, b64)
     if use_resid:
         y64 = y64 + r64
-    if relu:
-        y64 = F.relu(y64)
+    if relu:   # use the kernel's own ReLU mask in the reference backward: pre-activations within rounding of 0 may flip
+        y64 = y64 * (y.detach().double().cpu() > 0)
     y64.backward(gy.double())
-    close(y, y64, msg="y")
-    close(xd.grad, x64.grad, msg="dx")
-    close(wd.grad, w64.grad, msg="dW")
-    close(bd.grad, b64.grad, msg="db")
+    t = tol(precision)
+    close(y, y64, msg="y", **t)
+    close(xd.grad, x64.grad, msg="dx", **t)
+    close(wd.grad, w64.grad, msg="dW", **t)
+    close(bd.grad, b64.grad, msg="db", **t)
     if use_resid:
-        close(rd.grad, r64.grad, msg="dresid")
+        close(rd.grad, r64.grad, msg="dresid", **t)
 
 
 def test_linear_row_slices_accumulate():
@@ -93,7 +108,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,dil,H,W", CONV_CASES)
-def test_conv_forward_dgrad_wgrad(Cin, Cout, k, stride, pad, dil, H, W):
+def test_conv_forward_dgrad_wgrad(Cin, Cout, k, stride, pad, dil, H, W, precision):
     from counting_detr_amd import ops
     B = 2
     x = torch.randn(B, Cin, H, W, generator=g(1))
@@ -105,10 +120,11 @@ def test_conv_forward_dgrad_wgrad(Cin, Cout, k, stride, pad, dil, H, W):
     conv64 = F.conv2d(x64, w64, stride=stride, padding=pad, dilation=dil)
     Ho, Wo = conv64.shape[-2:]
     resid = torch.randn(B, Cout, Ho, Wo, generator=g(5))
-    y64 = F.relu(conv64 * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1) + resid.double())
+    pre64 = conv64 * scale.double().view(1, -1, 1, 1) + bias.double().view(1, -1, 1, 1) + resid.double()
     gy = torch.randn(B, Cout, Ho, Wo, generator=g(6))
-    dz64 = gy.double() * (y64 > 0)                       # gradient w.r.t. the pre-ReLU value
-    y64.backward(gy.double())
+    dz64 = gy.double() * (pre64 > 0)                     # gradient w.r.t. the pre-ReLU value
+    y64 = F.relu(pre64)
+    pre64.backward(dz64)
 
     xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
     wd = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last).to(DEV))
@@ -116,16 +132,17 @@ def test_conv_forward_dgrad_wgrad(Cin, Cout, k, stride, pad, dil, H, W):
     sd, bd = scale.to(DEV), bias.to(DEV)
     rd = resid.permute(0, 2, 3, 1).contiguous().to(DEV)
     y = ops.conv_fwd(xd, wd, sd, bd, stride=stride, pad=pad, dil=dil, relu=True, resid=rd)
-    close(y.permute(0, 3, 1, 2), y64, msg="conv fwd")
+    t = tol(precision)
+    close(y.permute(0, 3, 1, 2), y64, msg="conv fwd", **t)
     dz = dz64.float().permute(0, 2, 3, 1).contiguous().to(DEV)
     dx = ops.conv_dgrad(dz, wd, sd, (H, W), stride=stride, pad=pad, dil=dil)
-    close(dx.permute(0, 3, 1, 2), x64.grad, msg="conv dgrad")
+    close(dx.permute(0, 3, 1, 2), x64.grad, msg="conv dgrad", **t)
     # gate + resid epilogue of the data-gradient
     gate = torch.randn(B, H, W, Cin, generator=g(7)).to(DEV)
     extra = torch.randn(B, H, W, Cin, generator=g(8)).to(DEV)
     dx2 = ops.conv_dgrad(dz, wd, sd, (H, W), stride=stride, pad=pad, dil=dil, gate=gate, resid=extra)
     ref2 = (x64.grad.permute(0, 2, 3, 1) + extra.double().cpu()) * (gate.cpu() > 0)
-    close(dx2, ref2, msg="conv dgrad gate+resid")
+    close(dx2, ref2, msg="conv dgrad gate+resid", **t)
     ops.conv_wgrad_(dz, xd, wd, sd, stride=stride, pad=pad, dil=dil)
     ops.conv_wgrad_(dz, xd, wd, sd, stride=stride, pad=pad, dil=dil)    # accumulates
     close(wd.grad, 2 * w64.grad, msg="conv wgrad", rtol=5e-4)
@@ -183,7 +200,7 @@ def test_rcda_core(N, L, H, W, masked):
         close(a.grad, b.grad, msg=name, rtol=5e-4)
 
 
-def test_multihead_rcda_module_vs_oracle():
+def test_multihead_rcda_module_vs_oracle(precision):
     """Full module (projections + core + out_proj) against the oracle restatement, both mask branches."""
     from counting_detr_amd.transformer import MultiheadRCDA
     from oracle import model as OM

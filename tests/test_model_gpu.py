@@ -8,6 +8,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+@pytest.fixture(params=[0, 1], ids=["fp32mfma", "bf16x3"])
+def precision(request):
+    from counting_detr_amd import ops
+    old = ops.PRECISION
+    ops.PRECISION = request.param
+    yield request.param
+    ops.PRECISION = old
+
+
 def T(a):
     return torch.from_numpy(np.asarray(a))
 
@@ -34,7 +43,7 @@ def load_case(z, name):
 
 
 @pytest.mark.parametrize("name", ["b1_64x96", "b2_pad", "b1_grid20"])
-def test_forward_losses_grads_vs_reference(golden, name):
+def test_forward_losses_grads_vs_reference(golden, name, precision):
     z = golden("g6_e2e.npz")
     B, nq, prior, imgs, rects, tg = load_case(z, name)
     model, crit, args = build(nq, prior)
@@ -67,7 +76,7 @@ def test_forward_losses_grads_vs_reference(golden, name):
             np.testing.assert_allclose(p.grad.norm().item() * coef, r, rtol=1e-2, atol=1e-6, err_msg=n)
 
 
-def test_train_step_matches_reference_adamw(golden):
+def test_train_step_matches_reference_adamw(golden, precision):
     """Trainer (flat arenas, device matcher, flat clip + AdamW) reproduces the reference's post-step parameters."""
     from counting_detr_amd.engine import Trainer
     z = golden("g6_e2e.npz")

@@ -17,7 +17,7 @@ SHAPES = [  # (M, N, K, taps, layout, conv geometry or None)
     (20000, 512, 128, 1, 0, None), (20000, 128, 512, 1, 0, None), (20000, 512, 128, 1, 1, None),
     (80000, 64, 64, 9, 0, (200, 200, 1, 1, 1)), (80000, 256, 64, 1, 0, None), (80000, 64, 256, 1, 0, None),
 ]
-NAMES = {0: "auto", 1: "f128x128", 2: "f128x64", 3: "f64x64k64", 4: "f64x64k32", 5: "direct", 6: "generic"}
+NAMES = {0: "auto", 1: "f128x128", 2: "f128x64", 3: "f64x64k64", 4: "f64x64k32", 5: "direct", 6: "generic", 7: "f32x64k32"}
 
 
 def run(shape, variant, reps=20):
@@ -95,10 +95,11 @@ if __name__ == "__main__":
             print(row, flush=True)
         if "all" not in sys.argv:
             sys.exit(0)
-    print("%-34s" % "M,N,K,taps,layout" + "".join("%22s" % NAMES[v] for v in (0, 1, 2, 3, 4, 5)))
+    VS = (0, 1, 2, 3, 4, 7, 5)
+    print("%-34s" % "M,N,K,taps,layout" + "".join("%22s" % NAMES[v] for v in VS))
     for sh in SHAPES:
         row = "%-34s" % (",".join(str(x) for x in sh[:5]))
-        for v in (0, 1, 2, 3, 4, 5):
+        for v in VS:
             if v == 5 and (sh[5] is not None or sh[0] > 6000):
                 row += "%22s" % "-"
                 continue
