@@ -40,13 +40,13 @@ class WgradDesc(C.Structure):
 
 class RcdaFwdDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("nh", C.c_int32),
-                ("scale", C.c_float), ("q_row", _p), ("q_col", _p), ("k_row", _p), ("k_col", _p), ("v", _p),
+                ("precision", C.c_int32), ("scale", C.c_float), ("q_row", _p), ("q_col", _p), ("k_row", _p), ("k_col", _p), ("v", _p),
                 ("mask_row", _p), ("mask_col", _p), ("out", _p), ("a_row", _p), ("a_col", _p)]
 
 
 class RcdaBwdDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("nh", C.c_int32),
-                ("scale", C.c_float), ("d_out", _p), ("a_row", _p), ("a_col", _p), ("v", _p),
+                ("precision", C.c_int32), ("scale", C.c_float), ("d_out", _p), ("a_row", _p), ("a_col", _p), ("v", _p),
                 ("ds_row", _p), ("ds_col", _p), ("d_v", _p)]
 
 

@@ -48,7 +48,7 @@ __host__ __device__ inline FwdSmem fwd_smem(int H, int W, int NW) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NF, int NW>   // NF = 32-row key fragments along H (H <= 32*NF); NW = waves (x32 queries) per workgroup
+template <int NF, int NW, int PREC>   // NF = 32-row key fragments along H (H <= 32*NF); NW = waves (x32 queries) per workgroup; PREC 0 = fp32 MFMA, 1 = split-bf16 x3
 __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc d) {
     constexpr int NT = 64 * NW, QB = QW * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -184,16 +184,38 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
         if (w + 1 < W) vfetch(w + 1);
         const float arow = Srow[i32 * sm.sw + w];
         const float* vb = Vs + buf * Hp * D + (g * 4) * D + i32;
+        if (PREC == 0) {
 #pragma unroll
-        for (int kk = 0; kk < KH8; ++kk) {
-            if (kk * 8 < Hp) {
-                const float p0 = acol[kk].x * arow, p1 = acol[kk].y * arow, p2 = acol[kk].z * arow, p3 = acol[kk].w * arow;
-                const float b0 = vb[(kk * 8 + 0) * D], b1 = vb[(kk * 8 + 1) * D], b2 = vb[(kk * 8 + 2) * D],
-                            b3 = vb[(kk * 8 + 3) * D];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p0, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p1, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p2, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p3, b3, acc, 0, 0, 0);
+            for (int kk = 0; kk < KH8; ++kk) {
+                if (kk * 8 < Hp) {
+                    const float p0 = acol[kk].x * arow, p1 = acol[kk].y * arow, p2 = acol[kk].z * arow, p3 = acol[kk].w * arow;
+                    const float b0 = vb[(kk * 8 + 0) * D], b1 = vb[(kk * 8 + 1) * D], b2 = vb[(kk * 8 + 2) * D],
+                                b3 = vb[(kk * 8 + 3) * D];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p0, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p1, b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p2, b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(p3, b3, acc, 0, 0, 0);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int kp = 0; kp < KH8 / 2; ++kp) {          // 16 key rows per step: chunks 2kp and 2kp+1
+                if (kp * 16 < Hp) {
+                    const int k0 = 2 * kp, k1 = 2 * kp + 1;
+                    const bool has1 = k1 * 8 < Hp;           // Hp is a multiple of 8, not of 16 (acol[k1] is zero then)
+                    const float pa[8] = {acol[k0].x * arow, acol[k0].y * arow, acol[k0].z * arow, acol[k0].w * arow,
+                                         acol[k1].x * arow, acol[k1].y * arow, acol[k1].z * arow, acol[k1].w * arow};
+                    float vv[8];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        vv[t] = vb[(k0 * 8 + t) * D];
+                        vv[4 + t] = has1 ? vb[(k1 * 8 + t) * D] : 0.f;
+                    }
+                    bf16x8 ah, al, bh, bl;
+                    split_bf16x8(pa, ah, al);
+                    split_bf16x8(vv, bh, bl);
+                    acc = mfma_bf16x3(ah, al, bh, bl, acc);
+                }
             }
         }
         if (w + 1 < W) vstash(buf ^ 1);
@@ -225,7 +247,7 @@ __host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW) {
     return s;
 }
 
-template <int NF, int NW>
+template <int NF, int NW, int PREC>
 __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
     constexpr int NT = 64 * NW, QB = QW * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -274,6 +296,13 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
             dob[kk][0] = t.x; dob[kk][1] = t.y; dob[kk][2] = t.z; dob[kk][3] = t.w;
         }
     }
+    bf16x8 dobh[2], dobl[2];      // loop-invariant split of the dOut^T fragment (split-bf16 mode)
+#pragma unroll
+    for (int kp = 0; kp < 2; ++kp) {
+        const float x[8] = {dob[2 * kp][0], dob[2 * kp][1], dob[2 * kp][2], dob[2 * kp][3],
+                            dob[2 * kp + 1][0], dob[2 * kp + 1][1], dob[2 * kp + 1][2], dob[2 * kp + 1][3]};
+        split_bf16x8(x, dobh[kp], dobl[kp]);
+    }
     __syncthreads();
     // A_col in the transposed accumulator layout: element (f, r) <-> key row h = 32f + (r&3) + 8(r>>2) + 4g, query i32
     float acolT[NF][16], dacolT[NF][16];
@@ -319,13 +348,25 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
 #pragma unroll
             for (int r = 0; r < 16; ++r) gt[r] = 0.f;
             const float* va = Vs + buf * HR * VS + (32 * f + i32) * VS + g * 4;
+            if (PREC == 0) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const float4 a = *reinterpret_cast<const float4*>(va + kk * 8);
-                gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, dob[kk][0], gt, 0, 0, 0);
-                gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, dob[kk][1], gt, 0, 0, 0);
-                gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, dob[kk][2], gt, 0, 0, 0);
-                gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dob[kk][3], gt, 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float4 a = *reinterpret_cast<const float4*>(va + kk * 8);
+                    gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, dob[kk][0], gt, 0, 0, 0);
+                    gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, dob[kk][1], gt, 0, 0, 0);
+                    gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, dob[kk][2], gt, 0, 0, 0);
+                    gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dob[kk][3], gt, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kp = 0; kp < 2; ++kp) {
+                    const float4 a0 = *reinterpret_cast<const float4*>(va + (2 * kp) * 8);
+                    const float4 a1 = *reinterpret_cast<const float4*>(va + (2 * kp + 1) * 8);
+                    const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    bf16x8 ah, al;
+                    split_bf16x8(x, ah, al);
+                    gt = mfma_bf16x3(ah, al, dobh[kp], dobl[kp], gt);
+                }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -383,7 +424,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
 
 // ------------------------------------------------------------------------------------------------ backward (dV)
 // dV[h,w,c] += sum_q A_col[q,h] A_row[q,w] dOut[q,c].  Workgroup = (4 consecutive w (one per wave), (n,head), q-slice).
-template <int NF>
+template <int NF, int PREC>
 __global__ __launch_bounds__(256) void rcda_dv_kernel(const cdetr_rcda_bwd_desc d, const int q_per_slice) {
     constexpr int QT = 64;               // queries per LDS tile
     constexpr int HR = 32 * NF;
@@ -427,7 +468,7 @@ __global__ __launch_bounds__(256) void rcda_dv_kernel(const cdetr_rcda_bwd_desc 
                 (r < nq) ? ld4(gdo + (long)(q0 + r) * E + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         __syncthreads();
-        if (wvalid) {
+        if (wvalid && PREC == 0) {
 #pragma unroll 2
             for (int kk = 0; kk < QT / 8; ++kk) {
 #pragma unroll
@@ -440,6 +481,34 @@ __global__ __launch_bounds__(256) void rcda_dv_kernel(const cdetr_rcda_bwd_desc 
                         const float a = Ac[qq * HR + 32 * f + i32] * ar;
                         acc[f] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[f], 0, 0, 0);
                     }
+                }
+            }
+        }
+        if (wvalid && PREC == 1) {
+#pragma unroll 2
+            for (int kp = 0; kp < QT / 16; ++kp) {
+                float arv[8], bv[8];
+                int qs[8];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    qs[t] = (2 * kp) * 8 + g * 4 + t;
+                    qs[4 + t] = (2 * kp + 1) * 8 + g * 4 + t;
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    arv[t] = Ar[qs[t] * Wp + w];
+                    bv[t] = Do[qs[t] * D + i32];
+                }
+                bf16x8 bh, bl;
+                split_bf16x8(bv, bh, bl);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    float av[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) av[t] = Ac[qs[t] * HR + 32 * f + i32] * arv[t];
+                    bf16x8 ah, al;
+                    split_bf16x8(av, ah, al);
+                    acc[f] = mfma_bf16x3(ah, al, bh, bl, acc[f]);
                 }
             }
         }
@@ -476,9 +545,14 @@ int launch_rcda_fwd(const cdetr_rcda_fwd_desc& d, hipStream_t st) {
     const FwdSmem sm = fwd_smem(d.H, d.W, NW);
     const int bytes = sm.total * 4;
     int rc;
-    if ((rc = set_smem(rcda_fwd_kernel<NF, NW>, bytes, "cdetr_rcda_fwd"))) return rc;
     dim3 grid((d.L + QW * NW - 1) / (QW * NW), d.N * d.nh), block(64 * NW);
-    hipLaunchKernelGGL((rcda_fwd_kernel<NF, NW>), grid, block, bytes, st, d);
+    if (d.precision == 1) {
+        if ((rc = set_smem(rcda_fwd_kernel<NF, NW, 1>, bytes, "cdetr_rcda_fwd"))) return rc;
+        hipLaunchKernelGGL((rcda_fwd_kernel<NF, NW, 1>), grid, block, bytes, st, d);
+    } else {
+        if ((rc = set_smem(rcda_fwd_kernel<NF, NW, 0>, bytes, "cdetr_rcda_fwd"))) return rc;
+        hipLaunchKernelGGL((rcda_fwd_kernel<NF, NW, 0>), grid, block, bytes, st, d);
+    }
     return cdetr_launch_status("cdetr_rcda_fwd");
 }
 template <int NF, int NW>
@@ -486,9 +560,14 @@ int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st) {
     const BwdSmem sm = bwd_smem(d.H, d.W, NF, NW);
     const int bytes = sm.total * 4;
     int rc;
-    if ((rc = set_smem(rcda_bwd_kernel<NF, NW>, bytes, "cdetr_rcda_bwd"))) return rc;
     dim3 grid((d.L + QW * NW - 1) / (QW * NW), d.N * d.nh), block(64 * NW);
-    hipLaunchKernelGGL((rcda_bwd_kernel<NF, NW>), grid, block, bytes, st, d);
+    if (d.precision == 1) {
+        if ((rc = set_smem(rcda_bwd_kernel<NF, NW, 1>, bytes, "cdetr_rcda_bwd"))) return rc;
+        hipLaunchKernelGGL((rcda_bwd_kernel<NF, NW, 1>), grid, block, bytes, st, d);
+    } else {
+        if ((rc = set_smem(rcda_bwd_kernel<NF, NW, 0>, bytes, "cdetr_rcda_bwd"))) return rc;
+        hipLaunchKernelGGL((rcda_bwd_kernel<NF, NW, 0>), grid, block, bytes, st, d);
+    }
     return cdetr_launch_status("cdetr_rcda_bwd(dS)");
 }
 // waves per workgroup: 4 when that already gives >= 4 workgroups per CU, else 2 (finer granularity: less tail
@@ -542,16 +621,17 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
         per = ((per + 63) / 64) * 64;
         slices = (d.L + per - 1) / per;
         dim3 grid(wgroups, d.N * d.nh, slices), block(256);
-        if (NF == 1) {
-            if ((rc = set_smem(rcda_dv_kernel<1>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
-            hipLaunchKernelGGL(rcda_dv_kernel<1>, grid, block, bytes, st, d, per);
-        } else if (NF == 2) {
-            if ((rc = set_smem(rcda_dv_kernel<2>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
-            hipLaunchKernelGGL(rcda_dv_kernel<2>, grid, block, bytes, st, d, per);
+        auto dv = [&](auto kern) {
+            if ((rc = set_smem(kern, bytes, "cdetr_rcda_bwd(dV)"))) return;
+            hipLaunchKernelGGL(kern, grid, block, bytes, st, d, per);
+        };
+        rc = CDETR_OK;
+        if (d.precision == 1) {
+            if (NF == 1) dv(rcda_dv_kernel<1, 1>); else if (NF == 2) dv(rcda_dv_kernel<2, 1>); else dv(rcda_dv_kernel<4, 1>);
         } else {
-            if ((rc = set_smem(rcda_dv_kernel<4>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
-            hipLaunchKernelGGL(rcda_dv_kernel<4>, grid, block, bytes, st, d, per);
+            if (NF == 1) dv(rcda_dv_kernel<1, 0>); else if (NF == 2) dv(rcda_dv_kernel<2, 0>); else dv(rcda_dv_kernel<4, 0>);
         }
+        if (rc) return rc;
         if ((rc = cdetr_launch_status("cdetr_rcda_bwd(dV)"))) return rc;
     }
     return CDETR_OK;

@@ -258,6 +258,7 @@ class RcdaCoreFn(torch.autograd.Function):
         a_col = torch.empty((N, nh, L, Hp), device=v.device, dtype=torch.float32)
         d = RcdaFwdDesc()
         d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
+        d.precision = PRECISION
         d.q_row, d.q_col, d.k_row, d.k_col, d.v = ptr(q_row), ptr(q_col), ptr(k_row), ptr(k_col), ptr(v)
         d.mask_row, d.mask_col = ptr(mask_row), ptr(mask_col)
         d.out, d.a_row, d.a_col = ptr(out), ptr(a_row), ptr(a_col)
@@ -280,6 +281,7 @@ class RcdaCoreFn(torch.autograd.Function):
         d_v = torch.zeros_like(v)
         d = RcdaBwdDesc()
         d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
+        d.precision = PRECISION
         d.d_out, d.a_row, d.a_col, d.v = ptr(d_out), ptr(a_row), ptr(a_col), ptr(v)
         d.ds_row, d.ds_col, d.d_v = ptr(ds_row), ptr(ds_col), ptr(d_v)
         with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32)):

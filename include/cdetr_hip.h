@@ -110,6 +110,7 @@ int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_
  * for the backward pass.                                                                                      */
 typedef struct {
     int32_t N, L, H, W, nh; /* head dim fixed at 32 */
+    int32_t precision;      /* 0 = fp32 MFMA, 1 = split-bf16 x3 (as in cdetr_gemm_desc) */
     float scale;
     const float* q_row; const float* q_col; const float* k_row; const float* k_col; const float* v;
     const uint8_t* mask_row; const uint8_t* mask_col;
@@ -122,6 +123,7 @@ int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* d, void* stream);
  * `scale`) and accumulates d_v [N][H][W][E] (must be zeroed by the caller).                                    */
 typedef struct {
     int32_t N, L, H, W, nh;
+    int32_t precision;
     float scale;
     const float* d_out; const float* a_row; const float* a_col; const float* v;
     float* ds_row; float* ds_col; float* d_v;

@@ -176,7 +176,7 @@ def rcda_core_ref(qr, qc, kr, kc, v, mr, mc, nh):
 
 @pytest.mark.parametrize("N,L,H,W,masked", [(2, 300, 50, 50, False), (1, 600, 20, 30, True), (2, 77, 7, 5, True),
                                             (1, 130, 70, 40, True), (2, 2500, 50, 50, True), (1, 33, 24, 36, False)])
-def test_rcda_core(N, L, H, W, masked):
+def test_rcda_core(N, L, H, W, masked, precision):
     from counting_detr_amd import ops
     nh, E = 8, 256
     qr, qc = torch.randn(N, L, E, generator=g(1)), torch.randn(N, L, E, generator=g(2))
@@ -195,9 +195,9 @@ def test_rcda_core(N, L, H, W, masked):
     ins64 = [t.double().requires_grad_(True) for t in (qr, qc, kr, kc, v)]
     ref = rcda_core_ref(*ins64, mr, mc, nh)
     ref.backward(gout.double())
-    close(out, ref, msg="rcda out")
+    close(out, ref, msg="rcda out", **tol(precision))
     for name, a, b in zip(("dq_row", "dq_col", "dk_row", "dk_col", "dv"), ins, ins64):
-        close(a.grad, b.grad, msg=name, rtol=5e-4)
+        close(a.grad, b.grad, msg=name, rtol=5e-4, atol_scale=tol(precision)["atol_scale"])
 
 
 def test_multihead_rcda_module_vs_oracle(precision):
