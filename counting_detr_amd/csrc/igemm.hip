@@ -879,12 +879,14 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
 // per-head dq/dk of RCDA): one wave = one 16x16 output tile on v_mfma_f32_16x16x4_f32, operands loaded straight from
 // global/L2 in the MFMA register layout -- no LDS, no barrier, every wave independent, so a 600x256x256 GEMM runs as
 // 608 concurrent waves of 64 MFMAs instead of 40 workgroups stepping through 8 barrier-separated k-tiles.
-template <int BL, int UB>   // UB = 16-wide k-chunks whose loads are issued back-to-back before the first MFMA consumes one
+template <int BL, int UB>   // UB = 16-wide k-chunks (per wave) whose loads are all in flight before the first MFMA
 __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN,
                                                            const int vecA, const int vecB) {
+    // one WORKGROUP = one 16x16 output tile; its 4 waves split K four ways (each wave: one short memory round trip),
+    // partial accumulators are summed through LDS and wave 0 runs the fused epilogue.
+    __shared__ float red[4][256];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wid;
-    if (tile >= tilesM * tilesN) return;
+    const int tile = blockIdx.x;
     const int tm = tile % tilesM, tn = tile / tilesM;
     const int i = lane & 15, g4 = lane >> 4;
     const int m = tm * 16 + i, n = tn * 16 + i;
@@ -893,6 +895,9 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc
     const float* __restrict__ B = d.B + (long)z * d.sB;
     float* __restrict__ C = d.C + (long)z * d.sC;
     const int K = d.K;
+    const int kchunks = (K + 15) >> 4;
+    const int cpw = (kchunks + 3) >> 2;                 // chunks per wave
+    const int kbeg = wid * cpw * 16, kend = min(K, kbeg + cpw * 16);
     const bool mv = m < d.M, nv = n < d.N;
     const float* arow = A + (long)(mv ? m : 0) * d.lda;
     const float* brow = B + (BL == 0 ? (long)(nv ? n : 0) * d.ldb : (long)(nv ? n : 0));
@@ -901,40 +906,40 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc
     const float bm = nv ? s0 : 0.f;
     const float* wsc = d.w_scale;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = 0; k0 < K; k0 += 16 * UB) {
+    for (int k0 = kbeg; k0 < kend; k0 += 16 * UB) {
         float a[UB][4], b[UB][4];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {       // branch-free, clamped addresses: all loads of the batch are in flight together
             const int k = k0 + u * 16 + g4 * 4;
             if (vecA) {
-                const bool ok = k < K;
+                const bool ok = k < kend;
                 const float4 t = ld4(arow + (ok ? k : 0));
                 const float f = ok ? am : 0.f;
                 a[u][0] = t.x * f; a[u][1] = t.y * f; a[u][2] = t.z * f; a[u][3] = t.w * f;
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const bool ok = k + s < K;
+                    const bool ok = k + s < kend;
                     a[u][s] = arow[ok ? k + s : 0] * (ok ? am : 0.f);
                 }
             }
             if (BL == 0) {
                 if (vecB) {
-                    const bool ok = k < K;
+                    const bool ok = k < kend;
                     const float4 t = ld4(brow + (ok ? k : 0));
                     const float f = ok ? bm : 0.f;
                     b[u][0] = t.x * f; b[u][1] = t.y * f; b[u][2] = t.z * f; b[u][3] = t.w * f;
                 } else {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
-                        const bool ok = k + s < K;
+                        const bool ok = k + s < kend;
                         b[u][s] = brow[ok ? k + s : 0] * (ok ? bm : 0.f);
                     }
                 }
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const bool ok = k + s < K;
+                    const bool ok = k + s < kend;
                     const int kk = ok ? k + s : 0;
                     float v = brow[(long)kk * d.ldb];
                     if (wsc) v *= wsc[kk];
@@ -948,6 +953,10 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][s], acc, 0, 0, 0);
     }
     mfma_drain(acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wid][r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wid != 0) return;
     // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
     const int no = tn * 16 + i;
     if (no >= d.N) return;
@@ -956,7 +965,8 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc
     for (int r = 0; r < 4; ++r) {
         const int mo = tm * 16 + g4 * 4 + r;
         if (mo >= d.M) continue;
-        float v = (acc[r] + bias) * d.out_scale;
+        const float sum = (red[0][r * 64 + lane] + red[1][r * 64 + lane]) + (red[2][r * 64 + lane] + red[3][r * 64 + lane]);
+        float v = (sum + bias) * d.out_scale;
         if (d.resid) v += d.resid[(long)mo * d.ldr + no];
         if (d.gate) v = d.gate[(long)mo * d.ldg + no] > 0.f ? v : 0.f;
         if (d.relu) v = fmaxf(v, 0.f);
@@ -964,10 +974,11 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc
     }
 }
 
-// dW[i][c] += scale[i] * sum_p dY[p][i] X[p][c] (+ dbias[i] += sum_p dY[p][i]) for short reductions (P <= 1024).
+// dW[i][c] += scale[i] * sum_p dY[p][i] X[p][c] (+ dbias[i] += sum_p dY[p][i]) for short reductions (P <= 1024):
+// one wave = one 16x16 output tile x one slice of the pixel range (grid.y slices); results are added atomically.
 __global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
-                                                           float* __restrict__ dbias) {
-    constexpr int UB = 4;
+                                                           const int p_per_slice, float* __restrict__ dbias) {
+    constexpr int UB = 8;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int tile = blockIdx.x * 4 + wid;
     if (tile >= tilesI * tilesJ) return;
@@ -982,16 +993,17 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_des
     const float* ya = dY + (iv ? ci : 0);
     const float* xb = X + (cv ? cc : 0);
     const float fa = iv ? 1.f : 0.f, fb = cv ? 1.f : 0.f;
+    const int pbeg = blockIdx.y * p_per_slice, pend = min(d.P, pbeg + p_per_slice);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
-    for (int p0 = 0; p0 < d.P; p0 += 16 * UB) {
+    for (int p0 = pbeg; p0 < pend; p0 += 16 * UB) {
         float a[UB][4], b[UB][4];
 #pragma unroll
         for (int u = 0; u < UB; ++u)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const int p = p0 + u * 16 + g4 * 4 + s;
-                const bool pv = p < d.P;
+                const bool pv = p < pend;
                 const long pc = pv ? p : 0;
                 a[u][s] = ya[pc * d.ldy] * (pv ? fa : 0.f);
                 b[u][s] = xb[pc * d.ldx] * (pv ? fb : 0.f);
@@ -1006,6 +1018,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_des
     }
     mfma_drain(acc);
     const int co = tj * 16 + i;
+    const bool single = gridDim.y == 1;
     if (co < d.Cin) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1013,7 +1026,9 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_des
             if (io >= d.Nout) continue;
             float v = acc[r];
             if (d.w_scale) v *= d.w_scale[io];
-            dW[(long)io * d.ldw + co] += v;      // one owner per element within a launch
+            float* dst = dW + (long)io * d.ldw + co;
+            if (single) *dst += v;               // one owner per element within a launch
+            else atomicAdd(dst, v);
         }
     }
     if (dbias != nullptr && tj == 0) {
@@ -1158,16 +1173,15 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     }
     if ((force == 5 && d.g.mode == CDETR_ROWS_DENSE) || (d.g.mode == CDETR_ROWS_DENSE && (blocks(64, 64) <= 48 || !(vecA && vecB && (d.K % 32) == 0)) && blocks(64, 64) < 192)) {   // latency-bound: one wave per 16x16 tile
         const int tilesM = (d.M + 15) / 16, tilesN = (d.N + 15) / 16;
-        dim3 grid((tilesM * tilesN + 3) / 4, 1, d.batch);
-        // K <= 256: every operand load of the wave is in flight at once (one memory round trip per tile)
-        const bool deep = d.K > 128 && vecA && (d.b_layout == 1 || vecB);
-        if (d.b_layout == 0) {
-            if (deep) hipLaunchKernelGGL((igemm_direct_kernel<0, 16>), grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
-            else hipLaunchKernelGGL((igemm_direct_kernel<0, 8>), grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
-        } else {
-            if (deep) hipLaunchKernelGGL((igemm_direct_kernel<1, 16>), grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
-            else hipLaunchKernelGGL((igemm_direct_kernel<1, 8>), grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
-        }
+        dim3 grid(tilesM * tilesN, 1, d.batch);          // one workgroup (4 waves, K split 4 ways) per 16x16 tile
+        const int cpw = (((d.K + 15) >> 4) + 3) >> 2;    // 16-wide k-chunks per wave
+        auto go = [&](auto k0, auto k1) {
+            if (d.b_layout == 0) hipLaunchKernelGGL(k0, grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+            else hipLaunchKernelGGL(k1, grid, dim3(256), 0, st, d, tilesM, tilesN, vecA, vecB);
+        };
+        if (cpw <= 4) go(igemm_direct_kernel<0, 4>, igemm_direct_kernel<1, 4>);
+        else if (cpw <= 8) go(igemm_direct_kernel<0, 8>, igemm_direct_kernel<1, 8>);
+        else go(igemm_direct_kernel<0, 16>, igemm_direct_kernel<1, 16>);
         return cdetr_launch_status("cdetr_gemm");
     }
     if (vecA && vecB && (d.K % 32) == 0) {   // fast path: tap-uniform k-tiles, no integer division in the loop
@@ -1200,8 +1214,13 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (d.g.mode == CDETR_ROWS_DENSE && d.P <= 1024) {
         const int tilesI = (d.Nout + 15) / 16, tilesJ = (d.Cin + 15) / 16;
-        dim3 grid((tilesI * tilesJ + 3) / 4, 1, d.batch);
-        hipLaunchKernelGGL(wgrad_direct_kernel, grid, dim3(256), 0, st, d, tilesI, tilesJ, d.dbias);
+        int slices = (d.P + 127) / 128;                  // <= 128 pixels (8 chunks: one round trip) per wave
+        if (slices > 8) slices = 8;
+        int per = (d.P + slices - 1) / slices;
+        per = ((per + 15) / 16) * 16;
+        slices = (d.P + per - 1) / per;
+        dim3 grid((tilesI * tilesJ + 3) / 4, slices, d.batch);
+        hipLaunchKernelGGL(wgrad_direct_kernel, grid, dim3(256), 0, st, d, tilesI, tilesJ, per, d.dbias);
         return cdetr_launch_status("cdetr_wgrad");
     }
     const bool fast = (d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0;
