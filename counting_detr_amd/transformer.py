@@ -212,18 +212,21 @@ class Transformer(nn.Module):
             TransformerDecoderLayer(d_model, dim_feedforward, nhead) for _ in range(num_decoder_layers))
         self.spatial_prior = spatial_prior
         self.num_pattern = num_query_pattern
-        self.pattern = nn.Embedding(self.num_pattern, d_model)
+        if stage == 2:
+            self.pattern = nn.Embedding(self.num_pattern, d_model)
+        else:
+            self.modify_pattern = nn.Embedding(self.num_pattern, d_model)      # A1/models/transformer.py:66
         self.num_position = num_query_position
         if spatial_prior == "learned":
             self.position = nn.Embedding(self.num_position, 2)
         self.adapt_pos2d = PosMLP(d_model)
         self.adapt_pos1d = PosMLP(d_model)
         self.num_layers = num_decoder_layers
-        num_classes = 2 if stage == 2 else 1
-        cls_embed = Linear(d_model, num_classes)
+        cls_embed = Linear(d_model, 2)
         bbox_embed = MLP(d_model, d_model, 4, 3)
         prior_prob = 0.01
-        cls_embed.bias.data = torch.ones(num_classes) * (-math.log((1 - prior_prob) / prior_prob))   # :90-92
+        # stage 2: bias [2] (:90-92); stage 1: ONE bias element broadcast over the 2 logits (A1/models/transformer.py:82-86)
+        cls_embed.bias = nn.Parameter(torch.ones(2 if stage == 2 else 1) * (-math.log((1 - prior_prob) / prior_prob)))
         nn.init.constant_(bbox_embed.layers[-1].weight.data, 0)                                       # :94-95
         nn.init.constant_(bbox_embed.layers[-1].bias.data, 0)
         nn.init.constant_(bbox_embed.layers[-1].bias.data[2:], -2.0)                                  # :103
@@ -262,7 +265,8 @@ class Transformer(nn.Module):
         Returns ((classes [Ld,B,Q,ncls], coords [Ld,B,Q,4], vars [Ld,B,Q,2]), reference_points [B,Q,2])."""
         bs, h, w, c = src.shape
         reference_points = self.reference_points(bs, src.device, points)
-        tgt = (self.pattern.weight.reshape(1, self.num_pattern, 1, c).repeat(bs, 1, self.num_position, 1)
+        pattern = self.pattern if self.stage == 2 else self.modify_pattern
+        tgt = (pattern.weight.reshape(1, self.num_pattern, 1, c).repeat(bs, 1, self.num_position, 1)
                .reshape(bs, self.num_pattern * self.num_position, c))
         pos_col, pos_row = mask2pos(mask)
         posemb_row = self.adapt_pos1d(pos2posemb1d(pos_row))             # [B,w,C]
@@ -290,7 +294,11 @@ class Transformer(nn.Module):
             output = layer(output, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean, mask_row, mask_col)
             if not (self.all_layer_heads or lid == last):
                 continue     # the heads of layers 0..4 only feed the aux losses (the reference computes and drops them)
-            outputs_class = self.cls_embed[lid](output)
+            if self.stage == 2:
+                outputs_class = self.cls_embed[lid](output)
+            else:
+                ce = self.cls_embed[lid]
+                outputs_class = ops.linear(output, ce.weight, None) + ce.bias
             tmp = self.bbox_embed[lid](output)
             tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], dim=-1)                     # :200
             outputs_classes.append(outputs_class)

@@ -129,3 +129,12 @@ def counting_metrics(pred_counts, gt_counts):
     err = (g - p).abs()
     return {"MAE": err.mean().item(), "RMSE": (err ** 2).mean().sqrt().item(),
             "NAE": (err / g).mean().item(), "SRE": ((err ** 2) / g).mean().sqrt().item()}
+
+
+def bbox_criterion(outputs, targets):
+    """1st-stage BoundingBoxCriterion, A1/models/anchor_detr.py:317-337 (weights loss_wh 1, loss_giou 0.4)."""
+    tp = targets["points"].flatten(0, 1)
+    sw = outputs["pred_wh"].flatten(0, 1)
+    tw = targets["whs"].flatten(0, 1)
+    giou = torch.diag(generalized_box_iou(box_cxcywh_to_xyxy(torch.cat([tp, sw], -1)), box_cxcywh_to_xyxy(torch.cat([tp, tw], -1))))
+    return {"loss_wh": F.l1_loss(sw, tw), "loss_giou": (1 - giou).sum() / tw.shape[0]}

@@ -231,13 +231,14 @@ def reference_points(sd, bs, spatial_prior, num_position, num_pattern, points=No
 
 
 def transformer(src, mask, sd, spatial_prior="learned", num_position=300, num_pattern=1, enc=6, dec=6,
-                points=None, all_layers=False):
+                points=None, all_layers=False, stage=2):
     """A2/models/transformer.py:109-215 for num_feature_levels == 1.  src: [N,C,H,W]."""
     N, C, H, W = src.shape
     t = "transformer"
     ref = reference_points(sd, N, spatial_prior, num_position, num_pattern, points).to(src.dtype)
     Qp = ref.shape[1] // num_pattern
-    tgt = sd[t + ".pattern.weight"].reshape(1, num_pattern, 1, C).repeat(N, 1, Qp, 1).reshape(N, num_pattern * Qp, C)
+    pat = sd[t + (".pattern.weight" if stage == 2 else ".modify_pattern.weight")]     # A1/models/transformer.py:66
+    tgt = pat.reshape(1, num_pattern, 1, C).repeat(N, 1, Qp, 1).reshape(N, num_pattern * Qp, C)
     pos_col, pos_row = mask2pos(mask)
     posemb_row = mlp2(pos2posemb1d(pos_row).to(src.dtype), sd, t + ".adapt_pos1d")     # [N,W,C]
     posemb_col = mlp2(pos2posemb1d(pos_col).to(src.dtype), sd, t + ".adapt_pos1d")     # [N,H,C]
@@ -254,7 +255,7 @@ def transformer(src, mask, sd, spatial_prior="learned", num_position=300, num_pa
         tmp = mlp3(out, sd, f"{t}.bbox_embed.{i}")
         tmp = torch.cat([tmp[..., :2] + inv_ref, tmp[..., 2:]], -1)                     # :200
         boxes = tmp.sigmoid()
-        var = mlp3(out, sd, f"{t}.bbox_variance.{i}")
+        var = mlp3(out, sd, f"{t}.bbox_variance.{i}") if stage == 2 else None
         outs.append((logits, boxes, var))
     res = {"pred_logits": outs[-1][0], "pred_boxes": outs[-1][1], "pred_vars": outs[-1][2]}
     if all_layers:
@@ -284,3 +285,18 @@ def forward(images, rects, sd, mask=None, **kw):
     feat, m = extract_feature(images, mask, rects, sd)
     src = aggr_input_proj(feat, sd)
     return transformer(src, m, sd, **kw)
+
+
+def forward_stage1(images, points, sd, mask=None, **kw):
+    """1st-stage AnchorDETR.forward, A1/models/anchor_detr.py:80-113: plain backbone + input_proj, `defined` anchor points
+    (A1/models/transformer.py:114-121), no variance head -> {"pred_logits","pred_wh","pred_points"}."""
+    if mask is None:
+        images, mask = nested(images)
+    x = resnet50_dc5(images, sd)
+    h, w = x.shape[-2:]
+    m = F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]
+    src = aggr_input_proj(x, sd, p="input_proj.0")
+    pts = torch.as_tensor(points, dtype=torch.float32).reshape(-1, 2)
+    out, _ = transformer(src, m, sd, spatial_prior="defined", num_position=pts.shape[0], points=pts, stage=1, **kw)
+    b = out["pred_boxes"]
+    return {"pred_logits": out["pred_logits"], "pred_wh": b[..., 2:], "pred_points": b[..., :2]}

@@ -76,17 +76,16 @@ def transformer_schema(d=256, dff=1024, enc=6, dec=6, num_pattern=1, num_positio
         _linear(f"{p}.ffn.linear1", dff, d, out)
         _linear(f"{p}.ffn.linear2", d, dff, out)
         _ln(f"{p}.ffn.norm2", d, out)
-    out.append((f"{t}.pattern.weight", (num_pattern, d), "embed"))
+    out.append((f"{t}.pattern.weight" if stage == 2 else f"{t}.modify_pattern.weight", (num_pattern, d), "embed"))
     if spatial_prior == "learned":
         out.append((f"{t}.position.weight", (num_position, 2), "position"))
     for name in ("adapt_pos2d", "adapt_pos1d"):
         _linear(f"{t}.{name}.0", d, d, out)
         _linear(f"{t}.{name}.2", d, d, out)
     # heads: ONE module each, aliased `dec` times (A2/models/transformer.py:104-107) -> 6 identical copies
-    ncls = 2 if stage == 2 else 1
     for i in range(dec):
-        out.append((f"{t}.cls_embed.{i}.weight", (ncls, d), "alias:cls_w"))
-        out.append((f"{t}.cls_embed.{i}.bias", (ncls,), "alias:cls_b"))
+        out.append((f"{t}.cls_embed.{i}.weight", (2, d), "alias:cls_w"))
+        out.append((f"{t}.cls_embed.{i}.bias", (2 if stage == 2 else 1,), "alias:cls_b"))   # A1/models/transformer.py:82-86
         for j, (no, ni) in enumerate(((d, d), (d, d), (4, d))):
             out.append((f"{t}.bbox_embed.{i}.layers.{j}.weight", (no, ni), f"alias:box_w{j}"))
             out.append((f"{t}.bbox_embed.{i}.layers.{j}.bias", (no,), f"alias:box_b{j}"))
@@ -94,6 +93,15 @@ def transformer_schema(d=256, dff=1024, enc=6, dec=6, num_pattern=1, num_positio
             for j, (no, ni) in enumerate(((d, d), (d, d), (2, d))):
                 out.append((f"{t}.bbox_variance.{i}.layers.{j}.weight", (no, ni), f"alias:var_w{j}"))
                 out.append((f"{t}.bbox_variance.{i}.layers.{j}.bias", (no,), f"alias:var_b{j}"))
+    return out
+
+
+def stage1_schema(num_pattern=1, spatial_prior="defined", enc=6, dec=6, d=256, dff=1024):
+    """State dict of the 1st-stage model (A1/models/anchor_detr.py:34-79): backbone + input_proj + transformer (stage 1)."""
+    out = backbone_schema()
+    out += [("input_proj.0.0.weight", (d, 2048, 1, 1), "conv_xavier"), ("input_proj.0.0.bias", (d,), "bias"),
+            ("input_proj.0.1.weight", (d,), "ln_weight"), ("input_proj.0.1.bias", (d,), "ln_bias")]
+    out += transformer_schema(d, dff, enc, dec, num_pattern, 0, spatial_prior, stage=1)
     return out
 
 
@@ -155,7 +163,7 @@ def _make_alias(tag, shape):
     if tag == "cls_w":
         return r() * 0.05
     if tag == "cls_b":
-        return torch.full(shape, -math.log(99.0)) + 0.1 * r()
+        return torch.full(shape, -math.log(99.0)) + 0.1 * torch.randn((2,), generator=g, dtype=torch.float32)[: shape[0]]
     if tag in ("box_w0", "box_w1", "var_w0", "var_w1"):
         return r() * math.sqrt(2.0 / (shape[0] + shape[1]))
     if tag in ("box_b0", "box_b1", "var_b0", "var_b1"):

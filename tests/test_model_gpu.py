@@ -114,3 +114,28 @@ def test_graph_replay_equals_eager():
         res.append({k: float(v) for k, v in out.items()})
     for k in res[0]:
         np.testing.assert_allclose(res[1][k], res[0][k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["n3", "n57"])
+def test_stage1_vs_reference(golden, name, precision):
+    """1st-stage model on the HIP kernels vs golden vectors of the real 1st-stage reference."""
+    from counting_detr_amd import stage1
+    from counting_detr_amd.args import default_args
+    from oracle.weights import seeded_state_dict, stage1_schema
+    z = golden("g7_stage1.npz")
+    args = default_args(device=DEV, spatial_prior="defined")
+    model, crit, _ = stage1.build(args)
+    model.load_state_dict(seeded_state_dict(stage1_schema()), strict=True)
+    model.to(DEV).train()
+    pts, whs = T(z[f"{name}/points"]).to(DEV), T(z[f"{name}/whs"]).to(DEV)
+    out = model(T(z[f"{name}/img"]).to(DEV), pts)
+    for k in ("pred_logits", "pred_wh", "pred_points"):
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), z[f"{name}/{k}"], rtol=1e-3, atol=1e-4, err_msg=k)
+    losses = crit(out, {"points": pts, "whs": whs})
+    for k in ("loss_wh", "loss_giou"):
+        np.testing.assert_allclose(float(losses[k]), z[f"{name}/L_{k}"], rtol=1e-3, err_msg=k)
+    sum(losses[k] * crit.weight_dict[k] for k in losses).backward()
+    params = dict(model.named_parameters())
+    for n, r in zip([str(x) for x in z[f"{name}/param_names"]], z[f"{name}/grad_norms"]):
+        if r >= 0:
+            np.testing.assert_allclose(params[n].grad.norm().item(), r, rtol=1e-2, atol=1e-6, err_msg=n)

@@ -189,3 +189,33 @@ def test_g8_count_rule(golden):
     assert np.array_equal(counts.numpy(), z["counts"])
     m = OC.counting_metrics(counts.numpy(), z["gt"])
     np.testing.assert_allclose([m["MAE"], m["RMSE"], m["NAE"], m["SRE"]], z["metrics"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("name", ["n3", "n57"])
+def test_g7_stage1(golden, name):
+    """1st-stage variant: `defined` anchor points, no variance head, BoundingBoxCriterion."""
+    from oracle.weights import stage1_schema
+    z = golden("g7_stage1.npz")
+    sd = seeded_state_dict(stage1_schema())
+    names = [str(n) for n in z[f"{name}/param_names"]]
+    for n in names:
+        if not (n.startswith("backbone.body.conv1") or n.startswith("backbone.body.layer1")):
+            sd[n].requires_grad_(True)
+    for n in names:
+        for fam in ("cls_embed", "bbox_embed"):
+            if f"transformer.{fam}.0." in n:
+                for i in range(1, 6):
+                    sd[n.replace(f"{fam}.0.", f"{fam}.{i}.")] = sd[n]
+    pts, whs = T(z[f"{name}/points"]), T(z[f"{name}/whs"])
+    out = OM.forward_stage1(T(z[f"{name}/img"]), pts, sd)
+    for k in ("pred_logits", "pred_wh", "pred_points"):
+        np.testing.assert_allclose(out[k].detach().numpy(), z[f"{name}/{k}"], rtol=1e-3, atol=2e-5, err_msg=k)
+    losses = OC.bbox_criterion(out, {"points": pts, "whs": whs})
+    for k in ("loss_wh", "loss_giou"):
+        np.testing.assert_allclose(losses[k].item(), z[f"{name}/L_{k}"], rtol=1e-4, err_msg=k)
+    (losses["loss_wh"] * 1 + losses["loss_giou"] * 0.4).backward()
+    for n, r in zip(names, z[f"{name}/grad_norms"]):
+        if r < 0:
+            assert sd[n].grad is None, n
+        else:
+            np.testing.assert_allclose(sd[n].grad.norm().item(), r, rtol=5e-3, atol=1e-7, err_msg=n)
