@@ -50,7 +50,8 @@ class RcdaBwdDesc(C.Structure):
                 ("ds_row", _p), ("ds_col", _p), ("d_v", _p)]
 
 
-EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_maxpool3x3s2", "cdetr_rcda_fwd", "cdetr_rcda_bwd",
+EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_bwd", "cdetr_posadd2",
+           "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_maxpool3x3s2", "cdetr_rcda_fwd", "cdetr_rcda_bwd",
            "cdetr_match_cost", "cdetr_lsap", "cdetr_last_error", "cdetr_abi_version"]
 
 _lib = None
@@ -77,6 +78,16 @@ def lib():
         L.cdetr_adamw_step.argtypes = [_p, _p, _p, _p, _p, C.c_int64, _p, _p] + [C.c_float] * 6 + [_p]
         L.cdetr_relu_mask.restype = C.c_int
         L.cdetr_relu_mask.argtypes = [_p, _p, _p, C.c_int64, C.c_float, _p]
+        L.cdetr_layernorm_fwd.restype = C.c_int
+        L.cdetr_layernorm_fwd.argtypes = [_p] * 6 + [C.c_int32, C.c_int32, C.c_float, _p]
+        L.cdetr_layernorm_bwd.restype = C.c_int
+        L.cdetr_layernorm_bwd.argtypes = [_p] * 9 + [C.c_int32, C.c_int32, _p]
+        L.cdetr_posadd2.restype = C.c_int
+        L.cdetr_posadd2.argtypes = [_p] * 5 + [C.c_int32] * 4 + [_p]
+        L.cdetr_hw_reduce.restype = C.c_int
+        L.cdetr_hw_reduce.argtypes = [_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_float, _p]
+        L.cdetr_bcast_add2.restype = C.c_int
+        L.cdetr_bcast_add2.argtypes = [_p] * 4 + [C.c_int32] * 4 + [C.c_float, C.c_float, _p]
         L.cdetr_maxpool3x3s2.restype = C.c_int
         L.cdetr_maxpool3x3s2.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
         L.cdetr_match_cost.restype = C.c_int

@@ -134,3 +134,234 @@ extern "C" int cdetr_relu_mask(const float* y, const float* dy, float* dz, int64
                        (long)n, scale);
     return cdetr_launch_status("cdetr_relu_mask");
 }
+
+// =====================================================================================================================
+// Normalisation / broadcast kernels of the transformer layers (HBM-bound, one wave per row of C <= 1024 channels)
+// =====================================================================================================================
+namespace {
+
+constexpr int LN_MAXV = 4;   // float4 per lane: C <= 64 * 4 * 4 = 1024
+
+// y = (x - mean) * rstd * gamma + beta ; saves mean / rstd per row (A2/models/transformer.py norm1 / norm2 / ffn.norm2)
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int nv = C >> 8;   // float4 per lane (C multiple of 256) -- checked on the host
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
+        float4 v[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i)
+            if (i < nv) { v[i] = xr[lane + 64 * i]; s += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i)
+            if (i < nv) {
+                const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, dd = v[i].w - mu;
+                q += (a * a + b * b) + (c * c + dd * dd);
+            }
+        const float rs = rsqrtf(wave_sum(q) / C + eps);
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+        float4* yr = reinterpret_cast<float4*>(y + (long)row * C);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i)
+            if (i < nv) {
+                const float4 g4 = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+                const float4 b4 = reinterpret_cast<const float4*>(beta)[lane + 64 * i];
+                float4 o;
+                o.x = (v[i].x - mu) * rs * g4.x + b4.x; o.y = (v[i].y - mu) * rs * g4.y + b4.y;
+                o.z = (v[i].z - mu) * rs * g4.z + b4.z; o.w = (v[i].w - mu) * rs * g4.w + b4.w;
+                yr[lane + 64 * i] = o;
+            }
+    }
+}
+
+// dx = rstd * (dy*g - mean_c(dy*g) - xhat * mean_c(dy*g*xhat)) (+ add) ; dgamma += sum_rows dy*xhat ; dbeta += sum_rows dy
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ add,
+                                                     float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int rows, int C) {
+    __shared__ float red[2][4][1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nv = C >> 8;
+    float4 ag[LN_MAXV], ab[LN_MAXV], g4[LN_MAXV];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        ag[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        ab[i] = ag[i];
+        if (i < nv) g4[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
+    }
+    for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
+        const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
+        const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * C);
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[LN_MAXV], dg[LN_MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i)
+            if (i < nv) {
+                const float4 xv = xr[lane + 64 * i], dv = dr[lane + 64 * i];
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                dg[i] = make_float4(dv.x * g4[i].x, dv.y * g4[i].y, dv.z * g4[i].z, dv.w * g4[i].w);
+                s1 += (dg[i].x + dg[i].y) + (dg[i].z + dg[i].w);
+                s2 += (dg[i].x * xh[i].x + dg[i].y * xh[i].y) + (dg[i].z * xh[i].z + dg[i].w * xh[i].w);
+                ag[i].x += dv.x * xh[i].x; ag[i].y += dv.y * xh[i].y; ag[i].z += dv.z * xh[i].z; ag[i].w += dv.w * xh[i].w;
+                ab[i].x += dv.x; ab[i].y += dv.y; ab[i].z += dv.z; ab[i].w += dv.w;
+            }
+        const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+        float4* ox = reinterpret_cast<float4*>(dx + (long)row * C);
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i)
+            if (i < nv) {
+                float4 o;
+                o.x = rs * (dg[i].x - m1 - xh[i].x * m2); o.y = rs * (dg[i].y - m1 - xh[i].y * m2);
+                o.z = rs * (dg[i].z - m1 - xh[i].z * m2); o.w = rs * (dg[i].w - m1 - xh[i].w * m2);
+                if (add) {
+                    const float4 a4 = reinterpret_cast<const float4*>(add + (long)row * C)[lane + 64 * i];
+                    o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+                }
+                ox[lane + 64 * i] = o;
+            }
+    }
+    // reduce the 4 waves' partial dgamma / dbeta through LDS, one atomic per channel per workgroup
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+        if (i < nv) {
+            const int c = (lane + 64 * i) * 4;
+            red[0][wid][c] = ag[i].x; red[0][wid][c + 1] = ag[i].y; red[0][wid][c + 2] = ag[i].z; red[0][wid][c + 3] = ag[i].w;
+            red[1][wid][c] = ab[i].x; red[1][wid][c + 1] = ab[i].y; red[1][wid][c + 2] = ab[i].z; red[1][wid][c + 3] = ab[i].w;
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        atomicAdd(dgamma + c, (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]));
+        atomicAdd(dbeta + c, (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]));
+    }
+}
+
+// Encoder prologue: Qr[n,y,x,:] = X + Prow[n,x,:], Qc[n,y,x,:] = X + Pcol[n,y,:]  (A2/models/transformer.py:248-255)
+__global__ __launch_bounds__(256) void posadd2_kernel(const float* __restrict__ X, const float* __restrict__ Prow,
+                                                      const float* __restrict__ Pcol, float* __restrict__ Qr, float* __restrict__ Qc,
+                                                      int N, int H, int W, int C4) {
+    const long total = (long)N * H * W * C4;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C4);
+        long t = idx / C4;
+        const int xw = (int)(t % W); t /= W;
+        const int yh = (int)(t % H);
+        const int n = (int)(t / H);
+        const float4 v = reinterpret_cast<const float4*>(X)[idx];
+        const float4 pr = reinterpret_cast<const float4*>(Prow)[((long)n * W + xw) * C4 + c];
+        const float4 pc = reinterpret_cast<const float4*>(Pcol)[((long)n * H + yh) * C4 + c];
+        reinterpret_cast<float4*>(Qr)[idx] = make_float4(v.x + pr.x, v.y + pr.y, v.z + pr.z, v.w + pr.w);
+        reinterpret_cast<float4*>(Qc)[idx] = make_float4(v.x + pc.x, v.y + pc.y, v.z + pc.z, v.w + pc.w);
+    }
+}
+
+// Reductions of an NHWC map over one spatial axis (+ optional small addend):
+//   blocks [0, N*W):       Or[n,x,:] = scale_r * sum_y X[n,y,x,:] (+ Ar[n,x,:])
+//   blocks [N*W, N*W+N*H): Oc[n,y,:] = scale_c * sum_x X[n,y,x,:] (+ Ac[n,y,:])
+// forward: X = src, scale = 1/H, 1/W, addend = positional embeddings (k_row / k_col inputs, mean-before-project);
+// backward: X = a logit-gradient map, scale = 1 (sum over the broadcast axis).  Xc (second map) may differ from Xr.
+__global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict__ Xr, const float* __restrict__ Xc,
+                                                        const float* __restrict__ Ar, const float* __restrict__ Ac,
+                                                        float* __restrict__ Or, float* __restrict__ Oc, int N, int H, int W, int C,
+                                                        float scale_r, float scale_c) {
+    const int b = blockIdx.x;
+    const int c = threadIdx.x;          // C <= 256 handled per pass
+    if (b < N * W) {
+        const int n = b / W, xw = b % W;
+        for (int cc = c; cc < C; cc += 256) {
+            float s = 0.f;
+            for (int y = 0; y < H; ++y) s += Xr[(((long)n * H + y) * W + xw) * C + cc];
+            s *= scale_r;
+            if (Ar) s += Ar[(long)b * C + cc];
+            Or[(long)b * C + cc] = s;
+        }
+    } else {
+        const int r = b - N * W;            // = n*H + y
+        const float* base = Xc + (long)r * W * C;
+        for (int cc = c; cc < C; cc += 256) {
+            float s = 0.f;
+            for (int xw = 0; xw < W; ++xw) s += base[(long)xw * C + cc];
+            s *= scale_c;
+            if (Ac) s += Ac[(long)r * C + cc];
+            Oc[(long)r * C + cc] = s;
+        }
+    }
+}
+
+// out[n,y,x,:] = T[n,y,x,:] + sr * Br[n,x,:] + sc * Bc[n,y,:]   (backward of the two key means: broadcast back)
+__global__ __launch_bounds__(256) void bcast_add2_kernel(const float* __restrict__ T, const float* __restrict__ Br,
+                                                         const float* __restrict__ Bc, float* __restrict__ out, int N, int H,
+                                                         int W, int C4, float sr, float sc) {
+    const long total = (long)N * H * W * C4;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C4);
+        long t = idx / C4;
+        const int xw = (int)(t % W); t /= W;
+        const int yh = (int)(t % H);
+        const int n = (int)(t / H);
+        const float4 v = reinterpret_cast<const float4*>(T)[idx];
+        const float4 br = reinterpret_cast<const float4*>(Br)[((long)n * W + xw) * C4 + c];
+        const float4 bc = reinterpret_cast<const float4*>(Bc)[((long)n * H + yh) * C4 + c];
+        reinterpret_cast<float4*>(out)[idx] = make_float4(v.x + sr * br.x + sc * bc.x, v.y + sr * br.y + sc * bc.y,
+                                                          v.z + sr * br.z + sc * bc.z, v.w + sr * br.w + sc * bc.w);
+    }
+}
+
+}  // namespace
+
+extern "C" int cdetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                   int32_t rows, int32_t C, float eps, void* stream) {
+    CDETR_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows >= 0, "cdetr_layernorm_fwd: null pointer");
+    CDETR_CHECK_ARG(C > 0 && (C & 255) == 0 && C <= 1024, "cdetr_layernorm_fwd: C must be a multiple of 256, <= 1024 (got %d)", C);
+    if (rows == 0) return CDETR_OK;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gamma, beta, y, mean,
+                       rstd, rows, C, eps);
+    return cdetr_launch_status("cdetr_layernorm_fwd");
+}
+
+extern "C" int cdetr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                   const float* add, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, void* stream) {
+    CDETR_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && rows >= 0, "cdetr_layernorm_bwd: null pointer");
+    CDETR_CHECK_ARG(C > 0 && (C & 255) == 0 && C <= 1024, "cdetr_layernorm_bwd: C must be a multiple of 256, <= 1024 (got %d)", C);
+    if (rows == 0) return CDETR_OK;
+    int blocks = (rows + 15) / 16;       // >= 4 rows per wave: amortises the per-workgroup dgamma/dbeta atomics
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma,
+                       add, dx, dgamma, dbeta, rows, C);
+    return cdetr_launch_status("cdetr_layernorm_bwd");
+}
+
+extern "C" int cdetr_posadd2(const float* X, const float* Prow, const float* Pcol, float* Qr, float* Qc, int32_t N, int32_t H,
+                             int32_t W, int32_t C, void* stream) {
+    CDETR_CHECK_ARG(X && Prow && Pcol && Qr && Qc && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "cdetr_posadd2: bad args");
+    const long n4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(posadd2_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, Prow, Pcol, Qr,
+                       Qc, N, H, W, C / 4);
+    return cdetr_launch_status("cdetr_posadd2");
+}
+
+extern "C" int cdetr_hw_reduce(const float* Xr, const float* Xc, const float* Ar, const float* Ac, float* Or, float* Oc, int32_t N,
+                               int32_t H, int32_t W, int32_t C, float scale_r, float scale_c, void* stream) {
+    CDETR_CHECK_ARG(Xr && Xc && Or && Oc && N > 0 && H > 0 && W > 0 && C > 0, "cdetr_hw_reduce: bad args");
+    hipLaunchKernelGGL(hw_reduce_kernel, dim3(N * (W + H)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Xr, Xc, Ar, Ac, Or,
+                       Oc, N, H, W, C, scale_r, scale_c);
+    return cdetr_launch_status("cdetr_hw_reduce");
+}
+
+extern "C" int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc, float* out, int32_t N, int32_t H, int32_t W,
+                                int32_t C, float sr, float sc, void* stream) {
+    CDETR_CHECK_ARG(T && Br && Bc && out && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "cdetr_bcast_add2: bad args");
+    const long n4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(bcast_add2_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, Br, Bc, out, N,
+                       H, W, C / 4, sr, sc);
+    return cdetr_launch_status("cdetr_bcast_add2");
+}

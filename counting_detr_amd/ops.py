@@ -242,28 +242,63 @@ def rcda_pads(H, W):
     return (H + 7) & ~7, (W + 3) & ~3
 
 
+def rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
+    """-> (out [N,L,E], a_row [N,nh,L,Wp], a_col [N,nh,L,Hp]); inputs contiguous fp32."""
+    N, L, E = q_row.shape
+    H, W = v.shape[1:3]
+    assert E == nh * 32, "the RCDA kernels are specialised for head_dim 32"
+    Hp, Wp = rcda_pads(H, W)
+    out = torch.empty((N, L, E), device=v.device, dtype=torch.float32)
+    a_row = torch.empty((N, nh, L, Wp), device=v.device, dtype=torch.float32)
+    a_col = torch.empty((N, nh, L, Hp), device=v.device, dtype=torch.float32)
+    d = RcdaFwdDesc()
+    d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
+    d.precision = PRECISION
+    d.q_row, d.q_col, d.k_row, d.k_col, d.v = ptr(q_row), ptr(q_col), ptr(k_row), ptr(k_col), ptr(v)
+    d.mask_row, d.mask_col = ptr(mask_row), ptr(mask_col)
+    d.out, d.a_row, d.a_col = ptr(out), ptr(a_row), ptr(a_col)
+    with _Timed("rcda_fwd", 2.0 * N * nh * L * (H * W * 32 + (H + W) * 32)):
+        check(lib().cdetr_rcda_fwd(C.byref(d), stream_ptr()), "cdetr_rcda_fwd")
+    return out, a_row, a_col
+
+
+def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
+    """-> (dq_row, dq_col, dk_row, dk_col, dv)."""
+    N, L, E = q_row.shape
+    H, W = v.shape[1:3]
+    Hp, Wp = rcda_pads(H, W)
+    d_out = d_out.contiguous()
+    ds_row = torch.empty_like(a_row)
+    ds_col = torch.empty_like(a_col)
+    d_v = torch.zeros_like(v)
+    d = RcdaBwdDesc()
+    d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
+    d.precision = PRECISION
+    d.d_out, d.a_row, d.a_col, d.v = ptr(d_out), ptr(a_row), ptr(a_col), ptr(v)
+    d.ds_row, d.ds_col, d.d_v = ptr(ds_row), ptr(ds_col), ptr(d_v)
+    with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32)):
+        check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
+    # logits -> projected q/k gradients: four small batched GEMMs per image (batch over heads) on the same MFMA kernels
+    dq_row = torch.empty_like(q_row)
+    dq_col = torch.empty_like(q_col)
+    dk_row = torch.zeros_like(k_row)
+    dk_col = torch.zeros_like(k_col)
+    for n in range(N):
+        gemm_raw(ds_row[n], Wp, k_row[n], E, dq_row[n], E, L, 32, W, b_layout=1, batch=nh, sA=L * Wp, sB=32, sC=32)
+        gemm_raw(ds_col[n], Hp, k_col[n], E, dq_col[n], E, L, 32, H, b_layout=1, batch=nh, sA=L * Hp, sB=32, sC=32)
+        wgrad_raw(ds_row[n], Wp, q_row[n], E, dk_row[n], E, L, W, 32, batch=nh, sY=L * Wp, sX=32, sW=32)
+        wgrad_raw(ds_col[n], Hp, q_col[n], E, dk_col[n], E, L, H, 32, batch=nh, sY=L * Hp, sX=32, sW=32)
+    return dq_row, dq_col, dk_row, dk_col, d_v
+
+
 class RcdaCoreFn(torch.autograd.Function):
     """Fused two-softmax + double contraction of A2/models/row_column_decoupled_attention.py:215-309.
     q_row,q_col [N,L,E]; k_row [N,W,E]; k_col [N,H,E]; v [N,H,W,E]; masks uint8 [N,W] / [N,H] or None -> out [N,L,E]."""
 
     @staticmethod
     def forward(ctx, q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
-        N, L, E = q_row.shape
-        H, W = v.shape[1:3]
-        assert E == nh * 32, "the RCDA kernels are specialised for head_dim 32"
         q_row, q_col, k_row, k_col, v = [t.contiguous() for t in (q_row, q_col, k_row, k_col, v)]
-        Hp, Wp = rcda_pads(H, W)
-        out = torch.empty((N, L, E), device=v.device, dtype=torch.float32)
-        a_row = torch.empty((N, nh, L, Wp), device=v.device, dtype=torch.float32)
-        a_col = torch.empty((N, nh, L, Hp), device=v.device, dtype=torch.float32)
-        d = RcdaFwdDesc()
-        d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
-        d.precision = PRECISION
-        d.q_row, d.q_col, d.k_row, d.k_col, d.v = ptr(q_row), ptr(q_col), ptr(k_row), ptr(k_col), ptr(v)
-        d.mask_row, d.mask_col = ptr(mask_row), ptr(mask_col)
-        d.out, d.a_row, d.a_col = ptr(out), ptr(a_row), ptr(a_col)
-        with _Timed("rcda_fwd", 2.0 * N * nh * L * (H * W * 32 + (H + W) * 32)):
-            check(lib().cdetr_rcda_fwd(C.byref(d), stream_ptr()), "cdetr_rcda_fwd")
+        out, a_row, a_col = rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh)
         ctx.save_for_backward(q_row, q_col, k_row, k_col, v, a_row, a_col)
         ctx.nh = nh
         return out
@@ -271,38 +306,163 @@ class RcdaCoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         q_row, q_col, k_row, k_col, v, a_row, a_col = ctx.saved_tensors
-        nh = ctx.nh
-        N, L, E = q_row.shape
-        H, W = v.shape[1:3]
-        Hp, Wp = rcda_pads(H, W)
-        d_out = d_out.contiguous()
-        ds_row = torch.empty_like(a_row)
-        ds_col = torch.empty_like(a_col)
-        d_v = torch.zeros_like(v)
-        d = RcdaBwdDesc()
-        d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
-        d.precision = PRECISION
-        d.d_out, d.a_row, d.a_col, d.v = ptr(d_out), ptr(a_row), ptr(a_col), ptr(v)
-        d.ds_row, d.ds_col, d.d_v = ptr(ds_row), ptr(ds_col), ptr(d_v)
-        with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32)):
-            check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
-        # logits -> projected q/k gradients: four small batched GEMMs per (n, head) on the same MFMA kernels
-        dq_row = torch.empty_like(q_row)
-        dq_col = torch.empty_like(q_col)
-        dk_row = torch.zeros_like(k_row)
-        dk_col = torch.zeros_like(k_col)
-        for n in range(N):
-            # dq[n, :, head*32:(head+1)*32] = dS[n, head] @ k[n, :, head*32:...]   (batch over heads)
-            gemm_raw(ds_row[n], Wp, k_row[n], E, dq_row[n], E, L, 32, W, b_layout=1, batch=nh, sA=L * Wp, sB=32, sC=32)
-            gemm_raw(ds_col[n], Hp, k_col[n], E, dq_col[n], E, L, 32, H, b_layout=1, batch=nh, sA=L * Hp, sB=32, sC=32)
-            # dk[n, w, head*32+c] += sum_q dS[n, head, q, w] q[n, q, head*32+c]
-            wgrad_raw(ds_row[n], Wp, q_row[n], E, dk_row[n], E, L, W, 32, batch=nh, sY=L * Wp, sX=32, sW=32)
-            wgrad_raw(ds_col[n], Hp, q_col[n], E, dk_col[n], E, L, H, 32, batch=nh, sY=L * Hp, sX=32, sW=32)
-        return dq_row, dq_col, dk_row, dk_col, d_v, None, None, None
+        return rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, ctx.nh) + (None, None, None)
 
 
 def rcda_core(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
     return RcdaCoreFn.apply(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh)
+
+
+# ----------------------------------------------------------------------------------------------------- layer norm & glue
+def ln_fwd_raw(x2d, weight, bias, eps=1e-5):
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    mean = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    check(lib().cdetr_layernorm_fwd(ptr(x2d), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), rows, Cc, eps, stream_ptr()),
+          "cdetr_layernorm_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd_raw(dy2d, x2d, mean, rstd, weight, gw, gb, add=None):
+    """dx (+ add); dgamma / dbeta accumulate into gw / gb."""
+    rows, Cc = x2d.shape
+    dx = torch.empty_like(x2d)
+    check(lib().cdetr_layernorm_bwd(ptr(dy2d), ptr(x2d), ptr(mean), ptr(rstd), ptr(weight), ptr(add), ptr(dx), ptr(gw), ptr(gb),
+                                    rows, Cc, stream_ptr()), "cdetr_layernorm_bwd")
+    return dx
+
+
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dim on the fused HIP kernels; parameter gradients accumulate in place into .grad."""
+
+    @staticmethod
+    def forward(ctx, x, wparam, bparam, eps):
+        shp = x.shape
+        x2d = x.reshape(-1, shp[-1]).contiguous()
+        y, mean, rstd = ln_fwd_raw(x2d, wparam.detach(), bparam.detach(), eps)
+        ctx.save_for_backward(x2d, mean, rstd)
+        ctx.wparam, ctx.bparam, ctx.shp = wparam, bparam, shp
+        return y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, mean, rstd = ctx.saved_tensors
+        dy2d = dy.reshape(x2d.shape).contiguous()
+        dx = ln_bwd_raw(dy2d, x2d, mean, rstd, ctx.wparam.detach(), grad_buffer(ctx.wparam), grad_buffer(ctx.bparam))
+        return dx.reshape(ctx.shp), None, None, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    return LayerNormFn.apply(x, weight, bias, eps)
+
+
+def posadd2(X, Prow, Pcol):
+    N, H, W, Cc = X.shape
+    Qr, Qc = torch.empty_like(X), torch.empty_like(X)
+    check(lib().cdetr_posadd2(ptr(X), ptr(Prow), ptr(Pcol), ptr(Qr), ptr(Qc), N, H, W, Cc, stream_ptr()), "cdetr_posadd2")
+    return Qr, Qc
+
+
+def hw_reduce(Xr, Xc, Ar, Ac, scale_r, scale_c):
+    N, H, W, Cc = Xr.shape
+    Or = torch.empty((N, W, Cc), device=Xr.device, dtype=torch.float32)
+    Oc = torch.empty((N, H, Cc), device=Xr.device, dtype=torch.float32)
+    check(lib().cdetr_hw_reduce(ptr(Xr), ptr(Xc), ptr(Ar), ptr(Ac), ptr(Or), ptr(Oc), N, H, W, Cc, scale_r, scale_c, stream_ptr()),
+          "cdetr_hw_reduce")
+    return Or, Oc
+
+
+def bcast_add2(T, Br, Bc, sr, sc):
+    N, H, W, Cc = T.shape
+    out = torch.empty_like(T)
+    check(lib().cdetr_bcast_add2(ptr(T), ptr(Br), ptr(Bc), ptr(out), N, H, W, Cc, sr, sc, stream_ptr()), "cdetr_bcast_add2")
+    return out
+
+
+def _wg(dy2d, x2d, wparam, bparam, lo, hi):
+    """dW[lo:hi] += dy^T x (+ db[lo:hi] += colsum dy) straight into the parameters' gradient buffers."""
+    if not wparam.requires_grad:
+        return
+    gw = grad_buffer(wparam)[lo:hi]
+    gb = grad_buffer(bparam)[lo:hi] if (bparam is not None and bparam.requires_grad) else None
+    wgrad_raw(dy2d, dy2d.stride(0), x2d, x2d.stride(0), gw, gw.stride(0), dy2d.shape[0], hi - lo, x2d.shape[1], dbias=gb)
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """One RCDA encoder layer (A2/models/transformer.py:242-279) as ONE autograd node with a hand-scheduled backward:
+    fused positional-add / key-mean prologue, MFMA projections, fused RCDA core, residual adds fused into GEMM epilogues,
+    fused LayerNorm, and in backward every multi-consumer gradient sum (src feeds q_row, q_col, v, both key means and the
+    residual) chained through the data-gradient epilogues -- no autograd accumulation passes, no elementwise temporaries."""
+
+    @staticmethod
+    def forward(ctx, src, posemb_row, posemb_col, mask_row, mask_col, layer, anchor):
+        N, H, W, Cc = src.shape
+        R = N * H * W
+        att = layer.self_attn
+        E, nh = att.embed_dim, att.num_heads
+        Wi, bi = att.in_proj_weight.detach(), att.in_proj_bias.detach()
+        X = src.contiguous()
+        Prow, Pcol = posemb_row.contiguous(), posemb_col.contiguous()
+        Qr, Qc = posadd2(X, Prow, Pcol)
+        Kr, Kc = hw_reduce(X, X, Prow, Pcol, 1.0 / H, 1.0 / W)
+        q_row = linear_fwd(Qr.view(R, Cc), Wi[0:E], bi[0:E]).view(N, H * W, E)
+        q_col = linear_fwd(Qc.view(R, Cc), Wi[E:2 * E], bi[E:2 * E]).view(N, H * W, E)
+        k_row = linear_fwd(Kr.view(N * W, Cc), Wi[2 * E:3 * E], bi[2 * E:3 * E]).view(N, W, E)
+        k_col = linear_fwd(Kc.view(N * H, Cc), Wi[3 * E:4 * E], bi[3 * E:4 * E]).view(N, H, E)
+        v = linear_fwd(X.view(R, Cc), Wi[4 * E:5 * E], bi[4 * E:5 * E]).view(N, H, W, E)
+        o, a_row, a_col = rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh)
+        Y1 = linear_fwd(o.view(R, E), att.out_proj.weight.detach(), att.out_proj.bias.detach(), resid=X.view(R, Cc))
+        X1, mu1, rs1 = ln_fwd_raw(Y1, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
+        f = layer.ffn
+        Hd = linear_fwd(X1, f.linear1.weight.detach(), f.linear1.bias.detach(), relu=True)
+        Y2 = linear_fwd(Hd, f.linear2.weight.detach(), f.linear2.bias.detach(), resid=X1)
+        X2, mu2, rs2 = ln_fwd_raw(Y2, f.norm2.weight.detach(), f.norm2.bias.detach(), f.norm2.eps)
+        ctx.save_for_backward(X, Qr, Qc, Kr, Kc, q_row, q_col, k_row, k_col, v, a_row, a_col, o, Y1, mu1, rs1, X1, Hd, Y2, mu2, rs2)
+        ctx.layer, ctx.dims = layer, (N, H, W, Cc, E, nh)
+        return X2.view(N, H, W, Cc)
+
+    @staticmethod
+    def backward(ctx, dX2):
+        (X, Qr, Qc, Kr, Kc, q_row, q_col, k_row, k_col, v, a_row, a_col, o, Y1, mu1, rs1, X1, Hd, Y2, mu2, rs2) = ctx.saved_tensors
+        layer = ctx.layer
+        N, H, W, Cc, E, nh = ctx.dims
+        R = N * H * W
+        att, f = layer.self_attn, layer.ffn
+        Wi = att.in_proj_weight.detach()
+        Wip, bip = att.in_proj_weight, att.in_proj_bias
+        dX2 = dX2.reshape(R, Cc).contiguous()
+        # ---- FFN (post-norm): X2 = LN2(X1 + relu(X1 W1^T + b1) W2^T + b2)
+        dY2 = ln_bwd_raw(dX2, Y2, mu2, rs2, f.norm2.weight.detach(), grad_buffer(f.norm2.weight), grad_buffer(f.norm2.bias))
+        _wg(dY2, Hd, f.linear2.weight, f.linear2.bias, 0, Cc)
+        dHd = linear_dgrad(dY2, f.linear2.weight.detach(), gate=Hd)               # ReLU mask fused in the epilogue
+        _wg(dHd, X1, f.linear1.weight, f.linear1.bias, 0, Hd.shape[1])
+        dX1 = linear_dgrad(dHd, f.linear1.weight.detach(), resid=dY2)             # + residual branch
+        # ---- attention block: X1 = LN1(X + o Wo^T + bo)
+        dY1 = ln_bwd_raw(dX1, Y1, mu1, rs1, layer.norm1.weight.detach(), grad_buffer(layer.norm1.weight), grad_buffer(layer.norm1.bias))
+        o2d = o.view(R, E)
+        _wg(dY1, o2d, att.out_proj.weight, att.out_proj.bias, 0, Cc)
+        dO = linear_dgrad(dY1, att.out_proj.weight.detach()).view(N, H * W, E)
+        dq_row, dq_col, dk_row, dk_col, dv = rcda_bwd_raw(dO, q_row, q_col, k_row, k_col, v, a_row, a_col, nh)
+        dq_row2, dq_col2, dv2 = dq_row.view(R, E), dq_col.view(R, E), dv.view(R, E)
+        dk_row2, dk_col2 = dk_row.view(N * W, E), dk_col.view(N * H, E)
+        _wg(dq_row2, Qr.view(R, Cc), Wip, bip, 0, E)
+        _wg(dq_col2, Qc.view(R, Cc), Wip, bip, E, 2 * E)
+        _wg(dk_row2, Kr.view(N * W, Cc), Wip, bip, 2 * E, 3 * E)
+        _wg(dk_col2, Kc.view(N * H, Cc), Wip, bip, 3 * E, 4 * E)
+        _wg(dv2, X.view(R, Cc), Wip, bip, 4 * E, 5 * E)
+        # ---- d(src): residual + three projection inputs chained through the dgrad epilogues, then the two key means
+        t = linear_dgrad(dq_row2, Wi[0:E], resid=dY1)
+        t = linear_dgrad(dq_col2, Wi[E:2 * E], resid=t)
+        t = linear_dgrad(dv2, Wi[4 * E:5 * E], resid=t)
+        dKr = linear_dgrad(dk_row2, Wi[2 * E:3 * E])                               # [N*W, C]
+        dKc = linear_dgrad(dk_col2, Wi[3 * E:4 * E])                               # [N*H, C]
+        dX = bcast_add2(t.view(N, H, W, Cc), dKr, dKc, 1.0 / H, 1.0 / W)
+        # ---- d(posemb): sum over the broadcast axis BEFORE projecting back (linearity) + the key-mean terms
+        sr, sc = hw_reduce(dq_row.view(N, H, W, E), dq_col.view(N, H, W, E), None, None, 1.0, 1.0)
+        dProw = linear_dgrad(sr.view(N * W, E), Wi[0:E], resid=dKr).view(N, W, Cc)
+        dPcol = linear_dgrad(sc.view(N * H, E), Wi[E:2 * E], resid=dKc).view(N, H, Cc)
+        return dX, dProw, dPcol, None, None, None, None
 
 
 # ----------------------------------------------------------------------------------------------------- matcher

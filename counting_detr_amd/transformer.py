@@ -47,6 +47,13 @@ def mask2pos(mask):
     return (y - 0.5) / y[:, -1:], (x - 0.5) / x[:, -1:]
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm parameters; forward on the fused HIP kernels (C multiple of 256), in-place parameter gradients."""
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
 class Linear(nn.Linear):
     def forward(self, x, relu=False, resid=None):
         return ops.linear(x, self.weight, self.bias, relu=relu, resid=resid)
@@ -84,7 +91,7 @@ class FFN(nn.Module):
         super().__init__()
         self.linear1 = Linear(d_model, d_ffn)
         self.linear2 = Linear(d_ffn, d_model)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
 
     def forward(self, src):
         return self.norm2(self.linear2(self.linear1(src, relu=True), resid=src))
@@ -162,10 +169,17 @@ class TransformerEncoderLayerSpatial(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, n_heads=8):
         super().__init__()
         self.self_attn = MultiheadRCDA(d_model, n_heads)
-        self.norm1 = nn.LayerNorm(d_model)
+        self.norm1 = LayerNorm(d_model)
         self.ffn = FFN(d_model, d_ffn)
 
+    fused = True     # one autograd node with a hand-scheduled backward (ops.EncoderLayerFn); False = op-by-op autograd
+
     def forward(self, src, mask_row, mask_col, posemb_row, posemb_col):
+        if self.fused and torch.is_grad_enabled():
+            return ops.EncoderLayerFn.apply(src, posemb_row, posemb_col, mask_row, mask_col, self, self.norm1.weight)
+        return self.forward_unfused(src, mask_row, mask_col, posemb_row, posemb_col)
+
+    def forward_unfused(self, src, mask_row, mask_col, posemb_row, posemb_col):
         N, H, W, Cc = src.shape
         q_row = (src + posemb_row[:, None]).reshape(N, H * W, Cc)        # broadcast over h  (:248)
         q_col = (src + posemb_col[:, :, None]).reshape(N, H * W, Cc)     # broadcast over w  (:249)
@@ -183,9 +197,9 @@ class TransformerDecoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, n_heads=8):
         super().__init__()
         self.cross_attn = MultiheadRCDA(d_model, n_heads)
-        self.norm1 = nn.LayerNorm(d_model)
+        self.norm1 = LayerNorm(d_model)
         self.self_attn = MultiheadSelfAttention(d_model, n_heads)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
         self.ffn = FFN(d_model, d_ffn)
 
     def forward(self, tgt, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean, mask_row, mask_col):

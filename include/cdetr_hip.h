@@ -98,6 +98,24 @@ int cdetr_adamw_step(float* p, const float* g, float* m, float* v, const float* 
 /* dz[i] = y[i] > 0 ? dy[i] * scale : 0      (ReLU backward of the fused linear+ReLU layers) */
 int cdetr_relu_mask(const float* y, const float* dy, float* dz, int64_t n, float scale, void* stream);
 
+/* ---- transformer-layer glue (HBM-bound, fused so a layer touches its activations as few times as possible) --------
+ * cdetr_layernorm_fwd/bwd: nn.LayerNorm over the last dim C (multiple of 256, <= 1024); fwd saves mean/rstd per row;
+ *   bwd: dx (+ add), dgamma += ..., dbeta += ... (A2/models/transformer.py:233,274,334-339,420,425).
+ * cdetr_posadd2:   Qr = X + Prow (broadcast over h), Qc = X + Pcol (broadcast over w)   (transformer.py:248-255).
+ * cdetr_hw_reduce: Or[n,x,:] = sr * sum_y Xr[n,y,x,:] (+ Ar), Oc[n,y,:] = sc * sum_x Xc[n,y,x,:] (+ Ac)
+ *                  (forward: the mean-before-project key inputs; backward: sums of gradient maps over the broadcast axis).
+ * cdetr_bcast_add2: out = T + sr * Br[n,x,:] + sc * Bc[n,y,:]                                                   */
+int cdetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int32_t rows, int32_t C, float eps, void* stream);
+int cdetr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* add, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, void* stream);
+int cdetr_posadd2(const float* X, const float* Prow, const float* Pcol, float* Qr, float* Qc, int32_t N, int32_t H, int32_t W,
+                  int32_t C, void* stream);
+int cdetr_hw_reduce(const float* Xr, const float* Xc, const float* Ar, const float* Ac, float* Or, float* Oc, int32_t N,
+                    int32_t H, int32_t W, int32_t C, float scale_r, float scale_c, void* stream);
+int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
+                     float sr, float sc, void* stream);
+
 /* 3x3 stride-2 pad-1 max pooling, NHWC (A2/models/resnet.py:206,265) */
 int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream);
 

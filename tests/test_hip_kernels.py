@@ -299,3 +299,50 @@ def test_lsap_invalid_cost_raises():
     c[5] = float("nan")
     _, _, status = ops.lsap(c.to(DEV), plan)
     assert int(status[0]) == 2
+
+
+# ----------------------------------------------------------------------------------------------------- layer-level fusion
+@pytest.mark.parametrize("rows,C", [(600, 256), (5000, 256), (77, 1024), (3, 512)])
+def test_layer_norm(rows, C):
+    from counting_detr_amd import ops
+    x = torch.randn(rows, C, generator=g(1)) * 2 + 0.5
+    w, b = 1 + 0.1 * torch.randn(C, generator=g(2)), 0.1 * torch.randn(C, generator=g(3))
+    gy = torch.randn(rows, C, generator=g(4))
+    xd = x.to(DEV).requires_grad_(True)
+    wd, bd = torch.nn.Parameter(w.to(DEV)), torch.nn.Parameter(b.to(DEV))
+    y = ops.layer_norm(xd, wd, bd)
+    y.backward(gy.to(DEV))
+    x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    y64 = F.layer_norm(x64, (C,), w64, b64, 1e-5)
+    y64.backward(gy.double())
+    close(y, y64, rtol=1e-5, msg="ln y")
+    close(xd.grad, x64.grad, rtol=1e-5, msg="ln dx")
+    close(wd.grad, w64.grad, rtol=1e-5, msg="ln dgamma")
+    close(bd.grad, b64.grad, rtol=1e-5, msg="ln dbeta")
+
+
+def test_encoder_layer_fused_equals_unfused(precision):
+    """ops.EncoderLayerFn (one node, hand-scheduled backward) == the op-by-op autograd composition, incl. every gradient."""
+    from counting_detr_amd.transformer import TransformerEncoderLayerSpatial
+    torch.manual_seed(0)
+    N, H, W, Cc = 2, 9, 14, 256
+    res = []
+    for fused in (False, True):
+        torch.manual_seed(1)
+        layer = TransformerEncoderLayerSpatial(Cc, 1024, 8).to(DEV)
+        layer.fused = fused
+        src = torch.randn(N, H, W, Cc, generator=g(1)).to(DEV).requires_grad_(True)
+        pr = torch.randn(N, W, Cc, generator=g(2)).to(DEV).requires_grad_(True)
+        pc = torch.randn(N, H, Cc, generator=g(3)).to(DEV).requires_grad_(True)
+        mr = torch.zeros(N, W, dtype=torch.uint8); mr[1, W - 3:] = 1
+        mc = torch.zeros(N, H, dtype=torch.uint8); mc[1, H - 2:] = 1
+        y = layer(src, mr.to(DEV), mc.to(DEV), pr, pc)
+        y.backward(torch.randn(y.shape, generator=g(4)).to(DEV))
+        res.append((y, src.grad, pr.grad, pc.grad, {k: p.grad for k, p in layer.named_parameters()}))
+    (y0, s0, r0, c0, p0), (y1, s1, r1, c1, p1) = res
+    close(y1, y0, rtol=2e-5, msg="enc out")
+    close(s1, s0, rtol=1e-4, msg="enc dsrc")
+    close(r1, r0, rtol=1e-4, msg="enc dposrow")
+    close(c1, c0, rtol=1e-4, msg="enc dposcol")
+    for k in p0:
+        close(p1[k], p0[k], rtol=1e-4, msg="enc d" + k)
