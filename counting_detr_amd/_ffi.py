@@ -51,7 +51,7 @@ class RcdaBwdDesc(C.Structure):
 
 
 EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_bwd", "cdetr_posadd2",
-           "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_maxpool3x3s2", "cdetr_rcda_fwd", "cdetr_rcda_bwd",
+           "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_maxpool3x3s2", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_match_cost", "cdetr_lsap", "cdetr_last_error", "cdetr_abi_version"]
 
 _lib = None
@@ -90,6 +90,10 @@ def lib():
         L.cdetr_bcast_add2.argtypes = [_p] * 4 + [C.c_int32] * 4 + [C.c_float, C.c_float, _p]
         L.cdetr_maxpool3x3s2.restype = C.c_int
         L.cdetr_maxpool3x3s2.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
+        L.cdetr_mha_fwd.restype = C.c_int
+        L.cdetr_mha_fwd.argtypes = [_p] * 4 + [C.c_int32] * 3 + [C.c_float, _p]
+        L.cdetr_mha_bwd.restype = C.c_int
+        L.cdetr_mha_bwd.argtypes = [_p] * 8 + [C.c_int32] * 3 + [C.c_float, _p]
         L.cdetr_match_cost.restype = C.c_int
         L.cdetr_match_cost.argtypes = [_p, C.c_int32, _p, _p, _p, _p, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                        C.c_float, _p, _p]

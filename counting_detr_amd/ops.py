@@ -313,6 +313,50 @@ def rcda_core(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
     return RcdaCoreFn.apply(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh)
 
 
+# ----------------------------------------------------------------------------------------------------- decoder self-attention
+def mha_fwd_raw(qk, v, nh):
+    N, L, E2 = qk.shape
+    E = E2 // 2
+    o = torch.empty((N, L, E), device=qk.device, dtype=torch.float32)
+    lse = torch.empty((N, nh, L), device=qk.device, dtype=torch.float32)
+    check(lib().cdetr_mha_fwd(ptr(qk), ptr(v), ptr(o), ptr(lse), N, L, nh, (E // nh) ** -0.5, stream_ptr()), "cdetr_mha_fwd")
+    return o, lse
+
+
+def mha_bwd_raw(qk, v, o, d_o, lse, nh):
+    N, L, E2 = qk.shape
+    E = E2 // 2
+    d_qk = torch.empty_like(qk)
+    d_v = torch.empty_like(v)
+    work = torch.empty((N, nh, L), device=qk.device, dtype=torch.float32)
+    check(lib().cdetr_mha_bwd(ptr(qk), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(d_qk), ptr(d_v), ptr(work), N, L, nh,
+                              (E // nh) ** -0.5, stream_ptr()), "cdetr_mha_bwd")
+    return d_qk, d_v
+
+
+class MhaCoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v per head for the decoder queries (qk [N,L,2E] = q | k, v [N,L,E]) in one fused kernel."""
+
+    @staticmethod
+    def forward(ctx, qk, v, nh):
+        assert qk.shape[-1] == 2 * nh * 32, "the MHA kernels are specialised for head_dim 32"
+        qk, v = qk.contiguous(), v.contiguous()
+        o, lse = mha_fwd_raw(qk, v, nh)
+        ctx.save_for_backward(qk, v, o, lse)
+        ctx.nh = nh
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        qk, v, o, lse = ctx.saved_tensors
+        d_qk, d_v = mha_bwd_raw(qk, v, o, d_o.contiguous(), lse, ctx.nh)
+        return d_qk, d_v, None
+
+
+def mha_core(qk, v, nh):
+    return MhaCoreFn.apply(qk, v, nh)
+
+
 # ----------------------------------------------------------------------------------------------------- layer norm & glue
 def ln_fwd_raw(x2d, weight, bias, eps=1e-5):
     rows, Cc = x2d.shape

@@ -155,11 +155,7 @@ class MultiheadSelfAttention(nn.Module):
         nh, d = self.num_heads, E // self.num_heads
         qk = ops.linear(qk_in, self.in_proj_weight, self.in_proj_bias, rows=(0, 2 * E))        # q and k in one GEMM
         v = ops.linear(v_in, self.in_proj_weight, self.in_proj_bias, rows=(2 * E, 3 * E))
-        q = qk[..., :E].reshape(N, L, nh, d).permute(0, 2, 1, 3)
-        k = qk[..., E:].reshape(N, L, nh, d).permute(0, 2, 1, 3)
-        vv = v.reshape(N, L, nh, d).permute(0, 2, 1, 3)
-        a = ((q * (float(d) ** -0.5)) @ k.transpose(-1, -2)).softmax(-1)
-        o = (a @ vv).permute(0, 2, 1, 3).reshape(N, L, E)
+        o = ops.mha_core(qk, v, nh)                       # fused scale / QK^T / softmax / PV kernel
         return self.out_proj(o, resid=resid)
 
 

@@ -150,6 +150,14 @@ int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* d, void* stream);
 static inline int32_t cdetr_rcda_wp(int32_t W) { return (W + 3) & ~3; }
 static inline int32_t cdetr_rcda_hp(int32_t H) { return (H + 7) & ~7; }
 
+/* ---- decoder self-attention core (nn.MultiheadAttention(256, 8) at A2/models/transformer.py:337,369-370) ---------
+ * qk [N][L][2E] = projected queries | keys, v [N][L][E], E = nh*32; o = softmax(scale * q k^T) v per head, lse [N][nh][L]
+ * saved for backward.  cdetr_mha_bwd writes d_qk [N][L][2E], d_v [N][L][E]; work: N*nh*L floats.                 */
+int cdetr_mha_fwd(const float* qk, const float* v, float* o, float* lse, int32_t N, int32_t L, int32_t nh, float scale,
+                  void* stream);
+int cdetr_mha_bwd(const float* qk, const float* v, const float* o, const float* d_o, const float* lse, float* d_qk, float* d_v,
+                  float* work, int32_t N, int32_t L, int32_t nh, float scale, void* stream);
+
 /* ---- Hungarian matcher (A2/models/matcher.py:197-247 + scipy.optimize.linear_sum_assignment) -------------
  * cdetr_match_cost: per image b, cost[b] = 5*L1 + 2*focal-class + 2*(-GIoU) in fp32 with the reference's expression
  * order, written in SOLVER layout: [nr][nc] with nr = min(Q,T_b), nc = max(Q,T_b) (transposed when T_b < Q,

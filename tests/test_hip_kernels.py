@@ -346,3 +346,23 @@ def test_encoder_layer_fused_equals_unfused(precision):
     close(c1, c0, rtol=1e-4, msg="enc dposcol")
     for k in p0:
         close(p1[k], p0[k], rtol=1e-4, msg="enc d" + k)
+
+
+@pytest.mark.parametrize("N,L", [(2, 300), (1, 900), (2, 37), (1, 129)])
+def test_mha_core(N, L):
+    from counting_detr_amd import ops
+    nh, E = 8, 256
+    qk = torch.randn(N, L, 2 * E, generator=g(1))
+    v = torch.randn(N, L, E, generator=g(2))
+    go = torch.randn(N, L, E, generator=g(3))
+    qkd, vd = qk.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
+    o = ops.mha_core(qkd, vd, nh)
+    o.backward(go.to(DEV))
+    qk64, v64 = qk.double().requires_grad_(True), v.double().requires_grad_(True)
+    hs = lambda t: t.reshape(N, L, nh, 32).permute(0, 2, 1, 3)   # noqa: E731
+    a = ((hs(qk64[..., :E]) * 32 ** -0.5) @ hs(qk64[..., E:]).transpose(-1, -2)).softmax(-1)
+    ref = (a @ hs(v64)).permute(0, 2, 1, 3).reshape(N, L, E)
+    ref.backward(go.double())
+    close(o, ref, rtol=2e-5, msg="mha o")
+    close(qkd.grad, qk64.grad, rtol=1e-4, msg="mha dqk")
+    close(vd.grad, v64.grad, rtol=1e-4, msg="mha dv")
