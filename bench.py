@@ -150,7 +150,12 @@ def main():
     torch.cuda.synchronize()
     fam = {}
     shapes = {}
+    ig_alg_bytes = 0.0
     for family, flops, e0, e1, tag in ops.PROFILE:
+        if family == "igemm" and tag is not None:
+            M_, N_, K_, taps_ = tag[0], tag[1], tag[2], tag[3]
+            # compulsory fp32 bytes of one launch: input rows once (a strided/dilated conv reads <= M*K of them), weights, output
+            ig_alg_bytes += 4.0 * (M_ * K_ + N_ * K_ * taps_ + M_ * N_) * max(tag[5], 1)
         if tag is not None:
             sh = shapes.setdefault((family,) + tuple(tag), [0.0, 0.0, 0])
             sh[0] += flops; sh[1] += e0.elapsed_time(e1) * 1e-3; sh[2] += 1
@@ -171,8 +176,17 @@ def main():
     ig = fam.get("igemm", [0.0, 1.0, 1])
     achieved = ig[0] / ig[1] / 1e12
     peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+    # HBM traffic per launch of the same family: PMC counters need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE
+    # cannot share one), so the figure is read from the committed summary of those passes (tools/run_meas.sh).
+    traffic = traffic_src = None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
+    if os.path.exists(tpath) and (H, W, a.queries, a.batch, a.precision) == (800, 800, 300, 2, "bf16x3"):
+        with open(tpath) as f:
+            tj = json.load(f)
+        traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
     roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": None,
+                "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": ig_alg_bytes / max(ig[2], 1),
                 "peak_note": ("fp32 MFMA v_mfma_f32_32x32x2_f32" if a.precision == "fp32" else
                               "2500 TF dense bf16 MFMA / 3 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi)"),
                 "kernel": "igemm_fast_kernel (conv fwd / dgrad / linear) -- algorithmic FLOPs 2*M*N*K*taps per launch",
