@@ -62,6 +62,27 @@ __device__ __forceinline__ void split_bf16x8(const float (&x)[8], bf16x8& hi, bf
         lo[i] = (__bf16)(x[i] - (float)h);
     }
 }
+// Packed form used when a tile is split ONCE while it is staged into LDS: two consecutive-k values -> one dword of hi
+// and one of lo (v_cvt_pk_bf16_f32 + shift/and + v_pk_add_f32 + v_cvt_pk_bf16_f32 = 2.5 VALU ops per element).
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split_bf16_pk(float x0, float x1, unsigned& hi, unsigned& lo) {
+    const f32x2 v = {x0, x1};
+    const bf16x2 h = __builtin_convertvector(v, bf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const f32x2 hf = {__uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+    const f32x2 r = v - hf;
+    const bf16x2 l = __builtin_convertvector(r, bf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+// four consecutive-k fp32 values -> hi (8 bytes) at dst, lo (8 bytes) at dst + lo_off (both in bf16 elements)
+__device__ __forceinline__ void stash_split4(__bf16* dst, int lo_off, float x0, float x1, float x2, float x3) {
+    uint2 h, l;
+    split_bf16_pk(x0, x1, h.x, l.x);
+    split_bf16_pk(x2, x3, h.y, l.y);
+    *reinterpret_cast<uint2*>(dst) = h;
+    *reinterpret_cast<uint2*>(dst + lo_off) = l;
+}
 __device__ __forceinline__ f32x16 mfma_bf16x3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    // small terms first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);

@@ -101,6 +101,42 @@ inline int grid_for(long n4) {
     return (int)b;
 }
 
+
+// ---------------------------------------------------------------------------------------------------- weight mirrors
+// Wt[c][tap][o] = W[o][tap][c] * scale[o] for a table of weights in ONE launch: block -> item by binary search over the
+// tile prefix sums, 32x32 tile through LDS (row stride 33: conflict-free both ways), coalesced 128-byte rows in and out.
+__global__ __launch_bounds__(256) void weight_mirror_kernel(const cdetr_mirror_item* __restrict__ items, const int n_items) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.x;
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const cdetr_mirror_item it = items[lo];
+    const int tilesC = (it.C + 31) >> 5, tilesR = (it.R + 31) >> 5;
+    int t = b - it.tile0;
+    const int tap = t / (tilesR * tilesC);
+    t -= tap * tilesR * tilesC;
+    const int r0 = (t / tilesC) * 32, c0 = (t % tilesC) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + ty + 8 * p, c = c0 + tx;
+        float v = 0.f;
+        if (r < it.R && c < it.C) {
+            v = it.src[((long)r * it.taps + tap) * it.C + c];
+            if (it.scale) v *= it.scale[r];
+        }
+        tile[ty + 8 * p][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = c0 + ty + 8 * p, r = r0 + tx;
+        if (r < it.R && c < it.C) it.dst[((long)c * it.taps + tap) * it.R + r] = tile[tx][ty + 8 * p];
+    }
+}
 }  // namespace
 
 extern "C" int cdetr_sumsq(const float* g, int64_t n, float* out, void* stream) {
@@ -364,4 +400,10 @@ extern "C" int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc
     hipLaunchKernelGGL(bcast_add2_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, Br, Bc, out, N,
                        H, W, C / 4, sr, sc);
     return cdetr_launch_status("cdetr_bcast_add2");
+}
+
+extern "C" int cdetr_weight_mirror(const cdetr_mirror_item* items_dev, int32_t n_items, int32_t total_tiles, void* stream) {
+    CDETR_CHECK_ARG(items_dev && n_items > 0 && total_tiles > 0, "cdetr_weight_mirror: bad args");
+    hipLaunchKernelGGL(weight_mirror_kernel, dim3(total_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), items_dev, n_items);
+    return cdetr_launch_status("cdetr_weight_mirror");
 }

@@ -446,7 +446,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 //   * TWO k-tiles of global loads in flight: tile t+2 is issued before tile t is computed and is written to LDS one
 //     iteration later, so a load has two tile-times (>= 2048 matrix-pipe cycles) to land (ablation in tools/gemm_sweep.py:
 //     with a single tile in flight ~27 % of the kernel was exposed load latency).
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3; ABL: ablation builds
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
@@ -456,7 +456,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     constexpr int A_SLOTS = BM / RPP, B_SLOTS = (BL == 0) ? BN / RPP : BKF * BN / (4 * NT);
     constexpr int LDN = BN + 4;
     constexpr int A_TILE = BM * LDK;
-    constexpr int B_TILE = (BL == 0) ? BN * LDK : BKF * LDN;
+    // PREC == 1: the tile is split into bf16 hi / lo ONCE while it is staged; an LDS row holds [hi k0..BKF-1 | lo k0..BKF-1 | pad]
+    // = the same LDK*4 bytes as the fp32 row, and B is always stored [n][k] (a n-contiguous operand is transposed in
+    // registers: every thread fetches a 4k x NV n block).
+    constexpr bool TRB = (PREC == 2 && BL == 1);
+    constexpr int B_TILE = (BL == 0 || PREC == 2) ? BN * LDK : BKF * LDN;
+    constexpr int EB = BKF * BN / NT;                  // B elements per thread
+    constexpr int NV = (EB >= 16) ? 4 : 2;             // n-width of one transposing block
+    constexpr int NBLK = EB / (4 * NV);
+    static_assert(!TRB || (NBLK >= 1 && NBLK * 4 * NV == EB), "transposing fetch mapping");
     static_assert(BM % RPP == 0 && (BL != 0 || BN % RPP == 0) && (BKF * BN) % (4 * NT) == 0, "tile / thread mapping");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -504,18 +512,44 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
             bscale0[i] = (d.w_scale && n < d.N) ? d.w_scale[n] : 1.f;
         }
     }
-    float4 ra[2][A_SLOTS], rb[2][B_SLOTS];     // two register sets: tiles t+1 and t+2 in flight
-    auto fetch = [&](float4 (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], int tap, int kc) {
+    // register sets for the two k-tiles in flight.  Fetches are RAW loads (nothing in fetch() consumes a loaded value, so
+    // no s_waitcnt lands between issuing a tile and computing on the previous one); scaling / splitting happens in stash().
+    using BVec = typename std::conditional<TRB && NV == 2, float2, float4>::type;
+    constexpr int B_REGS = TRB ? NBLK * 4 : B_SLOTS;
+    float4 ra[2][A_SLOTS];
+    BVec rb[2][B_REGS];
+    float4 rs[2][TRB ? NBLK : 1];              // TRB: per-k-row weight scales of the fetched blocks
+    const float* tb[TRB ? NBLK : 1];           // TRB: this thread's block origin (k-group row, n column) at tap 0, kc 0
+    int tkg[TRB ? NBLK : 1], tng[TRB ? NBLK : 1];
+    if (TRB) {
+#pragma unroll
+        for (int j = 0; j < NBLK; ++j) {
+            const int b = tid + NT * j;
+            tkg[j] = b / (BN / NV);
+            tng[j] = b - tkg[j] * (BN / NV);
+            const int n = n0 + tng[j] * NV;
+            tb[j] = (n < d.N) ? B + (long)(tkg[j] * 4) * taps * d.ldb + n : nullptr;
+        }
+    }
+    auto fetch = [&](float4 (&qa)[A_SLOTS], BVec (&qb)[B_REGS], float4 (&qs)[TRB ? NBLK : 1], int tap, int kc) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) qa[i] = ap[i] ? ld4(ap[i] + kc) : zero4();
-        if (BL == 0) {
+        if constexpr (BL == 0) {
             const int koff = tap * K + kc;
 #pragma unroll
-            for (int i = 0; i < B_SLOTS; ++i) {
-                float4 v = bp[i] ? ld4(bp[i] + koff) : zero4();
-                const float s = bscale0[i];
-                v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-                qb[i] = v;
+            for (int i = 0; i < B_SLOTS; ++i) qb[i] = bp[i] ? ld4(bp[i] + koff) : zero4();
+        } else if constexpr (TRB) {
+            // 4 consecutive k rows x NV columns per block, raw
+            const long base = ((long)kc * taps + tap) * d.ldb;       // wave-uniform
+            const long rstep = (long)taps * d.ldb;
+#pragma unroll
+            for (int j = 0; j < NBLK; ++j) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    if constexpr (NV == 4) qb[j * 4 + kk] = tb[j] ? ld4(tb[j] + base + kk * rstep) : zero4();
+                    else qb[j * 4 + kk] = tb[j] ? *reinterpret_cast<const float2*>(tb[j] + base + kk * rstep) : make_float2(0.f, 0.f);
+                }
+                qs[j] = d.w_scale ? ld4(d.w_scale + kc + tkg[j] * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
             }
         } else {
 #pragma unroll
@@ -537,14 +571,42 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
             }
         }
     };
-    auto stash = [&](const float4 (&qa)[A_SLOTS], const float4 (&qb)[B_SLOTS], int buf) {
+    auto stash = [&](const float4 (&qa)[A_SLOTS], const BVec (&qb)[B_REGS], const float4 (&qs)[TRB ? NBLK : 1], int buf) __attribute__((always_inline)) {
         float* as = As + buf * A_TILE;
         float* bs = Bs + buf * B_TILE;
+        if constexpr (PREC == 2) {
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i)
+                stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + kq * 4, BKF, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
+            if constexpr (BL == 0) {
+#pragma unroll
+                for (int i = 0; i < B_SLOTS; ++i) {
+                    const float s = bscale0[i];
+                    stash_split4(reinterpret_cast<__bf16*>(bs + (r8 + RPP * i) * LDK) + kq * 4, BKF, qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NBLK; ++j) {
+                    __bf16* dst = reinterpret_cast<__bf16*>(bs + (tng[j] * NV) * LDK) + tkg[j] * 4;
+                    const BVec &k0 = qb[j * 4], &k1 = qb[j * 4 + 1], &k2 = qb[j * 4 + 2], &k3 = qb[j * 4 + 3];
+                    const float4 sc = qs[j];
+                    stash_split4(dst, BKF, k0.x * sc.x, k1.x * sc.y, k2.x * sc.z, k3.x * sc.w);
+                    stash_split4(dst + 2 * LDK, BKF, k0.y * sc.x, k1.y * sc.y, k2.y * sc.z, k3.y * sc.w);
+                    if constexpr (NV == 4) {
+                        stash_split4(dst + 4 * LDK, BKF, k0.z * sc.x, k1.z * sc.y, k2.z * sc.z, k3.z * sc.w);
+                        stash_split4(dst + 6 * LDK, BKF, k0.w * sc.x, k1.w * sc.y, k2.w * sc.z, k3.w * sc.w);
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = qa[i];
-        if (BL == 0) {
+        if constexpr (BL == 0) {
 #pragma unroll
-            for (int i = 0; i < B_SLOTS; ++i) *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = qb[i];
+            for (int i = 0; i < B_SLOTS; ++i) {
+                const float s = bscale0[i];
+                *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = make_float4(qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < B_SLOTS; ++i) {
@@ -553,6 +615,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
                 const int nq = idx - kr * (BN / 4);
                 *reinterpret_cast<float4*>(bs + kr * LDN + nq * 4) = qb[i];
             }
+        }
         }
     };
 
@@ -564,7 +627,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* as = As + buf * A_TILE + (wm * (32 * FM) + i32) * LDK + g * 4;
         const float* bs = (BL == 0) ? Bs + buf * B_TILE + (wn * (32 * FN) + i32) * LDK + g * 4
                                     : Bs + buf * B_TILE + (g * 4) * LDN + wn * (32 * FN) + i32;
@@ -596,37 +659,62 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[a][s], b4[b][s], acc[a][b], 0, 0, 0);
             }
         } else {
-            // split-bf16: 16 k per step; lane group g supplies k = 16hp + {4g..4g+3, 8+4g..8+4g+3} for A and B alike
-#pragma unroll
-            for (int hp = 0; hp < BKF / 16; ++hp) {
-                bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
-#pragma unroll
-                for (int a = 0; a < FM; ++a) {
-                    const float4 t0 = *reinterpret_cast<const float4*>(as + a * 32 * LDK + hp * 16);
-                    const float4 t1 = *reinterpret_cast<const float4*>(as + a * 32 * LDK + hp * 16 + 8);
-                    const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
-                    split_bf16x8(x, ah[a], al[a]);
-                }
-#pragma unroll
-                for (int b = 0; b < FN; ++b) {
-                    float x[8];
-                    if (BL == 0) {
-                        const float4 t0 = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + hp * 16);
-                        const float4 t1 = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + hp * 16 + 8);
-                        x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
-                    } else {
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) {
-                            x[s] = bs[(hp * 16 + s) * LDN + b * 32];
-                            x[4 + s] = bs[(hp * 16 + 8 + s) * LDN + b * 32];
-                        }
+            if constexpr (PREC == 1) {
+                // split-bf16: 16 k per step; lane group g supplies k = 16hp + {4g..4g+3, 8+4g..8+4g+3} for A and B alike
+    #pragma unroll
+                for (int hp = 0; hp < BKF / 16; ++hp) {
+                    bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+    #pragma unroll
+                    for (int a = 0; a < FM; ++a) {
+                        const float4 t0 = *reinterpret_cast<const float4*>(as + a * 32 * LDK + hp * 16);
+                        const float4 t1 = *reinterpret_cast<const float4*>(as + a * 32 * LDK + hp * 16 + 8);
+                        const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                        split_bf16x8(x, ah[a], al[a]);
                     }
-                    split_bf16x8(x, bh[b], bl[b]);
+    #pragma unroll
+                    for (int b = 0; b < FN; ++b) {
+                        float x[8];
+                        if (BL == 0) {
+                            const float4 t0 = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + hp * 16);
+                            const float4 t1 = *reinterpret_cast<const float4*>(bs + b * 32 * LDK + hp * 16 + 8);
+                            x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+                        } else {
+    #pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                x[s] = bs[(hp * 16 + s) * LDN + b * 32];
+                                x[4 + s] = bs[(hp * 16 + 8 + s) * LDN + b * 32];
+                            }
+                        }
+                        split_bf16x8(x, bh[b], bl[b]);
+                    }
+    #pragma unroll
+                    for (int a = 0; a < FM; ++a)
+    #pragma unroll
+                        for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
                 }
-#pragma unroll
-                for (int a = 0; a < FM; ++a)
-#pragma unroll
-                    for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+            } else {
+                // split-bf16: 16 k per step; lane group g supplies k = 16hp + 8g .. 8g+7 for A and B alike: one ds_read_b128
+                // of the hi plane and one of the lo plane per fragment, no VALU work between LDS and the matrix pipe
+                const __bf16* a16 = reinterpret_cast<const __bf16*>(As + buf * A_TILE + (wm * (32 * FM) + i32) * LDK) + g * 8;
+                const __bf16* b16 = reinterpret_cast<const __bf16*>(Bs + buf * B_TILE + (wn * (32 * FN) + i32) * LDK) + g * 8;
+    #pragma unroll
+                for (int hp = 0; hp < BKF / 16; ++hp) {
+                    bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+    #pragma unroll
+                    for (int a = 0; a < FM; ++a) {
+                        ah[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + hp * 16);
+                        al[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + BKF + hp * 16);
+                    }
+    #pragma unroll
+                    for (int b = 0; b < FN; ++b) {
+                        bh[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + hp * 16);
+                        bl[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + BKF + hp * 16);
+                    }
+    #pragma unroll
+                    for (int a = 0; a < FM; ++a)
+    #pragma unroll
+                        for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+                }
             }
         }
     };
@@ -638,21 +726,21 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
         if (f_kc == K) { f_kc = 0; ++f_tap; set_tap(f_tap); }
     };
     set_tap(0);
-    fetch(ra[0], rb[0], 0, 0);
-    if (nkt > 1) { advance(); fetch(ra[1], rb[1], f_tap, f_kc); }
-    stash(ra[0], rb[0], 0);
+    fetch(ra[0], rb[0], rs[0], 0, 0);
+    if (nkt > 1) { advance(); fetch(ra[1], rb[1], rs[1], f_tap, f_kc); }
+    stash(ra[0], rb[0], rs[0], 0);
     __syncthreads();
     for (int kt = 0; kt < nkt; kt += 2) {
         // even step: tile kt in LDS[0]; tile kt+1 in set 1; issue tile kt+2 into set 0
-        if (ABL == 0 && kt + 2 < nkt) { advance(); fetch(ra[0], rb[0], f_tap, f_kc); }
+        if (ABL == 0 && kt + 2 < nkt) { advance(); fetch(ra[0], rb[0], rs[0], f_tap, f_kc); }
         compute(0);
         if (kt + 1 < nkt) {
-            if (ABL == 0) stash(ra[1], rb[1], 1);
+            if (ABL == 0) stash(ra[1], rb[1], rs[1], 1);
             if (ABL != 2) __syncthreads();
             // odd step: tile kt+1 in LDS[1]; tile kt+2 in set 0; issue tile kt+3 into set 1
-            if (ABL == 0 && kt + 3 < nkt) { advance(); fetch(ra[1], rb[1], f_tap, f_kc); }
+            if (ABL == 0 && kt + 3 < nkt) { advance(); fetch(ra[1], rb[1], rs[1], f_tap, f_kc); }
             compute(ABL == 0 ? 1 : 0);
-            if (ABL == 0 && kt + 2 < nkt) stash(ra[0], rb[0], 0);
+            if (ABL == 0 && kt + 2 < nkt) stash(ra[0], rb[0], rs[0], 0);
         }
         if (ABL != 2) __syncthreads();
     }
@@ -1112,7 +1200,7 @@ int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
         if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>, bytes, "cdetr_gemm"))) return rc;
         hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>), grid, block, bytes, st, d, tilesM);
     } else {
-        const int bytes = (2 * BM * (BKF + 4) + 2 * BKF * (BN + 4)) * 4;
+        const int bytes = (2 * BM * (BKF + 4) + 2 * (PREC == 2 ? BN * (BKF + 4) : BKF * (BN + 4))) * 4;
         if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC, ABL>, bytes, "cdetr_gemm"))) return rc;
         hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC, ABL>), grid, block, bytes, st, d, tilesM);
     }
@@ -1121,7 +1209,14 @@ int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
 
 template <int WM, int WN, int FM, int FN, int BKF, int ABL = 0>
 int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
-    if (ABL == 0 && d.precision == 1) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 1, 0>(d, st);
+    if (ABL == 0 && d.precision == 1) {
+        // bf16x3: k-contiguous operands (b_layout 0) are split once while they are staged into LDS; the n-contiguous operand
+        // keeps the per-fragment split (its staging transpose costs more than it saves -- tools/split_sweep.py).
+        // CDETR_GEMM_SPLIT: 0 = per-fragment everywhere, 2 = staging split everywhere.
+        static const int split_mode = getenv("CDETR_GEMM_SPLIT") ? atoi(getenv("CDETR_GEMM_SPLIT")) : 1;
+        if (split_mode == 2 || (split_mode == 1 && d.b_layout == 0)) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 2, 0>(d, st);
+        return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 1, 0>(d, st);
+    }
     return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 0, ABL>(d, st);
 }
 

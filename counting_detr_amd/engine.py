@@ -110,8 +110,30 @@ class Trainer:
         self.epoch = 0
         self._graph = None
         self._static = None
+        self.mirror = self._build_mirror(named)
         self.exchange = FlatGradExchange(self.flat_g, self.seg_bounds)
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
+
+    def _build_mirror(self, named):
+        """k-contiguous mirrors (ops.WeightMirror) of every trainable matrix that is a data-gradient operand: backbone
+        convs (FrozenBN scale folded in), 1x1 projections and all linears with both dims >= 32."""
+        from . import ops
+        entries, seen = [], set()
+        for m in self.model.modules():
+            if isinstance(m, _bb.Bottleneck):
+                pairs = [(m.conv1, m.bn1), (m.conv2, m.bn2), (m.conv3, m.bn3)]
+                if m.downsample is not None:
+                    pairs.append((m.downsample[0], m.downsample[1]))
+                for conv, bn in pairs:
+                    if conv.weight.requires_grad:
+                        entries.append((conv.weight.data, bn.affine()[0]))
+                        seen.add(conv.weight.data_ptr())
+        for _, p in named:
+            if p.data_ptr() in seen or min(p.shape[:2] if p.dim() >= 2 else (0,)) < 32:
+                continue
+            if p.dim() == 2 or (p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1):
+                entries.append((p.data, None))
+        return ops.WeightMirror(entries) if entries else None
 
     @staticmethod
     def _view_like(chunk, p):
@@ -174,12 +196,20 @@ class Trainer:
 
     def _fwd_bwd(self, images, mask, rects, targets, num_boxes):
         from .misc import NestedTensor
+        from . import ops
         self.flat_g.zero_()
         outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
         loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
         wd = self.criterion.weight_dict
         losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)             # A2/engine.py:37
-        losses.backward()
+        # data-gradient GEMMs read the k-contiguous weight mirrors: rewritten here (one launch), armed only for this backward
+        if self.mirror is not None:
+            self.mirror.refresh()
+        ops.MIRROR = self.mirror
+        try:
+            losses.backward()
+        finally:
+            ops.MIRROR = None
         out = dict(loss_dict)
         out["loss"] = losses.detach()
         return out

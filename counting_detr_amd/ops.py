@@ -9,7 +9,7 @@ weight-gradient kernels -- autograd only carries activation gradients.
 import torch
 
 from . import _ffi
-from ._ffi import ConvGeom, GemmDesc, RcdaBwdDesc, RcdaFwdDesc, WgradDesc, check, lib, ptr, stream_ptr
+from ._ffi import MirrorItem, ConvGeom, GemmDesc, RcdaBwdDesc, RcdaFwdDesc, WgradDesc, check, lib, ptr, stream_ptr
 
 import ctypes as C
 
@@ -99,6 +99,64 @@ def grad_buffer(p):
     return p.grad
 
 
+# ----------------------------------------------------------------------------------------------------- weight mirrors
+class WeightMirror:
+    """k-contiguous mirrors Wt[c][tap][o] = W[o][tap][c] * scale[o] of weights used as data-gradient operands
+    (cdetr_weight_mirror).  `entries` = [(weight, scale or None)]; weights are [R, C] or channels_last [R, C, kh, kw].
+    `refresh()` rewrites every mirror in one launch (the trainer calls it at the start of each step, inside the graph);
+    `lookup(w, scale)` maps a weight (or a row slice of a registered 2-D weight) to its mirror operand."""
+
+    def __init__(self, entries):
+        import bisect
+        import numpy as np
+        self._bisect = bisect
+        total = sum(w.numel() for w, _ in entries)
+        dev = entries[0][0].device
+        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.entries, self._keep = [], []
+        items = (MirrorItem * len(entries))()
+        off = tile0 = 0
+        for i, (w, sc) in enumerate(entries):
+            R, Cc = w.shape[0], w.shape[1]
+            taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+            if w.dim() == 4:
+                assert taps == 1 or w.is_contiguous(memory_format=torch.channels_last)
+            else:
+                assert w.is_contiguous()
+            items[i].src, items[i].dst = w.data_ptr(), self.flat.data_ptr() + 4 * off
+            items[i].scale = sc.data_ptr() if sc is not None else None
+            items[i].R, items[i].C, items[i].taps, items[i].tile0 = R, Cc, taps, tile0
+            self.entries.append((w.data_ptr(), w.numel() * 4, off, R, Cc, taps, sc.data_ptr() if sc is not None else 0))
+            self._keep.append((w, sc))
+            tile0 += ((R + 31) // 32) * ((Cc + 31) // 32) * taps
+            off += w.numel()
+        self.total_tiles, self.n = tile0, len(entries)
+        raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
+        self.items_dev = torch.from_numpy(raw).to(dev)
+        self.entries.sort()
+        self._bases = [e[0] for e in self.entries]
+
+    def refresh(self):
+        check(lib().cdetr_weight_mirror(ptr(self.items_dev), self.n, self.total_tiles, stream_ptr()), "cdetr_weight_mirror")
+
+    def lookup(self, w, scale=None):
+        """-> (mirror tensor positioned at this weight / row slice, ldb, K) or None"""
+        p = w.data_ptr()
+        i = self._bisect.bisect_right(self._bases, p) - 1
+        if i < 0:
+            return None
+        base, nbytes, off, R, Cc, taps, sptr = self.entries[i]
+        if p >= base + nbytes or sptr != (scale.data_ptr() if scale is not None else 0):
+            return None
+        row0 = (p - base) // (4 * Cc * taps)
+        if (p - base) != row0 * 4 * Cc * taps or (row0 and taps != 1):
+            return None
+        return self.flat[off + row0:], taps * R
+
+
+MIRROR = None      # set by engine.Trainer; None -> data gradients read the weight itself as the n-contiguous operand
+
+
 # ----------------------------------------------------------------------------------------------------- linear
 def linear_fwd(x2d, weight, bias=None, relu=False, resid=None, out_scale=1.0, out=None):
     M, K = x2d.shape
@@ -114,6 +172,12 @@ def linear_dgrad(dy2d, weight, gate=None, resid=None):
     M, N = dy2d.shape
     K = weight.shape[1]
     dx = torch.empty((M, K), device=dy2d.device, dtype=torch.float32)
+    m = MIRROR.lookup(weight) if MIRROR is not None else None
+    if m is not None:
+        gemm_raw(dy2d, dy2d.stride(0), m[0], m[1], dx, K, M, K, N, b_layout=0,
+                 gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
+                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0))
+        return dx
     gemm_raw(dy2d, dy2d.stride(0), weight, weight.stride(0), dx, K, M, K, N, b_layout=1,
              gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
              resid=resid, ldr=(resid.stride(0) if resid is not None else 0))
@@ -213,6 +277,11 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     dense = kh == 1 and kw == 1 and stride == 1 and pad == 0
     g = _geom() if dense else _geom(_ffi.ROWS_CONV_DGRAD, Ho, Wo, Hin, Win, kh, kw, stride, pad, dil)
     dx = torch.empty((Nb, Hin, Win, Cin), device=dz.device, dtype=torch.float32)
+    m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
+    if m is not None:     # FrozenBN scale is folded into the mirror
+        gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
+                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g)
+        return dx
     gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
              gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g)
     return dx

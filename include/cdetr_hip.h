@@ -116,6 +116,19 @@ int cdetr_hw_reduce(const float* Xr, const float* Xc, const float* Ar, const flo
 int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
                      float sr, float sc, void* stream);
 
+/* ---- k-contiguous mirrors of the weights used as data-gradient operands ------------------------------------------------
+ * The data-gradient GEMMs of A2/models/resnet.py:140-160 (conv backward) and of every F.linear site contract over the
+ * OUTPUT channels of a weight W[o][tap][c]; the matrix pipe wants that axis contiguous.  One launch rewrites every
+ * registered weight as Wt[c][tap][o] = W[o][tap][c] * scale[o] (scale = folded FrozenBN, may be NULL); items live in
+ * device memory, `tile0` = prefix sum of ceil(R/32)*ceil(C/32)*taps.                                                  */
+typedef struct {
+    const float* src;     /* W  [R][taps][C]  */
+    float* dst;           /* Wt [C][taps][R]  */
+    const float* scale;   /* [R] or NULL      */
+    int32_t R, C, taps, tile0;
+} cdetr_mirror_item;
+int cdetr_weight_mirror(const cdetr_mirror_item* items_dev, int32_t n_items, int32_t total_tiles, void* stream);
+
 /* 3x3 stride-2 pad-1 max pooling, NHWC (A2/models/resnet.py:206,265) */
 int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream);
 

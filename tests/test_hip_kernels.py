@@ -366,3 +366,39 @@ def test_mha_core(N, L):
     close(o, ref, rtol=2e-5, msg="mha o")
     close(qkd.grad, qk64.grad, rtol=1e-4, msg="mha dqk")
     close(vd.grad, v64.grad, rtol=1e-4, msg="mha dv")
+
+
+def test_weight_mirror_and_dgrad(precision):
+    """cdetr_weight_mirror: Wt[c][tap][o] = W[o][tap][c] * scale[o]; data gradients through the mirror == through the weight."""
+    from counting_detr_amd import ops
+    torch.manual_seed(5)
+    dev = "cuda"
+    w3 = torch.randn(64, 32, 3, 3, device=dev).contiguous(memory_format=torch.channels_last)
+    s3 = torch.rand(64, device=dev) + 0.5
+    wl = torch.randn(160, 96, device=dev)
+    w1 = torch.randn(48, 64, 1, 1, device=dev).contiguous(memory_format=torch.channels_last)
+    mir = ops.WeightMirror([(w3, s3), (wl, None), (w1, None)])
+    mir.refresh()
+    m3, ld3 = mir.lookup(w3, s3)
+    ref3 = (w3 * s3.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(32, 9 * 64)        # [c][tap][o]
+    assert ld3 == 9 * 64 and torch.equal(m3[:32 * 9 * 64].view(32, 9 * 64), ref3)
+    ml, ldl = mir.lookup(wl[32:96])
+    assert ldl == 160 and float(ml[0]) == float(wl[32, 0]) and float(ml[160]) == float(wl[32, 1])
+    full = mir.lookup(wl)[0][:96 * 160].view(96, 160)
+    assert torch.equal(full, wl.t())
+    assert mir.lookup(w3, None) is None and mir.lookup(torch.randn(4, 4, device=dev)) is None
+    # dgrad equivalence (conv 3x3 with scale + gate/resid, linear slice)
+    dz = torch.randn(2, 10, 12, 64, device=dev)
+    gate = torch.randn(2, 10, 12, 32, device=dev)
+    a = ops.conv_dgrad(dz, w3, s3, (10, 12), stride=1, pad=1, dil=1, gate=gate)
+    dy = torch.randn(300, 64, device=dev)
+    b = ops.linear_dgrad(dy, wl[32:96])
+    ops.MIRROR = mir
+    try:
+        a2 = ops.conv_dgrad(dz, w3, s3, (10, 12), stride=1, pad=1, dil=1, gate=gate)
+        b2 = ops.linear_dgrad(dy, wl[32:96])
+    finally:
+        ops.MIRROR = None
+    close(a2, a.double().cpu(), **tol(precision))
+    close(b2, b.double().cpu(), **tol(precision))
+    close(b2, dy.double().cpu() @ wl[32:96].double().cpu(), **tol(precision))
