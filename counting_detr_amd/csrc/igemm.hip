@@ -449,6 +449,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
     constexpr int NT = 64 * WM * WN;
+    constexpr bool ABL_PIPE = (ABL == 0 || ABL >= 3);     // ablations 3 / 4 keep the full pipeline, only drop split work
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
     constexpr int F4R = BKF / 4;             // float4 per k-row (8 or 16)
@@ -576,9 +577,14 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
         float* bs = Bs + buf * B_TILE;
         if constexpr (PREC == 2) {
 #pragma unroll
-            for (int i = 0; i < A_SLOTS; ++i)
-                stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + kq * 4, BKF, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
-            if constexpr (BL == 0) {
+            for (int i = 0; i < A_SLOTS; ++i) {
+                if constexpr (ABL == 4) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = qa[i];      // ablation: no split
+                else stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + kq * 4, BKF, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
+            }
+            if constexpr (BL == 0 && ABL >= 3) {
+#pragma unroll
+                for (int i = 0; i < B_SLOTS; ++i) *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = qb[i];    // ablation
+            } else if constexpr (BL == 0) {
 #pragma unroll
                 for (int i = 0; i < B_SLOTS; ++i) {
                     const float s = bscale0[i];
@@ -732,15 +738,15 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     __syncthreads();
     for (int kt = 0; kt < nkt; kt += 2) {
         // even step: tile kt in LDS[0]; tile kt+1 in set 1; issue tile kt+2 into set 0
-        if (ABL == 0 && kt + 2 < nkt) { advance(); fetch(ra[0], rb[0], rs[0], f_tap, f_kc); }
+        if (ABL_PIPE && kt + 2 < nkt) { advance(); fetch(ra[0], rb[0], rs[0], f_tap, f_kc); }
         compute(0);
         if (kt + 1 < nkt) {
-            if (ABL == 0) stash(ra[1], rb[1], rs[1], 1);
+            if (ABL_PIPE) stash(ra[1], rb[1], rs[1], 1);
             if (ABL != 2) __syncthreads();
             // odd step: tile kt+1 in LDS[1]; tile kt+2 in set 0; issue tile kt+3 into set 1
-            if (ABL == 0 && kt + 3 < nkt) { advance(); fetch(ra[1], rb[1], rs[1], f_tap, f_kc); }
-            compute(ABL == 0 ? 1 : 0);
-            if (ABL == 0 && kt + 2 < nkt) stash(ra[0], rb[0], rs[0], 0);
+            if (ABL_PIPE && kt + 3 < nkt) { advance(); fetch(ra[1], rb[1], rs[1], f_tap, f_kc); }
+            compute(ABL_PIPE ? 1 : 0);
+            if (ABL_PIPE && kt + 2 < nkt) stash(ra[0], rb[0], rs[0], 0);
         }
         if (ABL != 2) __syncthreads();
     }
@@ -1200,9 +1206,11 @@ int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
         if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>, bytes, "cdetr_gemm"))) return rc;
         hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>), grid, block, bytes, st, d, tilesM);
     } else {
-        const int bytes = (2 * BM * (BKF + 4) + 2 * (PREC == 2 ? BN * (BKF + 4) : BKF * (BN + 4))) * 4;
-        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC, ABL>, bytes, "cdetr_gemm"))) return rc;
-        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC, ABL>), grid, block, bytes, st, d, tilesM);
+        // the staging-split variant of the n-contiguous operand needs >= 8 elements per thread (4k x 2n blocks)
+        constexpr int P1 = (PREC == 2 && (BKF * BN) / (64 * WM * WN) < 8) ? 1 : PREC;
+        const int bytes = (2 * BM * (BKF + 4) + 2 * (P1 == 2 ? BN * (BKF + 4) : BKF * (BN + 4))) * 4;
+        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL>), grid, block, bytes, st, d, tilesM);
     }
     return cdetr_launch_status("cdetr_gemm");
 }
@@ -1217,6 +1225,7 @@ int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
         if (split_mode == 2 || (split_mode == 1 && d.b_layout == 0)) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 2, 0>(d, st);
         return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 1, 0>(d, st);
     }
+    if (ABL >= 3) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 2, ABL>(d, st);
     return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 0, ABL>(d, st);
 }
 
@@ -1253,6 +1262,9 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     const int force = force_s ? atoi(force_s) : 0;
     const bool fast_ok = vecA && vecB && (d.K % 32) == 0;
     if (force == 7 && fast_ok) return launch_gemm_fast<1, 2, 1, 1, 32>(d, st);                 // 32x64, 2 waves
+    if (force == 8 && fast_ok) return launch_gemm_fast<4, 2, 1, 1, 32>(d, st);                 // 128x64, 8 waves of 32x32
+    if (force == 9 && fast_ok) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);                 // 64x128, 8 waves of 32x32
+    if (force == 10 && fast_ok) return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);                // 128x128, 16 waves of 32x32
     if (force >= 1 && force <= 4 && fast_ok) {
         if (force == 1) return launch_gemm_fast<2, 2, 2, 2, 32>(d, st);                       // 128x128
         if (force == 2) return launch_gemm_fast<2, 2, 2, 1, 32>(d, st);                       // 128x64
@@ -1260,6 +1272,8 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         const char* abl = getenv("CDETR_GEMM_ABL");
         if (abl && atoi(abl) == 1) return launch_gemm_fast<2, 2, 1, 1, 32, 1>(d, st);
         if (abl && atoi(abl) == 2) return launch_gemm_fast<2, 2, 1, 1, 32, 2>(d, st);
+        if (abl && atoi(abl) == 3) return launch_gemm_fast<2, 2, 1, 1, 32, 3>(d, st);
+        if (abl && atoi(abl) == 4) return launch_gemm_fast<2, 2, 1, 1, 32, 4>(d, st);
         return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);                                       // 64x64, BK 32
     }
     if (force == 6) {
@@ -1285,6 +1299,10 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         // measured on MI355X (tools/gemm_sweep.py, profiles/r1_gemm_sweep.txt): 64x64 tiles at 4 workgroups/CU beat the
         // 128-wide tiles on every shape of this model (latency hiding by occupancy matters more than operand reuse at
         // the fp32-MFMA rate); BK = 64 only pays when the grid is too small to give every CU two workgroups.
+        // bf16x3 with a long reduction is bound by L2->CU operand delivery (~8 TB/s measured, tools/split_sweep.py): a
+        // 128x128 tile shared by 16 waves of 32x32 halves that traffic at the same per-wave structure and occupancy.
+        if (d.precision == 1 && d.b_layout == 0 && (long)d.K * d.taps >= 1024 && (d.N % 128) == 0 && blocks(128, 128) >= 150)
+            return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
         if ((d.K % 64) == 0 && blocks(64, 64) < 512) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);
         return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);
     }
