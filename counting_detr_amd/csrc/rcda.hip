@@ -17,6 +17,7 @@
 // Head dim is fixed at 32 (E = 256, 8 heads in every shipped config).
 #include "../../include/cdetr_hip.h"
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -47,26 +48,16 @@ __host__ __device__ inline FwdSmem fwd_smem(int H, int W, int NW) {
     return s;
 }
 
-// ------------------------------------------------------------------------------------------------ forward
-template <int NF, int NW, int PREC>   // NF = 32-row key fragments along H (H <= 32*NF); NW = waves (x32 queries) per workgroup; PREC 0 = fp32 MFMA, 1 = split-bf16 x3
-__global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc d) {
-    constexpr int NT = 64 * NW, QB = QW * NW;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KH8 = NF * 4;
+// Phases 0-1 shared by both forward kernels: stage the projected keys of (n, head), compute both logit matrices with VALU
+// FMAs (lanes 0-31 own a full row of S_row, lanes 32-63 a full row of S_col: the softmax needs no cross-lane traffic),
+// leave A_row / A_col in this wave's LDS tiles and save them for the backward pass.  Ends with the K tiles dead.
+template <int NT>
+__device__ __forceinline__ void rcda_scores(const cdetr_rcda_fwd_desc& d, const FwdSmem& sm, float* smem, float* Srow, float* Scol,
+                                            int tid, int lane, int i32, int g, int n, int head, int qbase, int q, bool qvalid) {
     const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
-    const FwdSmem sm = fwd_smem(H, W, NW);
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int i32 = lane & 31, g = lane >> 5;
-    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
-    const int qbase = blockIdx.x * QB + wid * QW;
-    const int q = qbase + i32;
-    const bool qvalid = q < L;
-
     float* Krow = smem + sm.off_k;             // [W][32]
     float* Kcol = Krow + W * D;                // [H][32]
-    float* Srow = smem + sm.off_srow + wid * QW * sm.sw;
-    float* Scol = smem + sm.off_scol + wid * QW * sm.sh;
 
     // ---- phase 0: stage the projected keys of this (n, head)
     for (int idx = tid; idx < (W + H) * 8; idx += NT) {
@@ -140,6 +131,28 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
             }
         }
     }
+
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int NF, int NW, int PREC>   // NF = 32-row key fragments along H (H <= 32*NF); NW = waves (x32 queries) per workgroup; PREC 0 = fp32 MFMA, 1 = split-bf16 x3
+__global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_desc d) {
+    constexpr int NT = 64 * NW, QB = QW * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KH8 = NF * 4;
+    const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
+    const int Hp = (H + 7) & ~7;
+    const FwdSmem sm = fwd_smem(H, W, NW);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
+    const int qbase = blockIdx.x * QB + wid * QW;
+    const int q = qbase + i32;
+    const bool qvalid = q < L;
+
+    float* Srow = smem + sm.off_srow + wid * QW * sm.sw;
+    float* Scol = smem + sm.off_scol + wid * QW * sm.sh;
+    rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
 
     // ---- phase 2: out = sum_w (A_col * A_row[:,w]) . V[:,w,:]
     float* Vs = smem + sm.off_v;   // [2][Hp][32]
@@ -227,6 +240,149 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
     for (int r = 0; r < 16; ++r) {
         const int qq = qbase + (r & 3) + 8 * (r >> 2) + 4 * g;
         if (qq < L) d.out[((long)n * L + qq) * E + head * D + i32] = acc[r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, two-step form
+// split-bf16 only, W <= 64.  The contraction is evaluated as the reference factorises it
+//     T_h[q,c] = sum_w A_row[q,w] V[h,w,c]          out[q,c] = sum_h A_col[q,h] T_h[q,c]
+// but transposed, so that everything that is constant over h stays in registers:
+//   * T_h^T[c,q] = sum_w V_h^T[c,w] A_row^T[w,q] is one short MFMA chain per h (KS = ceil(W/16) k-steps of 3 bf16 MFMAs).  Its
+//     B operand (lane = query, 8 consecutive w) is A_row itself: split into bf16 hi/lo ONCE per kernel and kept in 8*KS
+//     registers; the A operand is the V_h tile, transposed and split once per workgroup while it is staged into LDS
+//     (4 w x 2 c register blocks, ds_write_b64), read back with two ds_read_b128 per k-step and no VALU work;
+//   * in the transposed accumulator layout a query is a LANE, so out^T[c,q] += A_col[q,h] * T_h^T[c,q] is 16 FMAs with one
+//     per-lane scalar (the form with A_col*A_row as the MFMA operand needs a multiply + bf16 split per element per h);
+//   * V tiles are prefetched PD = 4 iterations ahead (8 registers per tile per thread): an iteration is never bound by
+//     the global-load latency, which is what limited the one-tile-ahead pipeline of rcda_fwd_kernel.
+struct Fwd2Smem { int off_v, vts, total; };
+__host__ __device__ inline Fwd2Smem fwd2_smem(const FwdSmem& sm, int H, int W, int KS) {
+    Fwd2Smem s;
+    s.off_v = sm.off_k;
+    s.vts = 32 * KS + 8;                                   // bf16 per V^T row: [hi 16KS | lo 16KS | pad 8] -> odd multiple of 16 bytes
+    const int vfloats = 2 * 32 * s.vts / 2;                // two buffers of 32 channel rows
+    const int kfloats = (W + H) * D;
+    s.total = sm.off_k + (kfloats > vfloats ? kfloats : vfloats);
+    return s;
+}
+
+template <int NW, int KS>
+__global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd_desc d) {
+    constexpr int NT = 64 * NW, QB = QW * NW;
+    constexpr int PD = 4;                                  // V tiles in flight
+    constexpr int NBLK = 16 * 4 * KS;                      // 4w x 2c blocks of one tile: (4 KS w-groups) x 16 channel pairs
+    constexpr int VB = (NBLK + NT - 1) / NT;               // blocks per thread
+    constexpr int VTS = 32 * KS + 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
+    const FwdSmem sm = fwd_smem(H, W, NW);
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
+    const int qbase = blockIdx.x * QB + wid * QW;
+    const int q = qbase + i32;
+    const bool qvalid = q < L;
+    float* Srow = smem + sm.off_srow + wid * QW * sm.sw;
+    float* Scol = smem + sm.off_scol + wid * QW * sm.sh;
+    rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
+
+    // ---- hoisted B operand: this lane's A_row row, k-slot j of step s <-> w = 16s + 8g + j
+    bf16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = 16 * s + 8 * g + j;
+            x[j] = (w < W) ? Srow[i32 * sm.sw + w] : 0.f;
+        }
+        split_bf16x8(x, bh[s], bl[s]);
+    }
+
+    // ---- V staging: block (wg, cp) = rows w0 = 4wg .. +3, channels 2cp, 2cp+1
+    __bf16* VT = reinterpret_cast<__bf16*>(smem + sm.off_k);            // [2][32][VTS]
+    // Loads are UNCONDITIONAL (a predicated load sits in its own basic block and the compiler then drains vmcnt every
+    // iteration, which serialises the prefetch ring): rows w >= W are clamped to W-1 -- their products vanish because the
+    // A_row operand is zero there -- and tiles h >= H re-read tile H-1 and are weighted with A_col = 0.
+    const float* vsrc[VB];          // -> this thread's block of the NEXT tile to fetch
+    long vrow[VB][4];               // clamped row offsets (floats) of the block's 4 key columns
+    int vdst[VB];
+#pragma unroll
+    for (int b = 0; b < VB; ++b) {
+        const int blk = tid + NT * b;
+        const int wg = (blk < NBLK) ? (blk >> 4) : 0, cp = blk & 15;
+        vdst[b] = (blk < NBLK) ? (2 * cp) * VTS + 4 * wg : -1;
+        vsrc[b] = d.v + (long)n * H * W * E + head * D + 2 * cp;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) vrow[b][kk] = (long)min(4 * wg + kk, W - 1) * E;
+    }
+    float rv[PD][VB][8];                                    // [kk] -> (x = channel 2cp, y = 2cp+1) as plain scalars
+    const long tileE = (long)W * E;
+    int hf = 0;                                             // next tile to fetch; vsrc[] points at it
+    auto vfetch = [&](float (&r)[VB][8]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < VB; ++b) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const float2 t = *reinterpret_cast<const float2*>(vsrc[b] + vrow[b][kk]);
+                r[b][2 * kk] = t.x;
+                r[b][2 * kk + 1] = t.y;
+            }
+        }
+        ++hf;
+        if (hf < H) {               // wave-uniform
+#pragma unroll
+            for (int b = 0; b < VB; ++b) vsrc[b] += tileE;
+        }
+    };
+    auto vstash = [&](const float (&r)[VB][8], int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int b = 0; b < VB; ++b) {
+            if (vdst[b] < 0) continue;
+            __bf16* dst = VT + buf * 32 * VTS + vdst[b];
+            stash_split4(dst, 16 * KS, r[b][0], r[b][2], r[b][4], r[b][6]);
+            stash_split4(dst + VTS, 16 * KS, r[b][1], r[b][3], r[b][5], r[b][7]);
+        }
+    };
+
+    float outT[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) outT[r] = 0.f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    vfetch(rv[0]); vfetch(rv[1]); vfetch(rv[2]); vfetch(rv[3]);
+    vstash(rv[0], 0);          // the K tiles this overlays are dead: rcda_scores ended with a barrier
+    __syncthreads();
+    // one iteration; U = h mod PD is a compile-time constant so the register ring is statically indexed
+    auto step = [&](auto U, int h) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        vfetch(rv[u]);                                                   // tile h + PD; set u was stashed one iteration ago
+        const float acolh = (h < H) ? Scol[i32 * sm.sh + h] : 0.f;
+        const __bf16* vt = VT + (u & 1) * 32 * VTS + i32 * VTS + 8 * g;
+        f32x16 T = zero;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(vt + 16 * s);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(vt + 16 * KS + 16 * s);
+            T = mfma_bf16x3(ah, al, bh[s], bl[s], T);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) outT[r] = fmaf(acolh, T[r], outT[r]);
+        vstash(rv[(u + 1) % PD], (u + 1) & 1);                          // tile h+1 -> the buffer tile h-1 used
+        __syncthreads();
+    };
+    for (int h0 = 0; h0 < H; h0 += PD) {
+        step(std::integral_constant<int, 0>{}, h0);
+        step(std::integral_constant<int, 1>{}, h0 + 1);
+        step(std::integral_constant<int, 2>{}, h0 + 2);
+        step(std::integral_constant<int, 3>{}, h0 + 3);
+    }
+    // out^T layout: lane = query i32, register r = channel (r&3) + 8*(r>>2) + 4g
+    if (qvalid) {
+        float* op = d.out + ((long)n * L + q) * E + head * D + 4 * g;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<float4*>(op + 8 * j) = make_float4(outT[4 * j], outT[4 * j + 1], outT[4 * j + 2], outT[4 * j + 3]);
     }
 }
 
@@ -589,6 +745,29 @@ extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
     CDETR_CHECK_ARG(d.q_row && d.q_col && d.k_row && d.k_col && d.v && d.out && d.a_row && d.a_col, "cdetr_rcda_fwd: null pointer");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nw = pick_nw(d.L, d.N * d.nh);
+    static const int use_v2 = getenv("CDETR_RCDA_FWD2") ? atoi(getenv("CDETR_RCDA_FWD2")) : 1;
+    if (use_v2 && d.precision == 1 && d.W <= 64) {      // two-step form (see rcda_fwd2_kernel)
+        const int ks = (d.W + 15) / 16;
+        auto go = [&](auto kern, int NWv) -> int {
+            const FwdSmem sm = fwd_smem(d.H, d.W, NWv);
+            const int bytes = fwd2_smem(sm, d.H, d.W, ks).total * 4;
+            int rc;
+            if ((rc = set_smem(kern, bytes, "cdetr_rcda_fwd"))) return rc;
+            dim3 grid((d.L + QW * NWv - 1) / (QW * NWv), d.N * d.nh), block(64 * NWv);
+            hipLaunchKernelGGL(kern, grid, block, bytes, st, d);
+            return cdetr_launch_status("cdetr_rcda_fwd");
+        };
+        if (nw == 4) {
+            if (ks == 1) return go(rcda_fwd2_kernel<4, 1>, 4);
+            if (ks == 2) return go(rcda_fwd2_kernel<4, 2>, 4);
+            if (ks == 3) return go(rcda_fwd2_kernel<4, 3>, 4);
+            return go(rcda_fwd2_kernel<4, 4>, 4);
+        }
+        if (ks == 1) return go(rcda_fwd2_kernel<2, 1>, 2);
+        if (ks == 2) return go(rcda_fwd2_kernel<2, 2>, 2);
+        if (ks == 3) return go(rcda_fwd2_kernel<2, 3>, 2);
+        return go(rcda_fwd2_kernel<2, 4>, 2);
+    }
     if (d.H <= 32) return nw == 4 ? launch_rcda_fwd<1, 4>(d, st) : launch_rcda_fwd<1, 2>(d, st);
     if (d.H <= 64) return nw == 4 ? launch_rcda_fwd<2, 4>(d, st) : launch_rcda_fwd<2, 2>(d, st);
     return nw == 4 ? launch_rcda_fwd<4, 4>(d, st) : launch_rcda_fwd<4, 2>(d, st);
