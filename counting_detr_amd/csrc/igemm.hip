@@ -449,7 +449,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
     constexpr int NT = 64 * WM * WN;
-    constexpr bool ABL_PIPE = (ABL == 0 || ABL >= 3);     // ablations 3 / 4 keep the full pipeline, only drop split work
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
     constexpr int F4R = BKF / 4;             // float4 per k-row (8 or 16)
@@ -492,15 +491,22 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     const int nkt = (K / BKF) * taps;
 
     const int kq = tid % F4R, r8 = tid / F4R;
+    // Every global load of the pipeline is UNCONDITIONAL: a predicated load sits in its own basic block, the compiler then
+    // loses track of the outstanding-load count and drains vmcnt(0) before every LDS stash, which serialises the two tiles
+    // in flight (measured: ~1.2 us per k-tile).  Rows that do not exist (conv padding, m >= M, n >= N) are redirected to
+    // row 0 / the last row; padding rows are zeroed when they are staged (amask), the others are never stored.
     RowCoord arow[A_SLOTS];
     const float* ap[A_SLOTS];
+    unsigned amask = 0;            // bit i: slot i of the tap being fetched is a real row
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) arow[i] = decode_row(d.g, m0 + r8 + RPP * i, d.M);
     auto set_tap = [&](int tap) {
+        amask = 0;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const long row = gather_row(d.g, arow[i], tap);
-            ap[i] = (row >= 0) ? A + row * d.lda + kq * 4 : nullptr;
+            ap[i] = A + (row >= 0 ? row : 0) * d.lda + kq * 4;
+            amask |= (row >= 0 ? 1u : 0u) << i;
         }
     };
     const float* bp[B_SLOTS];
@@ -508,9 +514,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     if (BL == 0) {
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
-            const int n = n0 + r8 + RPP * i;
-            bp[i] = (n < d.N) ? B + (long)n * d.ldb + kq * 4 : nullptr;
-            bscale0[i] = (d.w_scale && n < d.N) ? d.w_scale[n] : 1.f;
+            const int n = min(n0 + r8 + RPP * i, d.N - 1);
+            bp[i] = B + (long)n * d.ldb + kq * 4;
+            bscale0[i] = d.w_scale ? d.w_scale[n] : 1.f;
         }
     }
     // register sets for the two k-tiles in flight.  Fetches are RAW loads (nothing in fetch() consumes a loaded value, so
@@ -518,6 +524,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     using BVec = typename std::conditional<TRB && NV == 2, float2, float4>::type;
     constexpr int B_REGS = TRB ? NBLK * 4 : B_SLOTS;
     float4 ra[2][A_SLOTS];
+    unsigned rm[2] = {0, 0};                   // amask of each register set
     BVec rb[2][B_REGS];
     float4 rs[2][TRB ? NBLK : 1];              // TRB: per-k-row weight scales of the fetched blocks
     const float* tb[TRB ? NBLK : 1];           // TRB: this thread's block origin (k-group row, n column) at tap 0, kc 0
@@ -528,17 +535,18 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
             const int b = tid + NT * j;
             tkg[j] = b / (BN / NV);
             tng[j] = b - tkg[j] * (BN / NV);
-            const int n = n0 + tng[j] * NV;
-            tb[j] = (n < d.N) ? B + (long)(tkg[j] * 4) * taps * d.ldb + n : nullptr;
+            const int n = min(n0 + tng[j] * NV, d.N - NV);
+            tb[j] = B + (long)(tkg[j] * 4) * taps * d.ldb + n;
         }
     }
-    auto fetch = [&](float4 (&qa)[A_SLOTS], BVec (&qb)[B_REGS], float4 (&qs)[TRB ? NBLK : 1], int tap, int kc) __attribute__((always_inline)) {
+    auto fetch = [&](float4 (&qa)[A_SLOTS], BVec (&qb)[B_REGS], float4 (&qs)[TRB ? NBLK : 1], unsigned& qm, int tap, int kc) __attribute__((always_inline)) {
+        qm = amask;
 #pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) qa[i] = ap[i] ? ld4(ap[i] + kc) : zero4();
+        for (int i = 0; i < A_SLOTS; ++i) qa[i] = ld4(ap[i] + kc);
         if constexpr (BL == 0) {
             const int koff = tap * K + kc;
 #pragma unroll
-            for (int i = 0; i < B_SLOTS; ++i) qb[i] = bp[i] ? ld4(bp[i] + koff) : zero4();
+            for (int i = 0; i < B_SLOTS; ++i) qb[i] = ld4(bp[i] + koff);
         } else if constexpr (TRB) {
             // 4 consecutive k rows x NV columns per block, raw
             const long base = ((long)kc * taps + tap) * d.ldb;       // wave-uniform
@@ -547,8 +555,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
             for (int j = 0; j < NBLK; ++j) {
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    if constexpr (NV == 4) qb[j * 4 + kk] = tb[j] ? ld4(tb[j] + base + kk * rstep) : zero4();
-                    else qb[j * 4 + kk] = tb[j] ? *reinterpret_cast<const float2*>(tb[j] + base + kk * rstep) : make_float2(0.f, 0.f);
+                    if constexpr (NV == 4) qb[j * 4 + kk] = ld4(tb[j] + base + kk * rstep);
+                    else qb[j * 4 + kk] = *reinterpret_cast<const float2*>(tb[j] + base + kk * rstep);
                 }
                 qs[j] = d.w_scale ? ld4(d.w_scale + kc + tkg[j] * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
             }
@@ -558,23 +566,23 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
                 const int idx = tid + NT * i;
                 const int kr = idx / (BN / 4);
                 const int nq = idx - kr * (BN / 4);
-                const int n = n0 + nq * 4;
+                const int n = min(n0 + nq * 4, d.N - 4);
                 const int k = kc + kr;
-                float4 v = zero4();
-                if (n < d.N) {
-                    v = ld4(B + ((long)k * taps + tap) * d.ldb + n);
-                    if (d.w_scale) {
-                        const float s = d.w_scale[k];
-                        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
-                    }
+                float4 v = ld4(B + ((long)k * taps + tap) * d.ldb + n);
+                if (d.w_scale) {
+                    const float s = d.w_scale[k];
+                    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
                 }
                 qb[i] = v;
             }
         }
     };
-    auto stash = [&](const float4 (&qa)[A_SLOTS], const BVec (&qb)[B_REGS], const float4 (&qs)[TRB ? NBLK : 1], int buf) __attribute__((always_inline)) {
+    auto stash = [&](const float4 (&qa0)[A_SLOTS], const BVec (&qb)[B_REGS], const float4 (&qs)[TRB ? NBLK : 1], unsigned qm, int buf) __attribute__((always_inline)) {
         float* as = As + buf * A_TILE;
         float* bs = Bs + buf * B_TILE;
+        float4 qa[A_SLOTS];
+#pragma unroll
+        for (int i = 0; i < A_SLOTS; ++i) qa[i] = ((qm >> i) & 1u) ? qa0[i] : zero4();
         if constexpr (PREC == 2) {
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
@@ -725,31 +733,38 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
         }
     };
 
-    // ---- software pipeline: LDS[t & 1] holds tile t, register set (t+1) & 1 holds tile t+1, tile t+2 is being issued
-    int f_tap = 0, f_kc = 0;       // coordinates of the most recently issued tile
+    // ---- software pipeline: LDS[t & 1] holds tile t, register set (t+1) & 1 holds tile t+1, tile t+2 is being issued.
+    // The loop body is branch-free around the loads (every step fetches; past the end the last tile is fetched again and
+    // never used): with conditional fetches the loaded registers become loop PHIs, the allocator copies them right after
+    // the load is issued and the copy drags an s_waitcnt vmcnt(~0) in front of the MFMA block -- one tile in flight at best.
+    int f_tap = 0, f_kc = 0, f_idx = 0;       // coordinates of the most recently issued tile
     auto advance = [&]() {
-        f_kc += BKF;
-        if (f_kc == K) { f_kc = 0; ++f_tap; set_tap(f_tap); }
+        if (f_idx + 1 < nkt) {
+            ++f_idx;
+            f_kc += BKF;
+            if (f_kc == K) { f_kc = 0; ++f_tap; set_tap(f_tap); }
+        }
     };
     set_tap(0);
-    fetch(ra[0], rb[0], rs[0], 0, 0);
-    if (nkt > 1) { advance(); fetch(ra[1], rb[1], rs[1], f_tap, f_kc); }
-    stash(ra[0], rb[0], rs[0], 0);
+    fetch(ra[0], rb[0], rs[0], rm[0], 0, 0);
+    advance();
+    fetch(ra[1], rb[1], rs[1], rm[1], f_tap, f_kc);
+    stash(ra[0], rb[0], rs[0], rm[0], 0);
     __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-        // even step: tile kt in LDS[0]; tile kt+1 in set 1; issue tile kt+2 into set 0
-        if (ABL_PIPE && kt + 2 < nkt) { advance(); fetch(ra[0], rb[0], rs[0], f_tap, f_kc); }
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        advance();                                             // even step: tile kt in LDS[0], tile kt+1 in set 1
+        fetch(ra[0], rb[0], rs[0], rm[0], f_tap, f_kc);        // tile kt+2 -> set 0
         compute(0);
-        if (kt + 1 < nkt) {
-            if (ABL_PIPE) stash(ra[1], rb[1], rs[1], 1);
-            if (ABL != 2) __syncthreads();
-            // odd step: tile kt+1 in LDS[1]; tile kt+2 in set 0; issue tile kt+3 into set 1
-            if (ABL_PIPE && kt + 3 < nkt) { advance(); fetch(ra[1], rb[1], rs[1], f_tap, f_kc); }
-            compute(ABL_PIPE ? 1 : 0);
-            if (ABL_PIPE && kt + 2 < nkt) stash(ra[0], rb[0], rs[0], 0);
-        }
-        if (ABL != 2) __syncthreads();
+        stash(ra[1], rb[1], rs[1], rm[1], 1);
+        __syncthreads();
+        advance();                                             // odd step: tile kt+1 in LDS[1], tile kt+2 in set 0
+        fetch(ra[1], rb[1], rs[1], rm[1], f_tap, f_kc);        // tile kt+3 -> set 1
+        compute(1);
+        stash(ra[0], rb[0], rs[0], rm[0], 0);
+        __syncthreads();
     }
+    if (kt < nkt) compute(0);                                  // odd tile count: the last tile sits in LDS[0]
     mfma_drain(acc);
 
 #pragma unroll
@@ -1270,8 +1285,6 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         if (force == 2) return launch_gemm_fast<2, 2, 2, 1, 32>(d, st);                       // 128x64
         if (force == 3 && (d.K % 64) == 0) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);    // 64x64, BK 64
         const char* abl = getenv("CDETR_GEMM_ABL");
-        if (abl && atoi(abl) == 1) return launch_gemm_fast<2, 2, 1, 1, 32, 1>(d, st);
-        if (abl && atoi(abl) == 2) return launch_gemm_fast<2, 2, 1, 1, 32, 2>(d, st);
         if (abl && atoi(abl) == 3) return launch_gemm_fast<2, 2, 1, 1, 32, 3>(d, st);
         if (abl && atoi(abl) == 4) return launch_gemm_fast<2, 2, 1, 1, 32, 4>(d, st);
         return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);                                       // 64x64, BK 32
