@@ -839,16 +839,23 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
 #pragma unroll
     for (int s = 0; s < A_SLOTS; ++s) bsum[s] = zero4();
 
-    float4 ra[A_SLOTS], rb[B_SLOTS];
-    auto fetch = [&]() {   // loads the tile whose pixel row for this thread is (p; pn, py, px), then advances by 32 pixels
-        const bool pv = p < d.P;
+    // Two register sets = two pixel tiles in flight.  Loads are unconditional (see igemm_fast_kernel): a pixel beyond P or a
+    // padding tap reads a clamped address and is zeroed when it is staged (flag bits), column tails are clamped and never stored.
+    float4 ra[2][A_SLOTS], rb[2][B_SLOTS];
+    unsigned rf[2] = {0, 0};                 // bit 0: dY row is real, bit 1: X row is real
+    int acol[A_SLOTS], bcol[B_SLOTS];
+    const int nk = kt_end - kt_begin;
+    int ft = 0;                              // tiles fetched so far
 #pragma unroll
-        for (int s = 0; s < A_SLOTS; ++s) {
-            const int i = i0 + cq + 32 * s;
-            float4 v = zero4();
-            if (pv && i < d.Nout) v = ld4(dY + (long)p * d.ldy + i);
-            ra[s] = v;
-        }
+    for (int s = 0; s < A_SLOTS; ++s) acol[s] = min(i0 + cq + 32 * s, d.Nout - 4);
+#pragma unroll
+    for (int s = 0; s < B_SLOTS; ++s) bcol[s] = min(c0 + cq + 32 * s, d.Cin - 4);
+    auto fetch = [&](float4 (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], unsigned& qf) __attribute__((always_inline)) {
+        // loads the tile whose pixel row for this thread is (p; pn, py, px), then advances by 32 pixels
+        const bool pv = p < d.P;
+        const float* yp = dY + (long)(pv ? p : d.P - 1) * d.ldy;
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) qa[s] = ld4(yp + acol[s]);
         long row = -1;
         if (pv) {
             if (dense) row = p;
@@ -858,11 +865,11 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
                 if (iy >= 0 && iy < d.g.Ha && ix >= 0 && ix < d.g.Wa) row = ((long)pn * d.g.Ha + iy) * d.g.Wa + ix;
             }
         }
+        qf = ((pv && ft < nk) ? 1u : 0u) | (row >= 0 ? 2u : 0u);     // surplus tiles past the slice end stage zeros
+        ++ft;
+        const float* xp = X + (row >= 0 ? row : 0) * d.ldx;
 #pragma unroll
-        for (int s = 0; s < B_SLOTS; ++s) {
-            const int c = c0 + cq + 32 * s;
-            rb[s] = (row >= 0 && c < d.Cin) ? ld4(X + row * d.ldx + c) : zero4();
-        }
+        for (int s = 0; s < B_SLOTS; ++s) qb[s] = ld4(xp + bcol[s]);
         p += BKF;
         if (!dense) {
             px += BKF;
@@ -870,14 +877,16 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
             while (py >= d.g.Hc) { py -= d.g.Hc; ++pn; }
         }
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](const float4 (&qa)[A_SLOTS], const float4 (&qb)[B_SLOTS], unsigned qf, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) {
-            *reinterpret_cast<float4*>(As + buf * BKF * LDI + kr * LDI + cq + 32 * s) = ra[s];
-            if (do_bias) { bsum[s].x += ra[s].x; bsum[s].y += ra[s].y; bsum[s].z += ra[s].z; bsum[s].w += ra[s].w; }
+            const float4 v = (qf & 1u) ? qa[s] : zero4();
+            *reinterpret_cast<float4*>(As + buf * BKF * LDI + kr * LDI + cq + 32 * s) = v;
+            if (do_bias) { bsum[s].x += v.x; bsum[s].y += v.y; bsum[s].z += v.z; bsum[s].w += v.w; }
         }
 #pragma unroll
-        for (int s = 0; s < B_SLOTS; ++s) *reinterpret_cast<float4*>(Bs + buf * BKF * LDJ + kr * LDJ + cq + 32 * s) = rb[s];
+        for (int s = 0; s < B_SLOTS; ++s)
+            *reinterpret_cast<float4*>(Bs + buf * BKF * LDJ + kr * LDJ + cq + 32 * s) = (qf & 2u) ? qb[s] : zero4();
     };
 
     f32x16 acc[FM][FN];
@@ -888,12 +897,7 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    fetch();
-    stash(0);
-    __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        if (kt + 1 < kt_end) fetch();
+    auto compute = [&](int buf) __attribute__((always_inline)) {
         const float* as = As + buf * BKF * LDI + (g * 4) * LDI + wm * (BI / 2) + i32;
         const float* bs = Bs + buf * BKF * LDJ + (g * 4) * LDJ + wn * (BJ / 2) + i32;
         if (PREC == 0) {
@@ -943,9 +947,26 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
                     for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
             }
         }
-        if (kt + 1 < kt_end) stash(buf ^ 1);
+    };
+
+    // branch-free two-deep pipeline: tiles past the slice end have p >= their bound only at the global end (zeroed);
+    // inside the loop every step fetches, the surplus fetches of the last steps are never staged
+    fetch(ra[0], rb[0], rf[0]);
+    fetch(ra[1], rb[1], rf[1]);
+    stash(ra[0], rb[0], rf[0], 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        fetch(ra[0], rb[0], rf[0]);            // tile kt+2
+        compute(0);
+        stash(ra[1], rb[1], rf[1], 1);
+        __syncthreads();
+        fetch(ra[1], rb[1], rf[1]);            // tile kt+3
+        compute(1);
+        stash(ra[0], rb[0], rf[0], 0);
         __syncthreads();
     }
+    if (kt < nk) compute(0);
 
     mfma_drain(acc);
     const bool single = (gridDim.y == 1);
