@@ -387,19 +387,25 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
 }
 
 // ------------------------------------------------------------------------------------------------ backward (dS)
+// LDS plan of the dS kernel (56 KB at 50x50, 4 waves -> two workgroups per CU):
+//   U: per-wave [32][su] slices holding A_col at the start and the ds_col / A_row staging at the end; while the main loop
+//      runs (A_col lives in registers) the same memory is the double-buffered V tile shared by the workgroup;
+//   R: per-wave [32][sw] A_row; element (q, w) is overwritten by dA_row[q, w] as soon as column w has been consumed.
 struct BwdSmem {
-    int sw, sh, off_acol, off_arow, off_darow, off_v, total;
+    int sw, sh, su, off_u, off_r, total;
 };
 __host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW) {
     BwdSmem s;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
     s.sw = Wp + 1;
     s.sh = Hp + 1;
-    s.off_acol = 0;
-    s.off_arow = s.off_acol + NW * QW * s.sh;
-    s.off_darow = s.off_arow + NW * QW * s.sw;
-    s.off_v = (s.off_darow + NW * QW * s.sw + 3) & ~3;
-    s.total = s.off_v + 2 * (32 * NF) * 36;
+    s.su = s.sw > s.sh ? s.sw : s.sh;
+    s.off_u = 0;
+    int u = NW * QW * s.su;
+    const int v = 2 * (32 * NF) * 36;
+    if (v > u) u = v;
+    s.off_r = (u + 3) & ~3;
+    s.total = s.off_r + NW * QW * s.sw;
     return s;
 }
 
@@ -420,10 +426,10 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
     const bool qvalid = q < L;
     const int nq = min(QW, L - qbase);
 
-    float* Acol = smem + sm.off_acol + wid * QW * sm.sh;     // [32][sh]
-    float* Arow = smem + sm.off_arow + wid * QW * sm.sw;     // [32][sw]
-    float* dArow = smem + sm.off_darow + wid * QW * sm.sw;   // [32][sw]
-    float* Vs = smem + sm.off_v;                             // [2][HR][36]
+    float* Acol = smem + sm.off_u + wid * QW * sm.su;        // this wave's U slice, [32][sh] view
+    float* Arow = smem + sm.off_r + wid * QW * sm.sw;        // [32][sw]; turns into dA_row column by column
+    float* dArow = Arow;
+    float* Vs = smem + sm.off_u;                             // [2][HR][36], overlays U during the main loop
 
     // ---- load the saved attention rows of this wave (coalesced), zero for tail queries
     {
@@ -438,9 +444,6 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
             Acol[r * sm.sh + c] = (r < nq) ? gac[idx] : 0.f;
         }
     }
-    // zero V tiles completely once (rows >= H and the 4 pad columns stay zero)
-    for (int idx = tid; idx < 2 * HR * VS; idx += NT) Vs[idx] = 0.f;
-
     // dOut^T fragment (B operand, loop invariant): lane (j = query, g) holds dOut[q][8kk + 4g + s]
     float dob[4][4];
     {
@@ -470,41 +473,62 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
             acolT[f][r] = (h < Hp) ? Acol[i32 * sm.sh + h] : 0.f;
             dacolT[f][r] = 0.f;
         }
+    __syncthreads();           // every wave holds its A_col rows in registers: U becomes the V tile buffers
 
-    const float* vbase = d.v + (long)n * H * W * E + head * D;
+    // ---- main loop over key columns w.  V[:, w, :] tiles run through a ring of PD register sets (unconditional loads: rows
+    // h >= H re-read row H-1 -- A_col is zero there -- and columns w >= W re-read column W-1, weighted by A_row = 0) and are
+    // staged once per workgroup; in split-bf16 mode the tile is split while it is staged, in the slot order the dOut^T
+    // fragment uses (k-slot j of lane group g at step kp <-> channel 16kp + 8(j>>2) + 4g + (j&3)).
+    constexpr int PD = 2;      // two columns ahead covers the load latency here (an iteration is ~1 us of MFMA + FMA work)
     constexpr int VSLOTS = (NF * 256 + NT - 1) / NT;
-    float4 rv[VSLOTS];
-    auto vfetch = [&](int w) {
+    const float* vsrc[VSLOTS];
+    int vdst[VSLOTS];
 #pragma unroll
-        for (int s = 0; s < VSLOTS; ++s) {
-            const int idx = tid + NT * s;
-            const int h = idx >> 3, c4 = idx & 7;
-            rv[s] = (h < H) ? ld4(vbase + ((long)h * W + w) * E + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s = 0; s < VSLOTS; ++s) {
+        const int idx = tid + NT * s;
+        const int h = idx >> 3, c4 = idx & 7;
+        vsrc[s] = d.v + (long)n * H * W * E + head * D + (long)min(h, H - 1) * W * E + c4 * 4;
+        if (PREC == 1) {
+            const int kp = c4 >> 2, qd = c4 & 3;
+            vdst[s] = (h < HR) ? h * (2 * VS) + kp * 16 + (qd & 1) * 8 + (qd >> 1) * 4 : -1;     // bf16 units
+        } else {
+            vdst[s] = (h < HR) ? h * VS + c4 * 4 : -1;                                            // float units
+        }
+    }
+    float4 rv[PD][VSLOTS];
+    int wf = 0;                                             // next column to fetch; vsrc[] points at it
+    auto vfetch = [&](float4 (&r)[VSLOTS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < VSLOTS; ++s) r[s] = ld4(vsrc[s]);
+        ++wf;
+        if (wf < W) {
+#pragma unroll
+            for (int s = 0; s < VSLOTS; ++s) vsrc[s] += E;
         }
     };
-    auto vstash = [&](int buf) {
+    auto vstash = [&](const float4 (&r)[VSLOTS], int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < VSLOTS; ++s) {
-            const int idx = tid + NT * s;
-            const int h = idx >> 3, c4 = idx & 7;
-            if (h < H) *reinterpret_cast<float4*>(Vs + buf * HR * VS + h * VS + c4 * 4) = rv[s];
+            if (vdst[s] < 0) continue;
+            if (PREC == 1) stash_split4(reinterpret_cast<__bf16*>(Vs + buf * HR * VS) + vdst[s], 32, r[s].x, r[s].y, r[s].z, r[s].w);
+            else *reinterpret_cast<float4*>(Vs + buf * HR * VS + vdst[s]) = r[s];
         }
     };
-    vfetch(0);
-    vstash(0);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    vfetch(rv[0]); vfetch(rv[1]);
+    vstash(rv[0], 0);
     __syncthreads();
-    for (int w = 0; w < W; ++w) {
-        const int buf = w & 1;
-        if (w + 1 < W) vfetch(w + 1);
-        const float arow = Arow[i32 * sm.sw + w];
+    auto step = [&](auto U, int w) __attribute__((always_inline)) {
+        constexpr int u = decltype(U)::value;
+        const int buf = u & 1;
+        vfetch(rv[u]);                                                   // column w + PD; set u was staged one step ago
+        const float arow = Arow[i32 * sm.sw + w];                        // zero for W <= w < Wp
         float part = 0.f;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
-            f32x16 gt;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) gt[r] = 0.f;
-            const float* va = Vs + buf * HR * VS + (32 * f + i32) * VS + g * 4;
+            f32x16 gt = zero16;
             if (PREC == 0) {
+                const float* va = Vs + buf * HR * VS + (32 * f + i32) * VS + g * 4;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const float4 a = *reinterpret_cast<const float4*>(va + kk * 8);
@@ -514,13 +538,11 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
                     gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dob[kk][3], gt, 0, 0, 0);
                 }
             } else {
+                const __bf16* va = reinterpret_cast<const __bf16*>(Vs + buf * HR * VS) + (32 * f + i32) * (2 * VS) + g * 8;
 #pragma unroll
                 for (int kp = 0; kp < 2; ++kp) {
-                    const float4 a0 = *reinterpret_cast<const float4*>(va + (2 * kp) * 8);
-                    const float4 a1 = *reinterpret_cast<const float4*>(va + (2 * kp + 1) * 8);
-                    const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                    bf16x8 ah, al;
-                    split_bf16x8(x, ah, al);
+                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(va + kp * 16);
+                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(va + 32 + kp * 16);
                     gt = mfma_bf16x3(ah, al, dobh[kp], dobl[kp], gt);
                 }
             }
@@ -532,11 +554,45 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
         }
         part += __shfl_xor(part, 32, 64);
         if (g == 0) dArow[i32 * sm.sw + w] = part;
-        if (w + 1 < W) vstash(buf ^ 1);
+        vstash(rv[(u + 1) % PD], buf ^ 1);
         __syncthreads();
+    };
+    for (int w0 = 0; w0 < W; w0 += PD) {          // w runs to Wp - 1 at most: Arow / dArow rows hold Wp (+1) entries
+        step(std::integral_constant<int, 0>{}, w0);
+        step(std::integral_constant<int, 1>{}, w0 + 1);
     }
 
-    // ---- softmax backward, column attention (registers)
+    // The loop ended with a barrier: the V buffers are dead and every wave owns its U slice again.
+    auto wave_sync = [&]() {     // same-wave LDS hand-off: order the writes above before the reads below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // ---- softmax backward, row attention: A_row comes back from HBM (coalesced, L2-hot) into the U slice
+    {
+        float* Ar = Acol;          // [32][sw] view of the slice
+        const float* gar = d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp;
+        for (int idx = lane; idx < QW * Wp; idx += 64) {
+            const int r = idx / Wp, c = idx - r * Wp;
+            Ar[r * sm.sw + c] = (r < nq) ? gar[idx] : 0.f;
+        }
+        wave_sync();
+        float dot = 0.f;
+        for (int w = g; w < W; w += 2) dot = fmaf(Ar[i32 * sm.sw + w], dArow[i32 * sm.sw + w], dot);
+        dot += __shfl_xor(dot, 32, 64);
+        for (int w = g; w < Wp; w += 2)
+            dArow[i32 * sm.sw + w] = (w < W) ? d.scale * Ar[i32 * sm.sw + w] * (dArow[i32 * sm.sw + w] - dot) : 0.f;
+        wave_sync();
+        if (nq > 0) {
+            float* gdr = d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp;
+            for (int idx = lane; idx < nq * Wp; idx += 64) {
+                const int r = idx / Wp, c = idx - r * Wp;
+                gdr[idx] = dArow[r * sm.sw + c];
+            }
+        }
+        wave_sync();               // the slice is rewritten below
+    }
+    // ---- softmax backward, column attention (registers), staged through the U slice for a coalesced store
     {
         float dot = 0.f;
 #pragma unroll
@@ -551,29 +607,13 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
                 const int h = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
                 if (h < Hp) Acol[i32 * sm.sh + h] = d.scale * acolT[f][r] * (dacolT[f][r] - dot);
             }
-    }
-    // ---- softmax backward, row attention (lane (i, g) handles keys w = g, g+2, ...)
-    {
-        float dot = 0.f;
-        for (int w = g; w < W; w += 2) dot = fmaf(Arow[i32 * sm.sw + w], dArow[i32 * sm.sw + w], dot);
-        dot += __shfl_xor(dot, 32, 64);
-        for (int w = g; w < Wp; w += 2)
-            dArow[i32 * sm.sw + w] = (w < W) ? d.scale * Arow[i32 * sm.sw + w] * (dArow[i32 * sm.sw + w] - dot) : 0.f;
-    }
-    // same-wave LDS hand-off: order the writes above before the reads below
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    if (nq > 0) {
-        float* gdr = d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp;
-        for (int idx = lane; idx < nq * Wp; idx += 64) {
-            const int r = idx / Wp, c = idx - r * Wp;
-            gdr[idx] = dArow[r * sm.sw + c];
-        }
-        float* gdc = d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp;
-        for (int idx = lane; idx < nq * Hp; idx += 64) {
-            const int r = idx / Hp, c = idx - r * Hp;
-            gdc[idx] = Acol[r * sm.sh + c];
+        wave_sync();
+        if (nq > 0) {
+            float* gdc = d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp;
+            for (int idx = lane; idx < nq * Hp; idx += 64) {
+                const int r = idx / Hp, c = idx - r * Hp;
+                gdc[idx] = Acol[r * sm.sh + c];
+            }
         }
     }
 }
