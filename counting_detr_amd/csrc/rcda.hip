@@ -720,6 +720,149 @@ __global__ __launch_bounds__(256) void rcda_dv_kernel(const cdetr_rcda_bwd_desc 
         }
 }
 
+// ------------------------------------------------------------------------------------------------ backward (dV), two-step form
+// split-bf16 only, W <= 64.   dV[h,w,c] = sum_q A_row[q,w] * (A_col[q,h] dOut[q,c])
+// Workgroup = 8 waves = 8 key rows h (one per wave) of one (n, head) over a slice of the queries; the reduction runs over q:
+//   A operand  A_row^T[w, q]  (rows w: two 32-row fragments) -- the same for every h: transposed and split into bf16 hi/lo
+//              ONCE per workgroup while the q-tile is staged (4q x 4w register blocks -> ds_write_b64);
+//   B operand  A_col[q,h] * dOut[q,c]  (lane = channel, 8 consecutive q): 8 multiplies + one packed split per k-step, fed
+//              from the fp32 tiles dOut^T[c, q] and A_col^T[h, q] with four ds_read_b128.
+// One k-step = 6 MFMAs against ~30 VALU instructions: matrix-pipe bound, where the A_col*A_row-operand form of
+// rcda_dv_kernel needs ~76 VALU per 6 MFMAs and reloads every tile synchronously.  Every thread has at most one staging
+// role (a_row block / dOut block / a_col quad); q-tiles run through two register sets with unconditional loads.
+struct Dv2Smem { int art, dot, act, tile, total; };
+__host__ __device__ inline Dv2Smem dv2_smem() {
+    Dv2Smem s;
+    s.art = 0;                       // A_row^T  [64 w][hi 64 | lo 64 | pad 8] bf16  = 64 * 68 floats
+    s.dot = 64 * 68;                 // dOut^T   [32 c][64 q + 4] fp32
+    s.act = s.dot + 32 * 68;         // A_col^T  [8 h][64 q + 4] fp32
+    s.tile = s.act + 8 * 68;
+    s.total = 2 * s.tile;
+    return s;
+}
+
+__global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc d, const int q_per_slice) {
+    constexpr int QT = 64, ARS = 136;                   // queries per tile; bf16 per A_row^T row
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Dv2Smem sm = dv2_smem();
+    const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
+    const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
+    const int h0 = blockIdx.x * 8, h = h0 + wid;
+    const int qs = blockIdx.z * q_per_slice;
+    const int qe = min(L, qs + q_per_slice);
+    const int ntile = (qe - qs + QT - 1) / QT;
+    if (ntile <= 0) return;
+
+    // ---- staging roles
+    const int nrb = 16 * (Wp >> 2);                     // a_row blocks: 16 q-groups x Wp/4 w-quads (<= 256)
+    int role, q4, x4;                                   // q4 = q-group (4 queries), x4 = w-quad / c-quad / h-quad
+    if (tid < nrb) { role = 0; q4 = tid & 15; x4 = tid >> 4; }
+    else if (tid >= 256 && tid < 384) { role = 1; q4 = (tid - 256) & 15; x4 = (tid - 256) >> 4; }
+    else if (tid >= 384 && tid < 416) { role = 2; q4 = (tid - 384) & 15; x4 = (tid - 384) >> 4; }     // 2 h-quads
+    else { role = 3; q4 = 0; x4 = 0; }
+    const float* src;                                   // row (qs + 4 q4), this thread's quad; advanced by one tile per fetch
+    long rstride;
+    if (role == 0) { src = d.a_row + (((long)n * d.nh + head) * L) * Wp + x4 * 4; rstride = Wp; }
+    else if (role == 1) { src = d.d_out + (long)n * L * E + head * D + x4 * 4; rstride = E; }
+    else { src = d.a_col + (((long)n * d.nh + head) * L) * Hp + min(h0 + x4 * 4, Hp - 4); rstride = Hp; }
+    float4 rs[2][4];
+    unsigned rmask[2] = {0, 0};                         // bit kk: query row kk of the block is inside the slice
+    int tf = 0;                                         // next tile to fetch
+    auto fetch = [&](float4 (&r)[4], unsigned& m) __attribute__((always_inline)) {
+        const int qb = qs + min(tf, ntile - 1) * QT + q4 * 4;        // surplus fetches re-read the last tile (never staged)
+        m = 0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int q = qb + kk;
+            r[kk] = ld4(src + (long)min(q, L - 1) * rstride);
+            m |= (q < qe ? 1u : 0u) << kk;
+        }
+        ++tf;
+    };
+    auto stash = [&](const float4 (&r0)[4], unsigned m, int buf) __attribute__((always_inline)) {
+        float4 r[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) r[kk] = ((m >> kk) & 1u) ? r0[kk] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* base = smem + buf * sm.tile;
+        if (role == 0) {            // 4q x 4w -> four rows w, 4 consecutive q each, split
+            __bf16* dst = reinterpret_cast<__bf16*>(base + sm.art) + (x4 * 4) * ARS + q4 * 4;
+            stash_split4(dst, 64, r[0].x, r[1].x, r[2].x, r[3].x);
+            stash_split4(dst + ARS, 64, r[0].y, r[1].y, r[2].y, r[3].y);
+            stash_split4(dst + 2 * ARS, 64, r[0].z, r[1].z, r[2].z, r[3].z);
+            stash_split4(dst + 3 * ARS, 64, r[0].w, r[1].w, r[2].w, r[3].w);
+        } else if (role == 1 || role == 2) {   // 4q x 4c (or 4h) -> four rows, fp32
+            float* dst = base + (role == 1 ? sm.dot : sm.act) + (x4 * 4) * 68 + q4 * 4;
+            *reinterpret_cast<float4*>(dst) = make_float4(r[0].x, r[1].x, r[2].x, r[3].x);
+            *reinterpret_cast<float4*>(dst + 68) = make_float4(r[0].y, r[1].y, r[2].y, r[3].y);
+            *reinterpret_cast<float4*>(dst + 2 * 68) = make_float4(r[0].z, r[1].z, r[2].z, r[3].z);
+            *reinterpret_cast<float4*>(dst + 3 * 68) = make_float4(r[0].w, r[1].w, r[2].w, r[3].w);
+        }
+    };
+    // rows w >= Wp of A_row^T are never written: zero them once in both buffers
+    for (int idx = tid; idx < 2 * (64 - Wp) * (ARS / 2); idx += 512) {
+        const int b = idx / ((64 - Wp) * (ARS / 2)), r = idx - b * (64 - Wp) * (ARS / 2);
+        smem[b * sm.tile + sm.art + Wp * (ARS / 2) + r] = 0.f;
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[f][r] = 0.f;
+
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float* base = smem + buf * sm.tile;
+        const __bf16* art = reinterpret_cast<const __bf16*>(base + sm.art) + i32 * ARS + 8 * g;
+        const float* dot = base + sm.dot + i32 * 68 + 8 * g;
+        const float* act = base + sm.act + wid * 68 + 8 * g;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 d0 = *reinterpret_cast<const float4*>(dot + 16 * ks), d1 = *reinterpret_cast<const float4*>(dot + 16 * ks + 4);
+            const float4 a0 = *reinterpret_cast<const float4*>(act + 16 * ks), a1 = *reinterpret_cast<const float4*>(act + 16 * ks + 4);
+            const float x[8] = {d0.x * a0.x, d0.y * a0.y, d0.z * a0.z, d0.w * a0.w, d1.x * a1.x, d1.y * a1.y, d1.z * a1.z, d1.w * a1.w};
+            bf16x8 bh, bl;
+            split_bf16x8(x, bh, bl);
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(art + 32 * f * ARS + 16 * ks);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(art + 32 * f * ARS + 64 + 16 * ks);
+                acc[f] = mfma_bf16x3(ah, al, bh, bl, acc[f]);
+            }
+        }
+    };
+
+    fetch(rs[0], rmask[0]);
+    fetch(rs[1], rmask[1]);
+    __syncthreads();               // zero fill above
+    stash(rs[0], rmask[0], 0);
+    __syncthreads();
+    int t = 0;
+    for (; t + 1 < ntile; t += 2) {
+        fetch(rs[0], rmask[0]);            // tile t+2
+        compute(0);
+        stash(rs[1], rmask[1], 1);
+        __syncthreads();
+        fetch(rs[1], rmask[1]);            // tile t+3
+        compute(1);
+        stash(rs[0], rmask[0], 0);
+        __syncthreads();
+    }
+    if (t < ntile) compute(0);
+    mfma_drain(acc);
+    if (h >= H) return;
+    // accumulator layout: row = key column w = 32f + (r&3) + 8(r>>2) + 4g, column = channel i32
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int w = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (w < W) atomicAdd(d.d_v + (((long)n * H + h) * W + w) * E + head * D + i32, acc[f][r]);
+        }
+}
+
 template <typename F>
 int set_smem(F func, int bytes, const char* what) {
     if (bytes > 160 * 1024) {
@@ -828,6 +971,22 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     else if (NF == 2) rc = nw == 4 ? launch_rcda_bwd<2, 4>(d, st) : launch_rcda_bwd<2, 2>(d, st);
     else rc = nw == 4 ? launch_rcda_bwd<4, 4>(d, st) : launch_rcda_bwd<4, 2>(d, st);
     if (rc) return rc;
+    static const int use_dv2 = getenv("CDETR_RCDA_DV2") ? atoi(getenv("CDETR_RCDA_DV2")) : 1;
+    if (use_dv2 && d.precision == 1 && d.W <= 64) {   // two-step dV (see rcda_dv2_kernel)
+        const int bytes = dv2_smem().total * 4;
+        const int hgroups = (d.H + 7) / 8;
+        const long base = (long)hgroups * d.N * d.nh;
+        int slices = (int)((512 + base - 1) / base);                 // ~2 workgroups of 8 waves per CU
+        const int max_slices = (d.L + 255) / 256;                    // >= 4 q-tiles per slice
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        int per = (d.L + slices - 1) / slices;
+        per = ((per + 63) / 64) * 64;
+        slices = (d.L + per - 1) / per;
+        if ((rc = set_smem(rcda_dv2_kernel, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
+        hipLaunchKernelGGL(rcda_dv2_kernel, dim3(hgroups, d.N * d.nh, slices), dim3(512), bytes, st, d, per);
+        return cdetr_launch_status("cdetr_rcda_bwd(dV)");
+    }
     {   // dV kernel
         const int bytes = (64 * 32 * NF + 64 * Wp + 64 * 32) * 4;
         const int wgroups = (d.W + 3) / 4;
