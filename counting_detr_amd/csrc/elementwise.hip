@@ -297,6 +297,37 @@ __global__ __launch_bounds__(256) void posadd2_kernel(const float* __restrict__ 
     }
 }
 
+// Decoder glue (A2/models/transformer.py:366-403): O1 = T + A, O2 = T + B (B / O2 optional) in one pass.
+__global__ __launch_bounds__(256) void add2_kernel(const float4* __restrict__ T, const float4* __restrict__ A, const float4* __restrict__ B,
+                                                   float4* __restrict__ O1, float4* __restrict__ O2, const long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 t = T[i], a = A[i];
+        O1[i] = make_float4(t.x + a.x, t.y + a.y, t.z + a.z, t.w + a.w);
+        if (B) {
+            const float4 b = B[i];
+            O2[i] = make_float4(t.x + b.x, t.y + b.y, t.z + b.z, t.w + b.w);
+        }
+    }
+}
+// Backward of the same sites: out = base + g1 (+ g2); acc1 += g1; acc2 += g2  (acc* = gradient accumulators of the
+// query-position terms shared by all decoder layers; any of g2 / acc1 / acc2 may be NULL).
+__global__ __launch_bounds__(256) void grad_merge_kernel(const float4* __restrict__ base, const float4* __restrict__ g1,
+                                                         const float4* __restrict__ g2, float4* __restrict__ acc1,
+                                                         float4* __restrict__ acc2, float4* __restrict__ out, const long n4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float4 o = base[i];
+        const float4 a = g1[i];
+        o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+        if (acc1) { float4 c = acc1[i]; c.x += a.x; c.y += a.y; c.z += a.z; c.w += a.w; acc1[i] = c; }
+        if (g2) {
+            const float4 b = g2[i];
+            o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w;
+            if (acc2) { float4 c = acc2[i]; c.x += b.x; c.y += b.y; c.z += b.z; c.w += b.w; acc2[i] = c; }
+        }
+        out[i] = o;
+    }
+}
+
 // Reductions of an NHWC map over one spatial axis (+ optional small addend):
 //   blocks [0, N*W):       Or[n,x,:] = scale_r * sum_y X[n,y,x,:] (+ Ar[n,x,:])
 //   blocks [N*W, N*W+N*H): Oc[n,y,:] = scale_c * sum_x X[n,y,x,:] (+ Ac[n,y,:])
@@ -406,4 +437,21 @@ extern "C" int cdetr_weight_mirror(const cdetr_mirror_item* items_dev, int32_t n
     CDETR_CHECK_ARG(items_dev && n_items > 0 && total_tiles > 0, "cdetr_weight_mirror: bad args");
     hipLaunchKernelGGL(weight_mirror_kernel, dim3(total_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), items_dev, n_items);
     return cdetr_launch_status("cdetr_weight_mirror");
+}
+
+extern "C" int cdetr_add2(const float* T, const float* A, const float* B, float* O1, float* O2, int64_t n, void* stream) {
+    CDETR_CHECK_ARG(T && A && O1 && n > 0 && (n & 3) == 0 && (!B == !O2), "cdetr_add2: bad args");
+    hipLaunchKernelGGL(add2_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(T), reinterpret_cast<const float4*>(A), reinterpret_cast<const float4*>(B),
+                       reinterpret_cast<float4*>(O1), reinterpret_cast<float4*>(O2), (long)(n >> 2));
+    return cdetr_launch_status("cdetr_add2");
+}
+
+extern "C" int cdetr_grad_merge(const float* base, const float* g1, const float* g2, float* acc1, float* acc2, float* out, int64_t n,
+                                void* stream) {
+    CDETR_CHECK_ARG(base && g1 && out && n > 0 && (n & 3) == 0 && (g2 || !acc2), "cdetr_grad_merge: bad args");
+    hipLaunchKernelGGL(grad_merge_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const float4*>(base), reinterpret_cast<const float4*>(g1), reinterpret_cast<const float4*>(g2),
+                       reinterpret_cast<float4*>(acc1), reinterpret_cast<float4*>(acc2), reinterpret_cast<float4*>(out), (long)(n >> 2));
+    return cdetr_launch_status("cdetr_grad_merge");
 }

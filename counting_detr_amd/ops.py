@@ -578,6 +578,138 @@ class EncoderLayerFn(torch.autograd.Function):
         return dX, dProw, dPcol, None, None, None, None
 
 
+def add2(T, A, B=None):
+    """(T + A, T + B) in one pass (B optional)."""
+    O1 = torch.empty_like(T)
+    O2 = torch.empty_like(T) if B is not None else None
+    check(lib().cdetr_add2(ptr(T), ptr(A), ptr(B), ptr(O1), ptr(O2), T.numel(), stream_ptr()), "cdetr_add2")
+    return O1, O2
+
+
+def grad_merge(base, g1, g2=None, acc1=None, acc2=None):
+    """out = base + g1 (+ g2); acc1 += g1, acc2 += g2 in place (gradient accumulators of shared inputs)."""
+    out = torch.empty_like(base)
+    check(lib().cdetr_grad_merge(ptr(base), ptr(g1), ptr(g2), ptr(acc1), ptr(acc2), ptr(out), base.numel(), stream_ptr()),
+          "cdetr_grad_merge")
+    return out
+
+
+class DecoderStackFn(torch.autograd.Function):
+    """All decoder layers (A2/models/transformer.py:316-409, single feature level) as ONE autograd node.
+    forward(tgt, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean, mask_row, mask_col, layers, anchor)
+    -> one output [N, L, E] per layer.  The backward is hand-scheduled: every multi-consumer gradient sum is chained
+    through a data-gradient epilogue (`resid=`) or one cdetr_grad_merge pass; the gradients of the inputs shared by all
+    layers (the three query-position terms, the memory and both key means) accumulate across layers inside the node, so
+    autograd never runs an accumulation kernel for them."""
+
+    @staticmethod
+    def forward(ctx, tgt, qpos, qx, qy, memory, krm, kcm, mask_row, mask_col, layers, anchor):
+        N, L, E = tgt.shape
+        _, H, W, _ = memory.shape
+        M = N * L
+        tgt, qpos, qx, qy = tgt.contiguous(), qpos.contiguous(), qx.contiguous(), qy.contiguous()
+        mem2 = memory.contiguous().view(N * H * W, E)
+        krm2, kcm2 = krm.contiguous().view(N * W, E), kcm.contiguous().view(N * H, E)
+        outs = []
+        saved = []
+        x = tgt.view(M, E)
+        for li, layer in enumerate(layers):
+            sa, ca, f = layer.self_attn, layer.cross_attn, layer.ffn
+            nh = sa.num_heads
+            Ws, bs = sa.in_proj_weight.detach(), sa.in_proj_bias.detach()
+            Wc, bc = ca.in_proj_weight.detach(), ca.in_proj_bias.detach()
+            a1, _ = add2(x, qpos.view(M, E))
+            qk = linear_fwd(a1, Ws[0:2 * E], bs[0:2 * E])
+            vs = linear_fwd(x, Ws[2 * E:3 * E], bs[2 * E:3 * E])
+            o1, lse = mha_fwd_raw(qk.view(N, L, 2 * E), vs.view(N, L, E), nh)
+            Y2 = linear_fwd(o1.view(M, E), sa.out_proj.weight.detach(), sa.out_proj.bias.detach(), resid=x)
+            T1, mu2, rs2 = ln_fwd_raw(Y2, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
+            qr_in, qc_in = add2(T1, qx.view(M, E), qy.view(M, E))
+            q_row = linear_fwd(qr_in, Wc[0:E], bc[0:E]).view(N, L, E)
+            q_col = linear_fwd(qc_in, Wc[E:2 * E], bc[E:2 * E]).view(N, L, E)
+            k_row = linear_fwd(krm2, Wc[2 * E:3 * E], bc[2 * E:3 * E]).view(N, W, E)
+            k_col = linear_fwd(kcm2, Wc[3 * E:4 * E], bc[3 * E:4 * E]).view(N, H, E)
+            v = linear_fwd(mem2, Wc[4 * E:5 * E], bc[4 * E:5 * E]).view(N, H, W, E)
+            o2, a_row, a_col = rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, ca.num_heads)
+            Y1 = linear_fwd(o2.view(M, E), ca.out_proj.weight.detach(), ca.out_proj.bias.detach(), resid=T1)
+            T2, mu1, rs1 = ln_fwd_raw(Y1, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
+            Hd = linear_fwd(T2, f.linear1.weight.detach(), f.linear1.bias.detach(), relu=True)
+            Y3 = linear_fwd(Hd, f.linear2.weight.detach(), f.linear2.bias.detach(), resid=T2)
+            out, mu3, rs3 = ln_fwd_raw(Y3, f.norm2.weight.detach(), f.norm2.bias.detach(), f.norm2.eps)
+            outs.append(out.view(N, L, E))
+            saved.append((x, a1, qk, vs, o1, lse, Y2, mu2, rs2, T1, qr_in, qc_in, q_row, q_col, k_row, k_col, v, a_row, a_col, o2,
+                          Y1, mu1, rs1, T2, Hd, Y3, mu3, rs3))
+            x = out
+        ctx.layers, ctx.saved, ctx.dims = layers, saved, (N, L, E, H, W)
+        ctx.shared = (mem2, krm2, kcm2)
+        ctx.set_materialize_grads(False)      # layers whose output feeds no loss term get None, not a zero tensor
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        layers, saved = ctx.layers, ctx.saved
+        N, L, E, H, W = ctx.dims
+        mem2, krm2, kcm2 = ctx.shared
+        M = N * L
+        dev = mem2.device
+        acc = torch.zeros((3, M, E), device=dev, dtype=torch.float32)          # d(query_pos), d(query_pos_x), d(query_pos_y)
+        acc_p, acc_x, acc_y = acc[0], acc[1], acc[2]
+        dMem = dKrm = dKcm = None
+        dx = None                                                               # gradient flowing into the layer output
+        for li in range(len(layers) - 1, -1, -1):
+            layer = layers[li]
+            sa, ca, f = layer.self_attn, layer.cross_attn, layer.ffn
+            (x, a1, qk, vs, o1, lse, Y2, mu2, rs2, T1, qr_in, qc_in, q_row, q_col, k_row, k_col, v, a_row, a_col, o2,
+             Y1, mu1, rs1, T2, Hd, Y3, mu3, rs3) = saved[li]
+            saved[li] = None
+            g_out = d_outs[li].reshape(M, E).contiguous() if d_outs[li] is not None else None
+            if dx is None:
+                dOut = g_out
+            else:
+                dOut = dx if g_out is None else grad_merge(dx, g_out)
+            if dOut is None:            # this layer's output feeds nothing (cannot happen for the last layer)
+                continue
+            Ws, Wc = sa.in_proj_weight.detach(), ca.in_proj_weight.detach()
+            # ---- FFN: out = LN3(T2 + relu(T2 W1^T + b1) W2^T + b2)
+            dY3 = ln_bwd_raw(dOut, Y3, mu3, rs3, f.norm2.weight.detach(), grad_buffer(f.norm2.weight), grad_buffer(f.norm2.bias))
+            _wg(dY3, Hd, f.linear2.weight, f.linear2.bias, 0, E)
+            dHd = linear_dgrad(dY3, f.linear2.weight.detach(), gate=Hd)
+            _wg(dHd, T2, f.linear1.weight, f.linear1.bias, 0, Hd.shape[1])
+            dT2 = linear_dgrad(dHd, f.linear1.weight.detach(), resid=dY3)
+            # ---- cross attention: T2 = LN1(T1 + rcda(...) Wo^T + bo)
+            dY1 = ln_bwd_raw(dT2, Y1, mu1, rs1, layer.norm1.weight.detach(), grad_buffer(layer.norm1.weight), grad_buffer(layer.norm1.bias))
+            _wg(dY1, o2.view(M, E), ca.out_proj.weight, ca.out_proj.bias, 0, E)
+            dO2 = linear_dgrad(dY1, ca.out_proj.weight.detach()).view(N, L, E)
+            dq_row, dq_col, dk_row, dk_col, dv = rcda_bwd_raw(dO2, q_row, q_col, k_row, k_col, v, a_row, a_col, ca.num_heads)
+            dq_row2, dq_col2 = dq_row.view(M, E), dq_col.view(M, E)
+            dk_row2, dk_col2, dv2 = dk_row.view(N * W, E), dk_col.view(N * H, E), dv.view(N * H * W, E)
+            Wcp, bcp = ca.in_proj_weight, ca.in_proj_bias
+            _wg(dq_row2, qr_in, Wcp, bcp, 0, E)
+            _wg(dq_col2, qc_in, Wcp, bcp, E, 2 * E)
+            _wg(dk_row2, krm2, Wcp, bcp, 2 * E, 3 * E)
+            _wg(dk_col2, kcm2, Wcp, bcp, 3 * E, 4 * E)
+            _wg(dv2, mem2, Wcp, bcp, 4 * E, 5 * E)
+            gx = linear_dgrad(dq_row2, Wc[0:E])
+            gy = linear_dgrad(dq_col2, Wc[E:2 * E])
+            dT1 = grad_merge(dY1, gx, gy, acc_x, acc_y)                        # + both query projections; d(qx) += gx, d(qy) += gy
+            dKrm = linear_dgrad(dk_row2, Wc[2 * E:3 * E], resid=dKrm)          # shared inputs: chained across layers
+            dKcm = linear_dgrad(dk_col2, Wc[3 * E:4 * E], resid=dKcm)
+            dMem = linear_dgrad(dv2, Wc[4 * E:5 * E], resid=dMem)
+            # ---- self attention: T1 = LN2(x + mha((x + qpos) Wqk, x Wv) Wo^T + bo)
+            dY2 = ln_bwd_raw(dT1, Y2, mu2, rs2, layer.norm2.weight.detach(), grad_buffer(layer.norm2.weight), grad_buffer(layer.norm2.bias))
+            _wg(dY2, o1.view(M, E), sa.out_proj.weight, sa.out_proj.bias, 0, E)
+            dO1 = linear_dgrad(dY2, sa.out_proj.weight.detach()).view(N, L, E)
+            dqk, dvs = mha_bwd_raw(qk.view(N, L, 2 * E), vs.view(N, L, E), o1, dO1, lse, sa.num_heads)
+            Wsp, bsp = sa.in_proj_weight, sa.in_proj_bias
+            _wg(dqk.view(M, 2 * E), a1, Wsp, bsp, 0, 2 * E)
+            _wg(dvs.view(M, E), x, Wsp, bsp, 2 * E, 3 * E)
+            ga1 = linear_dgrad(dqk.view(M, 2 * E), Ws[0:2 * E])
+            t = linear_dgrad(dvs.view(M, E), Ws[2 * E:3 * E], resid=dY2)
+            dx = grad_merge(t, ga1, None, acc_p, None)                         # d(x) = residual + v-path + q/k-path; d(qpos) += ga1
+        return (dx.view(N, L, E), acc_p.view(N, L, E), acc_x.view(N, L, E), acc_y.view(N, L, E), dMem.view(N, H, W, E),
+                dKrm.view(N, W, E), dKcm.view(N, H, E), None, None, None, None)
+
+
 # ----------------------------------------------------------------------------------------------------- matcher
 class MatchPlan:
     """Host-side (static) description of one batch of targets: sizes and device offset tables."""

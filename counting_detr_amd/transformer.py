@@ -216,6 +216,7 @@ class Transformer(nn.Module):
         assert num_feature_levels == 1 and attention_type == "RCDA" and dropout == 0.0 and activation == "relu"
         self.d_model, self.nhead, self.stage = d_model, nhead, stage
         self.all_layer_heads = True     # AnchorDETR sets this to its aux_loss flag
+        self.fused_decoder = True       # all decoder layers as one autograd node (ops.DecoderStackFn); False = op-by-op autograd
         self.encoder_layers = nn.ModuleList(
             TransformerEncoderLayerSpatial(d_model, dim_feedforward, nhead) for _ in range(num_encoder_layers))
         self.decoder_layers = nn.ModuleList(
@@ -297,11 +298,18 @@ class Transformer(nn.Module):
         query_pos_y = self.adapt_pos1d(pos2posemb1d(reference_points[..., 1]))
         reference = inverse_sigmoid(reference_points)
 
-        output = tgt
         outputs_classes, outputs_coords, outputs_vars = [], [], []
         last = len(self.decoder_layers) - 1
-        for lid, layer in enumerate(self.decoder_layers):
-            output = layer(output, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean, mask_row, mask_col)
+        if self.fused_decoder and torch.is_grad_enabled():
+            layer_outs = ops.DecoderStackFn.apply(tgt, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean,
+                                                  mask_row, mask_col, list(self.decoder_layers), self.pattern.weight if self.stage == 2 else self.modify_pattern.weight)
+        else:
+            layer_outs, output = [], tgt
+            for layer in self.decoder_layers:
+                output = layer(output, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean, mask_row, mask_col)
+                layer_outs.append(output)
+        for lid in range(len(self.decoder_layers)):
+            output = layer_outs[lid]
             if not (self.all_layer_heads or lid == last):
                 continue     # the heads of layers 0..4 only feed the aux losses (the reference computes and drops them)
             if self.stage == 2:

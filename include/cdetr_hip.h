@@ -115,6 +115,12 @@ int cdetr_hw_reduce(const float* Xr, const float* Xc, const float* Ar, const flo
                     int32_t H, int32_t W, int32_t C, float scale_r, float scale_c, void* stream);
 int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
                      float sr, float sc, void* stream);
+/* decoder-layer glue (A2/models/transformer.py:366-403): cdetr_add2: O1 = T + A, O2 = T + B (B and O2 NULL together);
+ * cdetr_grad_merge (backward of those sites): out = base + g1 (+ g2), acc1 += g1, acc2 += g2 (g2 / acc1 / acc2 may be NULL);
+ * n = element count, a multiple of 4, all pointers 16-byte aligned.                                                    */
+int cdetr_add2(const float* T, const float* A, const float* B, float* O1, float* O2, int64_t n, void* stream);
+int cdetr_grad_merge(const float* base, const float* g1, const float* g2, float* acc1, float* acc2, float* out, int64_t n,
+                     void* stream);
 
 /* ---- k-contiguous mirrors of the weights used as data-gradient operands ------------------------------------------------
  * The data-gradient GEMMs of A2/models/resnet.py:140-160 (conv backward) and of every F.linear site contract over the

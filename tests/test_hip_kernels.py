@@ -348,6 +348,43 @@ def test_encoder_layer_fused_equals_unfused(precision):
         close(p1[k], p0[k], rtol=1e-4, msg="enc d" + k)
 
 
+@pytest.mark.parametrize("used", [(2,), (0, 1, 2)])
+def test_decoder_stack_fused_equals_unfused(precision, used):
+    """ops.DecoderStackFn (all decoder layers in one node, hand-scheduled backward, shared-input gradients accumulated inside)
+    == the op-by-op autograd composition: layer outputs and every gradient, with only the last or with all layer outputs used."""
+    from counting_detr_amd import ops
+    from counting_detr_amd.transformer import TransformerDecoderLayer
+    N, L, H, W, E = 2, 40, 9, 14, 256
+    res = []
+    for fused in (False, True):
+        torch.manual_seed(3)
+        layers = [TransformerDecoderLayer(E, 1024, 8).to(DEV) for _ in range(3)]
+        mk = lambda shape, seed: torch.randn(*shape, generator=g(seed)).to(DEV).requires_grad_(True)   # noqa: E731
+        tgt, qp, qx, qy = mk((N, L, E), 1), mk((N, L, E), 2), mk((N, L, E), 3), mk((N, L, E), 4)
+        mem, krm, kcm = mk((N, H, W, E), 5), mk((N, W, E), 6), mk((N, H, E), 7)
+        mr = torch.zeros(N, W, dtype=torch.uint8); mr[1, W - 3:] = 1
+        mc = torch.zeros(N, H, dtype=torch.uint8); mc[1, H - 2:] = 1
+        mr, mc = mr.to(DEV), mc.to(DEV)
+        if fused:
+            outs = ops.DecoderStackFn.apply(tgt, qp, qx, qy, mem, krm, kcm, mr, mc, layers, tgt)
+        else:
+            outs, x = [], tgt
+            for layer in layers:
+                x = layer(x, qp, qx, qy, mem, krm, kcm, mr, mc)
+                outs.append(x)
+        loss = sum((outs[i] * torch.randn(outs[i].shape, generator=g(10 + i)).to(DEV)).sum() for i in used)
+        loss.backward()
+        grads = {f"{i}.{k}": p.grad for i, layer in enumerate(layers) for k, p in layer.named_parameters()}
+        res.append(([o.detach() for o in outs], [t.grad for t in (tgt, qp, qx, qy, mem, krm, kcm)], grads))
+    (o0, i0, p0), (o1, i1, p1) = res
+    for a, b in zip(o1, o0):
+        close(a, b, rtol=2e-5, msg="dec out")
+    for name, a, b in zip(("tgt", "qpos", "qx", "qy", "mem", "krm", "kcm"), i1, i0):
+        close(a, b, rtol=1e-4, msg="dec d" + name)
+    for k in p0:
+        close(p1[k], p0[k], rtol=1e-4, msg="dec d" + k)
+
+
 @pytest.mark.parametrize("N,L", [(2, 300), (1, 900), (2, 37), (1, 129)])
 def test_mha_core(N, L):
     from counting_detr_amd import ops
