@@ -1337,6 +1337,9 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         // 128x128 tile shared by 16 waves of 32x32 halves that traffic at the same per-wave structure and occupancy.
         if (d.precision == 1 && d.b_layout == 0 && (long)d.K * d.taps >= 1024 && (d.N % 128) == 0 && blocks(128, 128) >= 150)
             return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
+        // small grids (< 2 workgroups of 4 waves per CU): a 64x128 tile shared by 8 waves keeps the wave count and halves the
+        // A-operand traffic (tools/split_sweep.py: 6-11 % over 64x64 BK64 on the N = 256 encoder linears)
+        if (d.precision == 1 && d.b_layout == 0 && (d.N % 128) == 0 && blocks(64, 64) < 512) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);
         if ((d.K % 64) == 0 && blocks(64, 64) < 512) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);
         return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);
     }
