@@ -50,13 +50,20 @@ class RcdaBwdDesc(C.Structure):
                 ("ds_row", _p), ("ds_col", _p), ("d_v", _p)]
 
 
+class CriterionDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Q", C.c_int32), ("C", C.c_int32), ("num_classes", C.c_int32), ("Mmax", C.c_int32), ("alpha", C.c_float),
+                ("logits", _p), ("boxes", _p), ("vars", _p), ("tgt_boxes", _p), ("tgt_labels", _p), ("tgt_off", _p), ("idx_i", _p),
+                ("idx_j", _p), ("num_boxes", _p), ("losses", _p), ("g_logits", _p), ("g_l1", _p), ("g_giou", _p), ("g_var_box", _p),
+                ("g_vars", _p)]
+
+
 class MirrorItem(C.Structure):
     _fields_ = [("src", _p), ("dst", _p), ("scale", _p), ("R", C.c_int32), ("C", C.c_int32), ("taps", C.c_int32), ("tile0", C.c_int32)]
 
 
 EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_bwd", "cdetr_posadd2",
            "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_add2", "cdetr_grad_merge", "cdetr_maxpool3x3s2", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
-           "cdetr_match_cost", "cdetr_lsap", "cdetr_last_error", "cdetr_abi_version"]
+           "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
 
 _lib = None
 
@@ -90,6 +97,10 @@ def lib():
         L.cdetr_posadd2.argtypes = [_p] * 5 + [C.c_int32] * 4 + [_p]
         L.cdetr_hw_reduce.restype = C.c_int
         L.cdetr_hw_reduce.argtypes = [_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_float, _p]
+        L.cdetr_criterion_fwd.restype = C.c_int
+        L.cdetr_criterion_fwd.argtypes = [_p, _p]
+        L.cdetr_criterion_bwd.restype = C.c_int
+        L.cdetr_criterion_bwd.argtypes = [_p] * 9 + [C.c_int32, C.c_int32, _p]
         L.cdetr_add2.restype = C.c_int
         L.cdetr_add2.argtypes = [_p] * 5 + [C.c_int64, _p]
         L.cdetr_grad_merge.restype = C.c_int

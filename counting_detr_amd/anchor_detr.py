@@ -93,6 +93,9 @@ class SetCriterion(nn.Module):
         self.num_classes, self.matcher, self.weight_dict, self.losses, self.focal_alpha = \
             num_classes, matcher, weight_dict, losses, focal_alpha
         self.check_status = False   # set True to raise (with a host sync) on an invalid / infeasible cost matrix
+        import os
+        self.fused = os.environ.get("CDETR_FUSED_CRITERION", "1") != "0"   # losses + their gradients in one kernel (ops.CriterionFn); False = tensor-op composition
+        self._nb_cache = {}
         self._plans = {}            # (target counts, Q, device) -> MatchPlan (device offset tables built once: graph-safe)
 
     # -- matched (batch, query, target-row) index tensors on the device
@@ -126,9 +129,22 @@ class SetCriterion(nn.Module):
             num_boxes = torch.clamp(num_boxes, min=1)[0]                      # stays on the device (no .item())
         else:
             num_boxes = max(float(sum(plan.sizes)), 1.0)                      # :321-325
-        bidx, sidx, tidx = self._matched(idx_i, idx_j, plan)
         tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
         tgt_labels_all = torch.cat([t["labels"] for t in targets])
+        if self.fused and logits.is_cuda and list(self.losses) == ["labels", "boxes", "cardinality", "vars"] and "aux_outputs" not in outputs:
+            if not torch.is_tensor(num_boxes):
+                nbt = self._nb_cache.get((float(num_boxes), str(logits.device)))
+                if nbt is None:
+                    nbt = self._nb_cache[(float(num_boxes), str(logits.device))] = torch.full((1,), float(num_boxes), device=logits.device)
+            else:
+                nbt = num_boxes.reshape(-1)[:1].to(torch.float32)
+            vec = ops.CriterionFn.apply(logits, out["pred_boxes"], out["pred_vars"], tgt_boxes_all, tgt_labels_all.to(torch.int64), plan,
+                                        idx_i, idx_j, nbt, self.num_classes, self.focal_alpha)
+            self.last_vec = vec     # [loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, loss_variance]
+            return {"loss_ce": vec[0], "class_error": vec[1].detach(), "cardinality_error": vec[2].detach(), "loss_bbox": vec[3],
+                    "loss_giou": vec[4], "loss_variance": vec[5]}
+        self.last_vec = None
+        bidx, sidx, tidx = self._matched(idx_i, idx_j, plan)
         losses = {}
         for loss in self.losses:
             losses.update(getattr(self, "loss_" + loss)(out, plan, bidx, sidx, tidx, tgt_boxes_all, tgt_labels_all, num_boxes))

@@ -110,6 +110,8 @@ class Trainer:
         self.epoch = 0
         self._graph = None
         self._static = None
+        order = ("loss_ce", "class_error", "cardinality_error", "loss_bbox", "loss_giou", "loss_variance")
+        self._w6 = torch.tensor([float(criterion.weight_dict.get(k, 0.0)) for k in order], device=self.device)
         self.mirror = self._build_mirror(named)
         self.exchange = FlatGradExchange(self.flat_g, self.seg_bounds)
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
@@ -201,7 +203,11 @@ class Trainer:
         outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
         loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
         wd = self.criterion.weight_dict
-        losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)             # A2/engine.py:37
+        vec = getattr(self.criterion, "last_vec", None)
+        if vec is not None:          # fused criterion: one weighted reduction of its loss vector
+            losses = (vec * self._w6).sum()                                           # A2/engine.py:37
+        else:
+            losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
         # data-gradient GEMMs read the k-contiguous weight mirrors: rewritten here (one launch), armed only for this backward
         if self.mirror is not None:
             self.mirror.refresh()

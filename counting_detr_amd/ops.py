@@ -9,7 +9,7 @@ weight-gradient kernels -- autograd only carries activation gradients.
 import torch
 
 from . import _ffi
-from ._ffi import MirrorItem, ConvGeom, GemmDesc, RcdaBwdDesc, RcdaFwdDesc, WgradDesc, check, lib, ptr, stream_ptr
+from ._ffi import CriterionDesc, MirrorItem, ConvGeom, GemmDesc, RcdaBwdDesc, RcdaFwdDesc, WgradDesc, check, lib, ptr, stream_ptr
 
 import ctypes as C
 
@@ -754,3 +754,43 @@ def lsap(cost, plan):
     check(lib().cdetr_lsap(ptr(cost), ptr(plan.cost_off), ptr(plan.tgt_off), plan.B, plan.Q, plan.nc_max, plan.Mmax,
                            ptr(idx_i), ptr(idx_j), ptr(status), stream_ptr()), "cdetr_lsap")
     return idx_i, idx_j, status
+
+
+class CriterionFn(torch.autograd.Function):
+    """SetCriterion's six scalars in one launch (cdetr_criterion_fwd); returns the vector
+    [loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, loss_variance].  The forward kernel already leaves the
+    gradient of every loss w.r.t. logits / boxes / vars, so backward is one scaled sum (cdetr_criterion_bwd)."""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, pvars, tgt_boxes, tgt_labels, plan, idx_i, idx_j, num_boxes, num_classes, alpha):
+        B, Q, Cc = logits.shape
+        logits, boxes, pvars = logits.contiguous(), boxes.contiguous(), pvars.contiguous()
+        dev = logits.device
+        losses = torch.empty(6, device=dev, dtype=torch.float32)
+        g = torch.empty(B * Q * (Cc + 14), device=dev, dtype=torch.float32)
+        n = B * Q
+        g_logits, g_l1, g_giou, g_vb, g_vars = (g[:n * Cc], g[n * Cc:n * (Cc + 4)], g[n * (Cc + 4):n * (Cc + 8)],
+                                                g[n * (Cc + 8):n * (Cc + 12)], g[n * (Cc + 12):])
+        d = CriterionDesc()
+        d.B, d.Q, d.C, d.num_classes, d.Mmax, d.alpha = B, Q, Cc, num_classes, plan.Mmax, alpha
+        d.logits, d.boxes, d.vars = ptr(logits), ptr(boxes), ptr(pvars)
+        d.tgt_boxes = ptr(tgt_boxes) if tgt_boxes.numel() else ptr(losses)
+        d.tgt_labels = ptr(tgt_labels) if tgt_labels.numel() else ptr(losses)
+        d.tgt_off, d.idx_i, d.idx_j, d.num_boxes, d.losses = ptr(plan.tgt_off), ptr(idx_i), ptr(idx_j), ptr(num_boxes), ptr(losses)
+        d.g_logits, d.g_l1, d.g_giou, d.g_var_box, d.g_vars = ptr(g_logits), ptr(g_l1), ptr(g_giou), ptr(g_vb), ptr(g_vars)
+        check(lib().cdetr_criterion_fwd(C.byref(d), stream_ptr()), "cdetr_criterion_fwd")
+        ctx.g, ctx.dims = (g_logits, g_l1, g_giou, g_vb, g_vars), (B, Q, Cc)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g6):
+        B, Q, Cc = ctx.dims
+        g_logits, g_l1, g_giou, g_vb, g_vars = ctx.g
+        g6 = g6.contiguous()
+        dev = g6.device
+        d_logits = torch.empty((B, Q, Cc), device=dev, dtype=torch.float32)
+        d_boxes = torch.empty((B, Q, 4), device=dev, dtype=torch.float32)
+        d_vars = torch.empty((B, Q, 2), device=dev, dtype=torch.float32)
+        check(lib().cdetr_criterion_bwd(ptr(g6), ptr(g_logits), ptr(g_l1), ptr(g_giou), ptr(g_vb), ptr(g_vars), ptr(d_logits),
+                                        ptr(d_boxes), ptr(d_vars), B * Q, Cc, stream_ptr()), "cdetr_criterion_bwd")
+        return d_logits, d_boxes, d_vars, None, None, None, None, None, None, None, None

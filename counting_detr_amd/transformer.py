@@ -216,7 +216,8 @@ class Transformer(nn.Module):
         assert num_feature_levels == 1 and attention_type == "RCDA" and dropout == 0.0 and activation == "relu"
         self.d_model, self.nhead, self.stage = d_model, nhead, stage
         self.all_layer_heads = True     # AnchorDETR sets this to its aux_loss flag
-        self.fused_decoder = True       # all decoder layers as one autograd node (ops.DecoderStackFn); False = op-by-op autograd
+        import os
+        self.fused_decoder = os.environ.get("CDETR_FUSED_DECODER", "1") != "0"   # all decoder layers as one autograd node (ops.DecoderStackFn); False = op-by-op autograd
         self.encoder_layers = nn.ModuleList(
             TransformerEncoderLayerSpatial(d_model, dim_feedforward, nhead) for _ in range(num_encoder_layers))
         self.decoder_layers = nn.ModuleList(

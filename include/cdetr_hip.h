@@ -193,6 +193,38 @@ int cdetr_match_cost(const float* logits, int32_t ncls, const float* boxes, cons
 int cdetr_lsap(const float* cost, const int64_t* cost_off, const int32_t* tgt_off, int32_t B, int32_t Q,
                int32_t nc_max, int32_t Mmax, int64_t* idx_i, int64_t* idx_j, int32_t* status, void* stream);
 
+/* ---- SetCriterion (A2/models/anchor_detr.py:143-367, losses [labels, boxes, cardinality, vars], no aux) ----------------
+ * cdetr_criterion_fwd: from the raw predictions, the concatenated targets and the matcher's device indices
+ * (idx_i / idx_j [B][Mmax], first min(Q, T_b) entries of row b valid) compute
+ *   losses[6] = { loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, loss_variance }
+ * and the gradient of every differentiable loss w.r.t. its inputs:
+ *   g_logits [B,Q,C] = d loss_ce / d logits;  g_l1 / g_giou / g_var_box [B,Q,4] = d {loss_bbox, loss_giou, loss_variance} / d boxes;
+ *   g_vars [B,Q,2] = d loss_variance / d vars.   num_boxes is a DEVICE scalar (the data-parallel normaliser).
+ * cdetr_criterion_bwd: d_logits = g6[0] g_logits; d_boxes = g6[3] g_l1 + g6[4] g_giou + g6[5] g_var_box; d_vars = g6[5] g_vars
+ * (g6 = upstream gradient of the six scalars, device).                                                                   */
+typedef struct {
+    int32_t B, Q, C, num_classes, Mmax;
+    float alpha;
+    const float* logits;        /* [B,Q,C] */
+    const float* boxes;         /* [B,Q,4] cxcywh */
+    const float* vars;          /* [B,Q,2] */
+    const float* tgt_boxes;     /* [sum T,4] */
+    const int64_t* tgt_labels;  /* [sum T] */
+    const int32_t* tgt_off;     /* [B+1] */
+    const int64_t* idx_i;       /* [B,Mmax] */
+    const int64_t* idx_j;       /* [B,Mmax] */
+    const float* num_boxes;     /* device scalar */
+    float* losses;              /* [6] */
+    float* g_logits;
+    float* g_l1;
+    float* g_giou;
+    float* g_var_box;
+    float* g_vars;
+} cdetr_criterion_desc;
+int cdetr_criterion_fwd(const cdetr_criterion_desc* d, void* stream);
+int cdetr_criterion_bwd(const float* g6, const float* g_logits, const float* g_l1, const float* g_giou, const float* g_var_box,
+                        const float* g_vars, float* d_logits, float* d_boxes, float* d_vars, int32_t BQ, int32_t C, void* stream);
+
 const char* cdetr_last_error(void);
 int cdetr_abi_version(void);
 

@@ -54,7 +54,7 @@ def test_struct_fields_match_header():
         return out
     for cname, cls in (("cdetr_conv_geom", _ffi.ConvGeom), ("cdetr_gemm_desc", _ffi.GemmDesc),
                        ("cdetr_wgrad_desc", _ffi.WgradDesc), ("cdetr_rcda_fwd_desc", _ffi.RcdaFwdDesc),
-                       ("cdetr_rcda_bwd_desc", _ffi.RcdaBwdDesc), ("cdetr_mirror_item", _ffi.MirrorItem)):
+                       ("cdetr_rcda_bwd_desc", _ffi.RcdaBwdDesc), ("cdetr_mirror_item", _ffi.MirrorItem), ("cdetr_criterion_desc", _ffi.CriterionDesc)):
         assert fields(cname) == [f[0] for f in cls._fields_], cname
 
 

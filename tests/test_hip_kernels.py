@@ -250,6 +250,34 @@ def test_matcher_golden(golden, name):
         assert np.array_equal(idx[b][1].numpy(), z[f"{name}/idx_j{b}"]), f"idx_j image {b}"
 
 
+@pytest.mark.parametrize("name", ["q300_t37", "q576_t200", "q900_t56", "q300_t450", "q900_t900", "b2_q40", "b2_q300", "negvar", "t0"])
+@pytest.mark.parametrize("fused", [False, True])
+def test_criterion_golden(golden, name, fused):
+    """SetCriterion (fused kernel and tensor-op composition) vs the REFERENCE's losses and input gradients (golden vectors)."""
+    from counting_detr_amd.anchor_detr import SetCriterion
+    from counting_detr_amd.matcher import OriginalHungarianMatcher
+    z = golden("g45_matcher_criterion.npz")
+    B = int(z[f"{name}/B"])
+    outs = {k: torch.from_numpy(z[f"{name}/{k}"]).to(DEV).requires_grad_(True) for k in ("pred_logits", "pred_boxes", "pred_vars")}
+    tg = []
+    for b in range(B):
+        bx = torch.from_numpy(z[f"{name}/tgt{b}"]).reshape(-1, 4).to(DEV)
+        tg.append({"boxes": bx, "labels": torch.zeros(bx.shape[0], dtype=torch.int64, device=DEV)})
+    wd = {"loss_ce": 2, "loss_bbox": 5, "loss_giou": 2, "loss_variance": 2}
+    crit = SetCriterion(1, OriginalHungarianMatcher(2, 5, 2), wd, ["labels", "boxes", "cardinality", "vars"], focal_alpha=0.25)
+    crit.fused = fused
+    losses = crit(outs, tg)
+    assert (crit.last_vec is not None) == fused
+    for k in ("loss_ce", "class_error", "cardinality_error", "loss_bbox", "loss_giou", "loss_variance"):
+        np.testing.assert_allclose(float(losses[k]), float(z[f"{name}/L_{k}"]), rtol=1e-4, atol=1e-6, err_msg=k, equal_nan=True)
+    if f"{name}/g_pred_logits" in z.files:
+        total = sum(losses[k] * wd[k] for k in losses if k in wd)
+        total.backward()
+        for k in outs:
+            ref = torch.from_numpy(z[f"{name}/g_{k}"])
+            close(outs[k].grad, ref, rtol=2e-4, atol_scale=1e-5, msg="d" + k)
+
+
 def test_match_cost_values(golden):
     from counting_detr_amd import ops
     from oracle import criterion as OC
