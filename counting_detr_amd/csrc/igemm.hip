@@ -1004,6 +1004,226 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
 }
 
 
+
+// ------------------------------------------------------------------------------------------------ wgrad, staged-split form
+// split-bf16 only.  Same problem as wgrad_fast_kernel, but both operands are transposed and split into bf16 hi / lo ONCE per
+// workgroup while a 32-pixel tile is staged (the reduction runs over pixels, and both dY and X are channel-contiguous):
+//   * the tile is the concatenation Z = [dY tile | X tile] of (BI + BJ)/4 channel quads x 8 pixel quads; every thread owns
+//     SLOTS 4-pixel x 4-channel register blocks (4 float4 loads along the pixel axis), which it transposes in registers into
+//     four 4-pixel runs -> packed split -> ds_write_b64 of the hi and of the lo plane (row = channel, 144-byte stride);
+//   * a fragment is then two ds_read_b128 (hi, lo) and no VALU work: ~10 VALU instructions per MFMA instead of ~30 with the
+//     per-fragment split of wgrad_fast_kernel (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA), which was VALU-bound;
+//   * loads are unconditional (clamped rows / columns + per-pixel validity bits) and two tiles are in flight.
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_trb_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
+                                                        const int kt_per_slice, float* __restrict__ dbias) {
+    constexpr int BKF = 32, RS = 72;                        // pixels per tile; bf16 per LDS row: [hi 32 | lo 32 | pad 8]
+    constexpr int FM = BI / 64, FN = BJ / 64;
+    constexpr int NQ = (BI + BJ) / 4;                       // channel quads of Z
+    constexpr int SLOTS = (8 * NQ + 255) / 256;             // register blocks per thread (1, 2 (half used), 2)
+    constexpr int ZT = (BI + BJ) * RS;                      // bf16 per buffer
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* Zs = reinterpret_cast<__bf16*>(smem);           // [2][BI + BJ][RS]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int ti = blockIdx.x % tilesI;
+    const int tj = blockIdx.x / tilesI;
+    const int tap = tj / tilesJ;
+    const int c0 = (tj - tap * tilesJ) * BJ;
+    const int i0 = ti * BI;
+    const int z = blockIdx.z;
+    const float* __restrict__ dY = d.dY + (long)z * d.sY;
+    const float* __restrict__ X = d.X + (long)z * d.sX;
+    float* __restrict__ dW = d.dW + (long)z * d.sW;
+    const int nkt_all = (d.P + BKF - 1) / BKF;
+    const int kt_begin = blockIdx.y * kt_per_slice;
+    const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
+    if (kt_begin >= kt_end) return;
+    const int nk = kt_end - kt_begin;
+
+    const bool dense = d.g.mode == CDETR_ROWS_DENSE;
+    const int ky = dense ? 0 : tap / d.g.kw, kx = dense ? 0 : tap - (tap / d.g.kw) * d.g.kw;
+    const bool do_bias = (dbias != nullptr) && tj == 0;
+
+    // ---- this thread's blocks: block b -> pixel quad pg = b & 7, channel quad cq = b >> 3 (cq < BI/4: dY, else X)
+    const int pg = tid & 7;
+    const float* cbase[SLOTS];        // operand base + clamped channel offset
+    long rstride[SLOTS];
+    bool isx[SLOTS], used[SLOTS];
+    int zrow[SLOTS];                  // first LDS row (channel) of the block
+#pragma unroll
+    for (int s = 0; s < SLOTS; ++s) {
+        const int b = tid + 256 * s;
+        const int cq = b >> 3;
+        used[s] = cq < NQ;
+        const int cqc = used[s] ? cq : 0;
+        isx[s] = cqc >= BI / 4;
+        zrow[s] = cqc * 4;
+        if (isx[s]) { cbase[s] = X + min(c0 + (cqc - BI / 4) * 4, d.Cin - 4); rstride[s] = d.ldx; }
+        else { cbase[s] = dY + min(i0 + cqc * 4, d.Nout - 4); rstride[s] = d.ldy; }
+    }
+    // first pixel of this thread's quad in the first tile, and its (n, y, x) for the tap gather
+    int p = kt_begin * BKF + pg * 4;
+    int pn = 0, py = 0, px = 0;
+    if (!dense) {
+        const int hw = d.g.Hc * d.g.Wc;
+        pn = p / hw;
+        const int rem = p - pn * hw;
+        py = rem / d.g.Wc;
+        px = rem - py * d.g.Wc;
+    }
+    float4 rz[2][SLOTS][4];
+    unsigned rf[2][SLOTS];            // bit kk: pixel kk of the block contributes (inside P and the slice; for X also not padding)
+    int ft = 0;
+    auto fetch = [&](float4 (&q)[SLOTS][4], unsigned (&qf)[SLOTS]) __attribute__((always_inline)) {
+        const bool live = ft < nk;
+        ++ft;
+        long xrow[4];
+        unsigned xm = 0, ym = 0;
+        int qn = pn, qy = py, qx = px;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int pp = p + kk;
+            const bool pv = live && pp < d.P;
+            long row = -1;
+            if (pv) {
+                if (dense) row = pp;
+                else {
+                    const int iy = qy * d.g.stride - d.g.pad + ky * d.g.dil;
+                    const int ix = qx * d.g.stride - d.g.pad + kx * d.g.dil;
+                    if (iy >= 0 && iy < d.g.Ha && ix >= 0 && ix < d.g.Wa) row = ((long)qn * d.g.Ha + iy) * d.g.Wa + ix;
+                }
+            }
+            ym |= (pv ? 1u : 0u) << kk;
+            xm |= (row >= 0 ? 1u : 0u) << kk;
+            xrow[kk] = row >= 0 ? row : 0;
+            if (!dense) { if (++qx >= d.g.Wc) { qx = 0; if (++qy >= d.g.Hc) { qy = 0; ++qn; } } }
+        }
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            qf[s] = isx[s] ? xm : ym;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const long row = isx[s] ? xrow[kk] : (long)min(p + kk, d.P - 1);
+                q[s][kk] = ld4(cbase[s] + row * rstride[s]);
+            }
+        }
+        p += BKF;
+        if (!dense) {
+            px += BKF;
+            while (px >= d.g.Wc) { px -= d.g.Wc; ++py; }
+            while (py >= d.g.Hc) { py -= d.g.Hc; ++pn; }
+        }
+    };
+    float4 bsum = zero4();            // dY column sums of this thread's slot-0 block (slot 0 of every dY thread covers all of dY
+                                      // when BI <= 64; BI = 128 fills slot 0 of all 256 threads with dY as well)
+    auto stash = [&](const float4 (&q0)[SLOTS][4], const unsigned (&qf)[SLOTS], int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < SLOTS; ++s) {
+            float4 q[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) q[kk] = ((qf[s] >> kk) & 1u) ? q0[s][kk] : zero4();
+            if (s == 0 && do_bias && !isx[0]) {
+                bsum.x += (q[0].x + q[1].x) + (q[2].x + q[3].x);
+                bsum.y += (q[0].y + q[1].y) + (q[2].y + q[3].y);
+                bsum.z += (q[0].z + q[1].z) + (q[2].z + q[3].z);
+                bsum.w += (q[0].w + q[1].w) + (q[2].w + q[3].w);
+            }
+            if (!used[s]) continue;
+            __bf16* dst = Zs + buf * ZT + zrow[s] * RS + pg * 4;
+            stash_split4(dst, 32, q[0].x, q[1].x, q[2].x, q[3].x);
+            stash_split4(dst + RS, 32, q[0].y, q[1].y, q[2].y, q[3].y);
+            stash_split4(dst + 2 * RS, 32, q[0].z, q[1].z, q[2].z, q[3].z);
+            stash_split4(dst + 3 * RS, 32, q[0].w, q[1].w, q[2].w, q[3].w);
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const __bf16* as = Zs + buf * ZT + (wm * (BI / 2) + i32) * RS + g * 8;
+        const __bf16* bs = Zs + buf * ZT + (BI + wn * (BJ / 2) + i32) * RS + g * 8;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+                ah[a] = *reinterpret_cast<const bf16x8*>(as + a * 32 * RS + hp * 16);
+                al[a] = *reinterpret_cast<const bf16x8*>(as + a * 32 * RS + 32 + hp * 16);
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                bh[b] = *reinterpret_cast<const bf16x8*>(bs + b * 32 * RS + hp * 16);
+                bl[b] = *reinterpret_cast<const bf16x8*>(bs + b * 32 * RS + 32 + hp * 16);
+            }
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+        }
+    };
+
+    fetch(rz[0], rf[0]);
+    fetch(rz[1], rf[1]);
+    stash(rz[0], rf[0], 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        fetch(rz[0], rf[0]);                   // tile kt+2
+        compute(0);
+        stash(rz[1], rf[1], 1);
+        __syncthreads();
+        fetch(rz[1], rf[1]);                   // tile kt+3
+        compute(1);
+        stash(rz[0], rf[0], 0);
+        __syncthreads();
+    }
+    if (kt < nk) compute(0);
+
+    mfma_drain(acc);
+    const bool single = (gridDim.y == 1);
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int c = c0 + wn * (BJ / 2) + b * 32 + i32;
+            if (c >= d.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (i >= d.Nout) continue;
+                float v = acc[a][b][r];
+                if (d.w_scale) v *= d.w_scale[i];
+                float* dst = dW + (long)i * d.ldw + (long)tap * d.Cin + c;
+                if (single) *dst += v;
+                else atomicAdd(dst, v);
+            }
+        }
+    }
+    if (do_bias) {   // the 8 pixel quads of one channel quad sit in 8 consecutive lanes
+        bsum.x += __shfl_xor(bsum.x, 1, 64); bsum.y += __shfl_xor(bsum.y, 1, 64); bsum.z += __shfl_xor(bsum.z, 1, 64); bsum.w += __shfl_xor(bsum.w, 1, 64);
+        bsum.x += __shfl_xor(bsum.x, 2, 64); bsum.y += __shfl_xor(bsum.y, 2, 64); bsum.z += __shfl_xor(bsum.z, 2, 64); bsum.w += __shfl_xor(bsum.w, 2, 64);
+        bsum.x += __shfl_xor(bsum.x, 4, 64); bsum.y += __shfl_xor(bsum.y, 4, 64); bsum.z += __shfl_xor(bsum.z, 4, 64); bsum.w += __shfl_xor(bsum.w, 4, 64);
+        const int cq = tid >> 3;
+        if (pg == 0 && !isx[0] && cq < BI / 4) {
+            const int i = i0 + cq * 4;
+            if (i < d.Nout) atomicAdd(dbias + i, bsum.x);
+            if (i + 1 < d.Nout) atomicAdd(dbias + i + 1, bsum.y);
+            if (i + 2 < d.Nout) atomicAdd(dbias + i + 2, bsum.z);
+            if (i + 3 < d.Nout) atomicAdd(dbias + i + 3, bsum.w);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ direct small GEMMs
 // Latency-optimised path for the ~450 small contractions per step (decoder M = B*Q = 600 rows, positional MLPs,
 // per-head dq/dk of RCDA): one wave = one 16x16 output tile on v_mfma_f32_16x16x4_f32, operands loaded straight from
@@ -1390,7 +1610,14 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             slices = (nktf + per - 1) / per;
             const int bytes = (2 * 32 * (BI + 4) + 2 * 32 * (BJ + 4)) * 4;
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
-            if (d.precision == 1) {
+            // measured (tools/wgrad_pmc.py): the staged-split variant is 5-15 % SLOWER than the per-fragment split on every shape of
+            // this model (the transposing stash costs more than the VALU it saves) -> opt-in only
+            static const int use_trb = getenv("CDETR_WGRAD_TRB") ? atoi(getenv("CDETR_WGRAD_TRB")) : 0;
+            if (d.precision == 1 && use_trb) {
+                const int tbytes = 2 * (BI + BJ) * 72 * 2;
+                if ((rcf = raise_lds(wgrad_trb_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
+                hipLaunchKernelGGL((wgrad_trb_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
+            } else if (d.precision == 1) {
                 if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 1>, bytes, "cdetr_wgrad"))) return;
                 hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ, 1>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
             } else {

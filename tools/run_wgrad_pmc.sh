@@ -1,0 +1,6 @@
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+python tools/wgrad_pmc.py 2>&1 | grep -v amdgpu
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/pc1 -- python tools/wgrad_pmc.py > /dev/null 2>&1
+f=$(find /tmp/pc1 -name "*counter_collection.csv"); python tools/pmc_summary.py $f wgrad_fast
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d /tmp/pc2 -- python tools/wgrad_pmc.py > /dev/null 2>&1
+f=$(find /tmp/pc2 -name "*counter_collection.csv"); python tools/pmc_summary.py $f wgrad_fast
