@@ -16,7 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import backbone as _bb
-from .misc import get_world_size, is_dist_avail_and_initialized, nested_tensor_from_tensor_list, reduce_dict
+from .misc import NestedTensor, get_world_size, is_dist_avail_and_initialized, nested_tensor_from_tensor_list, reduce_dict
 
 UNUSED_PREFIXES = ("input_proj.",)   # built but never used on the stage-2 path: grad stays None in the reference
 
@@ -312,7 +312,8 @@ def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
     stats = {}
     n = 0
     for it, ret in enumerate(data_loader):
-        out = trainer.train_step(ret["image"], ret["ex_rects"], ret["targets"])
+        samples = NestedTensor(ret["image"], ret["mask"]) if "mask" in ret else ret["image"]     # data.collate pads + masks
+        out = trainer.train_step(samples, ret["ex_rects"], ret["targets"])
         if it % print_freq == 0:
             red = reduce_dict({k: v for k, v in out.items() if torch.is_tensor(v)})
             vals = {k: float(v) for k, v in red.items()}

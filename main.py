@@ -5,7 +5,8 @@ weights only, keys filtered like A2/main.py:195-209) -> per epoch train_one_epoc
 {"model","optimizer","lr_scheduler","epoch","args"} to <output_dir>/detr_retrain.pth (+ numbered copies), JSON log line.
 Differences: any number of images per GPU (--images_per_gpu), data-parallel over the GPUs of a node under torchrun
 (RCCL), and --synthetic (seeded tensors; FSC-147 is not available in this environment -- with a dataset, pass a
-DataLoader yielding the reference's sample dicts to `train_one_epoch`).
+DataLoader yielding the reference's sample dicts to `train_one_epoch`).  Without --synthetic the FSC-147 reader of
+counting_detr_amd/data.py feeds the step (batched collate + pinned-memory prefetch).
 
   python main.py --synthetic --no_aux_loss --num_query_pattern 1 --epochs 1 -o /tmp/out
   python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 main.py --synthetic --no_aux_loss ...
@@ -66,10 +67,16 @@ def main(args):
             print("Unexpected Keys: {}".format(unexpected))
 
     trainer = Trainer(model, criterion, args, device=device)           # 3 lr groups + flat AdamW (A2/main.py:157-189)
-    if not args.synthetic:
-        raise SystemExit("no dataset reader in this build (FSC-147 I/O is out of scope, SURVEY.md 8f): use --synthetic, or "
-                         "drive counting_detr_amd.engine.train_one_epoch with your own DataLoader")
-    loader = SyntheticLoader(args, device, args.steps_per_epoch)
+    if args.synthetic:
+        loader = SyntheticLoader(args, device, args.steps_per_epoch)
+    else:                                                               # A2/main.py:146-147 (+ batching, sharding, prefetch)
+        from torch.utils.data import DataLoader, DistributedSampler
+        from counting_detr_amd import data
+        ds = data.build_dataset(args)
+        sampler = DistributedSampler(ds, shuffle=True) if getattr(args, "distributed", False) else None
+        dl = DataLoader(ds, batch_size=args.images_per_gpu, shuffle=(sampler is None), sampler=sampler, collate_fn=data.collate,
+                        num_workers=args.num_workers, drop_last=True, pin_memory=False)
+        loader = data.Prefetcher(dl, device)
     print("Start training")
     start = time.time()
     output_dir = Path(args.output_dir)
