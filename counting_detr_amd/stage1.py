@@ -78,3 +78,35 @@ def generate_pseudo_boxes(model, image, points):
     model.eval()
     out = model(image, points)
     return torch.cat([points.reshape(1, -1, 2).expand(image.shape[0], -1, -1), out["pred_wh"]], dim=-1)
+
+
+@torch.no_grad()
+def write_pseudo_labels(model, loader, split, output_dir, device="cuda"):
+    """The 1st-stage -> 2nd-stage hand-off file (A1/engine.py:124-187): for every image, one pseudo box per annotated dot,
+    written as the COCO-style `pseudo_bbox_<split>.json` that the 2nd-stage training reader opens
+    (A2/data/fsc147.py:18-19; counting_detr_amd.data.FSC147Dataset): bbox = [cx, cy, w, h] in original pixels (ints),
+    file_name = "<im_id>.jpg", ids counted from 1.  `loader` yields dicts with image [1,3,H,W], points [1,P,2] (normalised),
+    orig_size [1,2] = (width, height), im_id.  Returns the annotation dict."""
+    import json
+    import os
+    model.eval()
+    ann = {"categories": [{"name": "fg", "id": 1}], "images": [], "annotations": []}
+    img_id = anno_id = 1
+    for ret in loader:
+        image, points = ret["image"].to(device), ret["points"].to(device)
+        wh = model(image, points)["pred_wh"]
+        size = ret["orig_size"].reshape(-1).tolist()                      # (width, height)
+        pts = points.reshape(-1, 2).cpu().numpy().copy()
+        whs = wh.reshape(-1, 2).cpu().numpy().copy()
+        whs[:, 0] *= size[0]; whs[:, 1] *= size[1]
+        pts[:, 0] *= size[0]; pts[:, 1] *= size[1]
+        for (x_cen, y_cen), (w, h) in zip(pts, whs):
+            ann["annotations"].append({"id": anno_id, "image_id": img_id, "area": int(w * h),
+                                       "bbox": [int(x_cen), int(y_cen), int(w), int(h)], "category_id": 1, "iscrowd": 0})
+            anno_id += 1
+        ann["images"].append({"id": img_id, "file_name": str(int(ret["im_id"])) + ".jpg", "height": int(size[1]), "width": int(size[0])})
+        img_id += 1
+    os.makedirs(output_dir, exist_ok=True)
+    with open(os.path.join(output_dir, "pseudo_bbox_" + split + ".json"), "w") as handle:
+        json.dump(ann, handle)
+    return ann

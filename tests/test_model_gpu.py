@@ -182,3 +182,49 @@ def test_dataset_train_epoch_and_infer(tmp_path):
         out, _ = model(NestedTensor(b["image"].to(DEV), b["mask"].to(DEV)), rects=b["ex_rects"].to(DEV))
     n0 = int((out["pred_logits"].sigmoid()[0, :, 0] >= 0.5).sum())
     assert n0 == sum(1 for a in pj["annotations"] if a["image_id"] == int(b["image_id"][0]))
+
+
+def test_stage1_to_stage2_handoff(tmp_path):
+    """the 1st-stage model writes pseudo_bbox_<split>.json (A1/engine.py:124-187 format) and the 2nd-stage
+    training reader consumes that very file."""
+    import argparse, json, os, shutil
+    from PIL import Image
+    from counting_detr_amd import data, stage1
+    from counting_detr_amd.args import default_args
+    from oracle.weights import seeded_state_dict, stage1_schema
+    args = default_args()
+    args.spatial_prior, args.num_query_pattern = "defined", 1
+    model, _, _ = stage1.build(args)
+    model.load_state_dict(seeded_state_dict(stage1_schema()), strict=True)
+    model.to(DEV)
+    here = os.path.dirname(os.path.abspath(__file__))
+    src = os.path.join(here, "golden", "fsc147_tiny")
+    root = tmp_path / "ds"
+    shutil.copytree(src, root)
+    names = {7: "1.png", 9: "2.png"}
+    anno = json.load(open(root / "annotation_FSC147_384.json"))
+    samples = []
+    for im_id, fn in names.items():
+        img = Image.open(root / "images_384_VarV2" / fn)
+        w, h = img.size
+        shutil.copy(root / "images_384_VarV2" / fn, root / "images_384_VarV2" / f"{im_id}.jpg")     # the hand-off names files <im_id>.jpg
+        anno[f"{im_id}.jpg"] = anno[fn]
+        pts = torch.tensor(anno[fn]["points"], dtype=torch.float32) / torch.tensor([w, h], dtype=torch.float32)
+        t = data.to_normalized_tensor(img.resize((32 * (w // 32), 32 * (h // 32))))
+        samples.append({"image": t[None], "points": pts[None], "orig_size": torch.tensor([[w, h]]), "im_id": torch.tensor(im_id)})
+    json.dump(anno, open(root / "annotation_FSC147_384.json", "w"))
+    ann = stage1.write_pseudo_labels(model, samples, "train", str(root / "annotations"), device=DEV)
+    assert [im["file_name"] for im in ann["images"]] == ["7.jpg", "9.jpg"] and [im["id"] for im in ann["images"]] == [1, 2]
+    assert len(ann["annotations"]) == sum(len(anno[fn]["points"]) for fn in names.values())
+    for a in ann["annotations"]:
+        assert set(a) == {"id", "image_id", "area", "bbox", "category_id", "iscrowd"} and all(isinstance(v, int) for v in a["bbox"])
+        assert a["bbox"][2] >= 0 and a["bbox"][3] >= 0
+    # the 2nd-stage reader opens the file the 1st stage wrote
+    ds = data.FSC147Dataset(argparse.Namespace(data_path=str(root)), split="train")
+    assert len(ds) == 2
+    s0 = ds[0]
+    n0 = len(anno["1.png"]["points"])
+    assert s0["boxes"].shape == (n0, 4) and s0["ex_rects"].shape == (3, 4)
+    w0, h0 = Image.open(root / "images_384_VarV2" / "7.jpg").size
+    want = np.array([a["bbox"] for a in ann["annotations"] if a["image_id"] == 1], dtype=np.float32) / np.array([w0, h0, w0, h0], dtype=np.float32)
+    np.testing.assert_allclose(s0["boxes"], want, rtol=0, atol=1e-7)
