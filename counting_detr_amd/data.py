@@ -138,7 +138,45 @@ class FSC147EvalDataset(Dataset):
                 "xyxy_boxes": xyxy / res4[None, :]}
 
 
+class FSCDLVISDataset(Dataset):
+    """FSCD-LVIS train / test readers (BASELINE config 4; L2/data/fscd_lvis.py:12-100, :103-190): same network, different
+    files -- `annotations_old/pseudo_lvis_<split>_cxcywh.json` (train) or `single_instances_<split>.json` (test), exemplars
+    from `count_<split>.json` (first three [x, y, w, h] boxes, clipped to the image on the training split only), RGB convert."""
+
+    def __init__(self, args, split="train", test=False):
+        data_path = args.data_path
+        name = ("single_instances_" + split + ".json") if test else ("pseudo_lvis_" + split + "_cxcywh.json")
+        self.coco = CocoIndex(os.path.join(data_path, "annotations_old", name))
+        self.image_ids = self.coco.getImgIds()
+        self.img_path = os.path.join(data_path, "images", "all_images")
+        self.count_anno = _load_json(os.path.join(data_path, "annotations_old", "count_" + split + ".json"))
+        self.clip = not test
+
+    def __len__(self):
+        return len(self.image_ids)
+
+    def __getitem__(self, idx):
+        img_id = self.image_ids[idx]
+        img_file = self.coco.loadImgs([img_id])[0]["file_name"]
+        img = Image.open(os.path.join(self.img_path, img_file)).convert("RGB")
+        wh = img.size
+        anns = self.coco.loadAnns(self.coco.getAnnIds([img_id]))
+        bboxes = np.array([a["bbox"] for a in anns], dtype=np.float32).reshape(-1, 4)
+        ex = np.array([[x, y, x + w, y + h] for x, y, w, h in self.count_anno["annotations"][idx]["boxes"][:3]], dtype=np.float32)
+        if self.clip:                                                                    # L2/data/fscd_lvis.py:60-63
+            ex[:, 0] = np.clip(ex[:, 0], 0, wh[0] - 1); ex[:, 1] = np.clip(ex[:, 1], 0, wh[1] - 1)
+            ex[:, 2] = np.clip(ex[:, 2], 0, wh[0] - 1); ex[:, 3] = np.clip(ex[:, 3], 0, wh[1] - 1)
+        img_w, img_h = wh
+        img = img.resize((32 * int(img_w / 32), 32 * int(img_h / 32)))
+        res = np.array([img_w, img_h, img_w, img_h], dtype=np.float32)
+        bboxes = bboxes / res[None, :]
+        return {"image": to_normalized_tensor(img), "boxes": bboxes, "ex_rects": ex / res[None, :], "origin_wh": wh,
+                "labels": torch.zeros([bboxes.shape[0]], dtype=torch.int64), "orig_size": np.array([img_h, img_w])}
+
+
 def build_dataset(args):
+    if getattr(args, "dataset", "fsc147") == "fscd_lvis":
+        return FSCDLVISDataset(args, split="train")
     return FSC147Dataset(args)
 
 

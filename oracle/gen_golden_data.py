@@ -146,6 +146,41 @@ def main():
     te = ref.FSC147_Dataset_Test(args, split="test")
     for i in range(len(te)):
         dump(f"test{i}", te[i])
+    # ---- FSCD-LVIS readers (L2/data/fscd_lvis.py) on the same images
+    LV = os.path.join(ROOT, "fscd_lvis_tiny")
+    os.makedirs(os.path.join(LV, "images", "all_images"), exist_ok=True)
+    os.makedirs(os.path.join(LV, "annotations_old"), exist_ok=True)
+    import shutil
+    rng = np.random.default_rng(11)
+    for sp, names in (("train", ["1.png", "2.png"]), ("test", ["4.png"])):
+        coco = {"images": [], "annotations": [], "categories": [{"id": 1, "name": "fg"}]}
+        cnt = {"annotations": []}
+        aid = 1
+        for i, n in enumerate(names, start=1):
+            shutil.copy(os.path.join(DS, "images_384_VarV2", n), os.path.join(LV, "images", "all_images", n))
+            w, h = Image.open(os.path.join(DS, "images_384_VarV2", n)).size
+            coco["images"].append({"id": 10 * i, "file_name": n, "width": w, "height": h})
+            for _ in range(4 + i):
+                coco["annotations"].append({"id": aid, "image_id": 10 * i, "category_id": 1, "iscrowd": 0,
+                                            "bbox": [float(rng.uniform(0, w)), float(rng.uniform(0, h)), float(rng.uniform(3, 15)), float(rng.uniform(3, 15))]})
+                aid += 1
+            # exemplar boxes, one of them sticking out of the image (clipped on the training split only)
+            cnt["annotations"].append({"boxes": [[float(rng.uniform(0, w * 0.5)), float(rng.uniform(0, h * 0.5)), float(rng.uniform(5, 30)), float(rng.uniform(5, 30))] for _ in range(3)]
+                                       + [[w - 5.0, h - 4.0, 20.0, 20.0]]})
+            cnt["annotations"][-1]["boxes"][1] = [w - 6.0, h - 7.0, 25.0, 25.0]
+        fn = "pseudo_lvis_train_cxcywh.json" if sp == "train" else "single_instances_test.json"
+        json.dump(coco, open(os.path.join(LV, "annotations_old", fn), "w"))
+        json.dump(cnt, open(os.path.join(LV, "annotations_old", f"count_{sp}.json"), "w"))
+    spec = importlib.util.spec_from_file_location("ref_lvis", "/root/reference/src/CountDETR_lvis_2nd_stage/data/fscd_lvis.py")
+    lv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lv)
+    largs = argparse.Namespace(data_path=LV)
+    tr = lv.FSCD_LVISDataset(largs, split="train")
+    for i in range(len(tr)):
+        dump(f"lvis_train{i}", tr[i])
+    te = lv.FSCD_LVIS_Dataset_Test(largs, split="test")
+    for i in range(len(te)):
+        dump(f"lvis_test{i}", te[i])
     np.savez_compressed(os.path.join(ROOT, "g9_data.npz"), **d)
     print("wrote", len(d), "arrays;", sorted(set(k.split("/")[0] for k in d)))
 

@@ -51,6 +51,20 @@ def test_eval_readers_match_reference(golden, args, split, n):
         _check(ds[i], z, f"{split}{i}")
 
 
+def test_fscd_lvis_readers_match_reference(golden):
+    """BASELINE config 4: same network, FSCD-LVIS files (L2/data/fscd_lvis.py); incl. the train-only exemplar clipping."""
+    from counting_detr_amd.data import FSCDLVISDataset
+    z = golden("g9_data.npz")
+    a = argparse.Namespace(data_path=os.path.join(HERE, "golden", "fscd_lvis_tiny"))
+    tr = FSCDLVISDataset(a, split="train")
+    assert len(tr) == 2
+    for i in range(2):
+        _check(tr[i], z, f"lvis_train{i}")
+    te = FSCDLVISDataset(a, split="test", test=True)
+    assert len(te) == 1
+    _check(te[0], z, "lvis_test0")
+
+
 def test_collate_pads_and_masks(args):
     from counting_detr_amd.data import build_dataset, collate
     ds = build_dataset(args)
