@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
                 ("B", _p), ("ldb", C.c_int64), ("sB", C.c_int64),
                 ("C", _p), ("ldc", C.c_int64), ("sC", C.c_int64),
                 ("w_scale", _p), ("bias", _p), ("resid", _p), ("ldr", C.c_int64), ("gate", _p), ("ldg", C.c_int64),
-                ("g", ConvGeom)]
+                ("g", ConvGeom), ("B_split", _p)]
 
 
 class WgradDesc(C.Structure):
@@ -58,7 +58,8 @@ class CriterionDesc(C.Structure):
 
 
 class MirrorItem(C.Structure):
-    _fields_ = [("src", _p), ("dst", _p), ("scale", _p), ("R", C.c_int32), ("C", C.c_int32), ("taps", C.c_int32), ("tile0", C.c_int32)]
+    _fields_ = [("src", _p), ("dst", _p), ("dst_split", _p), ("scale", _p), ("R", C.c_int32), ("C", C.c_int32), ("taps", C.c_int32),
+                ("tile0", C.c_int32), ("transpose", C.c_int32), ("pad_", C.c_int32)]
 
 
 EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_bwd", "cdetr_posadd2",

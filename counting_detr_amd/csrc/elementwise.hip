@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void weight_mirror_kernel(const cdetr_mirror_i
     t -= tap * tilesR * tilesC;
     const int r0 = (t / tilesC) * 32, c0 = (t % tilesC) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    __bf16* sp = reinterpret_cast<__bf16*>(it.dst_split);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int r = r0 + ty + 8 * p, c = c0 + tx;
@@ -129,12 +130,28 @@ __global__ __launch_bounds__(256) void weight_mirror_kernel(const cdetr_mirror_i
             if (it.scale) v *= it.scale[r];
         }
         tile[ty + 8 * p][tx] = v;
+        if (!it.transpose && sp && r < it.R && c < it.C) {      // forward image: row r, k = tap*C + c (C % 32 == 0: one group per tile row)
+            const __bf16 h = (__bf16)v;
+            __bf16* g = sp + (long)r * it.taps * it.C * 2 + (long)((tap * it.C + c0) >> 5) * 64;
+            g[tx] = h;
+            g[32 + tx] = (__bf16)(v - (float)h);
+        }
     }
+    if (!it.transpose) return;
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int c = c0 + ty + 8 * p, r = r0 + tx;
-        if (r < it.R && c < it.C) it.dst[((long)c * it.taps + tap) * it.R + r] = tile[tx][ty + 8 * p];
+        if (r < it.R && c < it.C) {
+            const float v = tile[tx][ty + 8 * p];
+            if (it.dst) it.dst[((long)c * it.taps + tap) * it.R + r] = v;
+            if (sp) {                                            // transposed image: row c, k = tap*R + r (R % 32 == 0)
+                const __bf16 h = (__bf16)v;
+                __bf16* g = sp + (long)c * it.taps * it.R * 2 + (long)((tap * it.R + r0) >> 5) * 64;
+                g[tx] = h;
+                g[32 + tx] = (__bf16)(v - (float)h);
+            }
+        }
     }
 }
 }  // namespace

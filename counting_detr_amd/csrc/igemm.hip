@@ -459,8 +459,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     // PREC == 1: the tile is split into bf16 hi / lo ONCE while it is staged; an LDS row holds [hi k0..BKF-1 | lo k0..BKF-1 | pad]
     // = the same LDK*4 bytes as the fp32 row, and B is always stored [n][k] (a n-contiguous operand is transposed in
     // registers: every thread fetches a 4k x NV n block).
+    constexpr bool SPL = (PREC == 2 || PREC == 3);     // operands live in LDS as bf16 hi / lo planes
+    constexpr bool BRAW = (PREC == 3);                  // B arrives pre-split from HBM (cdetr_gemm_desc.B_split): staged by a plain copy
+    static_assert(!BRAW || BL == 0, "pre-split B is a k-contiguous operand");
     constexpr bool TRB = (PREC == 2 && BL == 1);
-    constexpr int B_TILE = (BL == 0 || PREC == 2) ? BN * LDK : BKF * LDN;
+    constexpr int B_TILE = (BL == 0 || SPL) ? BN * LDK : BKF * LDN;
     constexpr int EB = BKF * BN / NT;                  // B elements per thread
     constexpr int NV = (EB >= 16) ? 4 : 2;             // n-width of one transposing block
     constexpr int NBLK = EB / (4 * NV);
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
     const float* __restrict__ A = d.A + (long)z * d.sA;
-    const float* __restrict__ B = d.B + (long)z * d.sB;
+    const float* __restrict__ B = (BRAW ? reinterpret_cast<const float*>(d.B_split) : d.B) + (long)z * d.sB;
     float* __restrict__ C = d.C + (long)z * d.sC;
     const int K = d.K, taps = d.taps;
     const int nkt = (K / BKF) * taps;
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
         for (int i = 0; i < B_SLOTS; ++i) {
             const int n = min(n0 + r8 + RPP * i, d.N - 1);
             bp[i] = B + (long)n * d.ldb + kq * 4;
-            bscale0[i] = d.w_scale ? d.w_scale[n] : 1.f;
+            bscale0[i] = (d.w_scale && !BRAW) ? d.w_scale[n] : 1.f;
         }
     }
     // register sets for the two k-tiles in flight.  Fetches are RAW loads (nothing in fetch() consumes a loaded value, so
@@ -583,13 +586,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
         float4 qa[A_SLOTS];
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) qa[i] = ((qm >> i) & 1u) ? qa0[i] : zero4();
-        if constexpr (PREC == 2) {
+        if constexpr (SPL) {
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
                 if constexpr (ABL == 4) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = qa[i];      // ablation: no split
                 else stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + kq * 4, BKF, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
             }
-            if constexpr (BL == 0 && ABL >= 3) {
+            if constexpr (BL == 0 && (ABL >= 3 || BRAW)) {
 #pragma unroll
                 for (int i = 0; i < B_SLOTS; ++i) *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = qb[i];    // ablation
             } else if constexpr (BL == 0) {
@@ -1463,7 +1466,8 @@ int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
         hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>), grid, block, bytes, st, d, tilesM);
     } else {
         // the staging-split variant of the n-contiguous operand needs >= 8 elements per thread (4k x 2n blocks)
-        constexpr int P1 = (PREC == 2 && (BKF * BN) / (64 * WM * WN) < 8) ? 1 : PREC;
+        constexpr int P0 = (PREC == 3) ? 2 : PREC;          // pre-split B only exists for the k-contiguous layout
+        constexpr int P1 = (P0 == 2 && (BKF * BN) / (64 * WM * WN) < 8) ? 1 : P0;
         const int bytes = (2 * BM * (BKF + 4) + 2 * (P1 == 2 ? BN * (BKF + 4) : BKF * (BN + 4))) * 4;
         if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL>, bytes, "cdetr_gemm"))) return rc;
         hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL>), grid, block, bytes, st, d, tilesM);
@@ -1478,6 +1482,11 @@ int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
         // keeps the per-fragment split (its staging transpose costs more than it saves -- tools/split_sweep.py).
         // CDETR_GEMM_SPLIT: 0 = per-fragment everywhere, 2 = staging split everywhere.
         static const int split_mode = getenv("CDETR_GEMM_SPLIT") ? atoi(getenv("CDETR_GEMM_SPLIT")) : 1;
+        static const int presplit = getenv("CDETR_GEMM_PRESPLIT") ? atoi(getenv("CDETR_GEMM_PRESPLIT")) : 1;
+        if constexpr (BKF == 32) {
+            if (presplit && d.B_split && d.b_layout == 0 && d.batch == 1 && split_mode >= 1)
+                return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 3, 0>(d, st);
+        }
         if (split_mode == 2 || (split_mode == 1 && d.b_layout == 0)) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 2, 0>(d, st);
         return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 1, 0>(d, st);
     }

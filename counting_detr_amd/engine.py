@@ -117,25 +117,33 @@ class Trainer:
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
 
     def _build_mirror(self, named):
-        """k-contiguous mirrors (ops.WeightMirror) of every trainable matrix that is a data-gradient operand: backbone
-        convs (FrozenBN scale folded in), 1x1 projections and all linears with both dims >= 32."""
+        """Weight images (ops.WeightMirror), rewritten once per step: k-contiguous transposes of every trainable matrix that
+        is a data-gradient operand (backbone convs with the FrozenBN scale folded in, 1x1 projections, linears with both dims
+        >= 32) and pre-split forward operands of every conv / linear weight with K % 32 == 0 (frozen layers included)."""
         from . import ops
-        entries, seen = [], set()
+        entries, fwd, seen = [], [], set()
         for m in self.model.modules():
             if isinstance(m, _bb.Bottleneck):
                 pairs = [(m.conv1, m.bn1), (m.conv2, m.bn2), (m.conv3, m.bn3)]
                 if m.downsample is not None:
                     pairs.append((m.downsample[0], m.downsample[1]))
                 for conv, bn in pairs:
+                    w = conv.weight.data
+                    seen.add(w.data_ptr())
+                    if not w.is_cuda:
+                        continue
                     if conv.weight.requires_grad:
-                        entries.append((conv.weight.data, bn.affine()[0]))
-                        seen.add(conv.weight.data_ptr())
+                        entries.append((w, bn.affine()[0]))
+                    if w.shape[1] % 32 == 0:
+                        fwd.append((w, bn.affine()[0]))
         for _, p in named:
-            if p.data_ptr() in seen or min(p.shape[:2] if p.dim() >= 2 else (0,)) < 32:
+            if p.data_ptr() in seen or not p.is_cuda or min(p.shape[:2] if p.dim() >= 2 else (0,)) < 32:
                 continue
             if p.dim() == 2 or (p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1):
                 entries.append((p.data, None))
-        return ops.WeightMirror(entries) if entries else None
+                if p.shape[1] % 32 == 0:
+                    fwd.append((p.data, None))
+        return ops.WeightMirror(entries, fwd) if (entries or fwd) else None
 
     @staticmethod
     def _view_like(chunk, p):
@@ -200,19 +208,19 @@ class Trainer:
         from .misc import NestedTensor
         from . import ops
         self.flat_g.zero_()
-        outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
-        loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
-        wd = self.criterion.weight_dict
-        vec = getattr(self.criterion, "last_vec", None)
-        if vec is not None:          # fused criterion: one weighted reduction of its loss vector
-            losses = (vec * self._w6).sum()                                           # A2/engine.py:37
-        else:
-            losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
-        # data-gradient GEMMs read the k-contiguous weight mirrors: rewritten here (one launch), armed only for this backward
+        # weight images (transposes for the data gradients, pre-split operands for both passes): one launch, armed for this step only
         if self.mirror is not None:
             self.mirror.refresh()
         ops.MIRROR = self.mirror
         try:
+            outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
+            loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
+            wd = self.criterion.weight_dict
+            vec = getattr(self.criterion, "last_vec", None)
+            if vec is not None:          # fused criterion: one weighted reduction of its loss vector
+                losses = (vec * self._w6).sum()                                       # A2/engine.py:37
+            else:
+                losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
             losses.backward()
         finally:
             ops.MIRROR = None

@@ -48,12 +48,13 @@ def _geom(mode=_ffi.ROWS_DENSE, Ha=0, Wa=0, Hc=0, Wc=0, kh=1, kw=1, stride=1, pa
 
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
-             gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0):
+             gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None):
     d = GemmDesc()
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION
     d.A, d.lda, d.sA = ptr(A), lda, sA
     d.B, d.ldb, d.sB = ptr(B), ldb, sB
+    d.B_split = ptr(B_split)
     d.C, d.ldc, d.sC = ptr(Cout), ldc, sC
     d.w_scale, d.bias = ptr(w_scale), ptr(bias)
     d.resid, d.ldr = ptr(resid), ldr
@@ -101,57 +102,102 @@ def grad_buffer(p):
 
 # ----------------------------------------------------------------------------------------------------- weight mirrors
 class WeightMirror:
-    """k-contiguous mirrors Wt[c][tap][o] = W[o][tap][c] * scale[o] of weights used as data-gradient operands
-    (cdetr_weight_mirror).  `entries` = [(weight, scale or None)]; weights are [R, C] or channels_last [R, C, kh, kw].
-    `refresh()` rewrites every mirror in one launch (the trainer calls it at the start of each step, inside the graph);
-    `lookup(w, scale)` maps a weight (or a row slice of a registered 2-D weight) to its mirror operand."""
+    """Device-side images of the weights, rewritten by ONE launch per step (cdetr_weight_mirror):
+      * `entries` = [(weight, scale or None)] used as data-gradient operands: the k-contiguous transpose
+        Wt[c][tap][o] = W[o][tap][c] * scale[o] in fp32 and (when R % 32 == 0) pre-split into bf16 hi / lo;
+      * `fwd_entries` = [(weight, scale or None)] used as forward operands: W * scale pre-split (needs C % 32 == 0).
+    Weights are [R, C] or channels_last [R, C, kh, kw].  The pre-split images let the bf16x3 GEMM kernels stage the weight
+    operand with a plain copy (cdetr_gemm_desc.B_split); `lookup*` also resolve row slices of registered 2-D weights."""
 
-    def __init__(self, entries):
+    def __init__(self, entries, fwd_entries=()):
         import bisect
         import numpy as np
         self._bisect = bisect
-        total = sum(w.numel() for w, _ in entries)
-        dev = entries[0][0].device
-        self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        self.entries, self._keep = [], []
-        items = (MirrorItem * len(entries))()
-        off = tile0 = 0
-        for i, (w, sc) in enumerate(entries):
+        dev = (entries or fwd_entries)[0][0].device
+        tot_t = sum(w.numel() for w, _ in entries)
+        tot_f = sum(w.numel() for w, _ in fwd_entries)
+        self.flat = torch.zeros(max(tot_t, 1), device=dev, dtype=torch.float32)          # fp32 transposes
+        self.flat_ts = torch.zeros(max(tot_t, 1), device=dev, dtype=torch.float32)       # their bf16 hi/lo images (same byte size)
+        self.flat_fs = torch.zeros(max(tot_f, 1), device=dev, dtype=torch.float32)       # forward bf16 hi/lo images
+        self._keep = []
+        items = (MirrorItem * (len(entries) + len(fwd_entries)))()
+        self.t_entries, self.f_entries = [], []
+        tile0 = 0
+
+        def geom(w):
             R, Cc = w.shape[0], w.shape[1]
             taps = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
             if w.dim() == 4:
                 assert taps == 1 or w.is_contiguous(memory_format=torch.channels_last)
             else:
                 assert w.is_contiguous()
-            items[i].src, items[i].dst = w.data_ptr(), self.flat.data_ptr() + 4 * off
-            items[i].scale = sc.data_ptr() if sc is not None else None
-            items[i].R, items[i].C, items[i].taps, items[i].tile0 = R, Cc, taps, tile0
-            self.entries.append((w.data_ptr(), w.numel() * 4, off, R, Cc, taps, sc.data_ptr() if sc is not None else 0))
+            return R, Cc, taps
+
+        off = 0
+        for i, (w, sc) in enumerate(entries):
+            R, Cc, taps = geom(w)
+            it = items[i]
+            it.src, it.dst = w.data_ptr(), self.flat.data_ptr() + 4 * off
+            has_split = R % 32 == 0
+            it.dst_split = (self.flat_ts.data_ptr() + 4 * off) if has_split else None
+            it.scale = sc.data_ptr() if sc is not None else None
+            it.R, it.C, it.taps, it.tile0, it.transpose = R, Cc, taps, tile0, 1
+            self.t_entries.append((w.data_ptr(), w.numel() * 4, off, R, Cc, taps, sc.data_ptr() if sc is not None else 0, has_split))
             self._keep.append((w, sc))
             tile0 += ((R + 31) // 32) * ((Cc + 31) // 32) * taps
             off += w.numel()
-        self.total_tiles, self.n = tile0, len(entries)
+        off = 0
+        for j, (w, sc) in enumerate(fwd_entries):
+            R, Cc, taps = geom(w)
+            assert Cc % 32 == 0
+            it = items[len(entries) + j]
+            it.src, it.dst, it.dst_split = w.data_ptr(), None, self.flat_fs.data_ptr() + 4 * off
+            it.scale = sc.data_ptr() if sc is not None else None
+            it.R, it.C, it.taps, it.tile0, it.transpose = R, Cc, taps, tile0, 0
+            self.f_entries.append((w.data_ptr(), w.numel() * 4, off, R, Cc, taps, sc.data_ptr() if sc is not None else 0, True))
+            self._keep.append((w, sc))
+            tile0 += ((R + 31) // 32) * ((Cc + 31) // 32) * taps
+            off += w.numel()
+        self.total_tiles, self.n = tile0, len(entries) + len(fwd_entries)
         raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
         self.items_dev = torch.from_numpy(raw).to(dev)
-        self.entries.sort()
-        self._bases = [e[0] for e in self.entries]
+        self.t_entries.sort()
+        self.f_entries.sort()
+        self._tb = [e[0] for e in self.t_entries]
+        self._fb = [e[0] for e in self.f_entries]
 
     def refresh(self):
         check(lib().cdetr_weight_mirror(ptr(self.items_dev), self.n, self.total_tiles, stream_ptr()), "cdetr_weight_mirror")
 
-    def lookup(self, w, scale=None):
-        """-> (mirror tensor positioned at this weight / row slice, ldb, K) or None"""
+    def _find(self, table, bases, w, scale):
         p = w.data_ptr()
-        i = self._bisect.bisect_right(self._bases, p) - 1
+        i = self._bisect.bisect_right(bases, p) - 1
         if i < 0:
             return None
-        base, nbytes, off, R, Cc, taps, sptr = self.entries[i]
-        if p >= base + nbytes or sptr != (scale.data_ptr() if scale is not None else 0):
+        e = table[i]
+        if p >= e[0] + e[1] or e[6] != (scale.data_ptr() if scale is not None else 0):
             return None
-        row0 = (p - base) // (4 * Cc * taps)
-        if (p - base) != row0 * 4 * Cc * taps or (row0 and taps != 1):
+        row0 = (p - e[0]) // (4 * e[4] * e[5])
+        if (p - e[0]) != row0 * 4 * e[4] * e[5] or (row0 and e[5] != 1):
             return None
-        return self.flat[off + row0:], taps * R
+        return e, row0
+
+    def lookup(self, w, scale=None):
+        """data-gradient operand of `w` (or of a row slice of it) -> (fp32 mirror view, ldb, pre-split view or None) or None"""
+        r = self._find(self.t_entries, self._tb, w, scale)
+        if r is None:
+            return None
+        (base, nbytes, off, R, Cc, taps, sptr, has_split), row0 = r
+        sp = self.flat_ts[off + row0:] if (has_split and row0 % 32 == 0) else None
+        return self.flat[off + row0:], taps * R, sp
+
+    def lookup_fwd(self, w, scale=None):
+        """pre-split forward operand of `w` (or of a row slice of it) or None"""
+        r = self._find(self.f_entries, self._fb, w, scale)
+        if r is None:
+            return None
+        (base, nbytes, off, R, Cc, taps, sptr, _), row0 = r
+        return self.flat_fs[off + row0 * Cc * taps:]
 
 
 MIRROR = None      # set by engine.Trainer; None -> data gradients read the weight itself as the n-contiguous operand
@@ -162,8 +208,9 @@ def linear_fwd(x2d, weight, bias=None, relu=False, resid=None, out_scale=1.0, ou
     M, K = x2d.shape
     N = weight.shape[0]
     y = out if out is not None else torch.empty((M, N), device=x2d.device, dtype=torch.float32)
+    sp = MIRROR.lookup_fwd(weight) if MIRROR is not None else None
     gemm_raw(x2d, x2d.stride(0), weight, weight.stride(0), y, y.stride(0), M, N, K, bias=bias, relu=relu,
-             resid=resid, ldr=(resid.stride(0) if resid is not None else 0), out_scale=out_scale)
+             resid=resid, ldr=(resid.stride(0) if resid is not None else 0), out_scale=out_scale, B_split=sp)
     return y
 
 
@@ -176,7 +223,7 @@ def linear_dgrad(dy2d, weight, gate=None, resid=None):
     if m is not None:
         gemm_raw(dy2d, dy2d.stride(0), m[0], m[1], dx, K, M, K, N, b_layout=0,
                  gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
-                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0))
+                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0), B_split=m[2])
         return dx
     gemm_raw(dy2d, dy2d.stride(0), weight, weight.stride(0), dx, K, M, K, N, b_layout=1,
              gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
@@ -264,8 +311,9 @@ def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=N
     assert Cin_w == Cin and x.is_contiguous()
     g, Ho, Wo = conv_geom_fwd(H, W, kh, kw, stride, pad, dil)
     y = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    sp = MIRROR.lookup_fwd(weight, scale) if MIRROR is not None else None
     gemm_raw(x, Cin, weight, kh * kw * Cin, y, Cout, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, bias=bias,
-             relu=relu, resid=resid, ldr=Cout, geom=g)
+             relu=relu, resid=resid, ldr=Cout, geom=g, B_split=sp)
     return y
 
 
@@ -280,7 +328,7 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
-                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g)
+                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2])
         return dx
     gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
              gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g)

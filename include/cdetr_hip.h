@@ -62,6 +62,10 @@ typedef struct {
     const float* resid; int64_t ldr;
     const float* gate; int64_t ldg;
     cdetr_conv_geom g;
+    const void* B_split; /* optional (NULL = absent), b_layout 0 + precision 1 + batch 1 only: the SAME operand pre-split for the
+                          * bf16x3 kernels, w_scale already folded in: row n = [taps*K/32 groups][hi 32 bf16 | lo 32 bf16], i.e.
+                          * the byte offsets of (n, tap, k-group) equal those of the fp32 operand (ldb applies unchanged);
+                          * written by cdetr_weight_mirror.  Kernels that cannot use it read B / w_scale instead.          */
 } cdetr_gemm_desc;
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 
@@ -125,13 +129,16 @@ int cdetr_grad_merge(const float* base, const float* g1, const float* g2, float*
 /* ---- k-contiguous mirrors of the weights used as data-gradient operands ------------------------------------------------
  * The data-gradient GEMMs of A2/models/resnet.py:140-160 (conv backward) and of every F.linear site contract over the
  * OUTPUT channels of a weight W[o][tap][c]; the matrix pipe wants that axis contiguous.  One launch rewrites every
- * registered weight as Wt[c][tap][o] = W[o][tap][c] * scale[o] (scale = folded FrozenBN, may be NULL); items live in
- * device memory, `tile0` = prefix sum of ceil(R/32)*ceil(C/32)*taps.                                                  */
+ * registered weight as Wt[c][tap][o] = W[o][tap][c] * scale[o] (scale = folded FrozenBN, may be NULL) and / or as the
+ * pre-split bf16 operand of the bf16x3 GEMM kernels; items live in device memory, `tile0` = prefix sum of
+ * ceil(R/32)*ceil(C/32)*taps.                                                                                          */
 typedef struct {
-    const float* src;     /* W  [R][taps][C]  */
-    float* dst;           /* Wt [C][taps][R]  */
-    const float* scale;   /* [R] or NULL      */
-    int32_t R, C, taps, tile0;
+    const float* src;     /* W  [R][taps][C]                                                                    */
+    float* dst;           /* transpose = 1: Wt [C][taps][R] fp32 (may be NULL)                                  */
+    void* dst_split;      /* pre-split bf16 image (may be NULL): transpose = 1: of Wt (needs R % 32 == 0),      */
+                          /* transpose = 0: of W itself (needs C % 32 == 0); layout as cdetr_gemm_desc.B_split  */
+    const float* scale;   /* [R] or NULL                                                                        */
+    int32_t R, C, taps, tile0, transpose, pad_;
 } cdetr_mirror_item;
 int cdetr_weight_mirror(const cdetr_mirror_item* items_dev, int32_t n_items, int32_t total_tiles, void* stream);
 

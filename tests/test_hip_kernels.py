@@ -442,28 +442,58 @@ def test_weight_mirror_and_dgrad(precision):
     s3 = torch.rand(64, device=dev) + 0.5
     wl = torch.randn(160, 96, device=dev)
     w1 = torch.randn(48, 64, 1, 1, device=dev).contiguous(memory_format=torch.channels_last)
-    mir = ops.WeightMirror([(w3, s3), (wl, None), (w1, None)])
+    mir = ops.WeightMirror([(w3, s3), (wl, None), (w1, None)], [(w3, s3), (wl, None)])
     mir.refresh()
-    m3, ld3 = mir.lookup(w3, s3)
+    m3, ld3, sp3 = mir.lookup(w3, s3)
     ref3 = (w3 * s3.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(32, 9 * 64)        # [c][tap][o]
     assert ld3 == 9 * 64 and torch.equal(m3[:32 * 9 * 64].view(32, 9 * 64), ref3)
-    ml, ldl = mir.lookup(wl[32:96])
-    assert ldl == 160 and float(ml[0]) == float(wl[32, 0]) and float(ml[160]) == float(wl[32, 1])
+
+    def unsplit(buf, rows, klen):      # [rows][klen/32][hi 32 | lo 32] bf16 -> (hi, lo) fp32 [rows, klen]
+        v = buf[:rows * klen].view(torch.bfloat16).view(rows, klen // 32, 2, 32).float()
+        return v[:, :, 0].reshape(rows, klen), v[:, :, 1].reshape(rows, klen)
+    hi, lo = unsplit(sp3, 32, 9 * 64)
+    assert torch.equal(hi, ref3.bfloat16().float()) and torch.equal(lo, (ref3 - ref3.bfloat16().float()).bfloat16().float())
+    ml, ldl, spl = mir.lookup(wl[32:96])
+    assert ldl == 160 and float(ml[0]) == float(wl[32, 0]) and float(ml[160]) == float(wl[32, 1]) and spl is not None
     full = mir.lookup(wl)[0][:96 * 160].view(96, 160)
     assert torch.equal(full, wl.t())
+    assert mir.lookup(wl[8:40])[2] is None            # a k offset that is not a multiple of 32 has no pre-split view
     assert mir.lookup(w3, None) is None and mir.lookup(torch.randn(4, 4, device=dev)) is None
+    # forward images: W * scale, k = (tap, c)
+    f3 = mir.lookup_fwd(w3, s3)
+    reff = (w3 * s3.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(64, 9 * 32)
+    hi, lo = unsplit(f3, 64, 9 * 32)
+    assert torch.equal(hi, reff.bfloat16().float()) and torch.equal(lo, (reff - reff.bfloat16().float()).bfloat16().float())
+    fl = mir.lookup_fwd(wl[32:96])
+    hi, _ = unsplit(fl, 64, 96)
+    assert torch.equal(hi, wl[32:96].bfloat16().float()) and mir.lookup_fwd(w1) is None
     # dgrad equivalence (conv 3x3 with scale + gate/resid, linear slice)
     dz = torch.randn(2, 10, 12, 64, device=dev)
     gate = torch.randn(2, 10, 12, 32, device=dev)
     a = ops.conv_dgrad(dz, w3, s3, (10, 12), stride=1, pad=1, dil=1, gate=gate)
     dy = torch.randn(300, 64, device=dev)
     b = ops.linear_dgrad(dy, wl[32:96])
+    xin = torch.randn(2, 10, 12, 32, device=dev)
+    bias3 = torch.randn(64, device=dev)
+    f0 = ops.conv_fwd(xin, w3, s3, bias3, stride=1, pad=1, dil=1, relu=True)
+    xl = torch.randn(5000, 96, device=dev)
+    l0 = ops.linear_fwd(xl, wl[32:96])
+    dyb = torch.randn(5000, 64, device=dev)
+    b0 = ops.linear_dgrad(dyb, wl[32:96])
     ops.MIRROR = mir
     try:
         a2 = ops.conv_dgrad(dz, w3, s3, (10, 12), stride=1, pad=1, dil=1, gate=gate)
         b2 = ops.linear_dgrad(dy, wl[32:96])
+        f1 = ops.conv_fwd(xin, w3, s3, bias3, stride=1, pad=1, dil=1, relu=True)      # pre-split forward operand
+        l1 = ops.linear_fwd(xl, wl[32:96])                                             # M = 5000: the tile kernel with B_split
+        b1 = ops.linear_dgrad(dyb, wl[32:96])
     finally:
         ops.MIRROR = None
+    if precision == 1:       # same products in the same order: the pre-split path is bit-identical to the in-kernel split
+        assert torch.equal(l1, l0)
+    close(f1, f0.double().cpu(), **tol(precision))
+    close(l1, l0.double().cpu(), **tol(precision))
+    close(b1, b0.double().cpu(), **tol(precision))
     close(a2, a.double().cpu(), **tol(precision))
     close(b2, b.double().cpu(), **tol(precision))
     close(b2, dy.double().cpu() @ wl[32:96].double().cpu(), **tol(precision))
