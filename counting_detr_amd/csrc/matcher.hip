@@ -274,9 +274,13 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
 
     double v[CPL], spc[CPL];
     int path[CPL], pos[CPL];
+    unsigned unas = 0;                       // bit c: this lane's column c is unassigned (row4col == -1), refreshed per row
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; path[c] = -1; }
+    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; path[c] = -1; if (lane + 64 * c < nc) unas |= 1u << c; }
 
+    // The scan's tie rule (strictly smaller value wins; among equal values the LAST unassigned column, else the FIRST
+    // column -- positions refer to the `remaining` array) is folded into ONE 32-bit key to minimise next to the value:
+    //   unassigned: key = 0x7fffffff - it      assigned: key = 0x80000000 + it      (no candidate: 0xffffffff)
     for (int cur = 0; cur < nr; ++cur) {
         unsigned sc = 0;                       // visited-column mask of this lane
 #pragma unroll
@@ -285,50 +289,46 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
         int i = cur, num_remaining = nc, sink = -1;
         double min_val = 0.0;
         while (true) {
-            const double ui = u[i];
             const float* crow = cost + (long)i * nc;
-            Cand best;
-            best.val = INFINITY; best.it = -1; best.unassigned = 0;
+            double bval = INFINITY;
+            unsigned bkey = 0xffffffffu;
             int best_j = -1;
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
                 const int j = lane + 64 * c;
                 if (j < nc && !((sc >> c) & 1u)) {
-                    const double r = ((min_val + (double)crow[j]) - ui) - v[c];
+                    const double r = ((min_val + (double)crow[j]) - u[i]) - v[c];
                     if (r < spc[c]) { path[c] = i; spc[c] = r; }
-                    Cand cd;
-                    cd.val = spc[c]; cd.it = pos[c]; cd.unassigned = (row4col[j] == -1);
-                    const Cand nb = better(best, cd);
-                    if (nb.it != best.it) best_j = j;
-                    best = nb;
+                    const unsigned key = ((unas >> c) & 1u) ? (0x7fffffffu - (unsigned)pos[c]) : (0x80000000u + (unsigned)pos[c]);
+                    if (spc[c] < bval || (spc[c] == bval && key < bkey)) { bval = spc[c]; bkey = key; best_j = j; }
                 }
             }
 #pragma unroll
             for (int m = 32; m > 0; m >>= 1) {
-                const Cand o = shfl_xor_cand(best, m);
+                const double ov = __shfl_xor(bval, m, 64);
+                const unsigned ok = (unsigned)__shfl_xor((int)bkey, m, 64);
                 const int oj2 = __shfl_xor(best_j, m, 64);
-                const Cand nb = better(best, o);
-                if (nb.it != best.it) best_j = oj2;
-                best = nb;
+                if (ov < bval || (ov == bval && ok < bkey)) { bval = ov; bkey = ok; best_j = oj2; }
             }
-            if (best.it < 0 || best.val == INFINITY) { sink = -2; break; }
-            min_val = best.val;
+            if (bkey == 0xffffffffu || bval == INFINITY) { sink = -2; break; }
+            min_val = bval;
             const int jstar = best_j;
+            const bool j_unassigned = (bkey & 0x80000000u) == 0u;
+            const int best_it = j_unassigned ? (int)(0x7fffffffu - bkey) : (int)(bkey - 0x80000000u);
             // visited-column bit on the owner lane
 #pragma unroll
             for (int c = 0; c < CPL; ++c)
                 if (lane + 64 * c == jstar) sc |= (1u << c);
-            // swap-removal from `remaining` (position best.it), keeping every column's position in registers
+            // swap-removal from `remaining` (position best_it), keeping every column's position in registers
             const int last = num_remaining - 1;
             const int jlast = remaining[last];
-            if (lane == 0) remaining[best.it] = jlast;
+            if (lane == 0) remaining[best_it] = jlast;
 #pragma unroll
             for (int c = 0; c < CPL; ++c)
-                if (lane + 64 * c == jlast) pos[c] = best.it;
+                if (lane + 64 * c == jlast) pos[c] = best_it;
             num_remaining = last;
-            const int owner_row = row4col[jstar];
-            if (owner_row == -1) { sink = jstar; break; }
-            i = owner_row;
+            if (j_unassigned) { sink = jstar; break; }
+            i = row4col[jstar];
         }
         if (sink == -2) { if (lane == 0) status[b] = 1; return; }
         // ---- dual update: rows visited (other than cur) = row4col[j] of the visited non-sink columns
@@ -355,6 +355,10 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
                 if (ii == cur) break;
             }
         }
+        // the walk assigned exactly one new column: the sink (same wave: the LDS writes above are ordered by program order)
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            if (lane + 64 * c == sink) unas &= ~(1u << c);
     }
     // ---- (query, target) pairs with ascending query index
     if (!transpose) {
@@ -412,7 +416,11 @@ extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int3
             if (wb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wb);
             hipLaunchKernelGGL(kern, dim3(B), dim3(64), wb, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status);
         };
-        if (nc_max <= 512) { if (cost_lds) go(lsap_wave_kernel<8, true>); else go(lsap_wave_kernel<8, false>); }
+        // columns per lane = ceil(nc_max / 64): the per-iteration column scan is unrolled exactly that far
+        if (nc_max <= 128) { if (cost_lds) go(lsap_wave_kernel<2, true>); else go(lsap_wave_kernel<2, false>); }
+        else if (nc_max <= 256) { if (cost_lds) go(lsap_wave_kernel<4, true>); else go(lsap_wave_kernel<4, false>); }
+        else if (nc_max <= 320) { if (cost_lds) go(lsap_wave_kernel<5, true>); else go(lsap_wave_kernel<5, false>); }
+        else if (nc_max <= 512) { if (cost_lds) go(lsap_wave_kernel<8, true>); else go(lsap_wave_kernel<8, false>); }
         else { if (cost_lds) go(lsap_wave_kernel<16, true>); else go(lsap_wave_kernel<16, false>); }
         return cdetr_launch_status("cdetr_lsap");
     }
