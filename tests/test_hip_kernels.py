@@ -175,7 +175,8 @@ def rcda_core_ref(qr, qc, kr, kc, v, mr, mc, nh):
 
 
 @pytest.mark.parametrize("N,L,H,W,masked", [(2, 300, 50, 50, False), (1, 600, 20, 30, True), (2, 77, 7, 5, True),
-                                            (1, 130, 70, 40, True), (2, 2500, 50, 50, True), (1, 33, 24, 36, False)])
+                                            (1, 130, 70, 40, True), (2, 2500, 50, 50, True), (1, 33, 24, 36, False),
+                                            (1, 200, 40, 84, True), (1, 100, 84, 70, False), (1, 64, 16, 64, True)])   # W > 64: the wide-map kernels
 def test_rcda_core(N, L, H, W, masked, precision):
     from counting_detr_amd import ops
     nh, E = 8, 256
@@ -497,3 +498,73 @@ def test_weight_mirror_and_dgrad(precision):
     close(a2, a.double().cpu(), **tol(precision))
     close(b2, b.double().cpu(), **tol(precision))
     close(b2, dy.double().cpu() @ wl[32:96].double().cpu(), **tol(precision))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 8, 9, 10])
+def test_gemm_variants_ragged_shapes(variant, monkeypatch):
+    """Every tile variant of the implicit-GEMM kernel (CDETR_GEMM_VARIANT), bf16x3, on shapes whose M / N / K are NOT multiples
+    of the tile (clamped-load tails), k-contiguous and n-contiguous weight operands, dense and 3x3 (strided / dilated) rows,
+    with the fused epilogue -- against fp64.  Guards the unconditional-load / clamping logic of the prefetch pipeline."""
+    from counting_detr_amd import ops, _ffi
+    monkeypatch.setenv("CDETR_GEMM_VARIANT", str(variant))
+    old = ops.PRECISION
+    ops.PRECISION = 1
+    try:
+        rng = np.random.default_rng(100 + variant)
+        cases = [(1, 32, 32), (63, 36, 64), (65, 132, 96), (130, 260, 160), (257, 64, 32), (600, 256, 256), (1000, 516, 128), (3, 4, 64)]
+        for M, N, K in cases:
+            for bl in (0, 1):
+                if variant == 3 and K % 64:
+                    continue
+                A = torch.randn(M, K, generator=g(M + N))
+                Bm = torch.randn(N, K, generator=g(M + K)) if bl == 0 else torch.randn(K, N, generator=g(M + K))
+                bias, resid, gate = torch.randn(N, generator=g(1)), torch.randn(M, N, generator=g(2)), torch.randn(M, N, generator=g(3))
+                ws = 1 + 0.1 * torch.randn(N if bl == 0 else K, generator=g(4))
+                ref = (A.double() @ (Bm.double() * ws.double()[:, None]).t()) if bl == 0 else (A.double() @ (Bm.double() * ws.double()[:, None]))
+                ref = torch.relu((ref + bias.double()) * 0.5 + resid.double()) * (gate > 0)
+                # kernel epilogue order: gate is applied before relu; both commute here since relu(x)*[g>0] == relu(x*[g>0])
+                out = torch.empty(M, N, device=DEV)
+                ops.gemm_raw(A.to(DEV), K, Bm.to(DEV), K if bl == 0 else N, out, N, M, N, K, b_layout=bl, bias=bias.to(DEV),
+                             w_scale=ws.to(DEV), resid=resid.to(DEV), ldr=N, gate=gate.to(DEV), ldg=N, relu=True, out_scale=0.5)
+                close(out, ref, msg=f"variant {variant} M{M} N{N} K{K} bl{bl}", **tol(1))
+        # 3x3 conv rows: stride 2 and dilation 2, odd spatial sizes, channel counts off the tile
+        for (Cin, Cout, st, pd, dl, H, W) in [(32, 48, 1, 1, 1, 9, 11), (64, 80, 2, 1, 1, 13, 10), (32, 144, 1, 2, 2, 8, 15)]:      # dgrad with taps needs Cout % 16 == 0
+            x = torch.randn(2, Cin, H, W, generator=g(Cin + H))
+            w = torch.randn(Cout, Cin, 3, 3, generator=g(Cout)) / (Cin * 9) ** 0.5
+            y64 = F.conv2d(x.double(), w.double(), stride=st, padding=pd, dilation=dl)
+            xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+            wd = w.contiguous(memory_format=torch.channels_last).to(DEV)
+            y = ops.conv_fwd(xd, wd, None, None, stride=st, pad=pd, dil=dl)
+            close(y.permute(0, 3, 1, 2), y64, msg=f"variant {variant} conv {Cin}->{Cout} s{st} d{dl}", **tol(1))
+            gy = torch.randn(y64.shape, generator=g(5))
+            x64 = x.double().requires_grad_(True)
+            F.conv2d(x64, w.double(), stride=st, padding=pd, dilation=dl).backward(gy.double())
+            dx = ops.conv_dgrad(gy.permute(0, 2, 3, 1).contiguous().to(DEV), wd, None, (H, W), stride=st, pad=pd, dil=dl)
+            close(dx.permute(0, 3, 1, 2), x64.grad, msg=f"variant {variant} dgrad {Cin}->{Cout}", **tol(1))
+    finally:
+        ops.PRECISION = old
+
+
+@pytest.mark.parametrize("wvariant", [0, 1, 2, 4])
+def test_wgrad_variants_ragged_shapes(wvariant, monkeypatch, precision):
+    """Weight-gradient tile variants on pixel counts / channel counts off the tile, with the fused bias gradient, 1x1 and 3x3."""
+    from counting_detr_amd import ops
+    monkeypatch.setenv("CDETR_WGRAD_VARIANT", str(wvariant))
+    for (P, Nout, Cin) in [(1100, 64, 64), (1500, 132, 68), (2049, 256, 36), (5000, 40, 260)]:
+        dY = torch.randn(P, Nout, generator=g(P))
+        X = torch.randn(P, Cin, generator=g(P + 1))
+        dW = torch.zeros(Nout, Cin, device=DEV)
+        db = torch.zeros(Nout, device=DEV)
+        for _ in range(2):
+            ops.wgrad_raw(dY.to(DEV), Nout, X.to(DEV), Cin, dW, Cin, P, Nout, Cin, dbias=db)
+        close(dW, 2 * dY.double().t() @ X.double(), msg=f"wgrad {P}x{Nout}x{Cin}", rtol=5e-4, atol_scale=6e-5)
+        close(db, 2 * dY.double().sum(0), msg="dbias", rtol=5e-4, atol_scale=6e-5)
+    for (Cin, Cout, st, pd, dl, H, W) in [(36, 40, 1, 1, 1, 19, 21), (64, 136, 2, 1, 1, 33, 30), (32, 64, 1, 2, 2, 28, 25)]:
+        x = torch.randn(2, Cin, H, W, generator=g(Cin))
+        w64 = (torch.randn(Cout, Cin, 3, 3, generator=g(Cout)).double() / (Cin * 9) ** 0.5).requires_grad_(True)
+        y64 = F.conv2d(x.double(), w64, stride=st, padding=pd, dilation=dl)
+        gy = torch.randn(y64.shape, generator=g(6))
+        y64.backward(gy.double())
+        wd = torch.nn.Parameter(w64.detach().float().contiguous(memory_format=torch.channels_last).to(DEV))
+        ops.conv_wgrad_(gy.permute(0, 2, 3, 1).contiguous().to(DEV), x.permute(0, 2, 3, 1).contiguous().to(DEV), wd, None, stride=st, pad=pd, dil=dl)
+        close(wd.grad, w64.grad, msg=f"conv wgrad {Cin}->{Cout} s{st} d{dl}", rtol=5e-4, atol_scale=6e-5)
