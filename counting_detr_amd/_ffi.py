@@ -113,9 +113,9 @@ def lib():
         L.cdetr_maxpool3x3s2.restype = C.c_int
         L.cdetr_maxpool3x3s2.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
         L.cdetr_mha_fwd.restype = C.c_int
-        L.cdetr_mha_fwd.argtypes = [_p] * 4 + [C.c_int32] * 3 + [C.c_float, _p]
+        L.cdetr_mha_fwd.argtypes = [_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_int32, _p]
         L.cdetr_mha_bwd.restype = C.c_int
-        L.cdetr_mha_bwd.argtypes = [_p] * 8 + [C.c_int32] * 3 + [C.c_float, _p]
+        L.cdetr_mha_bwd.argtypes = [_p] * 8 + [C.c_int32] * 3 + [C.c_float, C.c_int32, _p]
         L.cdetr_match_cost.restype = C.c_int
         L.cdetr_match_cost.argtypes = [_p, C.c_int32, _p, _p, _p, _p, C.c_int32, C.c_int32, C.c_float, C.c_float,
                                        C.c_float, _p, _p]

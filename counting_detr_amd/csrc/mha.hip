@@ -11,6 +11,7 @@
 // Layouts: qk [N][L][2E] (q | k), v [N][L][E], o / dO [N][L][E], lse / D [N][nh][L]; E = nh * 32.
 #include "../../include/cdetr_hip.h"
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -266,21 +267,313 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const float* __restrict
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ matrix-core variants
+// split-bf16 (bf16x3) flash attention for the same problem.  Workgroup = 2 waves; a wave OWNS 32 rows (queries for the
+// forward / dq kernels, keys for the dk-dv kernel) as the LANES of a transposed accumulator and walks over 32-row tiles of
+// the other side:
+//   X^T[other, own]  = sum_c Other[other, c] Own[own, c]      A = tile rows (k = c, natural layout), B = own rows (hoisted, split once)
+//   Y^T[c, own]     += sum_other W[other, c] Z[other, own]    A = W^T tile (k = other, transposed at staging), B = Z straight
+//                                                             from the registers of the first product (slot j of step s = reg 8s + j)
+// so softmax statistics, the log-sum-exp and D are per-LANE scalars and no probability ever touches LDS or HBM.  Tiles are
+// split into bf16 hi / lo once per workgroup while they are staged ([row][hi 32 | lo 32 | pad 8]); the transposed tiles
+// store the reduction index in the order the accumulator registers enumerate it (perm_pos).  One tile is prefetched in
+// registers (unconditional loads, rows clamped to L-1 and masked arithmetically).
+namespace flash {
+constexpr int NWF = 2, NTF = 64 * NWF, TS = 72, TILE = 32 * TS;
+
+// first position of the 4-row group starting at row k0 (multiple of 4) inside a transposed tile
+__device__ __forceinline__ int perm_pos(int k0) { return (k0 & 16) | ((k0 & 4) << 1) | ((k0 & 8) >> 1); }
+// tile-row index that accumulator register r of lane group g enumerates
+__device__ __forceinline__ int reg_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
+
+struct NatRegs { float4 v[2]; };
+struct TrRegs { float4 v[4]; };
+// natural tile: rows r0.. of a [L][ld] matrix, 32 columns from col0; thread -> (row = idx >> 3, c4 = idx & 7), idx = tid + 128 s
+__device__ __forceinline__ void nat_fetch(NatRegs& r, const float* __restrict__ src, long ld, int col0, int r0, int L, int tid) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int idx = tid + NTF * s;
+        r.v[s] = ld4(src + (long)min(r0 + (idx >> 3), L - 1) * ld + col0 + (idx & 7) * 4);
+    }
+}
+__device__ __forceinline__ void nat_stash(const NatRegs& r, __bf16* tile, int tid) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int idx = tid + NTF * s;
+        stash_split4(tile + (idx >> 3) * TS + (idx & 7) * 4, 32, r.v[s].x, r.v[s].y, r.v[s].z, r.v[s].w);
+    }
+}
+// transposed tile (64 threads `t`): block (row quad kq = t & 7, column quad cq = t >> 3) = 4 rows x 4 columns
+__device__ __forceinline__ void tr_fetch(TrRegs& r, const float* __restrict__ src, long ld, int col0, int r0, int L, int t) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) r.v[kk] = ld4(src + (long)min(r0 + 4 * (t & 7) + kk, L - 1) * ld + col0 + (t >> 3) * 4);
+}
+__device__ __forceinline__ void tr_stash(const TrRegs& r, __bf16* tile, int t) {
+    __bf16* dst = tile + (4 * (t >> 3)) * TS + perm_pos(4 * (t & 7));
+    stash_split4(dst, 32, r.v[0].x, r.v[1].x, r.v[2].x, r.v[3].x);
+    stash_split4(dst + TS, 32, r.v[0].y, r.v[1].y, r.v[2].y, r.v[3].y);
+    stash_split4(dst + 2 * TS, 32, r.v[0].z, r.v[1].z, r.v[2].z, r.v[3].z);
+    stash_split4(dst + 3 * TS, 32, r.v[0].w, r.v[1].w, r.v[2].w, r.v[3].w);
+}
+// acc += A(tile rows, this lane's row i32) * B (hi/lo fragments of the two k-steps)
+__device__ __forceinline__ f32x16 mma_tile(f32x16 acc, const __bf16* tile, int i32, int g, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
+    const __bf16* a = tile + i32 * TS + 8 * g;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a + 16 * s);
+        const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + 32 + 16 * s);
+        acc = mfma_bf16x3(ah, al, bh[s], bl[s], acc);
+    }
+    return acc;
+}
+// hoisted B operand from this lane's own row: columns 16s + 8g .. +7, scaled
+__device__ __forceinline__ void own_frag(const float* __restrict__ row, int g, float scale, bf16x8 (&bh)[2], bf16x8 (&bl)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float4 t0 = ld4(row + 16 * s + 8 * g), t1 = ld4(row + 16 * s + 8 * g + 4);
+        const float x[8] = {t0.x * scale, t0.y * scale, t0.z * scale, t0.w * scale, t1.x * scale, t1.y * scale, t1.z * scale, t1.w * scale};
+        split_bf16x8(x, bh[s], bl[s]);
+    }
+}
+__device__ __forceinline__ void reg_frag(const f32x16& z, bf16x8 (&bh)[2], bf16x8 (&bl)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const float x[8] = {z[8 * s], z[8 * s + 1], z[8 * s + 2], z[8 * s + 3], z[8 * s + 4], z[8 * s + 5], z[8 * s + 6], z[8 * s + 7]};
+        split_bf16x8(x, bh[s], bl[s]);
+    }
+}
+// transposed accumulator -> 32 contiguous floats of this lane's row (registers r = 4j..4j+3 are columns 8j + 4g ..)
+__device__ __forceinline__ void store_own(float* __restrict__ row, int g, const f32x16& a, float mul) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<float4*>(row + 8 * j + 4 * g) = make_float4(a[4 * j] * mul, a[4 * j + 1] * mul, a[4 * j + 2] * mul, a[4 * j + 3] * mul);
+}
+__device__ __forceinline__ f32x16 zero16() { return f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; }
+
+__global__ __launch_bounds__(NTF) void fwd_kernel(const float* __restrict__ qk, const float* __restrict__ v, float* __restrict__ o,
+                                                  float* __restrict__ lse, int N, int L, int nh, float scale) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 2 * TILE];          // [buf][K | V^T]
+    const int E = nh * D;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / nh, head = blockIdx.y % nh;
+    const int q = blockIdx.x * 32 * NWF + wid * 32 + i32;
+    const float* qkn = qk + (long)n * L * 2 * E;
+    const float* vn = v + (long)n * L * E;
+    bf16x8 qh[2], ql[2];
+    own_frag(qkn + (long)min(q, L - 1) * 2 * E + head * D, g, scale, qh, ql);
+    float m = -INFINITY, l = 0.f;
+    f32x16 OT = zero16();
+    NatRegs rk;
+    TrRegs rv;
+    const int ntile = (L + 31) / 32;
+    nat_fetch(rk, qkn, 2 * E, E + head * D, 0, L, tid);
+    if (wid == 0) tr_fetch(rv, vn, E, head * D, 0, L, lane);
+    nat_stash(rk, lds, tid);
+    if (wid == 0) tr_stash(rv, lds + TILE, lane);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        const int r1 = min(t + 1, ntile - 1) * 32;                             // surplus prefetch re-reads the last tile
+        nat_fetch(rk, qkn, 2 * E, E + head * D, r1, L, tid);
+        if (wid == 0) tr_fetch(rv, vn, E, head * D, r1, L, lane);
+        f32x16 S = mma_tile(zero16(), lds + buf * 2 * TILE, i32, g, qh, ql);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (t * 32 + reg_row(r, g) >= L) S[r] = -INFINITY;
+            mx = fmaxf(mx, S[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float corr = expf(m - mn);
+        float ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { S[r] = expf(S[r] - mn); ls += S[r]; }
+        ls += __shfl_xor(ls, 32, 64);
+        l = l * corr + ls;
+        m = mn;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) OT[r] *= corr;
+        bf16x8 ph[2], pl[2];
+        reg_frag(S, ph, pl);
+        OT = mma_tile(OT, lds + buf * 2 * TILE + TILE, i32, g, ph, pl);
+        nat_stash(rk, lds + (buf ^ 1) * 2 * TILE, tid);
+        if (wid == 0) tr_stash(rv, lds + (buf ^ 1) * 2 * TILE + TILE, lane);
+        __syncthreads();
+    }
+    if (q < L) {
+        store_own(o + ((long)n * L + q) * E + head * D, g, OT, 1.f / l);
+        if (g == 0) lse[((long)n * nh + head) * L + q] = m + logf(l);
+    }
+}
+
+__global__ __launch_bounds__(NTF) void bwd_q_kernel(const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ o,
+                                                    const float* __restrict__ dO, const float* __restrict__ lse, float* __restrict__ dqk,
+                                                    float* __restrict__ Dbuf, int N, int L, int nh, float scale) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 3 * TILE];          // [buf][K | V | K^T]
+    const int E = nh * D;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / nh, head = blockIdx.y % nh;
+    const int q = blockIdx.x * 32 * NWF + wid * 32 + i32;
+    const int qc = min(q, L - 1);
+    const float* qkn = qk + (long)n * L * 2 * E;
+    const float* vn = v + (long)n * L * E;
+    bf16x8 qh[2], ql[2], dh[2], dl[2];
+    own_frag(qkn + (long)qc * 2 * E + head * D, g, scale, qh, ql);
+    const float* dop = dO + ((long)n * L + qc) * E + head * D;
+    own_frag(dop, g, 1.f, dh, dl);
+    float Di = 0.f;
+    {
+        const float* op = o + ((long)n * L + qc) * E + head * D;
+#pragma unroll
+        for (int c4 = 0; c4 < 8; ++c4) {
+            const float4 u = ld4(dop + c4 * 4), w = ld4(op + c4 * 4);
+            Di += (u.x * w.x + u.y * w.y) + (u.z * w.z + u.w * w.w);
+        }
+    }
+    const float li = lse[((long)n * nh + head) * L + qc];
+    f32x16 dQT = zero16();
+    NatRegs rk, rvv;
+    TrRegs rkt;
+    const int ntile = (L + 31) / 32;
+    nat_fetch(rk, qkn, 2 * E, E + head * D, 0, L, tid);
+    nat_fetch(rvv, vn, E, head * D, 0, L, tid);
+    if (wid == 0) tr_fetch(rkt, qkn, 2 * E, E + head * D, 0, L, lane);
+    nat_stash(rk, lds, tid);
+    nat_stash(rvv, lds + TILE, tid);
+    if (wid == 0) tr_stash(rkt, lds + 2 * TILE, lane);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        const int r1 = min(t + 1, ntile - 1) * 32;
+        nat_fetch(rk, qkn, 2 * E, E + head * D, r1, L, tid);
+        nat_fetch(rvv, vn, E, head * D, r1, L, tid);
+        if (wid == 0) tr_fetch(rkt, qkn, 2 * E, E + head * D, r1, L, lane);
+        const __bf16* base = lds + buf * 3 * TILE;
+        f32x16 S = mma_tile(zero16(), base, i32, g, qh, ql);
+        const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, dh, dl);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = (t * 32 + reg_row(r, g) < L) ? expf(S[r] - li) : 0.f;
+            S[r] = p * (dP[r] - Di);
+        }
+        bf16x8 sh[2], sl[2];
+        reg_frag(S, sh, sl);
+        dQT = mma_tile(dQT, base + 2 * TILE, i32, g, sh, sl);
+        __bf16* nb = lds + (buf ^ 1) * 3 * TILE;
+        nat_stash(rk, nb, tid);
+        nat_stash(rvv, nb + TILE, tid);
+        if (wid == 0) tr_stash(rkt, nb + 2 * TILE, lane);
+        __syncthreads();
+    }
+    if (q < L) {
+        store_own(dqk + ((long)n * L + q) * 2 * E + head * D, g, dQT, scale);
+        if (g == 0) Dbuf[((long)n * nh + head) * L + q] = Di;
+    }
+}
+
+__global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ dO,
+                                                     const float* __restrict__ lse, const float* __restrict__ Dbuf, float* __restrict__ dqk,
+                                                     float* __restrict__ dv, int N, int L, int nh, float scale) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 4 * TILE];          // [buf][Q | dO | Q^T | dO^T]
+    __shared__ __attribute__((aligned(16))) float stat[2][2][32];              // [buf][lse | D][query of the tile]
+    const int E = nh * D;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i32 = lane & 31, g = lane >> 5;
+    const int n = blockIdx.y / nh, head = blockIdx.y % nh;
+    const int j = blockIdx.x * 32 * NWF + wid * 32 + i32;
+    const int jc = min(j, L - 1);
+    const float* qkn = qk + (long)n * L * 2 * E;
+    const float* don = dO + (long)n * L * E;
+    const float* lsn = lse + ((long)n * nh + head) * L;
+    const float* dbn = Dbuf + ((long)n * nh + head) * L;
+    bf16x8 kh[2], kl[2], vh[2], vl[2];
+    own_frag(qkn + (long)jc * 2 * E + E + head * D, g, scale, kh, kl);
+    own_frag(v + ((long)n * L + jc) * E + head * D, g, 1.f, vh, vl);
+    f32x16 dKT = zero16(), dVT = zero16();
+    NatRegs rq, rd;
+    TrRegs rt;
+    float rs = 0.f;
+    const int ntile = (L + 31) / 32;
+    auto fetch = [&](int r0) __attribute__((always_inline)) {
+        nat_fetch(rq, qkn, 2 * E, head * D, r0, L, tid);
+        nat_fetch(rd, don, E, head * D, r0, L, tid);
+        if (wid == 0) tr_fetch(rt, qkn, 2 * E, head * D, r0, L, lane);
+        else tr_fetch(rt, don, E, head * D, r0, L, lane);
+        if (tid < 64) {                                                    // lse (tid < 32) / D (32 <= tid < 64) of the tile's queries
+            const int qq = r0 + (tid & 31);
+            const float* src = (tid < 32) ? lsn : dbn;
+            rs = src[min(qq, L - 1)];
+            if (qq >= L) rs = (tid < 32) ? INFINITY : 0.f;                 // p = exp(s - inf) = 0 beyond L
+        }
+    };
+    auto stash = [&](int buf) __attribute__((always_inline)) {
+        __bf16* nb = lds + buf * 4 * TILE;
+        nat_stash(rq, nb, tid);
+        nat_stash(rd, nb + TILE, tid);
+        tr_stash(rt, nb + (wid == 0 ? 2 : 3) * TILE, lane);
+        if (tid < 64) stat[buf][tid >> 5][tid & 31] = rs;
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int t = 0; t < ntile; ++t) {
+        const int buf = t & 1;
+        fetch(min(t + 1, ntile - 1) * 32);
+        const __bf16* base = lds + buf * 4 * TILE;
+        f32x16 S = mma_tile(zero16(), base, i32, g, kh, kl);                   // S^T[q, key]
+        const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, vh, vl);     // dP^T[q, key]
+        f32x16 P;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const float4 ls4 = *reinterpret_cast<const float4*>(&stat[buf][0][8 * jj + 4 * g]);
+            const float4 d4 = *reinterpret_cast<const float4*>(&stat[buf][1][8 * jj + 4 * g]);
+            const float lsv[4] = {ls4.x, ls4.y, ls4.z, ls4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float p = expf(S[4 * jj + b] - lsv[b]);
+                P[4 * jj + b] = p;
+                S[4 * jj + b] = p * (dP[4 * jj + b] - dvv[b]);
+            }
+        }
+        bf16x8 ph[2], pl[2], sh[2], sl[2];
+        reg_frag(P, ph, pl);
+        dVT = mma_tile(dVT, base + 3 * TILE, i32, g, ph, pl);                  // dV^T[c, key] += dO^T[c, q] P[q, key]
+        reg_frag(S, sh, sl);
+        dKT = mma_tile(dKT, base + 2 * TILE, i32, g, sh, sl);                  // dK^T[c, key] += Q^T[c, q] dS[q, key]
+        stash(buf ^ 1);
+        __syncthreads();
+    }
+    if (j < L) {
+        store_own(dqk + ((long)n * L + j) * 2 * E + E + head * D, g, dKT, scale);
+        store_own(dv + ((long)n * L + j) * E + head * D, g, dVT, 1.f);
+    }
+}
+}  // namespace flash
+
 }  // namespace
 
 extern "C" int cdetr_mha_fwd(const float* qk, const float* v, float* o, float* lse, int32_t N, int32_t L, int32_t nh, float scale,
-                             void* stream) {
+                             int32_t precision, void* stream) {
     CDETR_CHECK_ARG(qk && v && o && lse && N > 0 && L > 0 && nh > 0, "cdetr_mha_fwd: bad args");
     dim3 grid((L + 63) / 64, N * nh);
-    hipLaunchKernelGGL(mha_fwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qk, v, o, lse, N, L, nh, scale);
+    static const int use_mfma = getenv("CDETR_MHA_MFMA") ? atoi(getenv("CDETR_MHA_MFMA")) : 1;
+    if (use_mfma && precision == 1) hipLaunchKernelGGL(flash::fwd_kernel, grid, dim3(flash::NTF), 0, reinterpret_cast<hipStream_t>(stream), qk, v, o, lse, N, L, nh, scale);
+    else hipLaunchKernelGGL(mha_fwd_kernel, grid, dim3(256), 0, reinterpret_cast<hipStream_t>(stream), qk, v, o, lse, N, L, nh, scale);
     return cdetr_launch_status("cdetr_mha_fwd");
 }
 
 extern "C" int cdetr_mha_bwd(const float* qk, const float* v, const float* o, const float* d_o, const float* lse, float* d_qk,
-                             float* d_v, float* work, int32_t N, int32_t L, int32_t nh, float scale, void* stream) {
+                             float* d_v, float* work, int32_t N, int32_t L, int32_t nh, float scale, int32_t precision, void* stream) {
     CDETR_CHECK_ARG(qk && v && o && d_o && lse && d_qk && d_v && work && N > 0 && L > 0 && nh > 0, "cdetr_mha_bwd: bad args");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((L + 63) / 64, N * nh);
+    static const int use_mfma = getenv("CDETR_MHA_MFMA") ? atoi(getenv("CDETR_MHA_MFMA")) : 1;
+    if (use_mfma && precision == 1) {
+        hipLaunchKernelGGL(flash::bwd_q_kernel, grid, dim3(flash::NTF), 0, st, qk, v, o, d_o, lse, d_qk, work, N, L, nh, scale);
+        hipLaunchKernelGGL(flash::bwd_kv_kernel, grid, dim3(flash::NTF), 0, st, qk, v, d_o, lse, work, d_qk, d_v, N, L, nh, scale);
+        return cdetr_launch_status("cdetr_mha_bwd");
+    }
     hipLaunchKernelGGL(mha_bwd_q_kernel, grid, dim3(256), 0, st, qk, v, o, d_o, lse, d_qk, work, N, L, nh, scale);
     hipLaunchKernelGGL(mha_bwd_kv_kernel, grid, dim3(256), 0, st, qk, v, d_o, lse, work, d_qk, d_v, N, L, nh, scale);
     return cdetr_launch_status("cdetr_mha_bwd");

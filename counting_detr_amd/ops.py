@@ -436,7 +436,7 @@ def mha_fwd_raw(qk, v, nh):
     E = E2 // 2
     o = torch.empty((N, L, E), device=qk.device, dtype=torch.float32)
     lse = torch.empty((N, nh, L), device=qk.device, dtype=torch.float32)
-    check(lib().cdetr_mha_fwd(ptr(qk), ptr(v), ptr(o), ptr(lse), N, L, nh, (E // nh) ** -0.5, stream_ptr()), "cdetr_mha_fwd")
+    check(lib().cdetr_mha_fwd(ptr(qk), ptr(v), ptr(o), ptr(lse), N, L, nh, (E // nh) ** -0.5, PRECISION, stream_ptr()), "cdetr_mha_fwd")
     return o, lse
 
 
@@ -447,7 +447,7 @@ def mha_bwd_raw(qk, v, o, d_o, lse, nh):
     d_v = torch.empty_like(v)
     work = torch.empty((N, nh, L), device=qk.device, dtype=torch.float32)
     check(lib().cdetr_mha_bwd(ptr(qk), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(d_qk), ptr(d_v), ptr(work), N, L, nh,
-                              (E // nh) ** -0.5, stream_ptr()), "cdetr_mha_bwd")
+                              (E // nh) ** -0.5, PRECISION, stream_ptr()), "cdetr_mha_bwd")
     return d_qk, d_v
 
 

@@ -180,9 +180,9 @@ static inline int32_t cdetr_rcda_hp(int32_t H) { return (H + 7) & ~7; }
  * qk [N][L][2E] = projected queries | keys, v [N][L][E], E = nh*32; o = softmax(scale * q k^T) v per head, lse [N][nh][L]
  * saved for backward.  cdetr_mha_bwd writes d_qk [N][L][2E], d_v [N][L][E]; work: N*nh*L floats.                 */
 int cdetr_mha_fwd(const float* qk, const float* v, float* o, float* lse, int32_t N, int32_t L, int32_t nh, float scale,
-                  void* stream);
+                  int32_t precision, void* stream);
 int cdetr_mha_bwd(const float* qk, const float* v, const float* o, const float* d_o, const float* lse, float* d_qk, float* d_v,
-                  float* work, int32_t N, int32_t L, int32_t nh, float scale, void* stream);
+                  float* work, int32_t N, int32_t L, int32_t nh, float scale, int32_t precision, void* stream);
 
 /* ---- Hungarian matcher (A2/models/matcher.py:197-247 + scipy.optimize.linear_sum_assignment) -------------
  * cdetr_match_cost: per image b, cost[b] = 5*L1 + 2*focal-class + 2*(-GIoU) in fp32 with the reference's expression

@@ -414,8 +414,8 @@ def test_decoder_stack_fused_equals_unfused(precision, used):
         close(p1[k], p0[k], rtol=1e-4, msg="dec d" + k)
 
 
-@pytest.mark.parametrize("N,L", [(2, 300), (1, 900), (2, 37), (1, 129)])
-def test_mha_core(N, L):
+@pytest.mark.parametrize("N,L", [(2, 300), (1, 900), (2, 37), (1, 129), (1, 64), (2, 5)])
+def test_mha_core(N, L, precision):
     from counting_detr_amd import ops
     nh, E = 8, 256
     qk = torch.randn(N, L, 2 * E, generator=g(1))
