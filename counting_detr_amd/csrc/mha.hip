@@ -12,6 +12,7 @@
 #include "../../include/cdetr_hip.h"
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -277,8 +278,8 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const float* __restrict
 //                                                             from the registers of the first product (slot j of step s = reg 8s + j)
 // so softmax statistics, the log-sum-exp and D are per-LANE scalars and no probability ever touches LDS or HBM.  Tiles are
 // split into bf16 hi / lo once per workgroup while they are staged ([row][hi 32 | lo 32 | pad 8]); the transposed tiles
-// store the reduction index in the order the accumulator registers enumerate it (perm_pos).  One tile is prefetched in
-// registers (unconditional loads, rows clamped to L-1 and masked arithmetically).
+// store the reduction index in the order the accumulator registers enumerate it (perm_pos).  Three tiles are in flight in a
+// statically indexed register ring (unconditional loads, rows clamped to L-1 and masked arithmetically).
 namespace flash {
 constexpr int NWF = 2, NTF = 64 * NWF, TS = 72, TILE = 32 * TS;
 
@@ -288,7 +289,7 @@ __device__ __forceinline__ int perm_pos(int k0) { return (k0 & 16) | ((k0 & 4) <
 __device__ __forceinline__ int reg_row(int r, int g) { return (r & 3) + 8 * (r >> 2) + 4 * g; }
 
 struct NatRegs { float4 v[2]; };
-struct TrRegs { float4 v[4]; };
+struct TrRegs { float t[16]; };      // t[4 kk + c]: plain scalars (a float4 array read component-wise ends up in scratch)
 // natural tile: rows r0.. of a [L][ld] matrix, 32 columns from col0; thread -> (row = idx >> 3, c4 = idx & 7), idx = tid + 128 s
 __device__ __forceinline__ void nat_fetch(NatRegs& r, const float* __restrict__ src, long ld, int col0, int r0, int L, int tid) {
 #pragma unroll
@@ -307,14 +308,15 @@ __device__ __forceinline__ void nat_stash(const NatRegs& r, __bf16* tile, int ti
 // transposed tile (64 threads `t`): block (row quad kq = t & 7, column quad cq = t >> 3) = 4 rows x 4 columns
 __device__ __forceinline__ void tr_fetch(TrRegs& r, const float* __restrict__ src, long ld, int col0, int r0, int L, int t) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) r.v[kk] = ld4(src + (long)min(r0 + 4 * (t & 7) + kk, L - 1) * ld + col0 + (t >> 3) * 4);
+    for (int kk = 0; kk < 4; ++kk) {
+        const float4 v = ld4(src + (long)min(r0 + 4 * (t & 7) + kk, L - 1) * ld + col0 + (t >> 3) * 4);
+        r.t[4 * kk] = v.x; r.t[4 * kk + 1] = v.y; r.t[4 * kk + 2] = v.z; r.t[4 * kk + 3] = v.w;
+    }
 }
 __device__ __forceinline__ void tr_stash(const TrRegs& r, __bf16* tile, int t) {
     __bf16* dst = tile + (4 * (t >> 3)) * TS + perm_pos(4 * (t & 7));
-    stash_split4(dst, 32, r.v[0].x, r.v[1].x, r.v[2].x, r.v[3].x);
-    stash_split4(dst + TS, 32, r.v[0].y, r.v[1].y, r.v[2].y, r.v[3].y);
-    stash_split4(dst + 2 * TS, 32, r.v[0].z, r.v[1].z, r.v[2].z, r.v[3].z);
-    stash_split4(dst + 3 * TS, 32, r.v[0].w, r.v[1].w, r.v[2].w, r.v[3].w);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) stash_split4(dst + c * TS, 32, r.t[c], r.t[4 + c], r.t[8 + c], r.t[12 + c]);
 }
 // acc += A(tile rows, this lane's row i32) * B (hi/lo fragments of the two k-steps)
 __device__ __forceinline__ f32x16 mma_tile(f32x16 acc, const __bf16* tile, int i32, int g, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
@@ -364,19 +366,25 @@ __global__ __launch_bounds__(NTF) void fwd_kernel(const float* __restrict__ qk, 
     own_frag(qkn + (long)min(q, L - 1) * 2 * E + head * D, g, scale, qh, ql);
     float m = -INFINITY, l = 0.f;
     f32x16 OT = zero16();
-    NatRegs rk;
-    TrRegs rv;
+    constexpr int PD = 3;                                                      // tiles in flight (register ring, statically indexed)
+    struct Ring { NatRegs k; TrRegs v; } r0, r1, r2;          // separate variables, not an array: keeps them in registers
     const int ntile = (L + 31) / 32;
-    nat_fetch(rk, qkn, 2 * E, E + head * D, 0, L, tid);
-    if (wid == 0) tr_fetch(rv, vn, E, head * D, 0, L, lane);
-    nat_stash(rk, lds, tid);
-    if (wid == 0) tr_stash(rv, lds + TILE, lane);
+    auto fetch = [&](NatRegs& a, TrRegs& b, int t) __attribute__((always_inline)) {
+        const int r0 = min(t, ntile - 1) * 32;                                 // surplus prefetches re-read the last tile
+        nat_fetch(a, qkn, 2 * E, E + head * D, r0, L, tid);
+        tr_fetch(b, vn, E, head * D, r0, L, lane);          // every wave loads (only wave 0 stages): keeps the ring in registers
+    };
+    auto stash = [&](const NatRegs& a, const TrRegs& b, int buf) __attribute__((always_inline)) {
+        nat_stash(a, lds + buf * 2 * TILE, tid);
+        if (wid == 0) tr_stash(b, lds + buf * 2 * TILE + TILE, lane);
+    };
+    fetch(r0.k, r0.v, 0); fetch(r1.k, r1.v, 1); fetch(r2.k, r2.v, 2);
+    stash(r0.k, r0.v, 0);
     __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
+    auto step = [&](Ring& cur, const Ring& nxt, int t) __attribute__((always_inline)) {
+        // steps past the last tile run on a re-read of it with every row masked: numerically a no-op, and the ring stays branch-free
         const int buf = t & 1;
-        const int r1 = min(t + 1, ntile - 1) * 32;                             // surplus prefetch re-reads the last tile
-        nat_fetch(rk, qkn, 2 * E, E + head * D, r1, L, tid);
-        if (wid == 0) tr_fetch(rv, vn, E, head * D, r1, L, lane);
+        fetch(cur.k, cur.v, t + PD);                                           // `cur` (tile t) was staged one step ago
         f32x16 S = mma_tile(zero16(), lds + buf * 2 * TILE, i32, g, qh, ql);
         float mx = -INFINITY;
 #pragma unroll
@@ -398,9 +406,13 @@ __global__ __launch_bounds__(NTF) void fwd_kernel(const float* __restrict__ qk, 
         bf16x8 ph[2], pl[2];
         reg_frag(S, ph, pl);
         OT = mma_tile(OT, lds + buf * 2 * TILE + TILE, i32, g, ph, pl);
-        nat_stash(rk, lds + (buf ^ 1) * 2 * TILE, tid);
-        if (wid == 0) tr_stash(rv, lds + (buf ^ 1) * 2 * TILE + TILE, lane);
+        stash(nxt.k, nxt.v, buf ^ 1);                                          // tile t + 1
         __syncthreads();
+    };
+    for (int t0 = 0; t0 < ntile; t0 += PD) {
+        step(r0, r1, t0);
+        step(r1, r2, t0 + 1);
+        step(r2, r0, t0 + 2);
     }
     if (q < L) {
         store_own(o + ((long)n * L + q) * E + head * D, g, OT, 1.f / l);
@@ -434,22 +446,27 @@ __global__ __launch_bounds__(NTF) void bwd_q_kernel(const float* __restrict__ qk
     }
     const float li = lse[((long)n * nh + head) * L + qc];
     f32x16 dQT = zero16();
-    NatRegs rk, rvv;
-    TrRegs rkt;
+    constexpr int PD = 3;
+    struct Ring { NatRegs k, v; TrRegs kt; } r0, r1, r2;
     const int ntile = (L + 31) / 32;
-    nat_fetch(rk, qkn, 2 * E, E + head * D, 0, L, tid);
-    nat_fetch(rvv, vn, E, head * D, 0, L, tid);
-    if (wid == 0) tr_fetch(rkt, qkn, 2 * E, E + head * D, 0, L, lane);
-    nat_stash(rk, lds, tid);
-    nat_stash(rvv, lds + TILE, tid);
-    if (wid == 0) tr_stash(rkt, lds + 2 * TILE, lane);
+    auto fetch = [&](NatRegs& a, NatRegs& b, TrRegs& c, int t) __attribute__((always_inline)) {
+        const int r0 = min(t, ntile - 1) * 32;
+        nat_fetch(a, qkn, 2 * E, E + head * D, r0, L, tid);
+        nat_fetch(b, vn, E, head * D, r0, L, tid);
+        tr_fetch(c, qkn, 2 * E, E + head * D, r0, L, lane);
+    };
+    auto stash = [&](const NatRegs& a, const NatRegs& b, const TrRegs& c, int buf) __attribute__((always_inline)) {
+        __bf16* nb = lds + buf * 3 * TILE;
+        nat_stash(a, nb, tid);
+        nat_stash(b, nb + TILE, tid);
+        if (wid == 0) tr_stash(c, nb + 2 * TILE, lane);
+    };
+    fetch(r0.k, r0.v, r0.kt, 0); fetch(r1.k, r1.v, r1.kt, 1); fetch(r2.k, r2.v, r2.kt, 2);
+    stash(r0.k, r0.v, r0.kt, 0);
     __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
+    auto step = [&](Ring& cur, const Ring& nxt, int t) __attribute__((always_inline)) {
         const int buf = t & 1;
-        const int r1 = min(t + 1, ntile - 1) * 32;
-        nat_fetch(rk, qkn, 2 * E, E + head * D, r1, L, tid);
-        nat_fetch(rvv, vn, E, head * D, r1, L, tid);
-        if (wid == 0) tr_fetch(rkt, qkn, 2 * E, E + head * D, r1, L, lane);
+        fetch(cur.k, cur.v, cur.kt, t + PD);
         const __bf16* base = lds + buf * 3 * TILE;
         f32x16 S = mma_tile(zero16(), base, i32, g, qh, ql);
         const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, dh, dl);
@@ -461,11 +478,13 @@ __global__ __launch_bounds__(NTF) void bwd_q_kernel(const float* __restrict__ qk
         bf16x8 sh[2], sl[2];
         reg_frag(S, sh, sl);
         dQT = mma_tile(dQT, base + 2 * TILE, i32, g, sh, sl);
-        __bf16* nb = lds + (buf ^ 1) * 3 * TILE;
-        nat_stash(rk, nb, tid);
-        nat_stash(rvv, nb + TILE, tid);
-        if (wid == 0) tr_stash(rkt, nb + 2 * TILE, lane);
+        stash(nxt.k, nxt.v, nxt.kt, buf ^ 1);
         __syncthreads();
+    };
+    for (int t0 = 0; t0 < ntile; t0 += PD) {
+        step(r0, r1, t0);
+        step(r1, r2, t0 + 1);
+        step(r2, r0, t0 + 2);
     }
     if (q < L) {
         store_own(dqk + ((long)n * L + q) * 2 * E + head * D, g, dQT, scale);
@@ -491,35 +510,34 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
     own_frag(qkn + (long)jc * 2 * E + E + head * D, g, scale, kh, kl);
     own_frag(v + ((long)n * L + jc) * E + head * D, g, 1.f, vh, vl);
     f32x16 dKT = zero16(), dVT = zero16();
-    NatRegs rq, rd;
-    TrRegs rt;
-    float rs = 0.f;
+    constexpr int PD = 3;
+    const float* trsrc = (wid == 0) ? qkn : don;                               // wave 0 stages Q^T, wave 1 dO^T
+    const long trld = (wid == 0) ? 2 * E : E;
+    const float* stsrc = (tid & 32) ? dbn : lsn;
+    struct Ring { NatRegs q, d; TrRegs t; float s; } r0, r1, r2;
     const int ntile = (L + 31) / 32;
-    auto fetch = [&](int r0) __attribute__((always_inline)) {
-        nat_fetch(rq, qkn, 2 * E, head * D, r0, L, tid);
-        nat_fetch(rd, don, E, head * D, r0, L, tid);
-        if (wid == 0) tr_fetch(rt, qkn, 2 * E, head * D, r0, L, lane);
-        else tr_fetch(rt, don, E, head * D, r0, L, lane);
-        if (tid < 64) {                                                    // lse (tid < 32) / D (32 <= tid < 64) of the tile's queries
-            const int qq = r0 + (tid & 31);
-            const float* src = (tid < 32) ? lsn : dbn;
-            rs = src[min(qq, L - 1)];
-            if (qq >= L) rs = (tid < 32) ? INFINITY : 0.f;                 // p = exp(s - inf) = 0 beyond L
-        }
+    auto fetch = [&](NatRegs& a, NatRegs& b, TrRegs& c, float& sv, int t) __attribute__((always_inline)) {
+        const int r0 = min(t, ntile - 1) * 32;
+        nat_fetch(a, qkn, 2 * E, head * D, r0, L, tid);
+        nat_fetch(b, don, E, head * D, r0, L, tid);
+        tr_fetch(c, trsrc, trld, head * D, r0, L, lane);
+        const int qq = t * 32 + (tid & 31);                                // lse (lanes 0-31 of wave 0) / D (lanes 32-63) of the tile
+        const float x = stsrc[min(qq, L - 1)];                             // (true, unclamped index: surplus tiles must be inert)
+        sv = (qq < L) ? x : ((tid & 32) ? 0.f : INFINITY);                 // p = exp(s - inf) = 0 beyond L
     };
-    auto stash = [&](int buf) __attribute__((always_inline)) {
+    auto stash = [&](const NatRegs& a, const NatRegs& b, const TrRegs& c, float sv, int buf) __attribute__((always_inline)) {
         __bf16* nb = lds + buf * 4 * TILE;
-        nat_stash(rq, nb, tid);
-        nat_stash(rd, nb + TILE, tid);
-        tr_stash(rt, nb + (wid == 0 ? 2 : 3) * TILE, lane);
-        if (tid < 64) stat[buf][tid >> 5][tid & 31] = rs;
+        nat_stash(a, nb, tid);
+        nat_stash(b, nb + TILE, tid);
+        tr_stash(c, nb + (wid == 0 ? 2 : 3) * TILE, lane);
+        if (tid < 64) stat[buf][tid >> 5][tid & 31] = sv;
     };
-    fetch(0);
-    stash(0);
+    fetch(r0.q, r0.d, r0.t, r0.s, 0); fetch(r1.q, r1.d, r1.t, r1.s, 1); fetch(r2.q, r2.d, r2.t, r2.s, 2);
+    stash(r0.q, r0.d, r0.t, r0.s, 0);
     __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
+    auto step = [&](Ring& cur, const Ring& nxt, int t) __attribute__((always_inline)) {
         const int buf = t & 1;
-        fetch(min(t + 1, ntile - 1) * 32);
+        fetch(cur.q, cur.d, cur.t, cur.s, t + PD);
         const __bf16* base = lds + buf * 4 * TILE;
         f32x16 S = mma_tile(zero16(), base, i32, g, kh, kl);                   // S^T[q, key]
         const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, vh, vl);     // dP^T[q, key]
@@ -541,8 +559,13 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
         dVT = mma_tile(dVT, base + 3 * TILE, i32, g, ph, pl);                  // dV^T[c, key] += dO^T[c, q] P[q, key]
         reg_frag(S, sh, sl);
         dKT = mma_tile(dKT, base + 2 * TILE, i32, g, sh, sl);                  // dK^T[c, key] += Q^T[c, q] dS[q, key]
-        stash(buf ^ 1);
+        stash(nxt.q, nxt.d, nxt.t, nxt.s, buf ^ 1);
         __syncthreads();
+    };
+    for (int t0 = 0; t0 < ntile; t0 += PD) {
+        step(r0, r1, t0);
+        step(r1, r2, t0 + 1);
+        step(r2, r0, t0 + 2);
     }
     if (j < L) {
         store_own(dqk + ((long)n * L + j) * 2 * E + E + head * D, g, dKT, scale);
