@@ -74,7 +74,10 @@ def main():
     ap.add_argument("--size", type=int, nargs=2, default=[800, 800])
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--queries", type=int, default=300)
-    ap.add_argument("--no-graph", action="store_true", help="eager step (bucketed all-reduce overlapped with backward)")
+    ap.add_argument("--mode", choices=["auto", "eager", "graph"], default="auto",
+                    help="eager = stream-ordered launches (bucketed all-reduce overlapped with backward); graph = HIP-graph replay of the "
+                         "sync-free step; auto (default) times 3 steps of each after a short warm-up and keeps the faster one")
+    ap.add_argument("--no-graph", action="store_true", help="same as --mode eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=list(PRECISIONS), default="bf16x3",
                     help="matrix-core arithmetic of the GEMM kernels: split-bf16 x3 (default, ~5e-6 rel) or fp32 MFMA (exact products)")
@@ -115,11 +118,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if a.no_graph:
-        step = lambda: trainer.train_step(images, rects, targets)      # noqa: E731
-    else:
+    eager_step = lambda: trainer.train_step(images, rects, targets)      # noqa: E731
+    mode = "eager" if a.no_graph else a.mode
+    probe = None
+    if mode == "auto":      # GPU-bound either way: pick by measurement (the graph saves CPU launch work, the stream path has no per-node overhead)
+        def timed(fn, n=3):
+            for _ in range(2):
+                fn()
+            barrier()
+            t = time.perf_counter()
+            for _ in range(n):
+                fn()
+            barrier()
+            return (time.perf_counter() - t) / n
+        te = timed(eager_step)
         trainer.capture(images, rects, targets, warmup=1)
-        step = trainer.replay
+        tg = timed(trainer.replay)
+        tt = torch.tensor([te, tg], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
+        te, tg = float(tt[0]), float(tt[1])
+        mode = "eager" if te <= tg else "graph"
+        probe = {"eager_ms": te * 1e3, "graph_ms": tg * 1e3}
+    elif mode == "graph":
+        trainer.capture(images, rects, targets, warmup=1)
+    a.no_graph = (mode == "eager")
+    step = eager_step if mode == "eager" else trainer.replay
     for _ in range(a.warmup):
         out = step()
     barrier()
@@ -200,19 +224,23 @@ def main():
            "config": {"workload": f"FSCD-147 2nd-stage train step (ResNet-50-DC5 + RCDA enc6/dec6, Q={a.queries} learned, "
                                   f"{H}x{W}, T={list(Ts)}), fwd+matcher+loss+bwd+clip+AdamW",
                       "images_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                      "graph": not a.no_graph, "precision": a.precision, "final_loss": loss},
+                      "graph": not a.no_graph, "mode_probe_ms": probe, "precision": a.precision, "final_loss": loss},
            "roofline": roofline}
-    if world == 1 and not a.no_alt and not a.no_graph:
-        # the same step in the other arithmetic mode (short run), for transparency
+    if world == 1 and not a.no_alt:
+        # the same step in the other arithmetic mode (short run, same launch mode), for transparency
         alt = "fp32" if a.precision != "fp32" else "bf16x3"
         ops.PRECISION = PRECISIONS[alt]
-        trainer.capture(images, rects, targets, warmup=1)
+        if a.no_graph:
+            alt_step = eager_step
+        else:
+            trainer.capture(images, rects, targets, warmup=1)
+            alt_step = trainer.replay
         for _ in range(2):
-            trainer.replay()
+            alt_step()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(5):
-            trainer.replay()
+            alt_step()
         torch.cuda.synchronize()
         dta = (time.perf_counter() - t1) / 5
         res["alt_precision"] = {"precision": alt, "value": a.batch / dta, "unit": "images/s", "ms_per_step": dta * 1e3, "steps": 5}
