@@ -391,6 +391,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
 //   U: per-wave [32][su] slices holding A_col at the start and the ds_col / A_row staging at the end; while the main loop
 //      runs (A_col lives in registers) the same memory is the double-buffered V tile shared by the workgroup;
 //   R: per-wave [32][sw] A_row; element (q, w) is overwritten by dA_row[q, w] as soon as column w has been consumed.
+constexpr int BWD_CG = 2;     // key columns staged and consumed per workgroup barrier of the dS kernel
 struct BwdSmem {
     int sw, sh, su, off_u, off_r, total;
 };
@@ -402,7 +403,7 @@ __host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW) {
     s.su = s.sw > s.sh ? s.sw : s.sh;
     s.off_u = 0;
     int u = NW * QW * s.su;
-    const int v = 2 * (32 * NF) * 36;
+    const int v = 2 * BWD_CG * (32 * NF) * 36;
     if (v > u) u = v;
     s.off_r = (u + 3) & ~3;
     s.total = s.off_r + NW * QW * s.sw;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
     float* Acol = smem + sm.off_u + wid * QW * sm.su;        // this wave's U slice, [32][sh] view
     float* Arow = smem + sm.off_r + wid * QW * sm.sw;        // [32][sw]; turns into dA_row column by column
     float* dArow = Arow;
-    float* Vs = smem + sm.off_u;                             // [2][HR][36], overlays U during the main loop
+    float* Vs = smem + sm.off_u;                             // [2][CG][HR][36], overlays U during the main loop
 
     // ---- load the saved attention rows of this wave (coalesced), zero for tail queries
     {
@@ -479,7 +480,8 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
     // h >= H re-read row H-1 -- A_col is zero there -- and columns w >= W re-read column W-1, weighted by A_row = 0) and are
     // staged once per workgroup; in split-bf16 mode the tile is split while it is staged, in the slot order the dOut^T
     // fragment uses (k-slot j of lane group g at step kp <-> channel 16kp + 8(j>>2) + 4g + (j&3)).
-    constexpr int PD = 2;      // two columns ahead covers the load latency here (an iteration is ~1 us of MFMA + FMA work)
+    constexpr int PD = 2;      // register sets in flight
+    constexpr int CG = BWD_CG; // key columns per set = per workgroup barrier
     constexpr int VSLOTS = (NF * 256 + NT - 1) / NT;
     const float* vsrc[VSLOTS];
     int vdst[VSLOTS];
@@ -495,40 +497,50 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
             vdst[s] = (h < HR) ? h * VS + c4 * 4 : -1;                                            // float units
         }
     }
-    float4 rv[PD][VSLOTS];
+    float4 rv[PD][CG][VSLOTS];
     int wf = 0;                                             // next column to fetch; vsrc[] points at it
-    auto vfetch = [&](float4 (&r)[VSLOTS]) __attribute__((always_inline)) {
+    auto vfetch = [&](float4 (&r)[CG][VSLOTS]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < VSLOTS; ++s) r[s] = ld4(vsrc[s]);
-        ++wf;
-        if (wf < W) {
+        for (int cc = 0; cc < CG; ++cc) {
 #pragma unroll
-            for (int s = 0; s < VSLOTS; ++s) vsrc[s] += E;
+            for (int s = 0; s < VSLOTS; ++s) r[cc][s] = ld4(vsrc[s]);
+            ++wf;
+            if (wf < W) {
+#pragma unroll
+                for (int s = 0; s < VSLOTS; ++s) vsrc[s] += E;
+            }
         }
     };
-    auto vstash = [&](const float4 (&r)[VSLOTS], int buf) __attribute__((always_inline)) {
+    auto vstash = [&](const float4 (&r)[CG][VSLOTS], int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < VSLOTS; ++s) {
-            if (vdst[s] < 0) continue;
-            if (PREC == 1) stash_split4(reinterpret_cast<__bf16*>(Vs + buf * HR * VS) + vdst[s], 32, r[s].x, r[s].y, r[s].z, r[s].w);
-            else *reinterpret_cast<float4*>(Vs + buf * HR * VS + vdst[s]) = r[s];
-        }
+        for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+            for (int s = 0; s < VSLOTS; ++s) {
+                if (vdst[s] < 0) continue;
+                float* tile = Vs + (buf * CG + cc) * HR * VS;
+                if (PREC == 1) stash_split4(reinterpret_cast<__bf16*>(tile) + vdst[s], 32, r[cc][s].x, r[cc][s].y, r[cc][s].z, r[cc][s].w);
+                else *reinterpret_cast<float4*>(tile + vdst[s]) = r[cc][s];
+            }
     };
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     vfetch(rv[0]); vfetch(rv[1]);
     vstash(rv[0], 0);
     __syncthreads();
-    auto step = [&](auto U, int w) __attribute__((always_inline)) {
+    auto step = [&](auto U, int w0s) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         const int buf = u & 1;
-        vfetch(rv[u]);                                                   // column w + PD; set u was staged one step ago
+        vfetch(rv[u]);                                                   // the set after next; set u was staged one step ago
+#pragma clang loop unroll(disable)
+      for (int cc = 0; cc < CG; ++cc) {       // rolled on purpose: unrolled, the compiler keeps CG accumulator sets live (380 VGPRs)
+        const int w = w0s + cc;
+        const float* tile = Vs + (buf * CG + cc) * HR * VS;
         const float arow = Arow[i32 * sm.sw + w];                        // zero for W <= w < Wp
         float part = 0.f;
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             f32x16 gt = zero16;
             if (PREC == 0) {
-                const float* va = Vs + buf * HR * VS + (32 * f + i32) * VS + g * 4;
+                const float* va = tile + (32 * f + i32) * VS + g * 4;
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
                     const float4 a = *reinterpret_cast<const float4*>(va + kk * 8);
@@ -538,7 +550,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
                     gt = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, dob[kk][3], gt, 0, 0, 0);
                 }
             } else {
-                const __bf16* va = reinterpret_cast<const __bf16*>(Vs + buf * HR * VS) + (32 * f + i32) * (2 * VS) + g * 8;
+                const __bf16* va = reinterpret_cast<const __bf16*>(tile) + (32 * f + i32) * (2 * VS) + g * 8;
 #pragma unroll
                 for (int kp = 0; kp < 2; ++kp) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(va + kp * 16);
@@ -554,12 +566,13 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
         }
         part += __shfl_xor(part, 32, 64);
         if (g == 0) dArow[i32 * sm.sw + w] = part;
+      }
         vstash(rv[(u + 1) % PD], buf ^ 1);
         __syncthreads();
     };
-    for (int w0 = 0; w0 < W; w0 += PD) {          // w runs to Wp - 1 at most: Arow / dArow rows hold Wp (+1) entries
+    for (int w0 = 0; w0 < W; w0 += PD * CG) {     // w runs to Wp - 1 at most (Wp % 4 == 0): Arow / dArow rows hold Wp (+1) entries
         step(std::integral_constant<int, 0>{}, w0);
-        step(std::integral_constant<int, 1>{}, w0 + 1);
+        step(std::integral_constant<int, 1>{}, w0 + CG);
     }
 
     // The loop ended with a barrier: the V buffers are dead and every wave owns its U slice again.
@@ -909,13 +922,13 @@ int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st) {
     }
     return cdetr_launch_status("cdetr_rcda_bwd(dS)");
 }
-// waves per workgroup: 4 when that already gives >= 4 workgroups per CU, else 2 (finer granularity: less tail
-// quantisation on 256 CUs and 2-3 co-resident workgroups per CU to hide the V-tile latency)
+// waves per workgroup: 4 (128 queries share every staged V tile).  2-wave workgroups used to pay for the short decoder query
+// sets; with the grouped / prefetched tile loops they no longer do (tools/rcda_bench.py: dS 66 vs 73 us, fwd 50 vs 52 us).
 inline int pick_nw(int L, int NH) {
-    const long b4 = (long)((L + 127) / 128) * NH;
+    (void)L; (void)NH;
     const char* f = getenv("CDETR_RCDA_NW");
-    if (f) return atoi(f) == 4 ? 4 : 2;
-    return b4 >= 128 ? 4 : 2;      // measured: 2-wave workgroups only pay for the short decoder query sets
+    if (f) return atoi(f) == 2 ? 2 : 4;
+    return 4;
 }
 
 }  // namespace
