@@ -1610,7 +1610,8 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             constexpr int BI = decltype(bi_c)::value, BJ = decltype(bj_c)::value;
             const int tilesI = (d.Nout + BI - 1) / BI, tilesJ = (d.Cin + BJ - 1) / BJ;
             const long base = (long)tilesI * tilesJ * d.taps * d.batch;
-            long slices = (768 + base - 1) / base;                  // ~3 workgroups per CU
+            static const long target = getenv("CDETR_WGRAD_TARGET") ? atol(getenv("CDETR_WGRAD_TARGET")) : 768;
+            long slices = (target + base - 1) / base;               // ~3 workgroups per CU
             const long max_slices = (nktf + 3) / 4;                 // >= 4 k-tiles (128 pixels) per slice
             if (slices > max_slices) slices = max_slices;
             if (slices < 1) slices = 1;
