@@ -100,14 +100,14 @@ def main():
     from counting_detr_amd import ops
     from counting_detr_amd.args import default_args
     from counting_detr_amd.engine import Trainer
-    from oracle.weights import model_schema, seeded_state_dict   # name-seeded random init (test infra used as an initialiser only)
+    from counting_detr_amd.init import seeded_init_
 
     ops.PRECISION = PRECISIONS[a.precision]
     H, W = a.size
     Ts = (37, 120)
     args = default_args(device=str(dev), num_query_position=a.queries)
     model, crit, _ = counting_detr_amd.build_model(args)
-    model.load_state_dict(seeded_state_dict(model_schema(num_position=a.queries)), strict=True)
+    seeded_init_(model)          # deterministic name-seeded random weights (no checkpoints in this environment)
     model.to(dev).train()
     crit.train()
     trainer = Trainer(model, crit, args, device=dev)
