@@ -115,6 +115,8 @@ class SetCriterion(nn.Module):
         key = (tuple(len(t["boxes"]) for t in targets), Q, str(logits.device))
         plan = self._plans.get(key)
         if plan is None:
+            if len(self._plans) > 256:          # real data: a new plan per distinct tuple of target counts
+                self._plans.clear()
             plan = self._plans[key] = ops.MatchPlan(key[0], Q, logits.device)
         idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan)
         if self.check_status and bool((status != 0).any()):
@@ -135,6 +137,8 @@ class SetCriterion(nn.Module):
             if not torch.is_tensor(num_boxes):
                 nbt = self._nb_cache.get((float(num_boxes), str(logits.device)))
                 if nbt is None:
+                    if len(self._nb_cache) > 64:
+                        self._nb_cache.clear()
                     nbt = self._nb_cache[(float(num_boxes), str(logits.device))] = torch.full((1,), float(num_boxes), device=logits.device)
             else:
                 nbt = num_boxes.reshape(-1)[:1].to(torch.float32)
