@@ -446,6 +446,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 //   * TWO k-tiles of global loads in flight: tile t+2 is issued before tile t is computed and is written to LDS one
 //     iteration later, so a load has two tile-times (>= 2048 matrix-pipe cycles) to land (ablation in tools/gemm_sweep.py:
 //     with a single tile in flight ~27 % of the kernel was exposed load latency).
+// split-plane LDS rows are groups of 32 k-values, [hi 32 | lo 32] each (= the byte layout of cdetr_gemm_desc.B_split): position
+// of k inside a row, in bf16 units; the lo plane of the same k sits 32 further.
+#define KPOS(k) ((((k) >> 5) << 6) + ((k) & 31))
 template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
     constexpr int NT = 64 * WM * WN;
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
                 if constexpr (ABL == 4) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = qa[i];      // ablation: no split
-                else stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + kq * 4, BKF, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
+                else stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + KPOS(kq * 4), 32, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
             }
             if constexpr (BL == 0 && (ABL >= 3 || BRAW)) {
 #pragma unroll
@@ -599,19 +602,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
 #pragma unroll
                 for (int i = 0; i < B_SLOTS; ++i) {
                     const float s = bscale0[i];
-                    stash_split4(reinterpret_cast<__bf16*>(bs + (r8 + RPP * i) * LDK) + kq * 4, BKF, qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
+                    stash_split4(reinterpret_cast<__bf16*>(bs + (r8 + RPP * i) * LDK) + KPOS(kq * 4), 32, qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < NBLK; ++j) {
-                    __bf16* dst = reinterpret_cast<__bf16*>(bs + (tng[j] * NV) * LDK) + tkg[j] * 4;
+                    __bf16* dst = reinterpret_cast<__bf16*>(bs + (tng[j] * NV) * LDK) + KPOS(tkg[j] * 4);
                     const BVec &k0 = qb[j * 4], &k1 = qb[j * 4 + 1], &k2 = qb[j * 4 + 2], &k3 = qb[j * 4 + 3];
                     const float4 sc = qs[j];
-                    stash_split4(dst, BKF, k0.x * sc.x, k1.x * sc.y, k2.x * sc.z, k3.x * sc.w);
-                    stash_split4(dst + 2 * LDK, BKF, k0.y * sc.x, k1.y * sc.y, k2.y * sc.z, k3.y * sc.w);
+                    stash_split4(dst, 32, k0.x * sc.x, k1.x * sc.y, k2.x * sc.z, k3.x * sc.w);
+                    stash_split4(dst + 2 * LDK, 32, k0.y * sc.x, k1.y * sc.y, k2.y * sc.z, k3.y * sc.w);
                     if constexpr (NV == 4) {
-                        stash_split4(dst + 4 * LDK, BKF, k0.z * sc.x, k1.z * sc.y, k2.z * sc.z, k3.z * sc.w);
-                        stash_split4(dst + 6 * LDK, BKF, k0.w * sc.x, k1.w * sc.y, k2.w * sc.z, k3.w * sc.w);
+                        stash_split4(dst + 4 * LDK, 32, k0.z * sc.x, k1.z * sc.y, k2.z * sc.z, k3.z * sc.w);
+                        stash_split4(dst + 6 * LDK, 32, k0.w * sc.x, k1.w * sc.y, k2.w * sc.z, k3.w * sc.w);
                     }
                 }
             }
@@ -719,13 +722,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
                     bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
     #pragma unroll
                     for (int a = 0; a < FM; ++a) {
-                        ah[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + hp * 16);
-                        al[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + BKF + hp * 16);
+                        ah[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + KPOS(hp * 16));
+                        al[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + KPOS(hp * 16) + 32);
                     }
     #pragma unroll
                     for (int b = 0; b < FN; ++b) {
-                        bh[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + hp * 16);
-                        bl[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + BKF + hp * 16);
+                        bh[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + KPOS(hp * 16));
+                        bl[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + KPOS(hp * 16) + 32);
                     }
     #pragma unroll
                     for (int a = 0; a < FM; ++a)
@@ -1483,10 +1486,8 @@ int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
         // CDETR_GEMM_SPLIT: 0 = per-fragment everywhere, 2 = staging split everywhere.
         static const int split_mode = getenv("CDETR_GEMM_SPLIT") ? atoi(getenv("CDETR_GEMM_SPLIT")) : 1;
         static const int presplit = getenv("CDETR_GEMM_PRESPLIT") ? atoi(getenv("CDETR_GEMM_PRESPLIT")) : 1;
-        if constexpr (BKF == 32) {
-            if (presplit && d.B_split && d.b_layout == 0 && d.batch == 1 && split_mode >= 1)
-                return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 3, 0>(d, st);
-        }
+        if (presplit && d.B_split && d.b_layout == 0 && d.batch == 1 && split_mode >= 1)
+            return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 3, 0>(d, st);
         if (split_mode == 2 || (split_mode == 1 && d.b_layout == 0)) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 2, 0>(d, st);
         return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 1, 0>(d, st);
     }
@@ -1530,6 +1531,8 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     if (force == 8 && fast_ok) return launch_gemm_fast<4, 2, 1, 1, 32>(d, st);                 // 128x64, 8 waves of 32x32
     if (force == 9 && fast_ok) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);                 // 64x128, 8 waves of 32x32
     if (force == 10 && fast_ok) return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);                // 128x128, 16 waves of 32x32
+    if (force == 11 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<4, 4, 1, 1, 64>(d, st);   // same, BK 64
+    if (force == 12 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<2, 4, 1, 1, 64>(d, st);   // 64x128 on 8 waves, BK 64
     if (force >= 1 && force <= 4 && fast_ok) {
         if (force == 1) return launch_gemm_fast<2, 2, 2, 2, 32>(d, st);                       // 128x128
         if (force == 2) return launch_gemm_fast<2, 2, 2, 1, 32>(d, st);                       // 128x64

@@ -17,7 +17,7 @@ SHAPES = [  # (M, N, K, taps, layout, conv geometry or None)
     (20000, 512, 128, 1, 0, None), (20000, 128, 512, 1, 0, None), (20000, 512, 128, 1, 1, None),
     (80000, 64, 64, 9, 0, (200, 200, 1, 1, 1)), (80000, 256, 64, 1, 0, None), (80000, 64, 256, 1, 0, None),
 ]
-NAMES = {0: "auto", 1: "f128x128", 2: "f128x64", 3: "f64x64k64", 4: "f64x64k32", 5: "direct", 6: "generic", 7: "f32x64k32", 8: "f128x64w8", 9: "f64x128w8", 10: "f128x128w16"}
+NAMES = {0: "auto", 1: "f128x128", 2: "f128x64", 3: "f64x64k64", 4: "f64x64k32", 5: "direct", 6: "generic", 7: "f32x64k32", 8: "f128x64w8", 9: "f64x128w8", 10: "f128x128w16", 11: "f128x128w16k64", 12: "f64x128w8k64"}
 
 
 def run(shape, variant, reps=20):

@@ -8,12 +8,12 @@ SH = [(5000, 256, 256, 1, 0, None), (5000, 256, 256, 1, 1, None), (5000, 1024, 2
       (5000, 512, 512, 9, 0, (50, 50, 1, 2, 2)), (5000, 512, 512, 9, 1, (50, 50, 1, 2, 2)),
       (20000, 128, 128, 9, 0, (100, 100, 1, 1, 1)), (20000, 128, 128, 9, 1, (100, 100, 1, 1, 1)),
       (20000, 512, 128, 1, 0, None), (20000, 128, 512, 1, 1, None), (80000, 256, 64, 1, 0, None)]
-VS = (4, 8, 9, 10, 3)
+VS = (4, 9, 12, 10, 11, 3)
 print("split =", os.environ.get("CDETR_GEMM_SPLIT", "0"))
 for sh in SH:
     row = []
     for v in VS:
-        if v == 3 and sh[2] % 64:
+        if v in (3, 11, 12) and sh[2] % 64:
             row.append("      -     "); continue
         us, tf = run(sh, v)
         row.append(f"{us:7.1f}us {tf:5.1f}")
