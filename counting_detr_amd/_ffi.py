@@ -63,7 +63,7 @@ class MirrorItem(C.Structure):
 
 
 EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_bwd", "cdetr_posadd2",
-           "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_add2", "cdetr_grad_merge", "cdetr_maxpool3x3s2", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
+           "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
 
 _lib = None
@@ -102,6 +102,10 @@ def lib():
         L.cdetr_criterion_fwd.argtypes = [_p, _p]
         L.cdetr_criterion_bwd.restype = C.c_int
         L.cdetr_criterion_bwd.argtypes = [_p] * 9 + [C.c_int32, C.c_int32, _p]
+        L.cdetr_sine_embed.restype = C.c_int
+        L.cdetr_sine_embed.argtypes = [_p, C.c_int32, _p, C.c_int64, C.c_int32, C.c_int32, C.c_float, _p]
+        L.cdetr_sine_embed_bwd.restype = C.c_int
+        L.cdetr_sine_embed_bwd.argtypes = [_p, C.c_int32, _p, C.c_int64, _p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, _p]
         L.cdetr_add2.restype = C.c_int
         L.cdetr_add2.argtypes = [_p] * 5 + [C.c_int64, _p]
         L.cdetr_grad_merge.restype = C.c_int

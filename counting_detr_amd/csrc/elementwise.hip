@@ -345,6 +345,41 @@ __global__ __launch_bounds__(256) void grad_merge_kernel(const float4* __restric
     }
 }
 
+// Sine positional embedding (A2/models/transformer.py:474-494): out[r, i] = i even ? sin(x) : cos(x),
+// x = (pos[r] * 2 pi) / T^(2 floor(i/2) / nfeat); one launch instead of ~12 tensor kernels.  `pos` is read with stride
+// `pstride` (so pos[..., 0] / pos[..., 1] of a [.., 2] tensor need no copy) and `out` rows with stride `ldo` (the 2-D
+// embedding is two calls into the two halves of one buffer).  Backward: dpos[r] (+)= sum_i dout[r, i] * d out / d pos.
+__global__ __launch_bounds__(256) void sine_embed_kernel(const float* __restrict__ pos, int pstride, float* __restrict__ out, long ldo,
+                                                         int rows, int nfeat, float temperature) {
+    const long total = (long)rows * nfeat;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int r = (int)(idx / nfeat), i = (int)(idx - (long)r * nfeat);
+        const float dim_t = powf(temperature, (float)(2 * (i >> 1)) / (float)nfeat);
+        const float x = (pos[(long)r * pstride] * 6.283185307179586f) / dim_t;
+        out[(long)r * ldo + i] = (i & 1) ? cosf(x) : sinf(x);
+    }
+}
+__global__ __launch_bounds__(256) void sine_embed_bwd_kernel(const float* __restrict__ pos, int pstride, const float* __restrict__ dout,
+                                                             long ldo, float* __restrict__ dpos, int dstride, int rows, int nfeat,
+                                                             float temperature, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);               // one wave per row
+    if (r >= rows) return;
+    const float p2 = pos[(long)r * pstride] * 6.283185307179586f;
+    float acc = 0.f;
+    for (int i = lane; i < nfeat; i += 64) {
+        const float dim_t = powf(temperature, (float)(2 * (i >> 1)) / (float)nfeat);
+        const float x = p2 / dim_t;
+        const float d = (i & 1) ? -sinf(x) : cosf(x);
+        acc = fmaf(dout[(long)r * ldo + i] * d, 6.283185307179586f / dim_t, acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float* dst = dpos + (long)r * dstride;
+        *dst = accumulate ? *dst + acc : acc;
+    }
+}
+
 // Reductions of an NHWC map over one spatial axis (+ optional small addend):
 //   blocks [0, N*W):       Or[n,x,:] = scale_r * sum_y X[n,y,x,:] (+ Ar[n,x,:])
 //   blocks [N*W, N*W+N*H): Oc[n,y,:] = scale_c * sum_x X[n,y,x,:] (+ Ac[n,y,:])
@@ -471,4 +506,22 @@ extern "C" int cdetr_grad_merge(const float* base, const float* g1, const float*
                        reinterpret_cast<const float4*>(base), reinterpret_cast<const float4*>(g1), reinterpret_cast<const float4*>(g2),
                        reinterpret_cast<float4*>(acc1), reinterpret_cast<float4*>(acc2), reinterpret_cast<float4*>(out), (long)(n >> 2));
     return cdetr_launch_status("cdetr_grad_merge");
+}
+
+extern "C" int cdetr_sine_embed(const float* pos, int32_t pstride, float* out, int64_t ldo, int32_t rows, int32_t nfeat, float temperature,
+                                void* stream) {
+    CDETR_CHECK_ARG(pos && out && rows > 0 && nfeat > 0 && pstride > 0 && ldo >= nfeat, "cdetr_sine_embed: bad args");
+    long blocks = ((long)rows * nfeat + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sine_embed_kernel, dim3((unsigned)blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pos, pstride, out,
+                       (long)ldo, rows, nfeat, temperature);
+    return cdetr_launch_status("cdetr_sine_embed");
+}
+
+extern "C" int cdetr_sine_embed_bwd(const float* pos, int32_t pstride, const float* dout, int64_t ldo, float* dpos, int32_t dstride,
+                                    int32_t rows, int32_t nfeat, float temperature, int32_t accumulate, void* stream) {
+    CDETR_CHECK_ARG(pos && dout && dpos && rows > 0 && nfeat > 0 && pstride > 0 && dstride > 0 && ldo >= nfeat, "cdetr_sine_embed_bwd: bad args");
+    hipLaunchKernelGGL(sine_embed_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pos, pstride,
+                       dout, (long)ldo, dpos, dstride, rows, nfeat, temperature, accumulate);
+    return cdetr_launch_status("cdetr_sine_embed_bwd");
 }

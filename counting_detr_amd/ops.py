@@ -842,3 +842,46 @@ class CriterionFn(torch.autograd.Function):
         check(lib().cdetr_criterion_bwd(ptr(g6), ptr(g_logits), ptr(g_l1), ptr(g_giou), ptr(g_vb), ptr(g_vars), ptr(d_logits),
                                         ptr(d_boxes), ptr(d_vars), B * Q, Cc, stream_ptr()), "cdetr_criterion_bwd")
         return d_logits, d_boxes, d_vars, None, None, None, None, None, None, None, None
+
+
+class SineEmbedFn(torch.autograd.Function):
+    """pos2posemb1d / pos2posemb2d (A2/models/transformer.py:474-494) in one launch per coordinate.
+    pos [..., ncoord] (ncoord 1 or 2); two coordinates give the reference's (y, x) concatenation of two nfeat-wide halves."""
+
+    @staticmethod
+    def forward(ctx, pos, nfeat, temperature, two_d):
+        p = pos.contiguous().to(torch.float32)
+        lead = p.shape[:-1] if two_d else p.shape
+        rows = 1
+        for d_ in lead:
+            rows *= int(d_)
+        width = 2 * nfeat if two_d else nfeat
+        out = torch.empty(tuple(lead) + (width,), device=p.device, dtype=torch.float32)
+        if two_d:      # first half from pos[..., 1] (y), second half from pos[..., 0] (x)
+            check(lib().cdetr_sine_embed(p.data_ptr() + 4, 2, out.data_ptr(), width, rows, nfeat, temperature, stream_ptr()), "cdetr_sine_embed")
+            check(lib().cdetr_sine_embed(p.data_ptr(), 2, out.data_ptr() + 4 * nfeat, width, rows, nfeat, temperature, stream_ptr()), "cdetr_sine_embed")
+        else:
+            check(lib().cdetr_sine_embed(ptr(p), 1, ptr(out), width, rows, nfeat, temperature, stream_ptr()), "cdetr_sine_embed")
+        ctx.save_for_backward(p)
+        ctx.cfg = (rows, nfeat, temperature, two_d, width, pos.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (p,) = ctx.saved_tensors
+        rows, nfeat, temperature, two_d, width, shape = ctx.cfg
+        dout = dout.contiguous()
+        dp = torch.empty_like(p)
+        if two_d:
+            check(lib().cdetr_sine_embed_bwd(p.data_ptr() + 4, 2, dout.data_ptr(), width, dp.data_ptr() + 4, 2, rows, nfeat, temperature, 0,
+                                             stream_ptr()), "cdetr_sine_embed_bwd")
+            check(lib().cdetr_sine_embed_bwd(p.data_ptr(), 2, dout.data_ptr() + 4 * nfeat, width, dp.data_ptr(), 2, rows, nfeat, temperature, 0,
+                                             stream_ptr()), "cdetr_sine_embed_bwd")
+        else:
+            check(lib().cdetr_sine_embed_bwd(ptr(p), 1, ptr(dout), width, ptr(dp), 1, rows, nfeat, temperature, 0, stream_ptr()),
+                  "cdetr_sine_embed_bwd")
+        return dp.view(shape), None, None, None
+
+
+def sine_embed(pos, nfeat, temperature=10000.0, two_d=False):
+    return SineEmbedFn.apply(pos, nfeat, float(temperature), two_d)

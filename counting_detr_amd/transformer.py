@@ -22,21 +22,14 @@ def inverse_sigmoid(x, eps=1e-5):
     return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
 
 
-def _sine(pos, nfeat, temperature=10000):
-    dim_t = torch.arange(nfeat, dtype=torch.float32, device=pos.device)
-    dim_t = temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / nfeat)
-    px = (pos * (2 * math.pi))[..., None] / dim_t
-    return torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=-1).flatten(-2)
-
-
 def pos2posemb1d(pos, num_pos_feats=256, temperature=10000):
     """A2/models/transformer.py:487-494."""
-    return _sine(pos, num_pos_feats, temperature)
+    return ops.sine_embed(pos, num_pos_feats, temperature)
 
 
 def pos2posemb2d(pos, num_pos_feats=128, temperature=10000):
     """A2/models/transformer.py:474-484 ((y, x) concatenation order)."""
-    return torch.cat((_sine(pos[..., 1], num_pos_feats, temperature), _sine(pos[..., 0], num_pos_feats, temperature)), dim=-1)
+    return ops.sine_embed(pos, num_pos_feats, temperature, two_d=True)
 
 
 def mask2pos(mask):

@@ -123,6 +123,13 @@ int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc, float* ou
  * cdetr_grad_merge (backward of those sites): out = base + g1 (+ g2), acc1 += g1, acc2 += g2 (g2 / acc1 / acc2 may be NULL);
  * n = element count, a multiple of 4, all pointers 16-byte aligned.                                                    */
 int cdetr_add2(const float* T, const float* A, const float* B, float* O1, float* O2, int64_t n, void* stream);
+/* sine positional embedding (A2/models/transformer.py:474-494): out[r][i] = i even ? sin(x) : cos(x),
+ * x = pos[r * pstride] * 2 pi / temperature^(2 floor(i/2) / nfeat), rows of `out` / `dout` ldo floats apart;
+ * backward: dpos[r * dstride] (+)= sum_i dout[r][i] * d out[r][i] / d pos (accumulate != 0 adds).                       */
+int cdetr_sine_embed(const float* pos, int32_t pstride, float* out, int64_t ldo, int32_t rows, int32_t nfeat, float temperature,
+                     void* stream);
+int cdetr_sine_embed_bwd(const float* pos, int32_t pstride, const float* dout, int64_t ldo, float* dpos, int32_t dstride, int32_t rows,
+                         int32_t nfeat, float temperature, int32_t accumulate, void* stream);
 int cdetr_grad_merge(const float* base, const float* g1, const float* g2, float* acc1, float* acc2, float* out, int64_t n,
                      void* stream);
 

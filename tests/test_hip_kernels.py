@@ -568,3 +568,29 @@ def test_wgrad_variants_ragged_shapes(wvariant, monkeypatch, precision):
         wd = torch.nn.Parameter(w64.detach().float().contiguous(memory_format=torch.channels_last).to(DEV))
         ops.conv_wgrad_(gy.permute(0, 2, 3, 1).contiguous().to(DEV), x.permute(0, 2, 3, 1).contiguous().to(DEV), wd, None, stride=st, pad=pd, dil=dl)
         close(wd.grad, w64.grad, msg=f"conv wgrad {Cin}->{Cout} s{st} d{dl}", rtol=5e-4, atol_scale=6e-5)
+
+
+def test_sine_embed_matches_reference_formula():
+    """cdetr_sine_embed fwd / bwd == the tensor-op formula of A2/models/transformer.py:474-494 (fp64)."""
+    import math
+    from counting_detr_amd.transformer import pos2posemb1d, pos2posemb2d
+
+    def sine64(pos, nfeat, T=10000):
+        dim_t = torch.arange(nfeat, dtype=torch.float64)
+        dim_t = T ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / nfeat)
+        px = (pos * (2 * math.pi))[..., None] / dim_t
+        return torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=-1).flatten(-2)
+    p1 = torch.rand(2, 37, generator=g(1))
+    p2 = torch.rand(2, 300, 2, generator=g(2))
+    a1 = p1.to(DEV).requires_grad_(True); a2 = p2.to(DEV).requires_grad_(True)
+    e1, e2 = pos2posemb1d(a1), pos2posemb2d(a2)
+    g1, g2 = torch.randn(e1.shape, generator=g(3)), torch.randn(e2.shape, generator=g(4))
+    (e1 * g1.to(DEV)).sum().backward(); (e2 * g2.to(DEV)).sum().backward()
+    r1 = p1.double().requires_grad_(True); r2 = p2.double().requires_grad_(True)
+    f1 = sine64(r1, 256); f2 = torch.cat((sine64(r2[..., 1], 128), sine64(r2[..., 0], 128)), dim=-1)
+    (f1 * g1.double()).sum().backward(); (f2 * g2.double()).sum().backward()
+    assert e1.shape == (2, 37, 256) and e2.shape == (2, 300, 256)
+    np.testing.assert_allclose(e1.detach().cpu().numpy(), f1.detach().numpy(), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(e2.detach().cpu().numpy(), f2.detach().numpy(), rtol=0, atol=2e-5)
+    close(a1.grad, r1.grad, rtol=1e-4, msg="dpos 1d")
+    close(a2.grad, r2.grad, rtol=1e-4, msg="dpos 2d")
