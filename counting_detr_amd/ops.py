@@ -398,8 +398,8 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
     # logits -> projected q/k gradients: four small batched GEMMs per image (batch over heads) on the same MFMA kernels
     dq_row = torch.empty_like(q_row)
     dq_col = torch.empty_like(q_col)
-    dk_row = torch.zeros_like(k_row)
-    dk_col = torch.zeros_like(k_col)
+    dk = torch.zeros(k_row.numel() + k_col.numel(), device=v.device, dtype=torch.float32)      # one fill: the k gradients accumulate
+    dk_row, dk_col = dk[:k_row.numel()].view(k_row.shape), dk[k_row.numel():].view(k_col.shape)
     for n in range(N):
         gemm_raw(ds_row[n], Wp, k_row[n], E, dq_row[n], E, L, 32, W, b_layout=1, batch=nh, sA=L * Wp, sB=32, sC=32)
         gemm_raw(ds_col[n], Hp, k_col[n], E, dq_col[n], E, L, 32, H, b_layout=1, batch=nh, sA=L * Hp, sB=32, sC=32)
