@@ -1011,25 +1011,35 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
 
 
 
-// ------------------------------------------------------------------------------------------------ wgrad, staged-split form
-// split-bf16 only.  Same problem as wgrad_fast_kernel, but both operands are transposed and split into bf16 hi / lo ONCE per
-// workgroup while a 32-pixel tile is staged (the reduction runs over pixels, and both dY and X are channel-contiguous):
-//   * the tile is the concatenation Z = [dY tile | X tile] of (BI + BJ)/4 channel quads x 8 pixel quads; every thread owns
-//     SLOTS 4-pixel x 4-channel register blocks (4 float4 loads along the pixel axis), which it transposes in registers into
-//     four 4-pixel runs -> packed split -> ds_write_b64 of the hi and of the lo plane (row = channel, 144-byte stride);
-//   * a fragment is then two ds_read_b128 (hi, lo) and no VALU work: ~10 VALU instructions per MFMA instead of ~30 with the
-//     per-fragment split of wgrad_fast_kernel (rocprofv3 SQ_INSTS_VALU / SQ_INSTS_MFMA), which was VALU-bound;
-//   * loads are unconditional (clamped rows / columns + per-pixel validity bits) and two tiles are in flight.
+// ------------------------------------------------------------------------------------------------ wgrad, transpose-read form
+// split-bf16 only.  The reduction runs over pixels while both operands are channel-contiguous, so an MFMA fragment (8
+// consecutive k = pixels per lane) is a TRANSPOSED view of the natural tile.  gfx950's ds_read_b64_tr_b16 does that transpose
+// in the LDS read path: within a 16-lane group, lane 4a+b receives element b of the 8-byte chunks addressed by lanes a, 4+a,
+// 8+a, 12+a (measured: tools/probe/tr_probe.hip).  So
+//   * the stash keeps the coalesced shape of wgrad_fast_kernel (thread = one pixel row x 4 channels, 128-byte runs) and only
+//     splits: packed hi / lo conversion + one ds_write_b64 per plane into [32-channel block][pixel][32] bf16 images (64-byte rows:
+//     a half-wave's transpose read covers 4 rows x 64 B = 256 contiguous bytes, one pass over the 64 banks);
+//   * a fragment is 4 transpose reads (hi, lo x two 4-pixel groups) and no VALU: ~8 VALU per MFMA instead of ~30.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p0));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p1));
+    const s16x8 c = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, c);
+}
+
 template <int BI, int BJ>
-__global__ __launch_bounds__(256) void wgrad_trb_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
-                                                        const int kt_per_slice, float* __restrict__ dbias) {
-    constexpr int BKF = 32, RS = 72;                        // pixels per tile; bf16 per LDS row: [hi 32 | lo 32 | pad 8]
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
+                                                       const int kt_per_slice, float* __restrict__ dbias) {
+    constexpr int BKF = 32;
     constexpr int FM = BI / 64, FN = BJ / 64;
-    constexpr int NQ = (BI + BJ) / 4;                       // channel quads of Z
-    constexpr int SLOTS = (8 * NQ + 255) / 256;             // register blocks per thread (1, 2 (half used), 2)
-    constexpr int ZT = (BI + BJ) * RS;                      // bf16 per buffer
+    constexpr int A_SLOTS = BI / 32, B_SLOTS = BJ / 32;
+    constexpr int BLK = 32 * 32;                                  // bf16 per [32 pixels][32 channels] block
+    constexpr int PLANE_A = A_SLOTS * BLK, PLANE_B = B_SLOTS * BLK;
+    constexpr int BUF = 2 * (PLANE_A + PLANE_B);                  // per buffer: dY hi | dY lo | X hi | X lo
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __bf16* Zs = reinterpret_cast<__bf16*>(smem);           // [2][BI + BJ][RS]
+    __bf16* Zs = reinterpret_cast<__bf16*>(smem);                 // [2][BUF]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -1048,31 +1058,11 @@ __global__ __launch_bounds__(256) void wgrad_trb_kernel(const cdetr_wgrad_desc d
     const int kt_begin = blockIdx.y * kt_per_slice;
     const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
     if (kt_begin >= kt_end) return;
-    const int nk = kt_end - kt_begin;
 
+    const int kr = tid >> 3, cq = (tid & 7) * 4;
     const bool dense = d.g.mode == CDETR_ROWS_DENSE;
     const int ky = dense ? 0 : tap / d.g.kw, kx = dense ? 0 : tap - (tap / d.g.kw) * d.g.kw;
-    const bool do_bias = (dbias != nullptr) && tj == 0;
-
-    // ---- this thread's blocks: block b -> pixel quad pg = b & 7, channel quad cq = b >> 3 (cq < BI/4: dY, else X)
-    const int pg = tid & 7;
-    const float* cbase[SLOTS];        // operand base + clamped channel offset
-    long rstride[SLOTS];
-    bool isx[SLOTS], used[SLOTS];
-    int zrow[SLOTS];                  // first LDS row (channel) of the block
-#pragma unroll
-    for (int s = 0; s < SLOTS; ++s) {
-        const int b = tid + 256 * s;
-        const int cq = b >> 3;
-        used[s] = cq < NQ;
-        const int cqc = used[s] ? cq : 0;
-        isx[s] = cqc >= BI / 4;
-        zrow[s] = cqc * 4;
-        if (isx[s]) { cbase[s] = X + min(c0 + (cqc - BI / 4) * 4, d.Cin - 4); rstride[s] = d.ldx; }
-        else { cbase[s] = dY + min(i0 + cqc * 4, d.Nout - 4); rstride[s] = d.ldy; }
-    }
-    // first pixel of this thread's quad in the first tile, and its (n, y, x) for the tap gather
-    int p = kt_begin * BKF + pg * 4;
+    int p = kt_begin * BKF + kr;
     int pn = 0, py = 0, px = 0;
     if (!dense) {
         const int hw = d.g.Hc * d.g.Wc;
@@ -1081,42 +1071,40 @@ __global__ __launch_bounds__(256) void wgrad_trb_kernel(const cdetr_wgrad_desc d
         py = rem / d.g.Wc;
         px = rem - py * d.g.Wc;
     }
-    float4 rz[2][SLOTS][4];
-    unsigned rf[2][SLOTS];            // bit kk: pixel kk of the block contributes (inside P and the slice; for X also not padding)
+    const bool do_bias = (dbias != nullptr) && tj == 0;
+    float4 bsum[A_SLOTS];
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) bsum[s] = zero4();
+
+    // two register sets = two pixel tiles in flight; unconditional clamped loads + validity bits (see wgrad_fast_kernel)
+    float4 ra[2][A_SLOTS], rb[2][B_SLOTS];
+    unsigned rf[2] = {0, 0};
+    int acol[A_SLOTS], bcol[B_SLOTS];
+    const int nk = kt_end - kt_begin;
     int ft = 0;
-    auto fetch = [&](float4 (&q)[SLOTS][4], unsigned (&qf)[SLOTS]) __attribute__((always_inline)) {
-        const bool live = ft < nk;
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) acol[s] = min(i0 + cq + 32 * s, d.Nout - 4);
+#pragma unroll
+    for (int s = 0; s < B_SLOTS; ++s) bcol[s] = min(c0 + cq + 32 * s, d.Cin - 4);
+    auto fetch = [&](float4 (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], unsigned& qf) __attribute__((always_inline)) {
+        const bool pv = p < d.P;
+        const float* yp = dY + (long)(pv ? p : d.P - 1) * d.ldy;
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) qa[s] = ld4(yp + acol[s]);
+        long row = -1;
+        if (pv) {
+            if (dense) row = p;
+            else {
+                const int iy = py * d.g.stride - d.g.pad + ky * d.g.dil;
+                const int ix = px * d.g.stride - d.g.pad + kx * d.g.dil;
+                if (iy >= 0 && iy < d.g.Ha && ix >= 0 && ix < d.g.Wa) row = ((long)pn * d.g.Ha + iy) * d.g.Wa + ix;
+            }
+        }
+        qf = ((pv && ft < nk) ? 1u : 0u) | (row >= 0 ? 2u : 0u);
         ++ft;
-        long xrow[4];
-        unsigned xm = 0, ym = 0;
-        int qn = pn, qy = py, qx = px;
+        const float* xp = X + (row >= 0 ? row : 0) * d.ldx;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int pp = p + kk;
-            const bool pv = live && pp < d.P;
-            long row = -1;
-            if (pv) {
-                if (dense) row = pp;
-                else {
-                    const int iy = qy * d.g.stride - d.g.pad + ky * d.g.dil;
-                    const int ix = qx * d.g.stride - d.g.pad + kx * d.g.dil;
-                    if (iy >= 0 && iy < d.g.Ha && ix >= 0 && ix < d.g.Wa) row = ((long)qn * d.g.Ha + iy) * d.g.Wa + ix;
-                }
-            }
-            ym |= (pv ? 1u : 0u) << kk;
-            xm |= (row >= 0 ? 1u : 0u) << kk;
-            xrow[kk] = row >= 0 ? row : 0;
-            if (!dense) { if (++qx >= d.g.Wc) { qx = 0; if (++qy >= d.g.Hc) { qy = 0; ++qn; } } }
-        }
-#pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            qf[s] = isx[s] ? xm : ym;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const long row = isx[s] ? xrow[kk] : (long)min(p + kk, d.P - 1);
-                q[s][kk] = ld4(cbase[s] + row * rstride[s]);
-            }
-        }
+        for (int s = 0; s < B_SLOTS; ++s) qb[s] = ld4(xp + bcol[s]);
         p += BKF;
         if (!dense) {
             px += BKF;
@@ -1124,26 +1112,18 @@ __global__ __launch_bounds__(256) void wgrad_trb_kernel(const cdetr_wgrad_desc d
             while (py >= d.g.Hc) { py -= d.g.Hc; ++pn; }
         }
     };
-    float4 bsum = zero4();            // dY column sums of this thread's slot-0 block (slot 0 of every dY thread covers all of dY
-                                      // when BI <= 64; BI = 128 fills slot 0 of all 256 threads with dY as well)
-    auto stash = [&](const float4 (&q0)[SLOTS][4], const unsigned (&qf)[SLOTS], int buf) __attribute__((always_inline)) {
+    __bf16* const wbase = Zs + kr * 32 + cq;
+    auto stash = [&](const float4 (&qa)[A_SLOTS], const float4 (&qb)[B_SLOTS], unsigned qf, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < SLOTS; ++s) {
-            float4 q[4];
+        for (int s = 0; s < A_SLOTS; ++s) {
+            const float4 v = (qf & 1u) ? qa[s] : zero4();
+            stash_split4(wbase + buf * BUF + s * BLK, PLANE_A, v.x, v.y, v.z, v.w);
+            if (do_bias) { bsum[s].x += v.x; bsum[s].y += v.y; bsum[s].z += v.z; bsum[s].w += v.w; }
+        }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) q[kk] = ((qf[s] >> kk) & 1u) ? q0[s][kk] : zero4();
-            if (s == 0 && do_bias && !isx[0]) {
-                bsum.x += (q[0].x + q[1].x) + (q[2].x + q[3].x);
-                bsum.y += (q[0].y + q[1].y) + (q[2].y + q[3].y);
-                bsum.z += (q[0].z + q[1].z) + (q[2].z + q[3].z);
-                bsum.w += (q[0].w + q[1].w) + (q[2].w + q[3].w);
-            }
-            if (!used[s]) continue;
-            __bf16* dst = Zs + buf * ZT + zrow[s] * RS + pg * 4;
-            stash_split4(dst, 32, q[0].x, q[1].x, q[2].x, q[3].x);
-            stash_split4(dst + RS, 32, q[0].y, q[1].y, q[2].y, q[3].y);
-            stash_split4(dst + 2 * RS, 32, q[0].z, q[1].z, q[2].z, q[3].z);
-            stash_split4(dst + 3 * RS, 32, q[0].w, q[1].w, q[2].w, q[3].w);
+        for (int s = 0; s < B_SLOTS; ++s) {
+            const float4 v = (qf & 2u) ? qb[s] : zero4();
+            stash_split4(wbase + buf * BUF + 2 * PLANE_A + s * BLK, PLANE_B, v.x, v.y, v.z, v.w);
         }
     };
 
@@ -1155,21 +1135,27 @@ __global__ __launch_bounds__(256) void wgrad_trb_kernel(const cdetr_wgrad_desc d
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+    // transpose-read source address of this lane: 16-lane group q -> channel half (q & 1), pixel octet (q >> 1) = the MFMA k-group;
+    // inside the group lane 4j + a addresses pixel j, channels 4a .. 4a+3
+    const int l16 = lane & 15;
+    const int roff = ((g * 8 + (l16 >> 2)) * 32) + ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+    const __bf16* const abase = Zs + (wm * FM) * BLK + roff;
+    const __bf16* const bbase = Zs + 2 * PLANE_A + (wn * FN) * BLK + roff;
     auto compute = [&](int buf) __attribute__((always_inline)) {
-        const __bf16* as = Zs + buf * ZT + (wm * (BI / 2) + i32) * RS + g * 8;
-        const __bf16* bs = Zs + buf * ZT + (BI + wn * (BJ / 2) + i32) * RS + g * 8;
+        const __bf16* as = abase + buf * BUF;
+        const __bf16* bs = bbase + buf * BUF;
 #pragma unroll
         for (int hp = 0; hp < 2; ++hp) {
             bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
 #pragma unroll
             for (int a = 0; a < FM; ++a) {
-                ah[a] = *reinterpret_cast<const bf16x8*>(as + a * 32 * RS + hp * 16);
-                al[a] = *reinterpret_cast<const bf16x8*>(as + a * 32 * RS + 32 + hp * 16);
+                ah[a] = lds_tr8(as + a * BLK + hp * 512, as + a * BLK + hp * 512 + 128);
+                al[a] = lds_tr8(as + PLANE_A + a * BLK + hp * 512, as + PLANE_A + a * BLK + hp * 512 + 128);
             }
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
-                bh[b] = *reinterpret_cast<const bf16x8*>(bs + b * 32 * RS + hp * 16);
-                bl[b] = *reinterpret_cast<const bf16x8*>(bs + b * 32 * RS + 32 + hp * 16);
+                bh[b] = lds_tr8(bs + b * BLK + hp * 512, bs + b * BLK + hp * 512 + 128);
+                bl[b] = lds_tr8(bs + PLANE_B + b * BLK + hp * 512, bs + PLANE_B + b * BLK + hp * 512 + 128);
             }
 #pragma unroll
             for (int a = 0; a < FM; ++a)
@@ -1178,19 +1164,19 @@ __global__ __launch_bounds__(256) void wgrad_trb_kernel(const cdetr_wgrad_desc d
         }
     };
 
-    fetch(rz[0], rf[0]);
-    fetch(rz[1], rf[1]);
-    stash(rz[0], rf[0], 0);
+    fetch(ra[0], rb[0], rf[0]);
+    fetch(ra[1], rb[1], rf[1]);
+    stash(ra[0], rb[0], rf[0], 0);
     __syncthreads();
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
-        fetch(rz[0], rf[0]);                   // tile kt+2
+        fetch(ra[0], rb[0], rf[0]);            // tile kt+2
         compute(0);
-        stash(rz[1], rf[1], 1);
+        stash(ra[1], rb[1], rf[1], 1);
         __syncthreads();
-        fetch(rz[1], rf[1]);                   // tile kt+3
+        fetch(ra[1], rb[1], rf[1]);            // tile kt+3
         compute(1);
-        stash(rz[0], rf[0], 0);
+        stash(ra[0], rb[0], rf[0], 0);
         __syncthreads();
     }
     if (kt < nk) compute(0);
@@ -1215,17 +1201,17 @@ __global__ __launch_bounds__(256) void wgrad_trb_kernel(const cdetr_wgrad_desc d
             }
         }
     }
-    if (do_bias) {   // the 8 pixel quads of one channel quad sit in 8 consecutive lanes
-        bsum.x += __shfl_xor(bsum.x, 1, 64); bsum.y += __shfl_xor(bsum.y, 1, 64); bsum.z += __shfl_xor(bsum.z, 1, 64); bsum.w += __shfl_xor(bsum.w, 1, 64);
-        bsum.x += __shfl_xor(bsum.x, 2, 64); bsum.y += __shfl_xor(bsum.y, 2, 64); bsum.z += __shfl_xor(bsum.z, 2, 64); bsum.w += __shfl_xor(bsum.w, 2, 64);
-        bsum.x += __shfl_xor(bsum.x, 4, 64); bsum.y += __shfl_xor(bsum.y, 4, 64); bsum.z += __shfl_xor(bsum.z, 4, 64); bsum.w += __shfl_xor(bsum.w, 4, 64);
-        const int cq = tid >> 3;
-        if (pg == 0 && !isx[0] && cq < BI / 4) {
-            const int i = i0 + cq * 4;
-            if (i < d.Nout) atomicAdd(dbias + i, bsum.x);
-            if (i + 1 < d.Nout) atomicAdd(dbias + i + 1, bsum.y);
-            if (i + 2 < d.Nout) atomicAdd(dbias + i + 2, bsum.z);
-            if (i + 3 < d.Nout) atomicAdd(dbias + i + 3, bsum.w);
+    if (do_bias) {   // column sums of dY: reduce the 32 pixel rows of the block through LDS, one atomic per column
+        __syncthreads();
+        float* red = smem;   // [32][BI]
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) *reinterpret_cast<float4*>(red + kr * BI + cq + 32 * s) = bsum[s];
+        __syncthreads();
+        for (int i = tid; i < BI; i += 256) {
+            float t = 0.f;
+#pragma unroll 8
+            for (int r = 0; r < 32; ++r) t += red[r * BI + i];
+            if (i0 + i < d.Nout) atomicAdd(dbias + i0 + i, t);
         }
     }
 }
@@ -1613,8 +1599,11 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             constexpr int BI = decltype(bi_c)::value, BJ = decltype(bj_c)::value;
             const int tilesI = (d.Nout + BI - 1) / BI, tilesJ = (d.Cin + BJ - 1) / BJ;
             const long base = (long)tilesI * tilesJ * d.taps * d.batch;
-            static const long target = getenv("CDETR_WGRAD_TARGET") ? atol(getenv("CDETR_WGRAD_TARGET")) : 768;
-            long slices = (target + base - 1) / base;               // ~3 workgroups per CU
+            static const long target_env = getenv("CDETR_WGRAD_TARGET") ? atol(getenv("CDETR_WGRAD_TARGET")) : 0;
+            // ~3 workgroups per CU; weights of <= 16 tiles pay slices x (atomic epilogue + pipeline fill) for little parallelism
+            // gained: half as many slices measured 10-15 % faster there (5000x256x256, 20000x512x128)
+            const long target = target_env ? target_env : (base <= 16 ? 384 : 768);
+            long slices = (target + base - 1) / base;
             const long max_slices = (nktf + 3) / 4;                 // >= 4 k-tiles (128 pixels) per slice
             if (slices > max_slices) slices = max_slices;
             if (slices < 1) slices = 1;
@@ -1623,13 +1612,13 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             slices = (nktf + per - 1) / per;
             const int bytes = (2 * 32 * (BI + 4) + 2 * 32 * (BJ + 4)) * 4;
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
-            // measured (tools/wgrad_pmc.py): the staged-split variant is 5-15 % SLOWER than the per-fragment split on every shape of
-            // this model (the transposing stash costs more than the VALU it saves) -> opt-in only
-            static const int use_trb = getenv("CDETR_WGRAD_TRB") ? atoi(getenv("CDETR_WGRAD_TRB")) : 0;
-            if (d.precision == 1 && use_trb) {
-                const int tbytes = 2 * (BI + BJ) * 72 * 2;
-                if ((rcf = raise_lds(wgrad_trb_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
-                hipLaunchKernelGGL((wgrad_trb_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
+            // split-bf16: the transpose-read kernel is 7-20 % faster than the per-fragment split on every shape of this model
+            // (profiles/r1_gemm_sweep.txt); CDETR_WGRAD_TR=0 keeps the older kernel reachable for A/B runs
+            const int use_tr = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
+            if (d.precision == 1 && use_tr) {
+                const int tbytes = 2 * 2 * (BI + BJ) * 32 * 2;
+                if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
+                hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
             } else if (d.precision == 1) {
                 if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 1>, bytes, "cdetr_wgrad"))) return;
                 hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ, 1>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
@@ -1647,9 +1636,16 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
         if (wforce) { if (rcf) return rcf; return cdetr_launch_status("cdetr_wgrad"); }
         // measured (tools/gemm_sweep.py wgrad, profiles/r1_gemm_sweep.txt): 64x64 tiles win for 1x1 / linear layers,
         // 128-wide tiles only for the 3x3 convolutions (9 taps = 9x more output tiles per k-slice)
+        const int use_tr_sel = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
         if (d.taps > 1 && d.Nout >= 512 && d.Cin >= 512)
             launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
-        else if (d.taps > 1 && d.Nout >= 128)
+        else if (d.precision == 1 && use_tr_sel) {
+            // transpose-read kernel (profiles/r1_gemm_sweep.txt, wgrad section): 64x128 once the weight has >= 1M elements, else 64x64
+            if (d.taps == 1 && (long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128)
+                launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 128>{});
+            else
+                launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
+        } else if (d.taps > 1 && d.Nout >= 128)
             launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{});
         else
             launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});

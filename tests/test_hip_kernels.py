@@ -545,11 +545,14 @@ def test_gemm_variants_ragged_shapes(variant, monkeypatch):
         ops.PRECISION = old
 
 
-@pytest.mark.parametrize("wvariant", [0, 1, 2, 4])
-def test_wgrad_variants_ragged_shapes(wvariant, monkeypatch, precision):
-    """Weight-gradient tile variants on pixel counts / channel counts off the tile, with the fused bias gradient, 1x1 and 3x3."""
+@pytest.mark.parametrize("tr", [1, 0])
+@pytest.mark.parametrize("wvariant", [0, 1, 2, 3, 4])
+def test_wgrad_variants_ragged_shapes(wvariant, tr, monkeypatch, precision):
+    """Weight-gradient tile variants on pixel counts / channel counts off the tile, with the fused bias gradient, 1x1 and 3x3;
+    tr = 1: the LDS transpose-read kernel (default for split-bf16), tr = 0: the per-fragment-split kernel."""
     from counting_detr_amd import ops
     monkeypatch.setenv("CDETR_WGRAD_VARIANT", str(wvariant))
+    monkeypatch.setenv("CDETR_WGRAD_TR", str(tr))
     for (P, Nout, Cin) in [(1100, 64, 64), (1500, 132, 68), (2049, 256, 36), (5000, 40, 260)]:
         dY = torch.randn(P, Nout, generator=g(P))
         X = torch.randn(P, Cin, generator=g(P + 1))
