@@ -27,7 +27,8 @@ class GemmDesc(C.Structure):
                 ("B", _p), ("ldb", C.c_int64), ("sB", C.c_int64),
                 ("C", _p), ("ldc", C.c_int64), ("sC", C.c_int64),
                 ("w_scale", _p), ("bias", _p), ("resid", _p), ("ldr", C.c_int64), ("gate", _p), ("ldg", C.c_int64),
-                ("g", ConvGeom), ("B_split", _p)]
+                ("g", ConvGeom), ("B_split", _p), ("batch_inner", C.c_int32), ("pad_", C.c_int32),
+                ("sA2", C.c_int64), ("sB2", C.c_int64), ("sC2", C.c_int64)]
 
 
 class WgradDesc(C.Structure):
@@ -35,7 +36,8 @@ class WgradDesc(C.Structure):
                 ("dY", _p), ("ldy", C.c_int64), ("sY", C.c_int64),
                 ("X", _p), ("ldx", C.c_int64), ("sX", C.c_int64),
                 ("dW", _p), ("ldw", C.c_int64), ("sW", C.c_int64),
-                ("w_scale", _p), ("dbias", _p), ("g", ConvGeom)]
+                ("w_scale", _p), ("dbias", _p), ("g", ConvGeom), ("batch_inner", C.c_int32), ("pad_", C.c_int32),
+                ("sY2", C.c_int64), ("sX2", C.c_int64), ("sW2", C.c_int64)]
 
 
 class RcdaFwdDesc(C.Structure):

@@ -17,6 +17,13 @@
 
 namespace {
 
+// two-level batch index: z = outer * batch_inner + inner -> inner * s + outer * s2 (batch_inner == 0: one level, z * s)
+__host__ __device__ __forceinline__ long batch_off(int z, int inner, long s, long s2) {
+    if (inner <= 0) return (long)z * s;
+    const int zo = z / inner;
+    return (long)(z - zo * inner) * s + (long)zo * s2;
+}
+
 constexpr int BK = 16;
 constexpr int LDS_K = BK + 4;  // padded k-contiguous row
 
@@ -94,9 +101,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const cdetr_gemm_desc d, con
     const int tm = blockIdx.x % tilesM, tn = blockIdx.x / tilesM;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
-    const float* __restrict__ A = d.A + (long)z * d.sA;
-    const float* __restrict__ B = d.B + (long)z * d.sB;
-    float* __restrict__ C = d.C + (long)z * d.sC;
+    const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
+    const float* __restrict__ B = d.B + batch_off(z, d.batch_inner, d.sB, d.sB2);
+    float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
     const int K = d.K, taps = d.taps, Ktot = d.K * d.taps;
     const int nkt = (Ktot + BK - 1) / BK;
 
@@ -303,9 +310,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
     const int c0 = (tj - tap * tilesJ) * BJ;
     const int i0 = ti * BI;
     const int z = blockIdx.z;
-    const float* __restrict__ dY = d.dY + (long)z * d.sY;
-    const float* __restrict__ X = d.X + (long)z * d.sX;
-    float* __restrict__ dW = d.dW + (long)z * d.sW;
+    const float* __restrict__ dY = d.dY + batch_off(z, d.batch_inner, d.sY, d.sY2);
+    const float* __restrict__ X = d.X + batch_off(z, d.batch_inner, d.sX, d.sX2);
+    float* __restrict__ dW = d.dW + batch_off(z, d.batch_inner, d.sW, d.sW2);
     const int nkt_all = (d.P + BK - 1) / BK;
     const int kt_begin = blockIdx.y * kt_per_slice;
     const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
@@ -449,8 +456,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 // split-plane LDS rows are groups of 32 k-values, [hi 32 | lo 32] each (= the byte layout of cdetr_gemm_desc.B_split): position
 // of k inside a row, in bf16 units; the lo plane of the same k sits 32 further.
 #define KPOS(k) ((((k) >> 5) << 6) + ((k) & 31))
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds; PD: k-tiles in flight in registers
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
+    static_assert(PD == 2 || PD == 4, "register ring depth");
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
@@ -490,9 +498,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     if (tm >= tilesM) return;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = blockIdx.z;
-    const float* __restrict__ A = d.A + (long)z * d.sA;
-    const float* __restrict__ B = (BRAW ? reinterpret_cast<const float*>(d.B_split) : d.B) + (long)z * d.sB;
-    float* __restrict__ C = d.C + (long)z * d.sC;
+    const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
+    const float* __restrict__ B = (BRAW ? reinterpret_cast<const float*>(d.B_split) : d.B) + batch_off(z, d.batch_inner, d.sB, d.sB2);
+    float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
     const int K = d.K, taps = d.taps;
     const int nkt = (K / BKF) * taps;
 
@@ -529,10 +537,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     // no s_waitcnt lands between issuing a tile and computing on the previous one); scaling / splitting happens in stash().
     using BVec = typename std::conditional<TRB && NV == 2, float2, float4>::type;
     constexpr int B_REGS = TRB ? NBLK * 4 : B_SLOTS;
-    float4 ra[2][A_SLOTS];
-    unsigned rm[2] = {0, 0};                   // amask of each register set
-    BVec rb[2][B_REGS];
-    float4 rs[2][TRB ? NBLK : 1];              // TRB: per-k-row weight scales of the fetched blocks
+    float4 ra[PD][A_SLOTS];
+    unsigned rm[PD];                           // amask of each register set
+    BVec rb[PD][B_REGS];
+    float4 rs[PD][TRB ? NBLK : 1];             // TRB: per-k-row weight scales of the fetched blocks
     const float* tb[TRB ? NBLK : 1];           // TRB: this thread's block origin (k-group row, n column) at tap 0, kc 0
     int tkg[TRB ? NBLK : 1], tng[TRB ? NBLK : 1];
     if (TRB) {
@@ -739,7 +747,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
         }
     };
 
-    // ---- software pipeline: LDS[t & 1] holds tile t, register set (t+1) & 1 holds tile t+1, tile t+2 is being issued.
+    // ---- software pipeline: LDS[t & 1] holds tile t, register set (t + j) % PD holds tile t + j (j = 1 .. PD-1), tile t + PD is
+    // being issued into the set tile t was staged from.  PD = 4 keeps three tiles in flight behind the one being computed: a
+    // GEMM of this model rarely has more than one or two workgroups per CU, so bytes in flight per CU -- not the matrix pipe --
+    // set the pace of the k-loop (Little: ~2 us of L2/HBM latency x the bandwidth a CU needs).
     // The loop body is branch-free around the loads (every step fetches; past the end the last tile is fetched again and
     // never used): with conditional fetches the loaded registers become loop PHIs, the allocator copies them right after
     // the load is issued and the copy drags an s_waitcnt vmcnt(~0) in front of the MFMA block -- one tile in flight at best.
@@ -751,26 +762,49 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
             if (f_kc == K) { f_kc = 0; ++f_tap; set_tap(f_tap); }
         }
     };
+    auto step = [&](auto sc) __attribute__((always_inline)) {      // tile t (t % PD == S): issue t + PD, compute t, stage t + 1
+        constexpr int S = decltype(sc)::value, NX = (S + 1) % PD;
+        advance();
+        fetch(ra[S], rb[S], rs[S], rm[S], f_tap, f_kc);
+        compute(S & 1);
+        stash(ra[NX], rb[NX], rs[NX], rm[NX], NX & 1);
+        __syncthreads();
+    };
+    auto drain_step = [&](auto sc) __attribute__((always_inline)) { // tail: stage tile t (already in registers) and compute it
+        constexpr int S = decltype(sc)::value;
+        stash(ra[S], rb[S], rs[S], rm[S], S & 1);
+        __syncthreads();
+        compute(S & 1);
+    };
     set_tap(0);
     fetch(ra[0], rb[0], rs[0], rm[0], 0, 0);
-    advance();
-    fetch(ra[1], rb[1], rs[1], rm[1], f_tap, f_kc);
+#pragma unroll
+    for (int j = 1; j < PD; ++j) {
+        advance();
+        fetch(ra[j], rb[j], rs[j], rm[j], f_tap, f_kc);
+    }
     stash(ra[0], rb[0], rs[0], rm[0], 0);
     __syncthreads();
     int kt = 0;
-    for (; kt + 1 < nkt; kt += 2) {
-        advance();                                             // even step: tile kt in LDS[0], tile kt+1 in set 1
-        fetch(ra[0], rb[0], rs[0], rm[0], f_tap, f_kc);        // tile kt+2 -> set 0
-        compute(0);
-        stash(ra[1], rb[1], rs[1], rm[1], 1);
-        __syncthreads();
-        advance();                                             // odd step: tile kt+1 in LDS[1], tile kt+2 in set 0
-        fetch(ra[1], rb[1], rs[1], rm[1], f_tap, f_kc);        // tile kt+3 -> set 1
-        compute(1);
-        stash(ra[0], rb[0], rs[0], rm[0], 0);
-        __syncthreads();
+    for (; kt + PD < nkt; kt += PD) {
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        if constexpr (PD == 4) {
+            step(std::integral_constant<int, 2>{});
+            step(std::integral_constant<int, 3>{});
+        }
     }
-    if (kt < nkt) compute(0);                                  // odd tile count: the last tile sits in LDS[0]
+    const int rem = nkt - kt;                                      // 1 .. PD tiles left: tile kt is staged, the others sit in registers
+    compute(0);
+    if (rem > 1) {
+        drain_step(std::integral_constant<int, 1>{});
+        if constexpr (PD == 4) {
+            if (rem > 2) {
+                drain_step(std::integral_constant<int, 2>{});
+                if (rem > 3) drain_step(std::integral_constant<int, 3>{});
+            }
+        }
+    }
     mfma_drain(acc);
 
 #pragma unroll
@@ -819,9 +853,9 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
     const int c0 = (tj - tap * tilesJ) * BJ;
     const int i0 = ti * BI;
     const int z = blockIdx.z;
-    const float* __restrict__ dY = d.dY + (long)z * d.sY;
-    const float* __restrict__ X = d.X + (long)z * d.sX;
-    float* __restrict__ dW = d.dW + (long)z * d.sW;
+    const float* __restrict__ dY = d.dY + batch_off(z, d.batch_inner, d.sY, d.sY2);
+    const float* __restrict__ X = d.X + batch_off(z, d.batch_inner, d.sX, d.sX2);
+    float* __restrict__ dW = d.dW + batch_off(z, d.batch_inner, d.sW, d.sW2);
     const int nkt_all = (d.P + BKF - 1) / BKF;
     const int kt_begin = blockIdx.y * kt_per_slice;
     const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
@@ -1051,9 +1085,9 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d,
     const int c0 = (tj - tap * tilesJ) * BJ;
     const int i0 = ti * BI;
     const int z = blockIdx.z;
-    const float* __restrict__ dY = d.dY + (long)z * d.sY;
-    const float* __restrict__ X = d.X + (long)z * d.sX;
-    float* __restrict__ dW = d.dW + (long)z * d.sW;
+    const float* __restrict__ dY = d.dY + batch_off(z, d.batch_inner, d.sY, d.sY2);
+    const float* __restrict__ X = d.X + batch_off(z, d.batch_inner, d.sX, d.sX2);
+    float* __restrict__ dW = d.dW + batch_off(z, d.batch_inner, d.sW, d.sW2);
     const int nkt_all = (d.P + BKF - 1) / BKF;
     const int kt_begin = blockIdx.y * kt_per_slice;
     const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
@@ -1233,9 +1267,9 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc
     const int i = lane & 15, g4 = lane >> 4;
     const int m = tm * 16 + i, n = tn * 16 + i;
     const int z = blockIdx.z;
-    const float* __restrict__ A = d.A + (long)z * d.sA;
-    const float* __restrict__ B = d.B + (long)z * d.sB;
-    float* __restrict__ C = d.C + (long)z * d.sC;
+    const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
+    const float* __restrict__ B = d.B + batch_off(z, d.batch_inner, d.sB, d.sB2);
+    float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
     const int K = d.K;
     const int kchunks = (K + 15) >> 4;
     const int cpw = (kchunks + 3) >> 2;                 // chunks per wave
@@ -1327,9 +1361,9 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_des
     const int ti = tile % tilesI, tj = tile / tilesI;
     const int i = lane & 15, g4 = lane >> 4;
     const int z = blockIdx.z;
-    const float* __restrict__ dY = d.dY + (long)z * d.sY;
-    const float* __restrict__ X = d.X + (long)z * d.sX;
-    float* __restrict__ dW = d.dW + (long)z * d.sW;
+    const float* __restrict__ dY = d.dY + batch_off(z, d.batch_inner, d.sY, d.sY2);
+    const float* __restrict__ X = d.X + batch_off(z, d.batch_inner, d.sX, d.sX2);
+    float* __restrict__ dW = d.dW + batch_off(z, d.batch_inner, d.sW, d.sW2);
     const int ci = ti * 16 + i, cc = tj * 16 + i;
     const bool iv = ci < d.Nout, cv = cc < d.Cin;
     const float* ya = dY + (iv ? ci : 0);
@@ -1443,25 +1477,35 @@ int raise_lds(F func, int bytes, const char* what) {
     return CDETR_OK;
 }
 
-template <int WM, int WN, int FM, int FN, int BKF, int PREC, int ABL = 0>
-int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
+template <int WM, int WN, int FM, int FN, int BKF, int PREC, int ABL = 0, int PD = 2>
+int launch_gemm_fast_pd(const cdetr_gemm_desc& d, hipStream_t st) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
     dim3 grid(8 * ((tilesM + 7) / 8) * tilesN, 1, d.batch), block(64 * WM * WN);      // 8 XCD bands (see the kernel)
     int rc;
     if (d.b_layout == 0) {
         const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
-        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>, bytes, "cdetr_gemm"))) return rc;
-        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL>), grid, block, bytes, st, d, tilesM);
+        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL, PD>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL, PD>), grid, block, bytes, st, d, tilesM);
     } else {
         // the staging-split variant of the n-contiguous operand needs >= 8 elements per thread (4k x 2n blocks)
         constexpr int P0 = (PREC == 3) ? 2 : PREC;          // pre-split B only exists for the k-contiguous layout
         constexpr int P1 = (P0 == 2 && (BKF * BN) / (64 * WM * WN) < 8) ? 1 : P0;
         const int bytes = (2 * BM * (BKF + 4) + 2 * (P1 == 2 ? BN * (BKF + 4) : BKF * (BN + 4))) * 4;
-        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL>, bytes, "cdetr_gemm"))) return rc;
-        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL>), grid, block, bytes, st, d, tilesM);
+        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL, PD>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL, PD>), grid, block, bytes, st, d, tilesM);
     }
     return cdetr_launch_status("cdetr_gemm");
+}
+
+template <int WM, int WN, int FM, int FN, int BKF, int PREC, int ABL = 0>
+int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
+    // register ring depth (k-tiles in flight): CDETR_GEMM_PD = 2 | 4
+    static const int pd = getenv("CDETR_GEMM_PD") ? atoi(getenv("CDETR_GEMM_PD")) : 2;
+    if constexpr (ABL == 0 && FM == 1 && FN == 1 && BKF == 32) {
+        if (pd == 4) return launch_gemm_fast_pd<WM, WN, FM, FN, BKF, PREC, ABL, 4>(d, st);
+    }
+    return launch_gemm_fast_pd<WM, WN, FM, FN, BKF, PREC, ABL, 2>(d, st);
 }
 
 template <int WM, int WN, int FM, int FN, int BKF, int ABL = 0>
@@ -1499,13 +1543,13 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         CDETR_CHECK_ARG(d.g.Hc > 0 && d.g.Wc > 0 && d.M % (d.g.Hc * d.g.Wc) == 0, "cdetr_gemm: M is not images*Hc*Wc");
     }
     if (d.b_layout == 1 && d.taps > 1) CDETR_CHECK_ARG(d.K % BK == 0, "cdetr_gemm: dgrad with taps needs K %% 16 == 0");
-    const int vecA = ((d.K & 3) == 0 && (d.lda & 3) == 0 && (d.sA & 3) == 0 && aligned16(d.A)) ? 1 : 0;
+    const int vecA = ((d.K & 3) == 0 && (d.lda & 3) == 0 && (d.sA & 3) == 0 && (d.sA2 & 3) == 0 && aligned16(d.A)) ? 1 : 0;
     if (!vecA) CDETR_CHECK_ARG(d.g.mode == CDETR_ROWS_DENSE, "cdetr_gemm: unaligned A only supported for dense rows");
     int vecB;
     if (d.b_layout == 0)
-        vecB = ((((long)d.K * d.taps) & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && aligned16(d.B)) ? 1 : 0;
+        vecB = ((((long)d.K * d.taps) & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && (d.sB2 & 3) == 0 && aligned16(d.B)) ? 1 : 0;
     else
-        vecB = ((d.N & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && aligned16(d.B)) ? 1 : 0;
+        vecB = ((d.N & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && (d.sB2 & 3) == 0 && aligned16(d.B)) ? 1 : 0;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile choice: the largest tile that still yields >= 1.5 waves of workgroups on 256 CUs
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
@@ -1571,7 +1615,7 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
     cdetr_wgrad_desc d = *dp;
     CDETR_CHECK_ARG(d.P >= 0 && d.Nout > 0 && d.Cin > 0 && d.taps > 0 && d.batch > 0, "cdetr_wgrad: bad sizes");
     CDETR_CHECK_ARG(d.dY && d.X && d.dW, "cdetr_wgrad: null pointer");
-    CDETR_CHECK_ARG(aligned16(d.dY) && aligned16(d.X) && (d.sY & 3) == 0 && (d.sX & 3) == 0, "cdetr_wgrad: dY/X must be 16-byte aligned");
+    CDETR_CHECK_ARG(aligned16(d.dY) && aligned16(d.X) && (d.sY & 3) == 0 && (d.sX & 3) == 0 && (d.sY2 & 3) == 0 && (d.sX2 & 3) == 0, "cdetr_wgrad: dY/X must be 16-byte aligned");
     if (d.P == 0) return CDETR_OK;
     if (d.g.mode == CDETR_ROWS_DENSE) {
         CDETR_CHECK_ARG(d.taps == 1, "cdetr_wgrad: dense rows need taps == 1");
@@ -1657,7 +1701,7 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
         const int rows_per_block = 64;
         dim3 cg((d.Nout + 255) / 256, (d.P + rows_per_block - 1) / rows_per_block, 1);
         for (int zb = 0; zb < d.batch; ++zb)
-            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, st, d.dY + (long)zb * d.sY, (long)d.ldy, d.P, d.Nout, d.dbias,
+            hipLaunchKernelGGL(colsum_kernel, cg, dim3(256), 0, st, d.dY + batch_off(zb, d.batch_inner, d.sY, d.sY2), (long)d.ldy, d.P, d.Nout, d.dbias,
                                rows_per_block);
     }
     auto launch = [&](auto bi_c, auto bj_c) {

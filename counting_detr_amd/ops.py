@@ -48,8 +48,10 @@ def _geom(mode=_ffi.ROWS_DENSE, Ha=0, Wa=0, Hc=0, Wc=0, kh=1, kw=1, stride=1, pa
 
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
-             gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None):
+             gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
+             batch_inner=0, sA2=0, sB2=0, sC2=0):
     d = GemmDesc()
+    d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION
     d.A, d.lda, d.sA = ptr(A), lda, sA
@@ -65,8 +67,9 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
 
 
 def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0,
-              dbias=None):
+              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0):
     d = WgradDesc()
+    d.batch_inner, d.sY2, d.sX2, d.sW2 = batch_inner, sY2, sX2, sW2
     d.P, d.Nout, d.Cin, d.taps, d.batch = P, Nout, Cin, taps, batch
     d.precision = PRECISION
     d.dY, d.ldy, d.sY = ptr(dY), ldy, sY
@@ -400,11 +403,15 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
     dq_col = torch.empty_like(q_col)
     dk = torch.zeros(k_row.numel() + k_col.numel(), device=v.device, dtype=torch.float32)      # one fill: the k gradients accumulate
     dk_row, dk_col = dk[:k_row.numel()].view(k_row.shape), dk[k_row.numel():].view(k_col.shape)
-    for n in range(N):
-        gemm_raw(ds_row[n], Wp, k_row[n], E, dq_row[n], E, L, 32, W, b_layout=1, batch=nh, sA=L * Wp, sB=32, sC=32)
-        gemm_raw(ds_col[n], Hp, k_col[n], E, dq_col[n], E, L, 32, H, b_layout=1, batch=nh, sA=L * Hp, sB=32, sC=32)
-        wgrad_raw(ds_row[n], Wp, q_row[n], E, dk_row[n], E, L, W, 32, batch=nh, sY=L * Wp, sX=32, sW=32)
-        wgrad_raw(ds_col[n], Hp, q_col[n], E, dk_col[n], E, L, H, 32, batch=nh, sY=L * Hp, sX=32, sW=32)
+    # two-level batch (image x head): one launch per contraction for the whole batch of images
+    gemm_raw(ds_row, Wp, k_row, E, dq_row, E, L, 32, W, b_layout=1, batch=N * nh, sA=L * Wp, sB=32, sC=32,
+             batch_inner=nh, sA2=nh * L * Wp, sB2=W * E, sC2=L * E)
+    gemm_raw(ds_col, Hp, k_col, E, dq_col, E, L, 32, H, b_layout=1, batch=N * nh, sA=L * Hp, sB=32, sC=32,
+             batch_inner=nh, sA2=nh * L * Hp, sB2=H * E, sC2=L * E)
+    wgrad_raw(ds_row, Wp, q_row, E, dk_row, E, L, W, 32, batch=N * nh, sY=L * Wp, sX=32, sW=32,
+              batch_inner=nh, sY2=nh * L * Wp, sX2=L * E, sW2=W * E)
+    wgrad_raw(ds_col, Hp, q_col, E, dk_col, E, L, H, 32, batch=N * nh, sY=L * Hp, sX=32, sW=32,
+              batch_inner=nh, sY2=nh * L * Hp, sX2=L * E, sW2=H * E)
     return dq_row, dq_col, dk_row, dk_col, d_v
 
 

@@ -49,7 +49,7 @@ typedef struct {
  *           their autograd data-gradients.                                                                    */
 typedef struct {
     int32_t M, N, K, taps;
-    int32_t batch; /* grid.z; per-batch element strides sA/sB/sC (0 = shared) */
+    int32_t batch; /* grid.z; per-batch element strides sA/sB/sC (0 = shared); see batch_inner for two-level batches */
     int32_t b_layout;
     int32_t relu;
     int32_t precision; /* 0 = fp32 MFMA (exact fp32 products), 1 = split-bf16 x3 on the bf16 matrix pipe (~1e-5 rel) */
@@ -66,6 +66,9 @@ typedef struct {
                           * bf16x3 kernels, w_scale already folded in: row n = [taps*K/32 groups][hi 32 bf16 | lo 32 bf16], i.e.
                           * the byte offsets of (n, tap, k-group) equal those of the fp32 operand (ldb applies unchanged);
                           * written by cdetr_weight_mirror.  Kernels that cannot use it read B / w_scale instead.          */
+    int32_t batch_inner; /* 0: batch item z sits at z*s.  > 0: z = outer*batch_inner + inner sits at inner*s + outer*s2      */
+    int32_t pad_;        /* (e.g. heads inside images: one launch for the per-head GEMMs of every image)                  */
+    int64_t sA2, sB2, sC2;
 } cdetr_gemm_desc;
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 
@@ -83,6 +86,9 @@ typedef struct {
     const float* w_scale;
     float* dbias;
     cdetr_conv_geom g; /* mode DENSE or CONV_FWD (p = output pixel) */
+    int32_t batch_inner; /* two-level batch, as in cdetr_gemm_desc */
+    int32_t pad_;
+    int64_t sY2, sX2, sW2;
 } cdetr_wgrad_desc;
 int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
 

@@ -573,6 +573,32 @@ def test_wgrad_variants_ragged_shapes(wvariant, tr, monkeypatch, precision):
         close(wd.grad, w64.grad, msg=f"conv wgrad {Cin}->{Cout} s{st} d{dl}", rtol=5e-4, atol_scale=6e-5)
 
 
+@pytest.mark.parametrize("N,nh,L,Wk", [(2, 8, 300, 50), (3, 4, 77, 37), (2, 8, 2500, 50)])
+def test_two_level_batch_image_by_head(N, nh, L, Wk, precision):
+    """batch_inner: one launch runs the per-head contractions of every image (inner stride = head, outer stride = image):
+    dq[n,l,h,:] = sum_w S[n,h,l,w] k[n,w,h,:]  (cdetr_gemm, n-contiguous B)  and  dk[n,w,h,:] += sum_l S[n,h,l,w] q[n,l,h,:]
+    (cdetr_wgrad) -- the logits -> q / k gradient step of the RCDA backward."""
+    from counting_detr_amd import ops
+    E = nh * 32
+    Wp = (Wk + 3) & ~3
+    S = torch.randn(N, nh, L, Wp, generator=g(1))
+    S[..., Wk:] = 0
+    k = torch.randn(N, Wk, E, generator=g(2))
+    q = torch.randn(N, L, E, generator=g(3))
+    Sd, kd, qd = S.to(DEV), k.to(DEV), q.to(DEV)
+    dq = torch.empty(N, L, E, device=DEV)
+    dk = torch.zeros(N, Wk, E, device=DEV)
+    ops.gemm_raw(Sd, Wp, kd, E, dq, E, L, 32, Wk, b_layout=1, batch=N * nh, sA=L * Wp, sB=32, sC=32,
+                 batch_inner=nh, sA2=nh * L * Wp, sB2=Wk * E, sC2=L * E)
+    ops.wgrad_raw(Sd, Wp, qd, E, dk, E, L, Wk, 32, batch=N * nh, sY=L * Wp, sX=32, sW=32,
+                  batch_inner=nh, sY2=nh * L * Wp, sX2=L * E, sW2=Wk * E)
+    S64 = S[..., :Wk].double()
+    k64 = k.double().view(N, Wk, nh, 32)
+    q64 = q.double().view(N, L, nh, 32)
+    close(dq.view(N, L, nh, 32), torch.einsum("nhlw,nwhd->nlhd", S64, k64), msg="dq", **tol(precision))
+    close(dk.view(N, Wk, nh, 32), torch.einsum("nhlw,nlhd->nwhd", S64, q64), msg="dk", **tol(precision))
+
+
 def test_sine_embed_matches_reference_formula():
     """cdetr_sine_embed fwd / bwd == the tensor-op formula of A2/models/transformer.py:474-494 (fp64)."""
     import math
