@@ -7,7 +7,7 @@ for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
     if filt and filt not in k:
         continue
-    k = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:44]
+    k = k.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:64]
     agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 for k in agg:
     print(k)
