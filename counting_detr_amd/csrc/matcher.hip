@@ -233,10 +233,63 @@ __global__ __launch_bounds__(NT) void lsap_kernel(const float* __restrict__ cost
 // Same algorithm, tie rule and scan order as lsap_kernel, organised for latency: ONE wavefront per image, no barriers.
 // Lane l owns columns l, l+64, ... (<= CPL per lane): their dual v, shortest-path cost, predecessor and position in
 // scipy's `remaining` list live in REGISTERS; rows' duals / assignments, row4col, `remaining` and -- when it fits -- the
-// whole fp32 cost matrix live in LDS.  One inner iteration = CPL fused updates per lane + a 6-step shuffle arg-min.
+// whole fp32 cost matrix live in LDS.  One inner iteration = CPL fused updates per lane + a 6-step arg-min over the wave.
 // The SR/SC bookkeeping of the reference algorithm collapses to a per-lane bit mask: the visited rows (other than the
 // current one) are exactly row4col[j] of the visited non-sink columns.
-template <int CPL, bool COST_LDS>
+// The iteration is one dependent chain (next row <- arg-min <- scan <- cost row), so its latency is the kernel's time:
+//   * the arg-min runs on DPP lane permutes (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror, row_bcast 15 / 31: ~10 VALU
+//     per step) instead of 24 ds_bpermute round trips through the LDS pipe; only (value, key) are reduced -- keys are unique, so
+//     the owner of the winning pair identifies itself and its column / row4col entry are fetched with v_readlane;
+//   * row4col of the owned columns is mirrored in registers (refreshed after each augmentation), the tie keys are cached and
+//     only recomputed when a column's position in `remaining` changes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_min_f64(double x) {
+    const int lo = __double2loint(x), hi = __double2hiint(x);
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const double o = __hiloint2double(ohi, olo);
+    return (o < x) ? o : x;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_min_u32(unsigned x) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROW_MASK, 0xf, false);
+    return o < x ? o : x;
+}
+// lexicographic minimum of (val, key) over the wave, returned in every lane: first the minimum value (DPP butterfly inside the
+// rows of 16, row_bcast across them, lane 63 holds the result), then the minimum key among the lanes that hold that value
+template <bool DPP>
+__device__ __forceinline__ void wave_lexmin(double& val, unsigned& key) {
+    if constexpr (!DPP) {          // A/B reference: butterfly over ds_bpermute
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) {
+            const double ov = __shfl_xor(val, m, 64);
+            const unsigned ok = (unsigned)__shfl_xor((int)key, m, 64);
+            const bool take = (ov < val) | ((ov == val) & (ok < key));
+            val = take ? ov : val;
+            key = take ? ok : key;
+        }
+        return;
+    }
+    double m = val;
+    m = dpp_min_f64<0xB1, 0xf>(m);       // quad_perm [1,0,3,2]
+    m = dpp_min_f64<0x4E, 0xf>(m);       // quad_perm [2,3,0,1]
+    m = dpp_min_f64<0x141, 0xf>(m);      // row_half_mirror: 8 lanes
+    m = dpp_min_f64<0x140, 0xf>(m);      // row_mirror: 16 lanes
+    m = dpp_min_f64<0x142, 0xa>(m);      // row_bcast:15 into rows 1 and 3
+    m = dpp_min_f64<0x143, 0xc>(m);      // row_bcast:31 into rows 2 and 3
+    const double gmin = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(m), 63), __builtin_amdgcn_readlane(__double2loint(m), 63));
+    unsigned k = (val == gmin) ? key : 0xffffffffu;
+    k = dpp_min_u32<0xB1, 0xf>(k);
+    k = dpp_min_u32<0x4E, 0xf>(k);
+    k = dpp_min_u32<0x141, 0xf>(k);
+    k = dpp_min_u32<0x140, 0xf>(k);
+    k = dpp_min_u32<0x142, 0xa>(k);
+    k = dpp_min_u32<0x143, 0xc>(k);
+    key = (unsigned)__builtin_amdgcn_readlane((int)k, 63);
+    val = gmin;
+}
+
+template <int CPL, bool COST_LDS, bool DPP = true>
 __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__ cost_all, const int64_t* __restrict__ cost_off,
                                                        const int* __restrict__ tgt_off, int Q, int Mmax,
                                                        int64_t* __restrict__ idx_i, int64_t* __restrict__ idx_j,
@@ -259,24 +312,63 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
     int* row4col = col4row + nr;
     int* remaining = row4col + nc;
     int* pathl = remaining + nc;
-    float* cost_l = reinterpret_cast<float*>(pathl + nc);
+    float* cost_l = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(pathl + nc) + 15) & ~(uintptr_t)15);   // 16-byte aligned (the host adds 64 B of slack)
     const float* cost = COST_LDS ? cost_l : cost_g;
 
+    // cost matrix -> LDS + validity scan.  One wave has to cover the whole L2 round trip per batch of loads, so the batch is made
+    // large: 16 unconditional loads in flight per lane (clamped index, masked use) -- 16 B each when the block is 16-byte aligned.
+    // (A plain one-element-per-trip loop spent ~200 us here for a 300 x 120 matrix: more than the assignment itself.)
     int bad = 0;
-    for (long k = lane; k < (long)nr * nc; k += 64) {
-        const float c = cost_g[k];
-        if (c != c || c == -INFINITY) bad = 1;
-        if (COST_LDS) cost_l[k] = c;
+    const long ntot = (long)nr * nc;
+    constexpr int LU = 16;
+    if ((reinterpret_cast<uintptr_t>(cost_g) & 15) == 0) {
+        const long n4 = ntot >> 2;
+        const float4* g4 = reinterpret_cast<const float4*>(cost_g);
+        for (long k0 = 0; k0 < n4; k0 += 64 * LU) {
+            float4 t[LU];
+#pragma unroll
+            for (int q = 0; q < LU; ++q) t[q] = g4[min(k0 + lane + 64 * q, n4 - 1)];
+#pragma unroll
+            for (int q = 0; q < LU; ++q) {
+                const long k = k0 + lane + 64 * q;
+                if (k < n4) {
+                    const float4 c = t[q];
+                    if (c.x != c.x || c.x == -INFINITY || c.y != c.y || c.y == -INFINITY || c.z != c.z || c.z == -INFINITY ||
+                        c.w != c.w || c.w == -INFINITY) bad = 1;
+                    if (COST_LDS) *reinterpret_cast<float4*>(cost_l + 4 * k) = c;
+                }
+            }
+        }
+        for (long k = (n4 << 2) + lane; k < ntot; k += 64) {
+            const float c = cost_g[k];
+            if (c != c || c == -INFINITY) bad = 1;
+            if (COST_LDS) cost_l[k] = c;
+        }
+    } else {
+        for (long k0 = 0; k0 < ntot; k0 += 64 * LU) {
+            float t[LU];
+#pragma unroll
+            for (int q = 0; q < LU; ++q) t[q] = cost_g[min(k0 + lane + 64 * q, ntot - 1)];
+#pragma unroll
+            for (int q = 0; q < LU; ++q) {
+                const long k = k0 + lane + 64 * q;
+                if (k < ntot) {
+                    if (t[q] != t[q] || t[q] == -INFINITY) bad = 1;
+                    if (COST_LDS) cost_l[k] = t[q];
+                }
+            }
+        }
     }
     if (__any(bad)) { if (lane == 0) status[b] = 2; return; }
     for (int i = lane; i < nr; i += 64) { u[i] = 0.0; col4row[i] = -1; }
     for (int j = lane; j < nc; j += 64) row4col[j] = -1;
 
     double v[CPL], spc[CPL];
-    int path[CPL], pos[CPL];
-    unsigned unas = 0;                       // bit c: this lane's column c is unassigned (row4col == -1), refreshed per row
+    int path[CPL], r4c[CPL];                 // r4c: register mirror of row4col for the owned columns
+    unsigned key[CPL];                       // tie key of the owned columns (see below), valid while the column is unvisited
+    unsigned valid = 0;                      // bit c: column lane + 64c exists
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; path[c] = -1; if (lane + 64 * c < nc) unas |= 1u << c; }
+    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; path[c] = -1; r4c[c] = -1; if (lane + 64 * c < nc) valid |= 1u << c; }
 
     // The scan's tie rule (strictly smaller value wins; among equal values the LAST unassigned column, else the FIRST
     // column -- positions refer to the `remaining` array) is folded into ONE 32-bit key to minimise next to the value:
@@ -284,51 +376,64 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
     for (int cur = 0; cur < nr; ++cur) {
         unsigned sc = 0;                       // visited-column mask of this lane
 #pragma unroll
-        for (int c = 0; c < CPL; ++c) { spc[c] = INFINITY; pos[c] = nc - 1 - (lane + 64 * c); }
+        for (int c = 0; c < CPL; ++c) {
+            spc[c] = INFINITY;
+            const unsigned p0 = (unsigned)(nc - 1 - (lane + 64 * c));
+            key[c] = (r4c[c] == -1) ? (0x7fffffffu - p0) : (0x80000000u + p0);
+        }
         for (int it = lane; it < nc; it += 64) remaining[it] = nc - 1 - it;
         int i = cur, num_remaining = nc, sink = -1;
         double min_val = 0.0;
         while (true) {
+            const int last = num_remaining - 1;
+            const int jlast = *reinterpret_cast<volatile int*>(remaining + last);   // needed only after the arg-min; volatile keeps the
+                                                                                   // read up here, off the critical path
             const float* crow = cost + (long)i * nc;
+            const double ui = u[i];
             double bval = INFINITY;
             unsigned bkey = 0xffffffffu;
-            int best_j = -1;
+            int best_c = 0;
+            const unsigned act = valid & ~sc;
+            // branch-free scan (selects, no exec-mask regions): columns past nc read a clamped address and are masked out
 #pragma unroll
             for (int c = 0; c < CPL; ++c) {
-                const int j = lane + 64 * c;
-                if (j < nc && !((sc >> c) & 1u)) {
-                    const double r = ((min_val + (double)crow[j]) - u[i]) - v[c];
-                    if (r < spc[c]) { path[c] = i; spc[c] = r; }
-                    const unsigned key = ((unas >> c) & 1u) ? (0x7fffffffu - (unsigned)pos[c]) : (0x80000000u + (unsigned)pos[c]);
-                    if (spc[c] < bval || (spc[c] == bval && key < bkey)) { bval = spc[c]; bkey = key; best_j = j; }
-                }
+                const bool a = (act >> c) & 1u;
+                const int jj = ((valid >> c) & 1u) ? lane + 64 * c : 0;
+                const double r = ((min_val + (double)crow[jj]) - ui) - v[c];
+                const bool upd = a & (r < spc[c]);
+                spc[c] = upd ? r : spc[c];
+                path[c] = upd ? i : path[c];
+                const bool better = a & ((spc[c] < bval) | ((spc[c] == bval) & (key[c] < bkey)));
+                bval = better ? spc[c] : bval;
+                bkey = better ? key[c] : bkey;
+                best_c = better ? c : best_c;
             }
-#pragma unroll
-            for (int m = 32; m > 0; m >>= 1) {
-                const double ov = __shfl_xor(bval, m, 64);
-                const unsigned ok = (unsigned)__shfl_xor((int)bkey, m, 64);
-                const int oj2 = __shfl_xor(best_j, m, 64);
-                if (ov < bval || (ov == bval && ok < bkey)) { bval = ov; bkey = ok; best_j = oj2; }
-            }
+            const double my_val = bval;
+            const unsigned my_key = bkey;
+            wave_lexmin<DPP>(bval, bkey);
             if (bkey == 0xffffffffu || bval == INFINITY) { sink = -2; break; }
             min_val = bval;
-            const int jstar = best_j;
+            // keys are unique among candidates: exactly one lane owns the winning pair
+            const bool mine = (my_key == bkey) && (my_val == bval);
+            const int wl = __builtin_ctzll(__ballot(mine));
+            int my_r = r4c[0];
+#pragma unroll
+            for (int c = 1; c < CPL; ++c) my_r = (best_c == c) ? r4c[c] : my_r;
+            const int jstar = __builtin_amdgcn_readlane(lane + 64 * best_c, wl);
+            const int inext = __builtin_amdgcn_readlane(my_r, wl);
             const bool j_unassigned = (bkey & 0x80000000u) == 0u;
             const int best_it = j_unassigned ? (int)(0x7fffffffu - bkey) : (int)(bkey - 0x80000000u);
-            // visited-column bit on the owner lane
-#pragma unroll
-            for (int c = 0; c < CPL; ++c)
-                if (lane + 64 * c == jstar) sc |= (1u << c);
-            // swap-removal from `remaining` (position best_it), keeping every column's position in registers
-            const int last = num_remaining - 1;
-            const int jlast = remaining[last];
+            sc |= mine ? (1u << best_c) : 0u;             // visited-column bit on the owner lane
+            // swap-removal from `remaining` (position best_it): the column that sat last moves to best_it
             if (lane == 0) remaining[best_it] = jlast;
 #pragma unroll
-            for (int c = 0; c < CPL; ++c)
-                if (lane + 64 * c == jlast) pos[c] = best_it;
+            for (int c = 0; c < CPL; ++c) {
+                const unsigned nk = (r4c[c] == -1) ? (0x7fffffffu - (unsigned)best_it) : (0x80000000u + (unsigned)best_it);
+                key[c] = (lane + 64 * c == jlast) ? nk : key[c];
+            }
             num_remaining = last;
             if (j_unassigned) { sink = jstar; break; }
-            i = row4col[jstar];
+            i = inext;
         }
         if (sink == -2) { if (lane == 0) status[b] = 1; return; }
         // ---- dual update: rows visited (other than cur) = row4col[j] of the visited non-sink columns
@@ -339,7 +444,7 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
             if ((sc >> c) & 1u) {
                 const double delta = min_val - spc[c];
                 v[c] -= delta;
-                if (j != sink) u[row4col[j]] += delta;
+                if (j != sink) u[r4c[c]] += delta;
             }
             if (j < nc) pathl[j] = path[c];
         }
@@ -355,10 +460,10 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
                 if (ii == cur) break;
             }
         }
-        // the walk assigned exactly one new column: the sink (same wave: the LDS writes above are ordered by program order)
+        // refresh the register mirror (same wave: the LDS writes above are ordered by program order)
 #pragma unroll
         for (int c = 0; c < CPL; ++c)
-            if (lane + 64 * c == sink) unas &= ~(1u << c);
+            if ((valid >> c) & 1u) r4c[c] = row4col[lane + 64 * c];
     }
     // ---- (query, target) pairs with ascending query index
     if (!transpose) {
@@ -419,7 +524,12 @@ extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int3
         // columns per lane = ceil(nc_max / 64): the per-iteration column scan is unrolled exactly that far
         if (nc_max <= 128) { if (cost_lds) go(lsap_wave_kernel<2, true>); else go(lsap_wave_kernel<2, false>); }
         else if (nc_max <= 256) { if (cost_lds) go(lsap_wave_kernel<4, true>); else go(lsap_wave_kernel<4, false>); }
-        else if (nc_max <= 320) { if (cost_lds) go(lsap_wave_kernel<5, true>); else go(lsap_wave_kernel<5, false>); }
+        else if (nc_max <= 320) {
+            static const bool shfl = getenv("CDETR_LSAP_SHFL") != nullptr;      // A/B knob: arg-min over ds_bpermute instead of DPP
+            if (cost_lds && shfl) go(lsap_wave_kernel<5, true, false>);
+            else if (cost_lds) go(lsap_wave_kernel<5, true>);
+            else go(lsap_wave_kernel<5, false>);
+        }
         else if (nc_max <= 512) { if (cost_lds) go(lsap_wave_kernel<8, true>); else go(lsap_wave_kernel<8, false>); }
         else { if (cost_lds) go(lsap_wave_kernel<16, true>); else go(lsap_wave_kernel<16, false>); }
         return cdetr_launch_status("cdetr_lsap");

@@ -298,7 +298,9 @@ def test_match_cost_values(golden):
 
 
 @pytest.mark.parametrize("Q,T,kind", [(300, 37, "float"), (64, 64, "ties"), (50, 120, "ties"), (120, 50, "ints"),
-                                      (900, 900, "float"), (300, 1500, "float"), (7, 1, "float")])
+                                      (900, 900, "float"), (300, 1500, "float"), (7, 1, "float"), (300, 120, "float"),
+                                      (300, 120, "ties"), (300, 120, "ints"), (576, 200, "ties"), (130, 128, "ties"),
+                                      (65, 64, "ints"), (320, 319, "ties"), (512, 3, "ints"), (1000, 64, "ties")])
 def test_lsap_vs_scipy(Q, T, kind):
     """The device solver returns scipy's (row_ind, col_ind), ties included, when fed the same matrix."""
     from scipy.optimize import linear_sum_assignment
