@@ -12,7 +12,7 @@ from collections import defaultdict
 
 
 def family(name):
-    for key in ("igemm_fast", "igemm_direct", "igemm_kernel", "wgrad_fast", "wgrad_direct", "wgrad_kernel", "rcda_fwd", "rcda_bwd",
+    for key in ("igemm_fast", "igemm_direct", "igemm_kernel", "wgrad_tr", "wgrad_fast", "wgrad_direct", "wgrad_kernel", "rcda_fwd", "rcda_bwd",
                 "rcda_dv", "mha_fwd", "mha_bwd", "lsap", "match_cost", "adamw", "sumsq", "ln_fwd", "ln_bwd", "maxpool"):
         if key in name:
             return key
