@@ -14,6 +14,8 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
+#include <algorithm>
 
 namespace {
 
@@ -1064,8 +1066,8 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
 }
 
 template <int BI, int BJ>
-__global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
-                                                       const int kt_per_slice, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const int tilesI, const int tilesJ, const int kt_per_slice,
+                                              float* __restrict__ dbias, const int bx, const int by, const int bz, const bool single) {
     constexpr int BKF = 32;
     constexpr int FM = BI / 64, FN = BJ / 64;
     constexpr int A_SLOTS = BI / 32, B_SLOTS = BJ / 32;
@@ -1079,17 +1081,17 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d,
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
     const int i32 = lane & 31, g = lane >> 5;
-    const int ti = blockIdx.x % tilesI;
-    const int tj = blockIdx.x / tilesI;
+    const int ti = bx % tilesI;
+    const int tj = bx / tilesI;
     const int tap = tj / tilesJ;
     const int c0 = (tj - tap * tilesJ) * BJ;
     const int i0 = ti * BI;
-    const int z = blockIdx.z;
+    const int z = bz;
     const float* __restrict__ dY = d.dY + batch_off(z, d.batch_inner, d.sY, d.sY2);
     const float* __restrict__ X = d.X + batch_off(z, d.batch_inner, d.sX, d.sX2);
     float* __restrict__ dW = d.dW + batch_off(z, d.batch_inner, d.sW, d.sW2);
     const int nkt_all = (d.P + BKF - 1) / BKF;
-    const int kt_begin = blockIdx.y * kt_per_slice;
+    const int kt_begin = by * kt_per_slice;
     const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
     if (kt_begin >= kt_end) return;
 
@@ -1216,7 +1218,6 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d,
     if (kt < nk) compute(0);
 
     mfma_drain(acc);
-    const bool single = (gridDim.y == 1);
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
 #pragma unroll
@@ -1248,6 +1249,31 @@ __global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d,
             if (i0 + i < d.Nout) atomicAdd(dbias + i0 + i, t);
         }
     }
+}
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
+                                                       const int kt_per_slice, float* __restrict__ dbias) {
+    wgrad_tr_body<BI, BJ>(d, tilesI, tilesJ, kt_per_slice, dbias, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
+}
+
+// Grouped launch: up to WG_MAX independent weight-gradient problems (arbitrary pointers / shapes, same kernel variant) in ONE
+// launch.  The problems' workgroups are concatenated along grid.x; a workgroup finds its problem with a short scalar scan of
+// the (kernel-argument resident) table.  Problems of one group may accumulate into the same dW, so every partial sum is added
+// atomically (`single` = false).
+constexpr int WG_MAX = 16;
+struct WgradGroupItem { cdetr_wgrad_desc d; int tilesI, tilesJ, per, nx, ny; int pad_; };
+struct WgradGroupArgs { int n; int blk0[WG_MAX + 1]; WgradGroupItem it[WG_MAX]; };
+static_assert(sizeof(WgradGroupArgs) <= 4000, "grouped launch arguments must fit the kernel-argument segment");
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const WgradGroupArgs g) {
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
+    const WgradGroupItem& it = g.it[p];
+    const int lb = blockIdx.x - g.blk0[p];
+    const int bx = lb % it.nx, r = lb / it.nx;
+    wgrad_tr_body<BI, BJ>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, bx, r % it.ny, r / it.ny, false);
 }
 
 // ------------------------------------------------------------------------------------------------ direct small GEMMs
@@ -1352,15 +1378,15 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc
 
 // dW[i][c] += scale[i] * sum_p dY[p][i] X[p][c] (+ dbias[i] += sum_p dY[p][i]) for short reductions (P <= 1024):
 // one wave = one 16x16 output tile x one slice of the pixel range (grid.y slices); results are added atomically.
-__global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
-                                                           const int p_per_slice, float* __restrict__ dbias) {
+__device__ __forceinline__ void wgrad_direct_body(const cdetr_wgrad_desc& d, const int tilesI, const int tilesJ, const int p_per_slice,
+                                                  float* __restrict__ dbias, const int bx, const int by, const int bz, const bool single) {
     constexpr int UB = 8;
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wid;
+    const int tile = bx * 4 + wid;
     if (tile >= tilesI * tilesJ) return;
     const int ti = tile % tilesI, tj = tile / tilesI;
     const int i = lane & 15, g4 = lane >> 4;
-    const int z = blockIdx.z;
+    const int z = bz;
     const float* __restrict__ dY = d.dY + batch_off(z, d.batch_inner, d.sY, d.sY2);
     const float* __restrict__ X = d.X + batch_off(z, d.batch_inner, d.sX, d.sX2);
     float* __restrict__ dW = d.dW + batch_off(z, d.batch_inner, d.sW, d.sW2);
@@ -1369,7 +1395,7 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_des
     const float* ya = dY + (iv ? ci : 0);
     const float* xb = X + (cv ? cc : 0);
     const float fa = iv ? 1.f : 0.f, fb = cv ? 1.f : 0.f;
-    const int pbeg = blockIdx.y * p_per_slice, pend = min(d.P, pbeg + p_per_slice);
+    const int pbeg = by * p_per_slice, pend = min(d.P, pbeg + p_per_slice);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     for (int p0 = pbeg; p0 < pend; p0 += 16 * UB) {
@@ -1394,7 +1420,6 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_des
     }
     mfma_drain(acc);
     const int co = tj * 16 + i;
-    const bool single = gridDim.y == 1;
     if (co < d.Cin) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1412,6 +1437,20 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_des
         bsum += __shfl_xor(bsum, 32, 64);
         if (g4 == 0 && iv) atomicAdd(dbias + ci, bsum);
     }
+}
+
+__global__ __launch_bounds__(256) void wgrad_direct_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
+                                                           const int p_per_slice, float* __restrict__ dbias) {
+    wgrad_direct_body(d, tilesI, tilesJ, p_per_slice, dbias, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
+}
+
+__global__ __launch_bounds__(256) void wgrad_direct_group_kernel(const WgradGroupArgs g) {
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
+    const WgradGroupItem& it = g.it[p];
+    const int lb = blockIdx.x - g.blk0[p];
+    const int bx = lb % it.nx, r = lb / it.nx;
+    wgrad_direct_body(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, bx, r % it.ny, r / it.ny, false);
 }
 
 // ------------------------------------------------------------------------------------------------ small kernels
@@ -1610,32 +1649,46 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     return launch_gemm<64, 64>(d, st, vecA, vecB);
 }
 
-extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
-    CDETR_CHECK_ARG(dp != nullptr, "cdetr_wgrad: null descriptor");
-    cdetr_wgrad_desc d = *dp;
+namespace {
+int check_wgrad_desc(const cdetr_wgrad_desc& d) {
     CDETR_CHECK_ARG(d.P >= 0 && d.Nout > 0 && d.Cin > 0 && d.taps > 0 && d.batch > 0, "cdetr_wgrad: bad sizes");
     CDETR_CHECK_ARG(d.dY && d.X && d.dW, "cdetr_wgrad: null pointer");
     CDETR_CHECK_ARG(aligned16(d.dY) && aligned16(d.X) && (d.sY & 3) == 0 && (d.sX & 3) == 0 && (d.sY2 & 3) == 0 && (d.sX2 & 3) == 0, "cdetr_wgrad: dY/X must be 16-byte aligned");
-    if (d.P == 0) return CDETR_OK;
     if (d.g.mode == CDETR_ROWS_DENSE) {
         CDETR_CHECK_ARG(d.taps == 1, "cdetr_wgrad: dense rows need taps == 1");
     } else {
         CDETR_CHECK_ARG(d.g.mode == CDETR_ROWS_CONV_FWD && d.taps == d.g.kh * d.g.kw, "cdetr_wgrad: geometry");
         CDETR_CHECK_ARG(d.P % (d.g.Hc * d.g.Wc) == 0, "cdetr_wgrad: P is not images*Hc*Wc");
     }
+    return CDETR_OK;
+}
+// few-pixel problems (decoder, positional MLPs): pixel slices of <= 128 pixels (8 chunks: one round trip) per wave
+void direct_wgrad_plan(const cdetr_wgrad_desc& d, int& tilesI, int& tilesJ, int& per, int& slices) {
+    tilesI = (d.Nout + 15) / 16; tilesJ = (d.Cin + 15) / 16;
+    slices = (d.P + 127) / 128;
+    if (slices > 8) slices = 8;
+    per = (d.P + slices - 1) / slices;
+    per = ((per + 15) / 16) * 16;
+    slices = (d.P + per - 1) / per;
+}
+bool wgrad_is_direct(const cdetr_wgrad_desc& d) { return d.g.mode == CDETR_ROWS_DENSE && d.P <= 1024; }
+bool wgrad_is_fast(const cdetr_wgrad_desc& d) { return (d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0; }
+}  // namespace
+
+extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
+    CDETR_CHECK_ARG(dp != nullptr, "cdetr_wgrad: null descriptor");
+    cdetr_wgrad_desc d = *dp;
+    if (int rcv = check_wgrad_desc(d)) return rcv;
+    if (d.P == 0) return CDETR_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (d.g.mode == CDETR_ROWS_DENSE && d.P <= 1024) {
-        const int tilesI = (d.Nout + 15) / 16, tilesJ = (d.Cin + 15) / 16;
-        int slices = (d.P + 127) / 128;                  // <= 128 pixels (8 chunks: one round trip) per wave
-        if (slices > 8) slices = 8;
-        int per = (d.P + slices - 1) / slices;
-        per = ((per + 15) / 16) * 16;
-        slices = (d.P + per - 1) / per;
+    if (wgrad_is_direct(d)) {
+        int tilesI, tilesJ, per, slices;
+        direct_wgrad_plan(d, tilesI, tilesJ, per, slices);
         dim3 grid((tilesI * tilesJ + 3) / 4, slices, d.batch);
         hipLaunchKernelGGL(wgrad_direct_kernel, grid, dim3(256), 0, st, d, tilesI, tilesJ, per, d.dbias);
         return cdetr_launch_status("cdetr_wgrad");
     }
-    const bool fast = (d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0;
+    const bool fast = wgrad_is_fast(d);
     if (fast) {
         const int nktf = (d.P + 31) / 32;
         int rcf = CDETR_OK;
@@ -1727,6 +1780,72 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
     else
         launch(std::integral_constant<int, 64>{}, std::integral_constant<int, 64>{});
     return cdetr_launch_status("cdetr_wgrad");
+}
+
+// A batch of INDEPENDENT weight-gradient problems.  Problems that the 64x64 transpose-read kernel or the few-pixel kernel would
+// take anyway are concatenated into grouped launches (wgrad_tr_group_kernel / wgrad_direct_group_kernel, <= WG_MAX problems
+// each); everything else runs through cdetr_wgrad one by one.  A layer's weight gradients depend on nothing but their own dY / X
+// and nothing but the optimizer consumes them, so the host queues them and submits them together: the ~100 few-pixel launches of
+// a step are latency bound (~7 us each for microseconds of work) and the encoder's 16-tile problems cannot fill the chip alone.
+extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void* stream) {
+    CDETR_CHECK_ARG(n >= 0 && (descs != nullptr || n == 0), "cdetr_wgrad_group: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static const int grouping = getenv("CDETR_WGRAD_GROUP") ? atoi(getenv("CDETR_WGRAD_GROUP")) : 1;
+    const int use_tr = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
+    const bool forced = getenv("CDETR_WGRAD_VARIANT") && atoi(getenv("CDETR_WGRAD_VARIANT")) != 0;
+    std::vector<int> direct, tr64;
+    for (int i = 0; i < n; ++i) {
+        const cdetr_wgrad_desc& d = descs[i];
+        if (int rcv = check_wgrad_desc(d)) return rcv;
+        if (d.P == 0) continue;
+        if (grouping && wgrad_is_direct(d)) direct.push_back(i);
+        else if (grouping && wgrad_is_fast(d) && d.precision == 1 && use_tr && !forced && d.g.mode == CDETR_ROWS_DENSE &&
+                 !((long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128))
+            tr64.push_back(i);                               // = the shapes cdetr_wgrad gives to wgrad_tr_kernel<64, 64>
+        else if (int rc1 = cdetr_wgrad(&d, stream)) return rc1;
+    }
+    for (size_t c0 = 0; c0 < direct.size(); c0 += WG_MAX) {
+        const int m = (int)std::min<size_t>(WG_MAX, direct.size() - c0);
+        if (m == 1) { if (int rc1 = cdetr_wgrad(&descs[direct[c0]], stream)) return rc1; continue; }
+        WgradGroupArgs g;
+        g.n = m; g.blk0[0] = 0;
+        for (int k = 0; k < m; ++k) {
+            WgradGroupItem& it = g.it[k];
+            it.d = descs[direct[c0 + k]];
+            int slices;
+            direct_wgrad_plan(it.d, it.tilesI, it.tilesJ, it.per, slices);
+            it.nx = (it.tilesI * it.tilesJ + 3) / 4; it.ny = slices; it.pad_ = 0;
+            g.blk0[k + 1] = g.blk0[k] + it.nx * it.ny * it.d.batch;
+        }
+        hipLaunchKernelGGL(wgrad_direct_group_kernel, dim3(g.blk0[m]), dim3(256), 0, st, g);
+        if (int rcl = cdetr_launch_status("cdetr_wgrad_group")) return rcl;
+    }
+    for (size_t c0 = 0; c0 < tr64.size(); c0 += WG_MAX) {
+        const int m = (int)std::min<size_t>(WG_MAX, tr64.size() - c0);
+        if (m == 1) { if (int rc1 = cdetr_wgrad(&descs[tr64[c0]], stream)) return rc1; continue; }
+        WgradGroupArgs g;
+        g.n = m; g.blk0[0] = 0;
+        // one common slice length (k-tiles per workgroup) for the whole launch: ~3 workgroups per CU in total, equal work each
+        long work = 0;
+        for (int k = 0; k < m; ++k) {
+            const cdetr_wgrad_desc& d = descs[tr64[c0 + k]];
+            work += (long)((d.Nout + 63) / 64) * ((d.Cin + 63) / 64) * d.batch * ((d.P + 31) / 32);
+        }
+        long per_all = (work + 767) / 768;
+        if (per_all < 4) per_all = 4;
+        for (int k = 0; k < m; ++k) {
+            WgradGroupItem& it = g.it[k];
+            it.d = descs[tr64[c0 + k]];
+            const int nkt = (it.d.P + 31) / 32;
+            it.tilesI = (it.d.Nout + 63) / 64; it.tilesJ = (it.d.Cin + 63) / 64;
+            it.per = (int)std::min<long>(per_all, nkt);
+            it.nx = it.tilesI * it.tilesJ; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
+            g.blk0[k + 1] = g.blk0[k] + it.nx * it.ny * it.d.batch;
+        }
+        hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
+        if (int rcl = cdetr_launch_status("cdetr_wgrad_group")) return rcl;
+    }
+    return CDETR_OK;
 }
 
 extern "C" int cdetr_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, void* stream) {

@@ -67,7 +67,7 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
 
 
 def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0,
-              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0):
+              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False):
     d = WgradDesc()
     d.batch_inner, d.sY2, d.sX2, d.sW2 = batch_inner, sY2, sX2, sW2
     d.P, d.Nout, d.Cin, d.taps, d.batch = P, Nout, Cin, taps, batch
@@ -78,8 +78,37 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
     d.w_scale = ptr(w_scale)
     d.dbias = ptr(dbias)
     d.g = geom if geom is not None else _geom()
+    if may_defer and _WG_QUEUE is not None:       # inside wgrad_queue(): submitted together by its exit (cdetr_wgrad_group)
+        _WG_QUEUE.append((d, 2.0 * P * Nout * Cin * taps * batch, (dY, X, dW, w_scale, dbias)))
+        return
     with _Timed("wgrad", 2.0 * P * Nout * Cin * taps * batch, (P, Nout, Cin, taps, -1, batch)):
         check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
+
+
+_WG_QUEUE = None
+
+
+class wgrad_queue:
+    """Context manager: PARAMETER-gradient calls (`_wg`) issued inside are queued and submitted as ONE cdetr_wgrad_group call on
+    exit (grouped launches).  Legal because a layer's parameter gradients are independent of each other and nothing inside a
+    backward reads the gradient buffers -- only the optimizer / gradient exchange do, after the block.  The operand tensors
+    are kept alive until the flush.  Weight-gradient-shaped contractions whose result the backward itself consumes (the RCDA
+    key gradients) are never deferred."""
+
+    def __enter__(self):
+        global _WG_QUEUE
+        self.prev = _WG_QUEUE
+        _WG_QUEUE = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _WG_QUEUE
+        q, _WG_QUEUE = _WG_QUEUE, self.prev
+        if et is None and q:
+            arr = (WgradDesc * len(q))(*[e[0] for e in q])
+            with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0)):
+                check(lib().cdetr_wgrad_group(arr, len(q), stream_ptr()), "cdetr_wgrad_group")
+        return False
 
 
 def colsum_(X2d, out):
@@ -554,7 +583,8 @@ def _wg(dy2d, x2d, wparam, bparam, lo, hi):
         return
     gw = grad_buffer(wparam)[lo:hi]
     gb = grad_buffer(bparam)[lo:hi] if (bparam is not None and bparam.requires_grad) else None
-    wgrad_raw(dy2d, dy2d.stride(0), x2d, x2d.stride(0), gw, gw.stride(0), dy2d.shape[0], hi - lo, x2d.shape[1], dbias=gb)
+    wgrad_raw(dy2d, dy2d.stride(0), x2d, x2d.stride(0), gw, gw.stride(0), dy2d.shape[0], hi - lo, x2d.shape[1], dbias=gb,
+              may_defer=True)
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -592,6 +622,11 @@ class EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dX2):
+        with wgrad_queue():          # the layer's 8 parameter gradients: one grouped submission at the end
+            return EncoderLayerFn._backward(ctx, dX2)
+
+    @staticmethod
+    def _backward(ctx, dX2):
         (X, Qr, Qc, Kr, Kc, q_row, q_col, k_row, k_col, v, a_row, a_col, o, Y1, mu1, rs1, X1, Hd, Y2, mu2, rs2) = ctx.saved_tensors
         layer = ctx.layer
         N, H, W, Cc, E, nh = ctx.dims
@@ -702,6 +737,11 @@ class DecoderStackFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *d_outs):
+        with wgrad_queue():          # ~13 small parameter gradients per layer, all layers: submitted in groups at the end
+            return DecoderStackFn._backward(ctx, *d_outs)
+
+    @staticmethod
+    def _backward(ctx, *d_outs):
         layers, saved = ctx.layers, ctx.saved
         N, L, E, H, W = ctx.dims
         mem2, krm2, kcm2 = ctx.shared

@@ -91,6 +91,12 @@ typedef struct {
     int64_t sY2, sX2, sW2;
 } cdetr_wgrad_desc;
 int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
+/* n INDEPENDENT weight-gradient problems submitted together (same semantics as n cdetr_wgrad calls in any order; problems may
+ * accumulate into the same dW / dbias).  Problems of the few-pixel and of the 64x64 transpose-read kernel class run as grouped
+ * launches (one kernel for up to 16 problems), the rest one by one.  Replaces: the per-parameter autograd weight-gradient nodes of
+ * one layer's backward (torch.autograd of F.linear at A2/models/transformer.py:242-279, 337-409), whose results only the
+ * optimizer reads.                                                                                                       */
+int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void* stream);
 
 /* out[n] += sum_m X[m][n]   (bias gradients; atomics) */
 int cdetr_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, void* stream);

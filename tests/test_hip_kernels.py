@@ -601,6 +601,38 @@ def test_two_level_batch_image_by_head(N, nh, L, Wk, precision):
     close(dk.view(N, Wk, nh, 32), torch.einsum("nhlw,nlhd->nwhd", S64, q64), msg="dk", **tol(precision))
 
 
+def test_wgrad_group_matches_individual_calls(precision):
+    """cdetr_wgrad_group: a queue of independent parameter gradients (few-pixel, 64x64 transpose-read and other kernel classes,
+    two of them accumulating into the SAME dW / dbias, 19 problems = two grouped launches of one class) == the sum of the
+    individual contractions (fp64 reference)."""
+    from counting_detr_amd import ops
+    shapes = [(600, 256, 256), (100, 256, 256), (5000, 256, 256), (5000, 1024, 256), (5000, 256, 1024), (1500, 132, 68),
+              (5000, 2048, 512), (77, 4, 256), (600, 2, 256)] + [(300 + 17 * k, 64, 96) for k in range(10)]
+    refs, bufs, keep = [], [], []
+    with ops.wgrad_queue():
+        for k, (P, Nout, Cin) in enumerate(shapes):
+            dY = torch.randn(P, Nout, generator=g(3 * k))
+            X = torch.randn(P, Cin, generator=g(3 * k + 1))
+            dW = torch.zeros(Nout, Cin, device=DEV)
+            db = torch.zeros(Nout, device=DEV)
+            dYd, Xd = dY.to(DEV), X.to(DEV)
+            ops.wgrad_raw(dYd, Nout, Xd, Cin, dW, Cin, P, Nout, Cin, dbias=db, may_defer=True)
+            ref_w, ref_b = dY.double().t() @ X.double(), dY.double().sum(0)
+            if k in (0, 2):       # a second problem accumulating into the same buffers
+                dY2 = torch.randn(P, Nout, generator=g(1000 + k))
+                X2 = torch.randn(P, Cin, generator=g(2000 + k))
+                dY2d, X2d = dY2.to(DEV), X2.to(DEV)
+                ops.wgrad_raw(dY2d, Nout, X2d, Cin, dW, Cin, P, Nout, Cin, dbias=db, may_defer=True)
+                ref_w = ref_w + dY2.double().t() @ X2.double()
+                ref_b = ref_b + dY2.double().sum(0)
+                keep += [dY2d, X2d]
+            refs.append((ref_w, ref_b)); bufs.append((dW, db)); keep += [dYd, Xd]
+        assert float(bufs[0][0].abs().max()) == 0.0          # nothing ran yet
+    for (P, Nout, Cin), (rw, rb), (dW, db) in zip(shapes, refs, bufs):
+        close(dW, rw, msg=f"group wgrad {P}x{Nout}x{Cin}", rtol=5e-4, atol_scale=6e-5)
+        close(db, rb, msg=f"group dbias {P}x{Nout}x{Cin}", rtol=5e-4, atol_scale=6e-5)
+
+
 def test_sine_embed_matches_reference_formula():
     """cdetr_sine_embed fwd / bwd == the tensor-op formula of A2/models/transformer.py:474-494 (fp64)."""
     import math
