@@ -155,6 +155,8 @@ class Trainer:
     # ------------------------------------------------------------------ data-parallel gradient exchange
     def _segment_done(self, seg):
         """Called from the backbone's backward: `seg` (0 = everything above the backbone, 1..3 = layer4..layer2) is final."""
+        from . import ops
+        ops.wgrad_flush()           # queued parameter gradients of the finished segment must land before its bucket ships
         self.exchange.segment_done(seg)
 
     def _finish_allreduce(self):
@@ -221,7 +223,8 @@ class Trainer:
                 losses = (vec * self._w6).sum()                                       # A2/engine.py:37
             else:
                 losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
-            losses.backward()
+            with ops.wgrad_queue():      # small parameter gradients outside the fused layer nodes (heads, positional MLPs): grouped
+                losses.backward()
         finally:
             ops.MIRROR = None
         out = dict(loss_dict)

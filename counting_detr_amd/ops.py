@@ -103,12 +103,20 @@ class wgrad_queue:
 
     def __exit__(self, et, ev, tb):
         global _WG_QUEUE
-        q, _WG_QUEUE = _WG_QUEUE, self.prev
-        if et is None and q:
-            arr = (WgradDesc * len(q))(*[e[0] for e in q])
-            with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0)):
-                check(lib().cdetr_wgrad_group(arr, len(q), stream_ptr()), "cdetr_wgrad_group")
+        if et is None:
+            wgrad_flush()
+        _WG_QUEUE = self.prev
         return False
+
+
+def wgrad_flush():
+    """Submit whatever the innermost wgrad_queue() holds (the gradient exchange calls this before it ships a bucket)."""
+    q = _WG_QUEUE
+    if q:
+        arr = (WgradDesc * len(q))(*[e[0] for e in q])
+        with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0)):
+            check(lib().cdetr_wgrad_group(arr, len(q), stream_ptr()), "cdetr_wgrad_group")
+        del q[:]
 
 
 def colsum_(X2d, out):
@@ -317,7 +325,7 @@ class LinearFn(torch.autograd.Function):
             gw = grad_buffer(wparam)[lo:hi]
             gb = grad_buffer(bparam)[lo:hi] if (bparam is not None and bparam.requires_grad) else None
             wgrad_raw(dy2d, dy2d.stride(0), x2d, x2d.stride(0), gw, gw.stride(0), dy2d.shape[0], w.shape[0], x2d.shape[1],
-                      dbias=gb)
+                      dbias=gb, may_defer=True)       # parameter gradient: queued when the trainer runs backward under wgrad_queue()
         return dx, None, None, None, None, None, d_resid, None
 
 
