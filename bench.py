@@ -176,7 +176,9 @@ def main():
     shapes = {}
     ig_alg_bytes = 0.0
     for family, flops, e0, e1, tag in ops.PROFILE:
-        if family == "igemm" and tag is not None:
+        if family == "igemm" and tag is not None and tag[0] == "group":
+            ig_alg_bytes += tag[1]           # grouped launch: the sum over its problems (ops.gemm_queue)
+        elif family == "igemm" and tag is not None:
             M_, N_, K_, taps_ = tag[0], tag[1], tag[2], tag[3]
             # compulsory fp32 bytes of one launch: input rows once (a strided/dilated conv reads <= M*K of them), weights, output
             ig_alg_bytes += 4.0 * (M_ * K_ + N_ * K_ * taps_ + M_ * N_) * max(tag[5], 1)

@@ -64,7 +64,7 @@ class MirrorItem(C.Structure):
                 ("tile0", C.c_int32), ("transpose", C.c_int32), ("pad_", C.c_int32)]
 
 
-EXPORTS = ["cdetr_gemm", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_bwd", "cdetr_posadd2",
+EXPORTS = ["cdetr_gemm", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_bwd", "cdetr_posadd2",
            "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
 
@@ -84,6 +84,8 @@ def lib():
         for name in ("cdetr_gemm", "cdetr_wgrad", "cdetr_rcda_fwd", "cdetr_rcda_bwd"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [_p, _p]
+        L.cdetr_gemm_group.restype = C.c_int
+        L.cdetr_gemm_group.argtypes = [_p, C.c_int32, _p]
         L.cdetr_wgrad_group.restype = C.c_int
         L.cdetr_wgrad_group.argtypes = [_p, C.c_int32, _p]
         L.cdetr_colsum.restype = C.c_int

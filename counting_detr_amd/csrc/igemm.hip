@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 // of k inside a row, in bf16 units; the lo plane of the same k sits 32 further.
 #define KPOS(k) ((((k) >> 5) << 6) + ((k) & 31))
 template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds; PD: k-tiles in flight in registers
-__global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
+__device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const int tilesM, const int bx, const int bz) {
     static_assert(PD == 2 || PD == 4, "register ring depth");
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
@@ -495,11 +495,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
     // from HBM/MALL once per XCD and the (small) weight matrix stays L2-resident.  Placement only affects speed.
     const int tilesN = (d.N + BN - 1) / BN;
     const int band = (tilesM + 7) >> 3;
-    const int xcd = blockIdx.x & 7, jloc = blockIdx.x >> 3;
+    const int xcd = bx & 7, jloc = bx >> 3;
     const int tm = xcd * band + jloc / tilesN, tn = jloc % tilesN;
     if (tm >= tilesM) return;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int z = blockIdx.z;
+    const int z = bz;
     const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
     const float* __restrict__ B = (BRAW ? reinterpret_cast<const float*>(d.B_split) : d.B) + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
@@ -828,6 +828,27 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_ge
             }
         }
     }
+}
+
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
+    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, ABL, PD>(d, tilesM, blockIdx.x, blockIdx.z);
+}
+
+// Grouped launch of up to GG_MAX independent GEMMs of one kernel class (same idea as WgradGroupArgs below): the problems'
+// workgroups are concatenated along grid.x, a workgroup finds its problem with a short scalar scan of the kernel-argument table.
+constexpr int GG_MAX = 12;
+struct GemmGroupItem { cdetr_gemm_desc d; int tilesM, tilesN, vecA, vecB, nx, pad_; };
+struct GemmGroupArgs { int n; int blk0[GG_MAX + 1]; GemmGroupItem it[GG_MAX]; };
+static_assert(sizeof(GemmGroupArgs) <= 4000, "grouped launch arguments must fit the kernel-argument segment");
+
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_fast_group_kernel(const GemmGroupArgs g) {
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
+    const GemmGroupItem& it = g.it[p];
+    const int lb = blockIdx.x - g.blk0[p];             // nx is a multiple of 8: the XCD banding of the body is preserved
+    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, 0, 2>(it.d, it.tilesM, lb % it.nx, lb / it.nx);
 }
 
 // ------------------------------------------------------------------------------------------------ fast wgrad
@@ -1282,17 +1303,17 @@ __global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const WgradGroupArg
 // global/L2 in the MFMA register layout -- no LDS, no barrier, every wave independent, so a 600x256x256 GEMM runs as
 // 608 concurrent waves of 64 MFMAs instead of 40 workgroups stepping through 8 barrier-separated k-tiles.
 template <int BL, int UB>   // UB = 16-wide k-chunks (per wave) whose loads are all in flight before the first MFMA
-__global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN,
-                                                           const int vecA, const int vecB) {
+__device__ __forceinline__ void igemm_direct_body(const cdetr_gemm_desc& d, const int tilesM, const int tilesN, const int vecA,
+                                                  const int vecB, const int bx, const int bz) {
     // one WORKGROUP = one 16x16 output tile; its 4 waves split K four ways (each wave: one short memory round trip),
     // partial accumulators are summed through LDS and wave 0 runs the fused epilogue.
     __shared__ float red[4][256];
     const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x;
+    const int tile = bx;
     const int tm = tile % tilesM, tn = tile / tilesM;
     const int i = lane & 15, g4 = lane >> 4;
     const int m = tm * 16 + i, n = tn * 16 + i;
-    const int z = blockIdx.z;
+    const int z = bz;
     const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
     const float* __restrict__ B = d.B + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
@@ -1374,6 +1395,21 @@ __global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc
         if (d.relu) v = fmaxf(v, 0.f);
         C[(long)mo * d.ldc + no] = v;
     }
+}
+
+template <int BL, int UB>
+__global__ __launch_bounds__(256) void igemm_direct_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN,
+                                                           const int vecA, const int vecB) {
+    igemm_direct_body<BL, UB>(d, tilesM, tilesN, vecA, vecB, blockIdx.x, blockIdx.z);
+}
+
+template <int BL, int UB>
+__global__ __launch_bounds__(256) void igemm_direct_group_kernel(const GemmGroupArgs g) {
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
+    const GemmGroupItem& it = g.it[p];
+    const int lb = blockIdx.x - g.blk0[p];
+    igemm_direct_body<BL, UB>(it.d, it.tilesM, it.tilesN, it.vecA, it.vecB, lb % it.nx, lb / it.nx);
 }
 
 // dW[i][c] += scale[i] * sum_p dY[p][i] X[p][c] (+ dbias[i] += sum_p dY[p][i]) for short reductions (P <= 1024):
@@ -1566,14 +1602,35 @@ int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
-    CDETR_CHECK_ARG(dp != nullptr, "cdetr_gemm: null descriptor");
-    cdetr_gemm_desc d = *dp;
+namespace {
+long gemm_blocks(const cdetr_gemm_desc& d, int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; }
+int gemm_vec_a(const cdetr_gemm_desc& d) {
+    return ((d.K & 3) == 0 && (d.lda & 3) == 0 && (d.sA & 3) == 0 && (d.sA2 & 3) == 0 && aligned16(d.A)) ? 1 : 0;
+}
+int gemm_vec_b(const cdetr_gemm_desc& d) {
+    if (d.b_layout == 0)
+        return ((((long)d.K * d.taps) & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && (d.sB2 & 3) == 0 && aligned16(d.B)) ? 1 : 0;
+    return ((d.N & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && (d.sB2 & 3) == 0 && aligned16(d.B)) ? 1 : 0;
+}
+// the kernel classes of the default dispatch (shared by cdetr_gemm and cdetr_gemm_group)
+bool gemm_is_direct(const cdetr_gemm_desc& d, int vecA, int vecB) {
+    return d.g.mode == CDETR_ROWS_DENSE && (gemm_blocks(d, 64, 64) <= 48 || !(vecA && vecB && (d.K % 32) == 0)) && gemm_blocks(d, 64, 64) < 192;
+}
+// bf16x3 with a long reduction is bound by L2->CU operand delivery (~8 TB/s measured, tools/split_sweep.py): a
+// 128x128 tile shared by 16 waves of 32x32 halves that traffic at the same per-wave structure and occupancy.
+bool gemm_is_f44(const cdetr_gemm_desc& d) {
+    return d.precision == 1 && d.b_layout == 0 && (long)d.K * d.taps >= 1024 && (d.N % 128) == 0 && gemm_blocks(d, 128, 128) >= 150;
+}
+// small grids (< 2 workgroups of 4 waves per CU): a 64x128 tile shared by 8 waves keeps the wave count and halves the
+// A-operand traffic (tools/split_sweep.py: 6-11 % over 64x64 BK64 on the N = 256 encoder linears)
+bool gemm_is_f24(const cdetr_gemm_desc& d) {
+    return d.precision == 1 && d.b_layout == 0 && (d.N % 128) == 0 && gemm_blocks(d, 64, 64) < 512;
+}
+int check_gemm_desc(const cdetr_gemm_desc& d) {
     CDETR_CHECK_ARG(d.M >= 0 && d.N > 0 && d.K > 0 && d.taps > 0 && d.batch > 0, "cdetr_gemm: bad sizes M=%d N=%d K=%d taps=%d batch=%d",
                     d.M, d.N, d.K, d.taps, d.batch);
     CDETR_CHECK_ARG(d.A && d.B && d.C, "cdetr_gemm: null A/B/C");
     CDETR_CHECK_ARG(d.b_layout == 0 || d.b_layout == 1, "cdetr_gemm: b_layout %d", d.b_layout);
-    if (d.M == 0) return CDETR_OK;
     if (d.g.mode == CDETR_ROWS_DENSE) {
         CDETR_CHECK_ARG(d.taps == 1, "cdetr_gemm: dense rows need taps == 1");
     } else {
@@ -1582,13 +1639,17 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         CDETR_CHECK_ARG(d.g.Hc > 0 && d.g.Wc > 0 && d.M % (d.g.Hc * d.g.Wc) == 0, "cdetr_gemm: M is not images*Hc*Wc");
     }
     if (d.b_layout == 1 && d.taps > 1) CDETR_CHECK_ARG(d.K % BK == 0, "cdetr_gemm: dgrad with taps needs K %% 16 == 0");
-    const int vecA = ((d.K & 3) == 0 && (d.lda & 3) == 0 && (d.sA & 3) == 0 && (d.sA2 & 3) == 0 && aligned16(d.A)) ? 1 : 0;
-    if (!vecA) CDETR_CHECK_ARG(d.g.mode == CDETR_ROWS_DENSE, "cdetr_gemm: unaligned A only supported for dense rows");
-    int vecB;
-    if (d.b_layout == 0)
-        vecB = ((((long)d.K * d.taps) & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && (d.sB2 & 3) == 0 && aligned16(d.B)) ? 1 : 0;
-    else
-        vecB = ((d.N & 3) == 0 && (d.ldb & 3) == 0 && (d.sB & 3) == 0 && (d.sB2 & 3) == 0 && aligned16(d.B)) ? 1 : 0;
+    if (!gemm_vec_a(d)) CDETR_CHECK_ARG(d.g.mode == CDETR_ROWS_DENSE, "cdetr_gemm: unaligned A only supported for dense rows");
+    return CDETR_OK;
+}
+}  // namespace
+
+extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
+    CDETR_CHECK_ARG(dp != nullptr, "cdetr_gemm: null descriptor");
+    cdetr_gemm_desc d = *dp;
+    if (int rcv = check_gemm_desc(d)) return rcv;
+    if (d.M == 0) return CDETR_OK;
+    const int vecA = gemm_vec_a(d), vecB = gemm_vec_b(d);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     // tile choice: the largest tile that still yields >= 1.5 waves of workgroups on 256 CUs
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
@@ -1615,7 +1676,7 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         if (d.N > 64 && d.M > 64) return launch_gemm<128, 128>(d, st, vecA, vecB);
         return launch_gemm<64, 64>(d, st, vecA, vecB);
     }
-    if ((force == 5 && d.g.mode == CDETR_ROWS_DENSE) || (d.g.mode == CDETR_ROWS_DENSE && (blocks(64, 64) <= 48 || !(vecA && vecB && (d.K % 32) == 0)) && blocks(64, 64) < 192)) {   // latency-bound: one wave per 16x16 tile
+    if ((force == 5 && d.g.mode == CDETR_ROWS_DENSE) || gemm_is_direct(d, vecA, vecB)) {   // latency-bound: one wave per 16x16 tile
         const int tilesM = (d.M + 15) / 16, tilesN = (d.N + 15) / 16;
         dim3 grid(tilesM * tilesN, 1, d.batch);          // one workgroup (4 waves, K split 4 ways) per 16x16 tile
         const int cpw = (((d.K + 15) >> 4) + 3) >> 2;    // 16-wide k-chunks per wave
@@ -1636,17 +1697,76 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         // the fp32-MFMA rate); BK = 64 only pays when the grid is too small to give every CU two workgroups.
         // bf16x3 with a long reduction is bound by L2->CU operand delivery (~8 TB/s measured, tools/split_sweep.py): a
         // 128x128 tile shared by 16 waves of 32x32 halves that traffic at the same per-wave structure and occupancy.
-        if (d.precision == 1 && d.b_layout == 0 && (long)d.K * d.taps >= 1024 && (d.N % 128) == 0 && blocks(128, 128) >= 150)
-            return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
+        if (gemm_is_f44(d)) return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
         // small grids (< 2 workgroups of 4 waves per CU): a 64x128 tile shared by 8 waves keeps the wave count and halves the
         // A-operand traffic (tools/split_sweep.py: 6-11 % over 64x64 BK64 on the N = 256 encoder linears)
-        if (d.precision == 1 && d.b_layout == 0 && (d.N % 128) == 0 && blocks(64, 64) < 512) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);
+        if (gemm_is_f24(d)) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);
         if ((d.K % 64) == 0 && blocks(64, 64) < 512) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);
         return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);
     }
     if (d.N > 64 && d.M > 64 && blocks(128, 128) >= 384) return launch_gemm<128, 128>(d, st, vecA, vecB);
     if (d.M > 64 && blocks(128, 64) >= 384) return launch_gemm<128, 64>(d, st, vecA, vecB);
     return launch_gemm<64, 64>(d, st, vecA, vecB);
+}
+
+// n INDEPENDENT GEMMs submitted together.  Problems of the few-row class (igemm_direct_kernel, k-contiguous weight) and of the
+// 64x128 / 8-wave class with a pre-split weight image run as grouped launches (<= GG_MAX problems per kernel); everything else goes
+// through cdetr_gemm one by one.  The ~150 few-row GEMMs of a step take ~6 us each for well under a microsecond of work, and the
+// N = 256 encoder projections launch 158 workgroups on 256 CUs: submitted together they share one launch and fill the chip.
+extern "C" int cdetr_gemm_group(const cdetr_gemm_desc* descs, int32_t n, void* stream) {
+    CDETR_CHECK_ARG(n >= 0 && (descs != nullptr || n == 0), "cdetr_gemm_group: bad arguments");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    static const bool grouping = !(getenv("CDETR_GEMM_GROUP") && atoi(getenv("CDETR_GEMM_GROUP")) == 0) && !getenv("CDETR_GEMM_VARIANT") &&
+                                 !getenv("CDETR_GEMM_SPLIT") && !getenv("CDETR_GEMM_PRESPLIT") && !getenv("CDETR_GEMM_PD") && !getenv("CDETR_GEMM_ABL");
+    std::vector<int> cls[4];          // direct UB 4 / 8 / 16 (k-contiguous weight), fast 64x128 with a pre-split weight
+    for (int i = 0; i < n; ++i) {
+        const cdetr_gemm_desc& d = descs[i];
+        if (int rcv = check_gemm_desc(d)) return rcv;
+        if (d.M == 0) continue;
+        const int vecA = gemm_vec_a(d), vecB = gemm_vec_b(d);
+        int c = -1;
+        if (grouping && gemm_is_direct(d, vecA, vecB)) {
+            if (d.b_layout == 0) {
+                const int cpw = (((d.K + 15) >> 4) + 3) >> 2;
+                c = cpw <= 4 ? 0 : (cpw <= 8 ? 1 : 2);
+            }
+        } else if (grouping && vecA && vecB && (d.K % 32) == 0 && !gemm_is_f44(d) && gemm_is_f24(d) && d.B_split && d.batch == 1) {
+            c = 3;
+        }
+        if (c >= 0) cls[c].push_back(i);
+        else if (int rc1 = cdetr_gemm(&d, stream)) return rc1;
+    }
+    for (int c = 0; c < 4; ++c) {
+        for (size_t c0 = 0; c0 < cls[c].size(); c0 += GG_MAX) {
+            const int m = (int)std::min<size_t>(GG_MAX, cls[c].size() - c0);
+            if (m == 1) { if (int rc1 = cdetr_gemm(&descs[cls[c][c0]], stream)) return rc1; continue; }
+            GemmGroupArgs g;
+            g.n = m; g.blk0[0] = 0;
+            for (int k = 0; k < m; ++k) {
+                GemmGroupItem& it = g.it[k];
+                it.d = descs[cls[c][c0 + k]];
+                it.vecA = gemm_vec_a(it.d); it.vecB = gemm_vec_b(it.d); it.pad_ = 0;
+                if (c < 3) {
+                    it.tilesM = (it.d.M + 15) / 16; it.tilesN = (it.d.N + 15) / 16;
+                    it.nx = it.tilesM * it.tilesN;
+                } else {
+                    it.tilesM = (it.d.M + 63) / 64; it.tilesN = (it.d.N + 127) / 128;
+                    it.nx = 8 * ((it.tilesM + 7) / 8) * it.tilesN;          // 8 XCD bands (see igemm_fast_body)
+                }
+                g.blk0[k + 1] = g.blk0[k] + it.nx * it.d.batch;
+            }
+            if (c == 0) hipLaunchKernelGGL((igemm_direct_group_kernel<0, 4>), dim3(g.blk0[m]), dim3(256), 0, st, g);
+            else if (c == 1) hipLaunchKernelGGL((igemm_direct_group_kernel<0, 8>), dim3(g.blk0[m]), dim3(256), 0, st, g);
+            else if (c == 2) hipLaunchKernelGGL((igemm_direct_group_kernel<0, 16>), dim3(g.blk0[m]), dim3(256), 0, st, g);
+            else {
+                const int bytes = (2 * 64 * 36 + 2 * 128 * 36) * 4;
+                if (int rcl = raise_lds(igemm_fast_group_kernel<2, 4, 1, 1, 0, 32, 3>, bytes, "cdetr_gemm_group")) return rcl;
+                hipLaunchKernelGGL((igemm_fast_group_kernel<2, 4, 1, 1, 0, 32, 3>), dim3(g.blk0[m]), dim3(512), bytes, st, g);
+            }
+            if (int rcl = cdetr_launch_status("cdetr_gemm_group")) return rcl;
+        }
+    }
+    return CDETR_OK;
 }
 
 namespace {

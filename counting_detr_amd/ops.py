@@ -62,8 +62,37 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
     d.resid, d.ldr = ptr(resid), ldr
     d.gate, d.ldg = ptr(gate), ldg
     d.g = geom if geom is not None else _geom()
+    if _GEMM_QUEUE is not None:       # inside gemm_queue(): submitted together by its exit (cdetr_gemm_group)
+        _GEMM_QUEUE.append((d, 2.0 * M * N * K * taps * batch, 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
+                            (A, B, Cout, bias, w_scale, resid, gate, B_split)))
+        return
     with _Timed("igemm", 2.0 * M * N * K * taps * batch, (M, N, K, taps, b_layout, batch)):
         check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
+
+
+_GEMM_QUEUE = None
+
+
+class gemm_queue:
+    """Context manager: every GEMM issued inside (linear_fwd / linear_dgrad / gemm_raw) is queued and the whole set is submitted as
+    ONE cdetr_gemm_group call on exit (grouped launches per kernel class).  The caller guarantees that the queued problems are
+    independent -- none reads another's output -- and that nothing inside the block reads an output tensor: they are filled at
+    exit.  Operand tensors are kept alive until then."""
+
+    def __enter__(self):
+        global _GEMM_QUEUE
+        assert _GEMM_QUEUE is None, "gemm_queue does not nest"
+        _GEMM_QUEUE = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _GEMM_QUEUE
+        q, _GEMM_QUEUE = _GEMM_QUEUE, None
+        if et is None and q:
+            arr = (GemmDesc * len(q))(*[e[0] for e in q])
+            with _Timed("igemm", sum(e[1] for e in q), ("group", sum(e[2] for e in q), len(q), 0, -1, 0)):
+                check(lib().cdetr_gemm_group(arr, len(q), stream_ptr()), "cdetr_gemm_group")
+        return False
 
 
 def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0,
@@ -612,11 +641,12 @@ class EncoderLayerFn(torch.autograd.Function):
         Prow, Pcol = posemb_row.contiguous(), posemb_col.contiguous()
         Qr, Qc = posadd2(X, Prow, Pcol)
         Kr, Kc = hw_reduce(X, X, Prow, Pcol, 1.0 / H, 1.0 / W)
-        q_row = linear_fwd(Qr.view(R, Cc), Wi[0:E], bi[0:E]).view(N, H * W, E)
-        q_col = linear_fwd(Qc.view(R, Cc), Wi[E:2 * E], bi[E:2 * E]).view(N, H * W, E)
-        k_row = linear_fwd(Kr.view(N * W, Cc), Wi[2 * E:3 * E], bi[2 * E:3 * E]).view(N, W, E)
-        k_col = linear_fwd(Kc.view(N * H, Cc), Wi[3 * E:4 * E], bi[3 * E:4 * E]).view(N, H, E)
-        v = linear_fwd(X.view(R, Cc), Wi[4 * E:5 * E], bi[4 * E:5 * E]).view(N, H, W, E)
+        with gemm_queue():           # the five in-projections are independent: one grouped submission
+            q_row = linear_fwd(Qr.view(R, Cc), Wi[0:E], bi[0:E]).view(N, H * W, E)
+            q_col = linear_fwd(Qc.view(R, Cc), Wi[E:2 * E], bi[E:2 * E]).view(N, H * W, E)
+            k_row = linear_fwd(Kr.view(N * W, Cc), Wi[2 * E:3 * E], bi[2 * E:3 * E]).view(N, W, E)
+            k_col = linear_fwd(Kc.view(N * H, Cc), Wi[3 * E:4 * E], bi[3 * E:4 * E]).view(N, H, E)
+            v = linear_fwd(X.view(R, Cc), Wi[4 * E:5 * E], bi[4 * E:5 * E]).view(N, H, W, E)
         o, a_row, a_col = rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh)
         Y1 = linear_fwd(o.view(R, E), att.out_proj.weight.detach(), att.out_proj.bias.detach(), resid=X.view(R, Cc))
         X1, mu1, rs1 = ln_fwd_raw(Y1, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
@@ -666,13 +696,15 @@ class EncoderLayerFn(torch.autograd.Function):
         t = linear_dgrad(dq_row2, Wi[0:E], resid=dY1)
         t = linear_dgrad(dq_col2, Wi[E:2 * E], resid=t)
         t = linear_dgrad(dv2, Wi[4 * E:5 * E], resid=t)
-        dKr = linear_dgrad(dk_row2, Wi[2 * E:3 * E])                               # [N*W, C]
-        dKc = linear_dgrad(dk_col2, Wi[3 * E:4 * E])                               # [N*H, C]
+        with gemm_queue():
+            dKr = linear_dgrad(dk_row2, Wi[2 * E:3 * E])                           # [N*W, C]
+            dKc = linear_dgrad(dk_col2, Wi[3 * E:4 * E])                           # [N*H, C]
         dX = bcast_add2(t.view(N, H, W, Cc), dKr, dKc, 1.0 / H, 1.0 / W)
         # ---- d(posemb): sum over the broadcast axis BEFORE projecting back (linearity) + the key-mean terms
         sr, sc = hw_reduce(dq_row.view(N, H, W, E), dq_col.view(N, H, W, E), None, None, 1.0, 1.0)
-        dProw = linear_dgrad(sr.view(N * W, E), Wi[0:E], resid=dKr).view(N, W, Cc)
-        dPcol = linear_dgrad(sc.view(N * H, E), Wi[E:2 * E], resid=dKc).view(N, H, Cc)
+        with gemm_queue():
+            dProw = linear_dgrad(sr.view(N * W, E), Wi[0:E], resid=dKr).view(N, W, Cc)
+            dPcol = linear_dgrad(sc.view(N * H, E), Wi[E:2 * E], resid=dKc).view(N, H, Cc)
         return dX, dProw, dPcol, None, None, None, None
 
 
@@ -711,23 +743,32 @@ class DecoderStackFn(torch.autograd.Function):
         outs = []
         saved = []
         x = tgt.view(M, E)
+        # the key / value projections of the encoder memory do not depend on the decoder state: all layers' up front, grouped
+        mem_side = []
+        with gemm_queue():
+            for layer in layers:
+                ca = layer.cross_attn
+                Wc, bc = ca.in_proj_weight.detach(), ca.in_proj_bias.detach()
+                mem_side.append((linear_fwd(krm2, Wc[2 * E:3 * E], bc[2 * E:3 * E]).view(N, W, E),
+                                 linear_fwd(kcm2, Wc[3 * E:4 * E], bc[3 * E:4 * E]).view(N, H, E),
+                                 linear_fwd(mem2, Wc[4 * E:5 * E], bc[4 * E:5 * E]).view(N, H, W, E)))
         for li, layer in enumerate(layers):
             sa, ca, f = layer.self_attn, layer.cross_attn, layer.ffn
             nh = sa.num_heads
             Ws, bs = sa.in_proj_weight.detach(), sa.in_proj_bias.detach()
             Wc, bc = ca.in_proj_weight.detach(), ca.in_proj_bias.detach()
             a1, _ = add2(x, qpos.view(M, E))
-            qk = linear_fwd(a1, Ws[0:2 * E], bs[0:2 * E])
-            vs = linear_fwd(x, Ws[2 * E:3 * E], bs[2 * E:3 * E])
+            with gemm_queue():
+                qk = linear_fwd(a1, Ws[0:2 * E], bs[0:2 * E])
+                vs = linear_fwd(x, Ws[2 * E:3 * E], bs[2 * E:3 * E])
             o1, lse = mha_fwd_raw(qk.view(N, L, 2 * E), vs.view(N, L, E), nh)
             Y2 = linear_fwd(o1.view(M, E), sa.out_proj.weight.detach(), sa.out_proj.bias.detach(), resid=x)
             T1, mu2, rs2 = ln_fwd_raw(Y2, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
             qr_in, qc_in = add2(T1, qx.view(M, E), qy.view(M, E))
-            q_row = linear_fwd(qr_in, Wc[0:E], bc[0:E]).view(N, L, E)
-            q_col = linear_fwd(qc_in, Wc[E:2 * E], bc[E:2 * E]).view(N, L, E)
-            k_row = linear_fwd(krm2, Wc[2 * E:3 * E], bc[2 * E:3 * E]).view(N, W, E)
-            k_col = linear_fwd(kcm2, Wc[3 * E:4 * E], bc[3 * E:4 * E]).view(N, H, E)
-            v = linear_fwd(mem2, Wc[4 * E:5 * E], bc[4 * E:5 * E]).view(N, H, W, E)
+            with gemm_queue():
+                q_row = linear_fwd(qr_in, Wc[0:E], bc[0:E]).view(N, L, E)
+                q_col = linear_fwd(qc_in, Wc[E:2 * E], bc[E:2 * E]).view(N, L, E)
+            k_row, k_col, v = mem_side[li]
             o2, a_row, a_col = rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, ca.num_heads)
             Y1 = linear_fwd(o2.view(M, E), ca.out_proj.weight.detach(), ca.out_proj.bias.detach(), resid=T1)
             T2, mu1, rs1 = ln_fwd_raw(Y1, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
@@ -792,12 +833,13 @@ class DecoderStackFn(torch.autograd.Function):
             _wg(dk_row2, krm2, Wcp, bcp, 2 * E, 3 * E)
             _wg(dk_col2, kcm2, Wcp, bcp, 3 * E, 4 * E)
             _wg(dv2, mem2, Wcp, bcp, 4 * E, 5 * E)
-            gx = linear_dgrad(dq_row2, Wc[0:E])
-            gy = linear_dgrad(dq_col2, Wc[E:2 * E])
+            with gemm_queue():         # the chained accumulators read the PREVIOUS layer's sums, written before this block
+                gx = linear_dgrad(dq_row2, Wc[0:E])
+                gy = linear_dgrad(dq_col2, Wc[E:2 * E])
+                dKrm = linear_dgrad(dk_row2, Wc[2 * E:3 * E], resid=dKrm)      # shared inputs: chained across layers
+                dKcm = linear_dgrad(dk_col2, Wc[3 * E:4 * E], resid=dKcm)
+                dMem = linear_dgrad(dv2, Wc[4 * E:5 * E], resid=dMem)
             dT1 = grad_merge(dY1, gx, gy, acc_x, acc_y)                        # + both query projections; d(qx) += gx, d(qy) += gy
-            dKrm = linear_dgrad(dk_row2, Wc[2 * E:3 * E], resid=dKrm)          # shared inputs: chained across layers
-            dKcm = linear_dgrad(dk_col2, Wc[3 * E:4 * E], resid=dKcm)
-            dMem = linear_dgrad(dv2, Wc[4 * E:5 * E], resid=dMem)
             # ---- self attention: T1 = LN2(x + mha((x + qpos) Wqk, x Wv) Wo^T + bo)
             dY2 = ln_bwd_raw(dT1, Y2, mu2, rs2, layer.norm2.weight.detach(), grad_buffer(layer.norm2.weight), grad_buffer(layer.norm2.bias))
             _wg(dY2, o1.view(M, E), sa.out_proj.weight, sa.out_proj.bias, 0, E)
@@ -806,8 +848,9 @@ class DecoderStackFn(torch.autograd.Function):
             Wsp, bsp = sa.in_proj_weight, sa.in_proj_bias
             _wg(dqk.view(M, 2 * E), a1, Wsp, bsp, 0, 2 * E)
             _wg(dvs.view(M, E), x, Wsp, bsp, 2 * E, 3 * E)
-            ga1 = linear_dgrad(dqk.view(M, 2 * E), Ws[0:2 * E])
-            t = linear_dgrad(dvs.view(M, E), Ws[2 * E:3 * E], resid=dY2)
+            with gemm_queue():
+                ga1 = linear_dgrad(dqk.view(M, 2 * E), Ws[0:2 * E])
+                t = linear_dgrad(dvs.view(M, E), Ws[2 * E:3 * E], resid=dY2)
             dx = grad_merge(t, ga1, None, acc_p, None)                         # d(x) = residual + v-path + q/k-path; d(qpos) += ga1
         return (dx.view(N, L, E), acc_p.view(N, L, E), acc_x.view(N, L, E), acc_y.view(N, L, E), dMem.view(N, H, W, E),
                 dKrm.view(N, W, E), dKcm.view(N, H, E), None, None, None, None)

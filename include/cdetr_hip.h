@@ -71,6 +71,11 @@ typedef struct {
     int64_t sA2, sB2, sC2;
 } cdetr_gemm_desc;
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
+/* n INDEPENDENT GEMMs submitted together (same results as n cdetr_gemm calls; no problem may read another's output).  Few-row
+ * problems and the 64x128-tile class with a pre-split weight run as grouped launches (one kernel for up to 12 problems).
+ * Replaces: sibling F.linear calls on independent inputs, e.g. the five in-projections of
+ * A2/models/row_column_decoupled_attention.py:165-208 and the memory-side projections of all decoder layers.               */
+int cdetr_gemm_group(const cdetr_gemm_desc* descs, int32_t n, void* stream);
 
 /* dW[i][tap][c] += w_scale[i] * sum_p dY[p][i] * X[row(p,tap)][c]      (weight-gradient, split-K + fp32 atomics)
  * dbias[i]      += sum_p dY[p][i]                                       (optional, fused: NULL = skip)

@@ -601,6 +601,50 @@ def test_two_level_batch_image_by_head(N, nh, L, Wk, precision):
     close(dk.view(N, Wk, nh, 32), torch.einsum("nhlw,nlhd->nwhd", S64, q64), msg="dk", **tol(precision))
 
 
+def test_gemm_group_matches_individual_calls(precision):
+    """cdetr_gemm_group (ops.gemm_queue): few-row problems of three k-lengths, the 64x128 class with a pre-split weight image,
+    a data-gradient operand (n-contiguous weight), epilogues (bias, residual, ReLU, gate) and 14 problems of one class (two
+    grouped launches) == the same calls issued one by one (bit-identical) == fp64 within tolerance."""
+    from counting_detr_amd import ops
+    shapes = [(600, 256, 256), (100, 256, 256), (600, 256, 512), (600, 256, 1024), (37, 40, 36), (5000, 256, 256), (5000, 256, 256),
+              (5000, 256, 256), (4000, 128, 64)] + [(50 + 13 * k, 256, 256) for k in range(14)]
+    Ws = [torch.randn(N, K, generator=g(11 * i)) / K ** 0.5 for i, (M, N, K) in enumerate(shapes)]
+    Wd = [w.to(DEV) for w in Ws]
+    entries = [(w, None) for w in Wd if w.shape[1] % 32 == 0 and w.shape[0] % 32 == 0]
+    mirror = ops.WeightMirror([], entries)
+    mirror.refresh()
+    old_m = ops.MIRROR
+    ops.MIRROR = mirror
+    try:
+        xs, outs_q, outs_1 = [], [], []
+        for i, (M, N, K) in enumerate(shapes):
+            x = torch.randn(M, K, generator=g(7 * i + 1))
+            b = torch.randn(N, generator=g(7 * i + 2))
+            r = torch.randn(M, N, generator=g(7 * i + 3))
+            xs.append((x, b, r, x.to(DEV), b.to(DEV), r.to(DEV)))
+        with ops.gemm_queue():
+            for i, (M, N, K) in enumerate(shapes):
+                x, b, r, xd, bd, rd = xs[i]
+                outs_q.append(ops.linear_fwd(xd, Wd[i], bd, relu=(i % 2 == 0), resid=rd if i % 3 == 0 else None))
+            gq = ops.linear_dgrad(xs[0][5], Wd[0].t().contiguous().t(), gate=xs[0][5])      # not in the mirror: n-contiguous operand
+        for i, (M, N, K) in enumerate(shapes):
+            x, b, r, xd, bd, rd = xs[i]
+            outs_1.append(ops.linear_fwd(xd, Wd[i], bd, relu=(i % 2 == 0), resid=rd if i % 3 == 0 else None))
+        g1 = ops.linear_dgrad(xs[0][5], Wd[0].t().contiguous().t(), gate=xs[0][5])
+    finally:
+        ops.MIRROR = old_m
+    assert torch.equal(gq, g1)
+    for i, (M, N, K) in enumerate(shapes):
+        x, b, r = xs[i][:3]
+        assert torch.equal(outs_q[i], outs_1[i]), f"grouped != single for {shapes[i]}"
+        ref = x.double() @ Ws[i].double().t() + b.double()
+        if i % 3 == 0:
+            ref = ref + r.double()
+        if i % 2 == 0:
+            ref = ref.clamp_min(0)
+        close(outs_q[i], ref, msg=f"gemm group {shapes[i]}", **tol(precision))
+
+
 def test_wgrad_group_matches_individual_calls(precision):
     """cdetr_wgrad_group: a queue of independent parameter gradients (few-pixel, 64x64 transpose-read and other kernel classes,
     two of them accumulating into the SAME dW / dbias, 19 problems = two grouped launches of one class) == the sum of the
