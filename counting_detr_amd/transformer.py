@@ -77,6 +77,31 @@ class MLP(nn.Module):
         return x
 
 
+def pos_mlp_many(mlp, xs):
+    """[mlp(x) for x in xs] for a PosMLP, level by level: the first linears of all inputs share one grouped submission
+    (ops.gemm_queue), then the second ones."""
+    if not (xs[0].is_cuda and torch.is_grad_enabled()):
+        return [mlp(x) for x in xs]
+    with ops.gemm_queue():
+        hs = [mlp[0](x, relu=True) for x in xs]
+    with ops.gemm_queue():
+        return [mlp[2](h) for h in hs]
+
+
+def mlps_levelwise(mlps, x):
+    """[m(x) for m in mlps] for MLP / Linear heads on the same input, level by level (sibling layers grouped)."""
+    if not (x.is_cuda and torch.is_grad_enabled()):
+        return [m(x) for m in mlps]
+    chains = [list(m.layers) if isinstance(m, MLP) else [m] for m in mlps]
+    cur = [x] * len(mlps)
+    for lvl in range(max(len(c) for c in chains)):
+        with ops.gemm_queue():
+            for i, c in enumerate(chains):
+                if lvl < len(c):
+                    cur[i] = c[lvl](cur[i], relu=(lvl < len(c) - 1))
+    return cur
+
+
 class FFN(nn.Module):
     """A2/models/transformer.py:412-426 (post-norm; the residual add is fused into linear2's epilogue)."""
 
@@ -274,8 +299,10 @@ class Transformer(nn.Module):
         tgt = (pattern.weight.reshape(1, self.num_pattern, 1, c).repeat(bs, 1, self.num_position, 1)
                .reshape(bs, self.num_pattern * self.num_position, c))
         pos_col, pos_row = mask2pos(mask)
-        posemb_row = self.adapt_pos1d(pos2posemb1d(pos_row))             # [B,w,C]
-        posemb_col = self.adapt_pos1d(pos2posemb1d(pos_col))             # [B,h,C]
+        # the four 1-d positional MLP applications (key rows / columns here, query x / y below) run level by level, grouped
+        posemb_row, posemb_col, query_pos_x, query_pos_y = pos_mlp_many(
+            self.adapt_pos1d, [pos2posemb1d(pos_row), pos2posemb1d(pos_col),                    # [B,w,C], [B,h,C]
+                               pos2posemb1d(reference_points[..., 0]), pos2posemb1d(reference_points[..., 1])])
         mask_row = mask[:, 0, :].to(torch.uint8).contiguous()
         mask_col = mask[:, :, 0].to(torch.uint8).contiguous()
 
@@ -288,8 +315,6 @@ class Transformer(nn.Module):
 
         # query positional terms do not depend on the layer (the reference recomputes them in every layer, :366-379)
         query_pos = self.adapt_pos2d(pos2posemb2d(reference_points))
-        query_pos_x = self.adapt_pos1d(pos2posemb1d(reference_points[..., 0]))
-        query_pos_y = self.adapt_pos1d(pos2posemb1d(reference_points[..., 1]))
         reference = inverse_sigmoid(reference_points)
 
         outputs_classes, outputs_coords, outputs_vars = [], [], []
@@ -307,16 +332,16 @@ class Transformer(nn.Module):
             if not (self.all_layer_heads or lid == last):
                 continue     # the heads of layers 0..4 only feed the aux losses (the reference computes and drops them)
             if self.stage == 2:
-                outputs_class = self.cls_embed[lid](output)
+                outputs_class, tmp, var = mlps_levelwise([self.cls_embed[lid], self.bbox_embed[lid], self.bbox_variance[lid]], output)
             else:
                 ce = self.cls_embed[lid]
                 outputs_class = ops.linear(output, ce.weight, None) + ce.bias
-            tmp = self.bbox_embed[lid](output)
+                tmp = self.bbox_embed[lid](output)
             tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], dim=-1)                     # :200
             outputs_classes.append(outputs_class)
             outputs_coords.append(tmp.sigmoid())
             if self.stage == 2:
-                outputs_vars.append(self.bbox_variance[lid](output))
+                outputs_vars.append(var)
         out = (torch.stack(outputs_classes), torch.stack(outputs_coords),
                torch.stack(outputs_vars) if self.stage == 2 else None)
         return out, reference_points
