@@ -1919,8 +1919,8 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
         if (int rcv = check_wgrad_desc(d)) return rcv;
         if (d.P == 0) continue;
         if (grouping && wgrad_is_direct(d)) direct.push_back(i);
-        else if (grouping && wgrad_is_fast(d) && d.precision == 1 && use_tr && !forced && d.g.mode == CDETR_ROWS_DENSE &&
-                 !((long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128))
+        else if (grouping && wgrad_is_fast(d) && d.precision == 1 && use_tr && !forced &&
+                 !(d.taps > 1 && d.Nout >= 512 && d.Cin >= 512) && !(d.taps == 1 && (long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128))
             tr64.push_back(i);                               // = the shapes cdetr_wgrad gives to wgrad_tr_kernel<64, 64>
         else if (int rc1 = cdetr_wgrad(&d, stream)) return rc1;
     }
@@ -1949,7 +1949,7 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
         long work = 0;
         for (int k = 0; k < m; ++k) {
             const cdetr_wgrad_desc& d = descs[tr64[c0 + k]];
-            work += (long)((d.Nout + 63) / 64) * ((d.Cin + 63) / 64) * d.batch * ((d.P + 31) / 32);
+            work += (long)((d.Nout + 63) / 64) * ((d.Cin + 63) / 64) * d.taps * d.batch * ((d.P + 31) / 32);
         }
         long per_all = (work + 767) / 768;
         if (per_all < 4) per_all = 4;
@@ -1959,7 +1959,7 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             const int nkt = (it.d.P + 31) / 32;
             it.tilesI = (it.d.Nout + 63) / 64; it.tilesJ = (it.d.Cin + 63) / 64;
             it.per = (int)std::min<long>(per_all, nkt);
-            it.nx = it.tilesI * it.tilesJ; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
+            it.nx = it.tilesI * it.tilesJ * it.d.taps; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
             g.blk0[k + 1] = g.blk0[k] + it.nx * it.ny * it.d.batch;
         }
         hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);

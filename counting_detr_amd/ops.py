@@ -412,7 +412,7 @@ def conv_wgrad_(dz, x, weight, scale, stride=1, pad=0, dil=1):
     assert (Ho2, Wo2) == (Ho, Wo)
     gw = grad_buffer(weight)
     assert gw.is_contiguous(memory_format=torch.channels_last) or (kh == 1 and kw == 1)
-    wgrad_raw(dz, Cout, x, Cin, gw, kh * kw * Cin, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, geom=g)
+    wgrad_raw(dz, Cout, x, Cin, gw, kh * kw * Cin, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, geom=g, may_defer=True)
 
 
 def maxpool3x3s2(x):
