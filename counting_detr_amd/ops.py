@@ -456,7 +456,9 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
     d_out = d_out.contiguous()
     ds_row = torch.empty_like(a_row)
     ds_col = torch.empty_like(a_col)
-    d_v = torch.zeros_like(v)
+    # one fill for everything the backward accumulates into atomically: dV and both key gradients
+    zbuf = torch.zeros(v.numel() + k_row.numel() + k_col.numel(), device=v.device, dtype=torch.float32)
+    d_v = zbuf[:v.numel()].view(v.shape)
     d = RcdaBwdDesc()
     d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
     d.precision = PRECISION
@@ -467,7 +469,7 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
     # logits -> projected q/k gradients: four small batched GEMMs per image (batch over heads) on the same MFMA kernels
     dq_row = torch.empty_like(q_row)
     dq_col = torch.empty_like(q_col)
-    dk = torch.zeros(k_row.numel() + k_col.numel(), device=v.device, dtype=torch.float32)      # one fill: the k gradients accumulate
+    dk = zbuf[v.numel():]
     dk_row, dk_col = dk[:k_row.numel()].view(k_row.shape), dk[k_row.numel():].view(k_col.shape)
     # two-level batch (image x head): one launch per contraction for the whole batch of images
     gemm_raw(ds_row, Wp, k_row, E, dq_row, E, L, 32, W, b_layout=1, batch=N * nh, sA=L * Wp, sB=32, sC=32,
