@@ -183,6 +183,8 @@ class ResNetBody(nn.Module):
                 inplanes = planes * 4
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self._stem_w4 = None
+        self._stem_wr = None
+        self.stem_packed = True       # row-packed stem (stem_rows); False = one tap per filter element (stem_weight4)
 
     def stem_weight4(self):
         """conv1 weight padded to 4 input channels ([64][7][7][4]) so a tap is one aligned 16-byte K-run."""
@@ -195,14 +197,46 @@ class ResNetBody(nn.Module):
             self._stem_w4 = (key, w4)
         return self._stem_w4[1]
 
+    def stem_weight_rows(self):
+        """conv1 weight as 7 row taps of K = 32: [64][ky][kx*4 + c] (kx < 7, c < 3; the 8th pixel and the 4th channel are zero).
+        A filter row of the 4-channel NHWC image is 28 contiguous floats, so the 7x7 stem becomes a 7-tap convolution whose
+        k-tiles are full 32-float runs -> the MFMA tile kernel (K % 32 == 0) instead of the generic 4-floats-per-tap path."""
+        w = self.conv1.weight
+        key = (w._version, w.data_ptr())
+        if self._stem_wr is None or self._stem_wr[0] != key:
+            with torch.no_grad():
+                wr = torch.zeros(64, 7, 8, 4, device=w.device)                # [o][ky][kx][c]
+                wr[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+                wr = wr.reshape(64, 7, 1, 32).permute(0, 3, 1, 2)             # logical [64, 32, 7, 1], channels_last memory
+            self._stem_wr = (key, wr)
+        return self._stem_wr[1]
+
+    def stem_rows(self, images):
+        """conv1 + bn1 + relu through the row-packed form: the image is written once into a zero-padded NHWC buffer (3 rows / 3
+        columns in front, enough behind for the 8-pixel runs), a GEMM row is the 32-float run starting at padded pixel (2y+ky, 2x)."""
+        B, _, H, W = images.shape
+        Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+        Ha, Wa = H + 6, W + 8 + (W & 1)
+        xp = torch.zeros((B, Ha, Wa, 4), device=images.device, dtype=torch.float32)
+        xp[:, 3:3 + H, 3:3 + W, :3] = images.permute(0, 2, 3, 1)
+        s, b = self.bn1.affine()
+        wr = self.stem_weight_rows()
+        y = torch.empty((B, Ho, Wo, 64), device=images.device, dtype=torch.float32)
+        g = ops._geom(ops._ffi.ROWS_CONV_FWD, Ha, Wa, Ho, Wo, 7, 1, 2, 0, 1)
+        ops.gemm_raw(xp, 4, wr, 7 * 32, y, 64, B * Ho * Wo, 64, 32, taps=7, w_scale=s, bias=b, relu=True, geom=g)
+        return y
+
     def forward_nhwc(self, images):
         """images [B,3,H,W] (NCHW, as the reference API) -> layer4 features NHWC [B,H/16,W/16,2048]."""
         B, _, H, W = images.shape
         with torch.no_grad():
-            x = torch.zeros((B, H, W, 4), device=images.device, dtype=torch.float32)
-            x[..., :3] = images.permute(0, 2, 3, 1)
-            s, b = self.bn1.affine()
-            x = ops.conv_fwd(x, self.stem_weight4(), s, b, stride=2, pad=3, relu=True)
+            if self.stem_packed:
+                x = self.stem_rows(images)
+            else:
+                x = torch.zeros((B, H, W, 4), device=images.device, dtype=torch.float32)
+                x[..., :3] = images.permute(0, 2, 3, 1)
+                s, b = self.bn1.affine()
+                x = ops.conv_fwd(x, self.stem_weight4(), s, b, stride=2, pad=3, relu=True)
             x = ops.maxpool3x3s2(x)
             for blk in self.layer1:
                 x = blk.forward_fused(x)

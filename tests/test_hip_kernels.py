@@ -601,6 +601,25 @@ def test_two_level_batch_image_by_head(N, nh, L, Wk, precision):
     close(dk.view(N, Wk, nh, 32), torch.einsum("nhlw,nlhd->nwhd", S64, q64), msg="dk", **tol(precision))
 
 
+@pytest.mark.parametrize("H,W", [(64, 96), (75, 53), (800, 800)])
+def test_stem_row_packed_equals_per_tap_form(H, W, precision):
+    """The 7x7 / stride-2 stem as 7 row taps of 32 floats on a zero-padded image == the per-element-tap form == F.conv2d (fp64)."""
+    from counting_detr_amd.backbone import ResNetBody
+    body = ResNetBody(True).to(DEV)
+    with torch.no_grad():
+        body.conv1.weight.copy_(torch.randn(body.conv1.weight.shape, generator=g(1)) * 0.05)
+        body.bn1.weight.copy_(torch.rand(64, generator=g(2)) + 0.5)
+        body.bn1.bias.copy_(torch.randn(64, generator=g(3)) * 0.1)
+        body.bn1.running_mean.copy_(torch.randn(64, generator=g(4)) * 0.1)
+        body.bn1.running_var.copy_(torch.rand(64, generator=g(5)) + 0.5)
+    img = torch.randn(2, 3, H, W, generator=g(6))
+    y_rows = body.stem_rows(img.to(DEV))
+    s, b = body.bn1.affine()
+    ref = F.conv2d(img.double(), body.conv1.weight.detach().double().cpu(), stride=2, padding=3)
+    ref = (ref * s.double().cpu().view(1, -1, 1, 1) + b.double().cpu().view(1, -1, 1, 1)).clamp_min(0)
+    close(y_rows.permute(0, 3, 1, 2), ref, msg="row-packed stem", **tol(precision))
+
+
 def test_gemm_group_matches_individual_calls(precision):
     """cdetr_gemm_group (ops.gemm_queue): few-row problems of three k-lengths, the 64x128 class with a pre-split weight image,
     a data-gradient operand (n-contiguous weight), epilogues (bias, residual, ReLU, gate) and 14 problems of one class (two
