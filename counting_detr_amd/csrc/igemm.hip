@@ -274,17 +274,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const cdetr_gemm_desc d, con
 #pragma unroll
         for (int b = 0; b < FN; ++b) {
             const int n = n0 + wn * (BN / 2) + b * 32 + i32;
-            if (n >= d.N) continue;
-            const float bias = d.bias ? d.bias[n] : 0.f;
+            const bool nvalid = n < d.N;
+            const int nc = nvalid ? n : d.N - 1;
+            const float bias = d.bias ? d.bias[nc] : 0.f;
+            const int mbase = m0 + wm * (BM / 2) + a * 32 + 4 * g;
+            float rv[16], gv[16];          // residual / gate operands as one batch of unconditional loads (see igemm_fast_body)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { rv[r] = 0.f; gv[r] = 1.f; }
+            if (d.resid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = d.resid[(long)min(mbase + (r & 3) + 8 * (r >> 2), d.M - 1) * d.ldr + nc];
+            }
+            if (d.gate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gv[r] = d.gate[(long)min(mbase + (r & 3) + 8 * (r >> 2), d.M - 1) * d.ldg + nc];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (m >= d.M) continue;
-                float v = (acc[a][b][r] + bias) * d.out_scale;
-                if (d.resid) v += d.resid[(long)m * d.ldr + n];
-                if (d.gate) v = d.gate[(long)m * d.ldg + n] > 0.f ? v : 0.f;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                float v = (acc[a][b][r] + bias) * d.out_scale + rv[r];
+                v = gv[r] > 0.f ? v : 0.f;
                 if (d.relu) v = fmaxf(v, 0.f);
-                C[(long)m * d.ldc + n] = v;
+                if (nvalid && m < d.M) C[(long)m * d.ldc + n] = v;
             }
         }
     }
@@ -430,12 +441,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
         for (int b = 0; b < FN; ++b) {
             const int c = c0 + wn * (BJ / 2) + b * 32 + i32;
             if (c >= d.Cin) continue;
+            float ws[16];                  // per-row weight scales as one batch of unconditional loads (clamped row)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[r] = 1.f;
+            if (d.w_scale) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[r] = d.w_scale[min(i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, d.Nout - 1)];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 if (i >= d.Nout) continue;
-                float v = acc[a][b][r];
-                if (d.w_scale) v *= d.w_scale[i];
+                float v = acc[a][b][r] * ws[r];
                 float* dst = dW + (long)i * d.ldw + (long)tap * d.Cin + c;
                 (void)single;
                 atomicAdd(dst, v);
@@ -809,22 +826,41 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
     mfma_drain(acc);
 
+    // Epilogue.  The residual / gate operands are fetched as ONE batch of 16 unconditional loads per fragment (clamped row / column,
+    // masked at the store): a load inside the per-element `if (m < M)` sits in its own basic block, the compiler then waits for
+    // each of the 16 round trips in turn -- measured with cold operands (tools/cold_gemm.py) that doubled the kernel time of
+    // every GEMM with a residual (20000x512x128: 30 -> 64 us).
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
 #pragma unroll
         for (int b = 0; b < FN; ++b) {
             const int n = n0 + wn * (32 * FN) + b * 32 + i32;
-            if (n >= d.N) continue;
-            const float bias = d.bias ? d.bias[n] : 0.f;
+            const bool nvalid = n < d.N;
+            const int nc = nvalid ? n : d.N - 1;
+            const float bias = d.bias ? d.bias[nc] : 0.f;
+            const int mbase = m0 + wm * (32 * FM) + a * 32 + 4 * g;
+            float rv[16], gv[16];
+            if (d.resid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = d.resid[(long)min(mbase + (r & 3) + 8 * (r >> 2), d.M - 1) * d.ldr + nc];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+            }
+            if (d.gate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gv[r] = d.gate[(long)min(mbase + (r & 3) + 8 * (r >> 2), d.M - 1) * d.ldg + nc];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gv[r] = 1.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (32 * FM) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (m >= d.M) continue;
-                float v = (acc[a][b][r] + bias) * d.out_scale;
-                if (d.resid) v += d.resid[(long)m * d.ldr + n];
-                if (d.gate) v = d.gate[(long)m * d.ldg + n] > 0.f ? v : 0.f;
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                float v = (acc[a][b][r] + bias) * d.out_scale + rv[r];
+                v = gv[r] > 0.f ? v : 0.f;
                 if (d.relu) v = fmaxf(v, 0.f);
-                C[(long)m * d.ldc + n] = v;
+                if (nvalid && m < d.M) C[(long)m * d.ldc + n] = v;
             }
         }
     }
@@ -1039,12 +1075,18 @@ __global__ __launch_bounds__(256) void wgrad_fast_kernel(const cdetr_wgrad_desc 
         for (int b = 0; b < FN; ++b) {
             const int c = c0 + wn * (BJ / 2) + b * 32 + i32;
             if (c >= d.Cin) continue;
+            float ws[16];                  // per-row weight scales as one batch of unconditional loads (clamped row)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[r] = 1.f;
+            if (d.w_scale) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[r] = d.w_scale[min(i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, d.Nout - 1)];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 if (i >= d.Nout) continue;
-                float v = acc[a][b][r];
-                if (d.w_scale) v *= d.w_scale[i];
+                float v = acc[a][b][r] * ws[r];
                 float* dst = dW + (long)i * d.ldw + (long)tap * d.Cin + c;
                 if (single) *dst += v;          // this launch owns the element: plain read-modify-write
                 else atomicAdd(dst, v);
@@ -1245,12 +1287,18 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
         for (int b = 0; b < FN; ++b) {
             const int c = c0 + wn * (BJ / 2) + b * 32 + i32;
             if (c >= d.Cin) continue;
+            float ws[16];                  // per-row weight scales as one batch of unconditional loads (clamped row)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[r] = 1.f;
+            if (d.w_scale) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[r] = d.w_scale[min(i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, d.Nout - 1)];
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
                 if (i >= d.Nout) continue;
-                float v = acc[a][b][r];
-                if (d.w_scale) v *= d.w_scale[i];
+                float v = acc[a][b][r] * ws[r];
                 float* dst = dW + (long)i * d.ldw + (long)tap * d.Cin + c;
                 if (single) *dst += v;
                 else atomicAdd(dst, v);
@@ -1328,6 +1376,22 @@ __device__ __forceinline__ void igemm_direct_body(const cdetr_gemm_desc& d, cons
     const float am = mv ? 1.f : 0.f;
     const float bm = nv ? s0 : 0.f;
     const float* wsc = d.w_scale;
+    // epilogue operands of the output elements wave 0 will write (row tm*16 + g4*4 + r, column tn*16 + i): fetched up front so
+    // their round trip overlaps the operand loads instead of following the reduction
+    float rv[4] = {0.f, 0.f, 0.f, 0.f}, gv[4] = {1.f, 1.f, 1.f, 1.f};
+    float bias = 0.f;
+    if (wid == 0) {
+        const int nc = min(n, d.N - 1);
+        if (d.bias) bias = d.bias[nc];
+        if (d.resid) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rv[r] = d.resid[(long)min(tm * 16 + g4 * 4 + r, d.M - 1) * d.ldr + nc];
+        }
+        if (d.gate) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gv[r] = d.gate[(long)min(tm * 16 + g4 * 4 + r, d.M - 1) * d.ldg + nc];
+        }
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = kbeg; k0 < kend; k0 += 16 * UB) {
         float a[UB][4], b[UB][4];
@@ -1383,15 +1447,13 @@ __device__ __forceinline__ void igemm_direct_body(const cdetr_gemm_desc& d, cons
     // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + r
     const int no = tn * 16 + i;
     if (no >= d.N) return;
-    const float bias = d.bias ? d.bias[no] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int mo = tm * 16 + g4 * 4 + r;
         if (mo >= d.M) continue;
         const float sum = (red[0][r * 64 + lane] + red[1][r * 64 + lane]) + (red[2][r * 64 + lane] + red[3][r * 64 + lane]);
-        float v = (sum + bias) * d.out_scale;
-        if (d.resid) v += d.resid[(long)mo * d.ldr + no];
-        if (d.gate) v = d.gate[(long)mo * d.ldg + no] > 0.f ? v : 0.f;
+        float v = (sum + bias) * d.out_scale + rv[r];
+        v = gv[r] > 0.f ? v : 0.f;
         if (d.relu) v = fmaxf(v, 0.f);
         C[(long)mo * d.ldc + no] = v;
     }
@@ -1432,6 +1494,11 @@ __device__ __forceinline__ void wgrad_direct_body(const cdetr_wgrad_desc& d, con
     const float* xb = X + (cv ? cc : 0);
     const float fa = iv ? 1.f : 0.f, fb = cv ? 1.f : 0.f;
     const int pbeg = by * p_per_slice, pend = min(d.P, pbeg + p_per_slice);
+    float ws[4] = {1.f, 1.f, 1.f, 1.f};        // output-row weight scales, fetched with the first operand batch
+    if (d.w_scale) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws[r] = d.w_scale[min(ti * 16 + g4 * 4 + r, d.Nout - 1)];
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
     for (int p0 = pbeg; p0 < pend; p0 += 16 * UB) {
@@ -1461,8 +1528,7 @@ __device__ __forceinline__ void wgrad_direct_body(const cdetr_wgrad_desc& d, con
         for (int r = 0; r < 4; ++r) {
             const int io = ti * 16 + g4 * 4 + r;
             if (io >= d.Nout) continue;
-            float v = acc[r];
-            if (d.w_scale) v *= d.w_scale[io];
+            const float v = acc[r] * ws[r];
             float* dst = dW + (long)io * d.ldw + co;
             if (single) *dst += v;               // one owner per element within a launch
             else atomicAdd(dst, v);
