@@ -813,6 +813,29 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
             step(std::integral_constant<int, 3>{});
         }
     }
+    // residual / gate operands of this wave's outputs: ONE batch of unconditional loads per fragment (clamped row / column, masked
+    // at the store), issued before the last k-tiles are computed so the round trip overlaps them.  (A load inside the per-element
+    // `if (m < M)` of the store loop sits in its own basic block and the compiler then waits for each of the 16 round trips in turn:
+    // measured with cold operands, tools/cold_gemm.py, that doubled every GEMM with a residual -- 20000x512x128: 30 -> 64 us.)
+    float rv[FM][FN][16], gv[FM][FN][16];
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int nc = min(n0 + wn * (32 * FN) + b * 32 + i32, d.N - 1);
+            const int mbase = m0 + wm * (32 * FM) + a * 32 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { rv[a][b][r] = 0.f; gv[a][b][r] = 1.f; }
+            if (d.resid) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) rv[a][b][r] = d.resid[(long)min(mbase + (r & 3) + 8 * (r >> 2), d.M - 1) * d.ldr + nc];
+            }
+            if (d.gate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) gv[a][b][r] = d.gate[(long)min(mbase + (r & 3) + 8 * (r >> 2), d.M - 1) * d.ldg + nc];
+            }
+        }
+    }
     const int rem = nkt - kt;                                      // 1 .. PD tiles left: tile kt is staged, the others sit in registers
     compute(0);
     if (rem > 1) {
@@ -826,39 +849,19 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
     mfma_drain(acc);
 
-    // Epilogue.  The residual / gate operands are fetched as ONE batch of 16 unconditional loads per fragment (clamped row / column,
-    // masked at the store): a load inside the per-element `if (m < M)` sits in its own basic block, the compiler then waits for
-    // each of the 16 round trips in turn -- measured with cold operands (tools/cold_gemm.py) that doubled the kernel time of
-    // every GEMM with a residual (20000x512x128: 30 -> 64 us).
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
 #pragma unroll
         for (int b = 0; b < FN; ++b) {
             const int n = n0 + wn * (32 * FN) + b * 32 + i32;
             const bool nvalid = n < d.N;
-            const int nc = nvalid ? n : d.N - 1;
-            const float bias = d.bias ? d.bias[nc] : 0.f;
+            const float bias = d.bias ? d.bias[nvalid ? n : d.N - 1] : 0.f;
             const int mbase = m0 + wm * (32 * FM) + a * 32 + 4 * g;
-            float rv[16], gv[16];
-            if (d.resid) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = d.resid[(long)min(mbase + (r & 3) + 8 * (r >> 2), d.M - 1) * d.ldr + nc];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) rv[r] = 0.f;
-            }
-            if (d.gate) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gv[r] = d.gate[(long)min(mbase + (r & 3) + 8 * (r >> 2), d.M - 1) * d.ldg + nc];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) gv[r] = 1.f;
-            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mbase + (r & 3) + 8 * (r >> 2);
-                float v = (acc[a][b][r] + bias) * d.out_scale + rv[r];
-                v = gv[r] > 0.f ? v : 0.f;
+                float v = (acc[a][b][r] + bias) * d.out_scale + rv[a][b][r];
+                v = gv[a][b][r] > 0.f ? v : 0.f;
                 if (d.relu) v = fmaxf(v, 0.f);
                 if (nvalid && m < d.M) C[(long)m * d.ldc + n] = v;
             }
