@@ -48,6 +48,32 @@ __host__ __device__ inline FwdSmem fwd_smem(int H, int W, int NW) {
     return s;
 }
 
+// Copy `rows` x `cols` (cols % 4 == 0, 16-byte aligned rows, row stride = cols) from global into an LDS tile of QW rows (row stride
+// lds_stride, any parity), zero-filling the rows >= rows_valid.  The global loads go out as batches of CH unconditional 16-byte loads
+// per lane (clamped index, masked use): a load inside `if (row < rows_valid)` / a runtime-trip loop of load -> LDS store makes the
+// wave wait for every round trip in turn (26 + 28 of them in the dS kernel's prologue before this was batched).
+template <int CH>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ gsrc, int rows_valid, int cols, float* lds, int lds_stride, int lane) {
+    const int cols4 = cols >> 2;
+    const int total4 = QW * cols4;
+    const int last4 = max(rows_valid * cols4 - 1, 0);
+    for (int base = 0; base < total4; base += 64 * CH) {
+        float4 t[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) t[u] = ld4(gsrc + 4 * (long)min(base + lane + 64 * u, last4));
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int i4 = base + lane + 64 * u;
+            if (i4 < total4) {
+                const int r = i4 / cols4, c = (i4 - r * cols4) * 4;
+                const bool ok = r < rows_valid;
+                float* dst = lds + r * lds_stride + c;
+                dst[0] = ok ? t[u].x : 0.f; dst[1] = ok ? t[u].y : 0.f; dst[2] = ok ? t[u].z : 0.f; dst[3] = ok ? t[u].w : 0.f;
+            }
+        }
+    }
+}
+
 // Phases 0-1 shared by both forward kernels: stage the projected keys of (n, head), compute both logit matrices with VALU
 // FMAs (lanes 0-31 own a full row of S_row, lanes 32-63 a full row of S_col: the softmax needs no cross-lane traffic),
 // leave A_row / A_col in this wave's LDS tiles and save them for the backward pass.  Ends with the K tiles dead.
@@ -60,11 +86,24 @@ __device__ __forceinline__ void rcda_scores(const cdetr_rcda_fwd_desc& d, const 
     float* Kcol = Krow + W * D;                // [H][32]
 
     // ---- phase 0: stage the projected keys of this (n, head)
-    for (int idx = tid; idx < (W + H) * 8; idx += NT) {
-        const int key = idx >> 3, c4 = idx & 7;
-        const float* src = (key < W) ? d.k_row + ((long)n * W + key) * E + head * D + c4 * 4
-                                     : d.k_col + ((long)n * H + (key - W)) * E + head * D + c4 * 4;
-        *reinterpret_cast<float4*>(Krow + key * D + c4 * 4) = ld4(src);
+    {   // batches of 4 unconditional loads per thread (clamped key, masked store)
+        const int nk8 = (W + H) * 8;
+        for (int base = 0; base < nk8; base += 4 * NT) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(base + tid + NT * u, nk8 - 1);
+                const int key = idx >> 3, c4 = idx & 7;
+                const float* src = (key < W) ? d.k_row + ((long)n * W + key) * E + head * D + c4 * 4
+                                             : d.k_col + ((long)n * H + (key - W)) * E + head * D + c4 * 4;
+                t[u] = ld4(src);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + tid + NT * u;
+                if (idx < nk8) *reinterpret_cast<float4*>(Krow + (idx >> 3) * D + (idx & 7) * 4) = t[u];
+            }
+        }
     }
     // this lane's query vector: half 0 -> q_row, half 1 -> q_col
     float qv[D];
@@ -434,16 +473,9 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
 
     // ---- load the saved attention rows of this wave (coalesced), zero for tail queries
     {
-        const float* gar = d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp;
-        for (int idx = lane; idx < QW * Wp; idx += 64) {
-            const int r = idx / Wp, c = idx - r * Wp;
-            Arow[r * sm.sw + c] = (r < nq) ? gar[idx] : 0.f;
-        }
-        const float* gac = d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp;
-        for (int idx = lane; idx < QW * Hp; idx += 64) {
-            const int r = idx / Hp, c = idx - r * Hp;
-            Acol[r * sm.sh + c] = (r < nq) ? gac[idx] : 0.f;
-        }
+        const int qb = min(qbase, L - 1), nqv = max(nq, 0);      // tail waves (qbase >= L) stage zeros from an in-bounds address
+        stage_rows<8>(d.a_row + (((long)n * d.nh + head) * L + qb) * Wp, nqv, Wp, Arow, sm.sw, lane);
+        stage_rows<8>(d.a_col + (((long)n * d.nh + head) * L + qb) * Hp, nqv, Hp, Acol, sm.sh, lane);
     }
     // dOut^T fragment (B operand, loop invariant): lane (j = query, g) holds dOut[q][8kk + 4g + s]
     float dob[4][4];
@@ -584,11 +616,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
     // ---- softmax backward, row attention: A_row comes back from HBM (coalesced, L2-hot) into the U slice
     {
         float* Ar = Acol;          // [32][sw] view of the slice
-        const float* gar = d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp;
-        for (int idx = lane; idx < QW * Wp; idx += 64) {
-            const int r = idx / Wp, c = idx - r * Wp;
-            Ar[r * sm.sw + c] = (r < nq) ? gar[idx] : 0.f;
-        }
+        stage_rows<8>(d.a_row + (((long)n * d.nh + head) * L + min(qbase, L - 1)) * Wp, max(nq, 0), Wp, Ar, sm.sw, lane);
         wave_sync();
         float dot = 0.f;
         for (int w = g; w < W; w += 2) dot = fmaf(Ar[i32 * sm.sw + w], dArow[i32 * sm.sw + w], dot);

@@ -1,3 +1,8 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pr -- python tools/rcda_bench.py 10 > /dev/null 2>&1
-f=$(find /tmp/pr -name "*kernel_stats.csv"); python tools/kernel_stats.py $f 12 1 | cut -c1-150
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prc -- python tools/rcda_bench.py 10 > /dev/null 2>&1
+f=$(find /tmp/prc -name "*kernel_stats.csv"); python - "$f" <<'PY'
+import csv, sys
+for r in csv.DictReader(open(sys.argv[1])):
+    if 'rcda' in r['Name'] or 'igemm' in r['Name'] or 'wgrad' in r['Name']:
+        print("  %-50s calls %4s avg %7.1f min %7.1f max %7.1f us" % (r['Name'].replace('(anonymous namespace)::','')[:50], r['Calls'], float(r['AverageNs'])/1e3, float(r['MinNs'])/1e3, float(r['MaxNs'])/1e3))
+PY
