@@ -252,8 +252,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
         const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * C);
         const float mu = mean[row], rs = rstd[row];
-        float4 xh[LN_MAXV], dg[LN_MAXV];
+        float4 xh[LN_MAXV], dg[LN_MAXV], a4[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
+        if (add) {      // the residual-branch gradient travels with the row's first round trip, not after the reductions
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i)
+                if (i < nv) a4[i] = reinterpret_cast<const float4*>(add + (long)row * C)[lane + 64 * i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i) a4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i)
             if (i < nv) {
@@ -273,10 +281,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 float4 o;
                 o.x = rs * (dg[i].x - m1 - xh[i].x * m2); o.y = rs * (dg[i].y - m1 - xh[i].y * m2);
                 o.z = rs * (dg[i].z - m1 - xh[i].z * m2); o.w = rs * (dg[i].w - m1 - xh[i].w * m2);
-                if (add) {
-                    const float4 a4 = reinterpret_cast<const float4*>(add + (long)row * C)[lane + 64 * i];
-                    o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
-                }
+                o.x += a4[i].x; o.y += a4[i].y; o.z += a4[i].z; o.w += a4[i].w;
                 ox[lane + 64 * i] = o;
             }
     }
@@ -391,6 +396,38 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict_
                                                         float scale_r, float scale_c) {
     const int b = blockIdx.x;
     const int c = threadIdx.x;          // C <= 256 handled per pass
+    if (C == 256) {
+        // thread = (channel quad, 1 of 4 interleaved slices of the reduced axis): 16-byte loads, 4 independent accumulation chains per
+        // workgroup column and an unrolled loop keep ~8 loads in flight per thread (the scalar loop below waits for each in turn)
+        __shared__ float4 part[4][64];
+        const int c4 = c & 63, sl = c >> 6;
+        const bool row = b < N * W;
+        const int r = row ? b : b - N * W;
+        const int cnt = row ? H : W;
+        const float* base;
+        long step;
+        if (row) { const int n = b / W, xw = b - n * W; base = Xr + (((long)n * H) * W + xw) * C + c4 * 4; step = (long)W * C; }
+        else { base = Xc + (long)r * W * C + c4 * 4; step = C; }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int k = sl; k < cnt; k += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(base + (long)k * step);
+            acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        part[sl][c4] = acc;
+        __syncthreads();
+        if (sl == 0) {
+            const float sc = row ? scale_r : scale_c;
+            float4 v = part[0][c4];
+            const float4 p1 = part[1][c4], p2 = part[2][c4], p3 = part[3][c4];
+            v.x = ((v.x + p1.x) + (p2.x + p3.x)) * sc; v.y = ((v.y + p1.y) + (p2.y + p3.y)) * sc;
+            v.z = ((v.z + p1.z) + (p2.z + p3.z)) * sc; v.w = ((v.w + p1.w) + (p2.w + p3.w)) * sc;
+            const float* add = row ? Ar : Ac;
+            if (add) { const float4 a = *reinterpret_cast<const float4*>(add + (long)r * C + c4 * 4); v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w; }
+            *reinterpret_cast<float4*>((row ? Or : Oc) + (long)r * C + c4 * 4) = v;
+        }
+        return;
+    }
     if (b < N * W) {
         const int n = b / W, xw = b % W;
         for (int cc = c; cc < C; cc += 256) {
@@ -451,7 +488,9 @@ extern "C" int cdetr_layernorm_bwd(const float* dy, const float* x, const float*
     CDETR_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && rows >= 0, "cdetr_layernorm_bwd: null pointer");
     CDETR_CHECK_ARG(C > 0 && (C & 255) == 0 && C <= 1024, "cdetr_layernorm_bwd: C must be a multiple of 256, <= 1024 (got %d)", C);
     if (rows == 0) return CDETR_OK;
-    int blocks = (rows + 15) / 16;       // >= 4 rows per wave: amortises the per-workgroup dgamma/dbeta atomics
+    // >= 4 rows per wave amortise the per-workgroup dgamma / dbeta atomics on long inputs; short ones (decoder: 600 rows) are latency
+    // bound, one row per wave there
+    int blocks = rows <= 2048 ? (rows + 3) / 4 : (rows + 15) / 16;
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma,
