@@ -981,6 +981,11 @@ extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
             hipLaunchKernelGGL(kern, grid, block, bytes, st, d);
             return cdetr_launch_status("cdetr_rcda_fwd");
         };
+        // 5-wave workgroups (160 queries) when that lands the grid on <= one workgroup per CU and 4 waves do not: the encoder's
+        // 2 x 8 x 2500 queries are 320 workgroups of 128 (64 CUs get two) but exactly 256 of 160
+        static const int nw5 = getenv("CDETR_RCDA_NW5") ? atoi(getenv("CDETR_RCDA_NW5")) : 1;
+        const long wg4 = (long)((d.L + QW * 4 - 1) / (QW * 4)) * d.N * d.nh, wg5 = (long)((d.L + QW * 5 - 1) / (QW * 5)) * d.N * d.nh;
+        if (nw5 && nw == 4 && ks == 4 && wg4 > 256 && wg4 <= 512 && wg5 <= 256) return go(rcda_fwd2_kernel<5, 4>, 5);
         if (nw == 4) {
             if (ks == 1) return go(rcda_fwd2_kernel<4, 1>, 4);
             if (ks == 2) return go(rcda_fwd2_kernel<4, 2>, 4);
@@ -1009,7 +1014,13 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     const int nw = pick_nw(d.L, d.N * d.nh);
     int rc;
     if (NF == 1) rc = nw == 4 ? launch_rcda_bwd<1, 4>(d, st) : launch_rcda_bwd<1, 2>(d, st);
-    else if (NF == 2) rc = nw == 4 ? launch_rcda_bwd<2, 4>(d, st) : launch_rcda_bwd<2, 2>(d, st);
+    else if (NF == 2) {
+        // 5-wave workgroups when they put the grid on <= one workgroup per CU and 4-wave ones do not (see cdetr_rcda_fwd)
+        static const int nw5 = getenv("CDETR_RCDA_NW5") ? atoi(getenv("CDETR_RCDA_NW5")) : 1;
+        const long wg4 = (long)((d.L + QW * 4 - 1) / (QW * 4)) * d.N * d.nh, wg5 = (long)((d.L + QW * 5 - 1) / (QW * 5)) * d.N * d.nh;
+        if (nw5 && nw == 4 && wg4 > 256 && wg4 <= 512 && wg5 <= 256) rc = launch_rcda_bwd<2, 5>(d, st);
+        else rc = nw == 4 ? launch_rcda_bwd<2, 4>(d, st) : launch_rcda_bwd<2, 2>(d, st);
+    }
     else rc = nw == 4 ? launch_rcda_bwd<4, 4>(d, st) : launch_rcda_bwd<4, 2>(d, st);
     if (rc) return rc;
     static const int use_dv2 = getenv("CDETR_RCDA_DV2") ? atoi(getenv("CDETR_RCDA_DV2")) : 1;

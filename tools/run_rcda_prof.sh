@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prc -- python tools/rcda_bench.py 10 > /dev/null 2>&1
-f=$(find /tmp/prc -name "*kernel_stats.csv"); python - "$f" <<'PY'
+rm -rf /tmp/prc; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prc -- python tools/rcda_bench.py 10 > /dev/null 2>&1
+f=$(find /tmp/prc -name "*kernel_stats.csv" | head -1); python - "$f" <<'PY'
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     if 'rcda' in r['Name'] or 'igemm' in r['Name'] or 'wgrad' in r['Name']:
