@@ -1028,7 +1028,8 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
         const int bytes = dv2_smem().total * 4;
         const int hgroups = (d.H + 7) / 8;
         const long base = (long)hgroups * d.N * d.nh;
-        int slices = (int)((512 + base - 1) / base);                 // ~2 workgroups of 8 waves per CU
+        static const int dv2_target = getenv("CDETR_RCDA_DV2_TARGET") ? atoi(getenv("CDETR_RCDA_DV2_TARGET")) : 448;
+        int slices = (int)((dv2_target + base - 1) / base);          // < 2 workgroups of 8 waves per CU (measured: 448 -> 46 us, 512 -> 54 us at the encoder shape)
         const int max_slices = (d.L + 255) / 256;                    // >= 4 q-tiles per slice
         if (slices > max_slices) slices = max_slices;
         if (slices < 1) slices = 1;
