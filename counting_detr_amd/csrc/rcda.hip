@@ -74,6 +74,22 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ gsrc, int r
     }
 }
 
+// The reverse of stage_rows: `rows` x `cols` (cols % 4 == 0) from an LDS tile (row stride lds_stride, any parity) to a contiguous, 16-byte
+// aligned global block, 16-byte stores, (row, column) advanced incrementally -- the per-element `idx / cols` of a flat loop costs ~40
+// instructions each and was a third of the score phase.
+__device__ __forceinline__ void save_rows(const float* lds, int lds_stride, float* __restrict__ gdst, int rows, int cols, int lane) {
+    const int cols4 = cols >> 2;
+    const int dr = 64 / cols4, dc = 64 - dr * cols4;        // one trip advances 64 float4 = dr rows + dc quads
+    int r = lane / cols4, c4 = lane - r * cols4;
+    const int total4 = rows * cols4;
+    for (int i4 = lane; i4 < total4; i4 += 64) {
+        const float* src = lds + r * lds_stride + 4 * c4;
+        *reinterpret_cast<float4*>(gdst + 4 * (long)i4) = make_float4(src[0], src[1], src[2], src[3]);
+        r += dr; c4 += dc;
+        if (c4 >= cols4) { c4 -= cols4; ++r; }
+    }
+}
+
 // Phases 0-1 shared by both forward kernels: stage the projected keys of (n, head), compute both logit matrices with VALU
 // FMAs (lanes 0-31 own a full row of S_row, lanes 32-63 a full row of S_col: the softmax needs no cross-lane traffic),
 // leave A_row / A_col in this wave's LDS tiles and save them for the backward pass.  Ends with the K tiles dead.
@@ -127,6 +143,7 @@ __device__ __forceinline__ void rcda_scores(const cdetr_rcda_fwd_desc& d, const 
         const uint8_t* mk = (g == 0) ? d.mask_row : d.mask_col;
         if (mk) mk += (long)n * nkeys;
         float mx = -INFINITY;
+#pragma unroll 2
         for (int k = 0; k < nkeys; ++k) {
             float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -143,12 +160,14 @@ __device__ __forceinline__ void rcda_scores(const cdetr_rcda_fwd_desc& d, const 
             mx = fmaxf(mx, s);
         }
         float sum = 0.f;
+#pragma unroll 4
         for (int k = 0; k < nkeys; ++k) {
             const float e = expf(S[k] - mx);
             S[k] = e;
             sum += e;
         }
         const float inv = 1.f / sum;
+#pragma unroll 4
         for (int k = 0; k < nkeys; ++k) S[k] *= inv;
         for (int k = nkeys; k < npad; ++k) S[k] = 0.f;
     }
@@ -158,16 +177,8 @@ __device__ __forceinline__ void rcda_scores(const cdetr_rcda_fwd_desc& d, const 
     {
         const int nq = min(QW, L - qbase);   // may be <= 0 for tail waves
         if (nq > 0) {
-            float* gar = d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp;
-            for (int idx = lane; idx < nq * Wp; idx += 64) {
-                const int r = idx / Wp, c = idx - r * Wp;
-                gar[idx] = Srow[r * sm.sw + c];
-            }
-            float* gac = d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp;
-            for (int idx = lane; idx < nq * Hp; idx += 64) {
-                const int r = idx / Hp, c = idx - r * Hp;
-                gac[idx] = Scol[r * sm.sh + c];
-            }
+            save_rows(Srow, sm.sw, d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
+            save_rows(Scol, sm.sh, d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
         }
     }
 
@@ -624,13 +635,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
         for (int w = g; w < Wp; w += 2)
             dArow[i32 * sm.sw + w] = (w < W) ? d.scale * Ar[i32 * sm.sw + w] * (dArow[i32 * sm.sw + w] - dot) : 0.f;
         wave_sync();
-        if (nq > 0) {
-            float* gdr = d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp;
-            for (int idx = lane; idx < nq * Wp; idx += 64) {
-                const int r = idx / Wp, c = idx - r * Wp;
-                gdr[idx] = dArow[r * sm.sw + c];
-            }
-        }
+        if (nq > 0) save_rows(dArow, sm.sw, d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
         wave_sync();               // the slice is rewritten below
     }
     // ---- softmax backward, column attention (registers), staged through the U slice for a coalesced store
@@ -649,13 +654,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
                 if (h < Hp) Acol[i32 * sm.sh + h] = d.scale * acolT[f][r] * (dacolT[f][r] - dot);
             }
         wave_sync();
-        if (nq > 0) {
-            float* gdc = d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp;
-            for (int idx = lane; idx < nq * Hp; idx += 64) {
-                const int r = idx / Hp, c = idx - r * Hp;
-                gdc[idx] = Acol[r * sm.sh + c];
-            }
-        }
+        if (nq > 0) save_rows(Acol, sm.sh, d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
     }
 }
 
