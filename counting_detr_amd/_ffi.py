@@ -49,7 +49,8 @@ class RcdaFwdDesc(C.Structure):
 class RcdaBwdDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("nh", C.c_int32),
                 ("precision", C.c_int32), ("scale", C.c_float), ("d_out", _p), ("a_row", _p), ("a_col", _p), ("v", _p),
-                ("ds_row", _p), ("ds_col", _p), ("d_v", _p)]
+                ("ds_row", _p), ("ds_col", _p), ("d_v", _p), ("k_row", _p), ("k_col", _p), ("dq_row", _p), ("dq_col", _p),
+                ("q_row", _p), ("q_col", _p), ("dk_row", _p), ("dk_col", _p)]
 
 
 class CriterionDesc(C.Structure):

@@ -443,9 +443,9 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
 //   R: per-wave [32][sw] A_row; element (q, w) is overwritten by dA_row[q, w] as soon as column w has been consumed.
 constexpr int BWD_CG = 2;     // key columns staged and consumed per workgroup barrier of the dS kernel
 struct BwdSmem {
-    int sw, sh, su, off_u, off_r, total;
+    int sw, sh, su, off_u, off_r, off_kk, total;
 };
-__host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW) {
+__host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW, bool with_k = false) {
     BwdSmem s;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
     s.sw = Wp + 1;
@@ -457,6 +457,8 @@ __host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW) {
     if (v > u) u = v;
     s.off_r = (u + 3) & ~3;
     s.total = s.off_r + NW * QW * s.sw;
+    s.off_kk = (s.total + 3) & ~3;                  // projected keys of (n, head) for the fused query gradients: [W][32] | [H][32]
+    if (with_k) s.total = s.off_kk + (W + H) * D;
     return s;
 }
 
@@ -468,7 +470,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
     constexpr int HR = 32 * NF;            // V tile rows (zero beyond H)
     const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
-    const BwdSmem sm = bwd_smem(H, W, NF, NW);
+    const BwdSmem sm = bwd_smem(H, W, NF, NW, d.dq_row != nullptr);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, g = lane >> 5;
     const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
@@ -476,6 +478,25 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
     const int q = qbase + i32;
     const bool qvalid = q < L;
     const int nq = min(QW, L - qbase);
+
+    // projected keys of (n, head) for the fused query gradients: requested now, parked in registers through the main loop and written
+    // to LDS at the end (no exposed round trip there); larger key sets are staged late
+    constexpr int KP = 4;
+    const int nk8 = (W + H) * 8;
+    const bool kpre_ok = d.dq_row != nullptr && nk8 <= KP * NT;
+    float4 kpre[KP];
+#pragma unroll
+    for (int u = 0; u < KP; ++u) kpre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kpre_ok) {
+#pragma unroll
+        for (int u = 0; u < KP; ++u) {
+            const int idx = min(tid + NT * u, nk8 - 1);
+            const int key = idx >> 3, c4 = idx & 7;
+            const float* src = (key < W) ? d.k_row + ((long)n * W + key) * E + head * D + c4 * 4
+                                         : d.k_col + ((long)n * H + (key - W)) * E + head * D + c4 * 4;
+            kpre[u] = ld4(src);
+        }
+    }
 
     float* Acol = smem + sm.off_u + wid * QW * sm.su;        // this wave's U slice, [32][sh] view
     float* Arow = smem + sm.off_r + wid * QW * sm.sw;        // [32][sw]; turns into dA_row column by column
@@ -655,6 +676,153 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
             }
         wave_sync();
         if (nq > 0) save_rows(Acol, sm.sh, d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
+    }
+    // ---- fused query gradients: dq_row[q][:] = sum_w dS_row[q][w] k_row[w][:], dq_col likewise.  dS_row / dS_col are still in this
+    // wave's LDS tiles; the projected keys of (n, head) are staged once per workgroup.  Lane (query i32, half g) owns channels 16g..16g+15.
+    if (d.dq_row) {
+        float* Kk = smem + sm.off_kk;
+        if (kpre_ok) {
+#pragma unroll
+            for (int u = 0; u < KP; ++u) {
+                const int idx = tid + NT * u;
+                if (idx < nk8) *reinterpret_cast<float4*>(Kk + (idx >> 3) * D + (idx & 7) * 4) = kpre[u];
+            }
+        } else
+        for (int base = 0; base < nk8; base += 4 * NT) {       // batches of 4 unconditional loads per thread (clamped key, masked store)
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(base + tid + NT * u, nk8 - 1);
+                const int key = idx >> 3, c4 = idx & 7;
+                const float* src = (key < W) ? d.k_row + ((long)n * W + key) * E + head * D + c4 * 4
+                                             : d.k_col + ((long)n * H + (key - W)) * E + head * D + c4 * 4;
+                t[u] = ld4(src);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + tid + NT * u;
+                if (idx < nk8) *reinterpret_cast<float4*>(Kk + (idx >> 3) * D + (idx & 7) * 4) = t[u];
+            }
+        }
+        __syncthreads();
+        if constexpr (PREC == 1) {
+            // dq^T[c][q] = sum_w k^T[c][w] dS^T[w][q] on the matrix pipe: A = k^T (row = channel i32, k-slot j of step s <-> key 16s + 8g + j),
+            // B = dS^T (column = query i32, same key slots, read from this lane's own LDS row); keys past the end are masked to zero
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int nkeys = side == 0 ? W : H;
+                const float* S = side == 0 ? dArow + i32 * sm.sw : Acol + i32 * sm.sh;
+                const float* Ks = Kk + (side == 0 ? 0 : W * D) + i32;
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const int nks = (nkeys + 15) >> 4;
+                for (int st = 0; st < nks; ++st) {
+                    float a[8], b[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int w = 16 * st + 8 * g + j;
+                        const int wc = min(w, nkeys - 1);
+                        const float av = Ks[wc * D], bv = S[wc];
+                        a[j] = (w < nkeys) ? av : 0.f;
+                        b[j] = (w < nkeys) ? bv : 0.f;
+                    }
+                    bf16x8 ah, al, bh, bl;
+                    split_bf16x8(a, ah, al);
+                    split_bf16x8(b, bh, bl);
+                    acc = mfma_bf16x3(ah, al, bh, bl, acc);
+                }
+                mfma_drain(acc);
+                if (qvalid) {      // lane = query i32; register r = channel (r & 3) + 8 (r >> 2) + 4 g
+                    float* dst = (side == 0 ? d.dq_row : d.dq_col) + ((long)n * L + q) * E + head * D + 4 * g;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        *reinterpret_cast<float4*>(dst + 8 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
+                }
+            }
+            if (d.dk_row) {
+                // ---- fused key gradients: dk[w][c] += sum_q dS[q][w] q[q][c] over this workgroup's queries.  Per wave: A = dS^T (row = key,
+                // k-slot j of step s <-> query 16s + 8g + j, column reads of the wave's LDS tile), B = the projected queries straight from
+                // global (lane = channel i32: 128-byte coalesced rows); every wave adds its partial [keys][32] tile to global atomically
+                // (summing the waves' tiles in LDS first cost more: ds_add_f32 runs at a few hundred cycles per wave instruction).
+                float qv[2][2][8];                                    // [side][step][j]: q[qbase + 16 step + 8g + j][head*32 + i32]
+#pragma unroll
+                for (int side = 0; side < 2; ++side)
+#pragma unroll
+                    for (int st = 0; st < 2; ++st)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int qq = qbase + 16 * st + 8 * g + j;
+                            const float t = (side == 0 ? d.q_row : d.q_col)[((long)n * L + min(max(qq, 0), L - 1)) * E + head * D + i32];
+                            qv[side][st][j] = t;
+                        }
+#pragma unroll
+                for (int side = 0; side < 2; ++side) {
+                    const int nkeys = side == 0 ? W : H;
+                    const float* S = side == 0 ? dArow : Acol;        // [32 queries][stride]
+                    const int sstr = side == 0 ? sm.sw : sm.sh;
+                    float* acc_g = (side == 0 ? d.dk_row + (long)n * W * E : d.dk_col + (long)n * H * E) + head * D + i32;
+                    bf16x8 bh[2], bl[2];
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        float b[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) b[j] = (qbase + 16 * st + 8 * g + j < L) ? qv[side][st][j] : 0.f;
+                        split_bf16x8(b, bh[st], bl[st]);
+                    }
+                    const int ntile = (nkeys + 31) >> 5;
+                    for (int tl = 0; tl < ntile; ++tl) {
+                        const int wkey = 32 * tl + i32, wc = min(wkey, nkeys - 1);
+                        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int st = 0; st < 2; ++st) {
+                            float a[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float av = S[(16 * st + 8 * g + j) * sstr + wc];      // rows of tail queries hold zeros
+                                a[j] = (wkey < nkeys) ? av : 0.f;
+                            }
+                            bf16x8 ah, al;
+                            split_bf16x8(a, ah, al);
+                            acc = mfma_bf16x3(ah, al, bh[st], bl[st], acc);
+                        }
+                        mfma_drain(acc);
+                        // accumulator: row = key 32 tl + (r & 3) + 8 (r >> 2) + 4 g, column = channel i32
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int wk = 32 * tl + (r & 3) + 8 * (r >> 2) + 4 * g;
+                            if (wk < nkeys) atomicAdd(acc_g + (long)wk * E, acc[r]);     // 128-byte rows per half-wave
+                        }
+                    }
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            const int nkeys = side == 0 ? W : H;
+            const float* S = side == 0 ? dArow + i32 * sm.sw : Acol + i32 * sm.sh;
+            const float* Ks = Kk + (side == 0 ? 0 : W * D) + 16 * g;
+            float acc[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+#pragma unroll 2
+            for (int k = 0; k < nkeys; ++k) {
+                const float a = S[k];
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const float4 kv = *reinterpret_cast<const float4*>(Ks + k * D + c4 * 4);
+                    acc[c4 * 4 + 0] = fmaf(a, kv.x, acc[c4 * 4 + 0]);
+                    acc[c4 * 4 + 1] = fmaf(a, kv.y, acc[c4 * 4 + 1]);
+                    acc[c4 * 4 + 2] = fmaf(a, kv.z, acc[c4 * 4 + 2]);
+                    acc[c4 * 4 + 3] = fmaf(a, kv.w, acc[c4 * 4 + 3]);
+                }
+            }
+            if (qvalid) {
+                float* dst = (side == 0 ? d.dq_row : d.dq_col) + ((long)n * L + q) * E + head * D + 16 * g;
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4)
+                    *reinterpret_cast<float4*>(dst + c4 * 4) = make_float4(acc[c4 * 4], acc[c4 * 4 + 1], acc[c4 * 4 + 2], acc[c4 * 4 + 3]);
+            }
+        }
     }
 }
 
@@ -936,7 +1104,7 @@ int launch_rcda_fwd(const cdetr_rcda_fwd_desc& d, hipStream_t st) {
 }
 template <int NF, int NW>
 int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st) {
-    const BwdSmem sm = bwd_smem(d.H, d.W, NF, NW);
+    const BwdSmem sm = bwd_smem(d.H, d.W, NF, NW, d.dq_row != nullptr);
     const int bytes = sm.total * 4;
     int rc;
     dim3 grid((d.L + QW * NW - 1) / (QW * NW), d.N * d.nh), block(64 * NW);
@@ -1007,6 +1175,9 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     CDETR_CHECK_ARG(d.N > 0 && d.L > 0 && d.H > 0 && d.W > 0 && d.nh > 0, "cdetr_rcda_bwd: bad sizes");
     CDETR_CHECK_ARG(d.H <= 128 && d.W <= 1024, "cdetr_rcda_bwd: H must be <= 128 (got %d)", d.H);
     CDETR_CHECK_ARG(d.d_out && d.a_row && d.a_col && d.v && d.ds_row && d.ds_col && d.d_v, "cdetr_rcda_bwd: null pointer");
+    CDETR_CHECK_ARG(!d.dq_row || (d.dq_col && d.k_row && d.k_col), "cdetr_rcda_bwd: dq_row needs dq_col, k_row and k_col");
+    CDETR_CHECK_ARG(!d.dk_row || (d.dq_row && d.dk_col && d.q_row && d.q_col && d.precision == 1),
+                    "cdetr_rcda_bwd: dk_row needs dk_col, q_row, q_col, the dq_* outputs and precision 1");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int NF = d.H <= 32 ? 1 : (d.H <= 64 ? 2 : 4);
     const int Wp = (d.W + 3) & ~3;

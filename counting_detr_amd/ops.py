@@ -6,6 +6,8 @@ channels_last memory (`[Cout][kh][kw][Cin]` physically) so a filter tap is a con
 parameter gradients are ACCUMULATED in place into `param.grad` (the trainer's flat gradient arena) by the
 weight-gradient kernels -- autograd only carries activation gradients.
 """
+import os
+
 import torch
 
 from . import _ffi
@@ -424,6 +426,10 @@ def maxpool3x3s2(x):
 
 
 # ----------------------------------------------------------------------------------------------------- RCDA core
+FUSE_RCDA_DQ = os.environ.get("CDETR_RCDA_FUSE_DQ", "1") != "0"     # query gradients inside the dS launch (A/B knob)
+FUSE_RCDA_DK = os.environ.get("CDETR_RCDA_FUSE_DK", "1") != "0"     # key gradients too (split-bf16 mode)
+
+
 def rcda_pads(H, W):
     return (H + 7) & ~7, (W + 3) & ~3
 
@@ -464,22 +470,30 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
     d.precision = PRECISION
     d.d_out, d.a_row, d.a_col, d.v = ptr(d_out), ptr(a_row), ptr(a_col), ptr(v)
     d.ds_row, d.ds_col, d.d_v = ptr(ds_row), ptr(ds_col), ptr(d_v)
-    with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32)):
-        check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
-    # logits -> projected q/k gradients: four small batched GEMMs per image (batch over heads) on the same MFMA kernels
+    # logits -> projected query gradients: fused into the dS launch (the kernel still holds dS_row / dS_col in LDS)
     dq_row = torch.empty_like(q_row)
     dq_col = torch.empty_like(q_col)
+    fuse_dq = FUSE_RCDA_DQ
+    fuse_dk = fuse_dq and FUSE_RCDA_DK and PRECISION == 1
     dk = zbuf[v.numel():]
     dk_row, dk_col = dk[:k_row.numel()].view(k_row.shape), dk[k_row.numel():].view(k_col.shape)
+    if fuse_dq:
+        d.k_row, d.k_col, d.dq_row, d.dq_col = ptr(k_row), ptr(k_col), ptr(dq_row), ptr(dq_col)
+    if fuse_dk:
+        d.q_row, d.q_col, d.dk_row, d.dk_col = ptr(q_row), ptr(q_col), ptr(dk_row), ptr(dk_col)
+    with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32)):
+        check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
     # two-level batch (image x head): one launch per contraction for the whole batch of images
-    gemm_raw(ds_row, Wp, k_row, E, dq_row, E, L, 32, W, b_layout=1, batch=N * nh, sA=L * Wp, sB=32, sC=32,
-             batch_inner=nh, sA2=nh * L * Wp, sB2=W * E, sC2=L * E)
-    gemm_raw(ds_col, Hp, k_col, E, dq_col, E, L, 32, H, b_layout=1, batch=N * nh, sA=L * Hp, sB=32, sC=32,
-             batch_inner=nh, sA2=nh * L * Hp, sB2=H * E, sC2=L * E)
-    wgrad_raw(ds_row, Wp, q_row, E, dk_row, E, L, W, 32, batch=N * nh, sY=L * Wp, sX=32, sW=32,
-              batch_inner=nh, sY2=nh * L * Wp, sX2=L * E, sW2=W * E)
-    wgrad_raw(ds_col, Hp, q_col, E, dk_col, E, L, H, 32, batch=N * nh, sY=L * Hp, sX=32, sW=32,
-              batch_inner=nh, sY2=nh * L * Hp, sX2=L * E, sW2=H * E)
+    if not fuse_dq:
+        gemm_raw(ds_row, Wp, k_row, E, dq_row, E, L, 32, W, b_layout=1, batch=N * nh, sA=L * Wp, sB=32, sC=32,
+                 batch_inner=nh, sA2=nh * L * Wp, sB2=W * E, sC2=L * E)
+        gemm_raw(ds_col, Hp, k_col, E, dq_col, E, L, 32, H, b_layout=1, batch=N * nh, sA=L * Hp, sB=32, sC=32,
+                 batch_inner=nh, sA2=nh * L * Hp, sB2=H * E, sC2=L * E)
+    if not fuse_dk:
+        wgrad_raw(ds_row, Wp, q_row, E, dk_row, E, L, W, 32, batch=N * nh, sY=L * Wp, sX=32, sW=32,
+                  batch_inner=nh, sY2=nh * L * Wp, sX2=L * E, sW2=W * E)
+        wgrad_raw(ds_col, Hp, q_col, E, dk_col, E, L, H, 32, batch=N * nh, sY=L * Hp, sX=32, sW=32,
+                  batch_inner=nh, sY2=nh * L * Hp, sX2=L * E, sW2=H * E)
     return dq_row, dq_col, dk_row, dk_col, d_v
 
 

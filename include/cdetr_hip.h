@@ -188,13 +188,20 @@ int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* d, void* stream);
 
 /* Backward of the core: given d_out [N][L][E] and the saved a_row/a_col, writes
  * ds_row [N][nh][L][Wp], ds_col [N][nh][L][Hp] (gradients of the PRE-softmax logits, already multiplied by
- * `scale`) and accumulates d_v [N][H][W][E] (must be zeroed by the caller).                                    */
+ * `scale`) and accumulates d_v [N][H][W][E] (must be zeroed by the caller).
+ * Optional (NULL = skip): with k_row [N][W][E], k_col [N][H][E] and dq_row / dq_col [N][L][E] given, the same launch also
+ * writes the query gradients dq_row[q] = sum_w ds_row[q][w] k_row[w], dq_col[q] = sum_h ds_col[q][h] k_col[h] (per head) --
+ * the logits -> projected-query step of the reference's autograd (A2/models/row_column_decoupled_attention.py:230-262).   */
 typedef struct {
     int32_t N, L, H, W, nh;
     int32_t precision;
     float scale;
     const float* d_out; const float* a_row; const float* a_col; const float* v;
     float* ds_row; float* ds_col; float* d_v;
+    const float* k_row; const float* k_col;
+    float* dq_row; float* dq_col;
+    const float* q_row; const float* q_col;   /* optional, with dq_*: also ACCUMULATE the key gradients                        */
+    float* dk_row; float* dk_col;             /* dk_row[n][w] += sum_q ds_row[q][w] q_row[q] (per head; caller zeroes them)    */
 } cdetr_rcda_bwd_desc;
 int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* d, void* stream);
 static inline int32_t cdetr_rcda_wp(int32_t W) { return (W + 3) & ~3; }
