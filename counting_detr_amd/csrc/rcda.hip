@@ -656,7 +656,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
         for (int w = g; w < Wp; w += 2)
             dArow[i32 * sm.sw + w] = (w < W) ? d.scale * Ar[i32 * sm.sw + w] * (dArow[i32 * sm.sw + w] - dot) : 0.f;
         wave_sync();
-        if (nq > 0) save_rows(dArow, sm.sw, d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
+        if (nq > 0 && d.ds_row) save_rows(dArow, sm.sw, d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
         wave_sync();               // the slice is rewritten below
     }
     // ---- softmax backward, column attention (registers), staged through the U slice for a coalesced store
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
                 if (h < Hp) Acol[i32 * sm.sh + h] = d.scale * acolT[f][r] * (dacolT[f][r] - dot);
             }
         wave_sync();
-        if (nq > 0) save_rows(Acol, sm.sh, d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
+        if (nq > 0 && d.ds_col) save_rows(Acol, sm.sh, d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
     }
     // ---- fused query gradients: dq_row[q][:] = sum_w dS_row[q][w] k_row[w][:], dq_col likewise.  dS_row / dS_col are still in this
     // wave's LDS tiles; the projected keys of (n, head) are staged once per workgroup.  Lane (query i32, half g) owns channels 16g..16g+15.
@@ -1174,7 +1174,9 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     const cdetr_rcda_bwd_desc d = *dp;
     CDETR_CHECK_ARG(d.N > 0 && d.L > 0 && d.H > 0 && d.W > 0 && d.nh > 0, "cdetr_rcda_bwd: bad sizes");
     CDETR_CHECK_ARG(d.H <= 128 && d.W <= 1024, "cdetr_rcda_bwd: H must be <= 128 (got %d)", d.H);
-    CDETR_CHECK_ARG(d.d_out && d.a_row && d.a_col && d.v && d.ds_row && d.ds_col && d.d_v, "cdetr_rcda_bwd: null pointer");
+    CDETR_CHECK_ARG(d.d_out && d.a_row && d.a_col && d.v && d.d_v, "cdetr_rcda_bwd: null pointer");
+    CDETR_CHECK_ARG((d.ds_row && d.ds_col) || (!d.ds_row && !d.ds_col && d.dk_row),
+                    "cdetr_rcda_bwd: ds_row / ds_col may only be omitted (both) when the fused q / k gradients are requested");
     CDETR_CHECK_ARG(!d.dq_row || (d.dq_col && d.k_row && d.k_col), "cdetr_rcda_bwd: dq_row needs dq_col, k_row and k_col");
     CDETR_CHECK_ARG(!d.dk_row || (d.dq_row && d.dk_col && d.q_row && d.q_col && d.precision == 1),
                     "cdetr_rcda_bwd: dk_row needs dk_col, q_row, q_col, the dq_* outputs and precision 1");

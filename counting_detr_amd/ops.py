@@ -460,8 +460,6 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
     H, W = v.shape[1:3]
     Hp, Wp = rcda_pads(H, W)
     d_out = d_out.contiguous()
-    ds_row = torch.empty_like(a_row)
-    ds_col = torch.empty_like(a_col)
     # one fill for everything the backward accumulates into atomically: dV and both key gradients
     zbuf = torch.zeros(v.numel() + k_row.numel() + k_col.numel(), device=v.device, dtype=torch.float32)
     d_v = zbuf[:v.numel()].view(v.shape)
@@ -469,7 +467,7 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
     d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
     d.precision = PRECISION
     d.d_out, d.a_row, d.a_col, d.v = ptr(d_out), ptr(a_row), ptr(a_col), ptr(v)
-    d.ds_row, d.ds_col, d.d_v = ptr(ds_row), ptr(ds_col), ptr(d_v)
+    d.d_v = ptr(d_v)
     # logits -> projected query gradients: fused into the dS launch (the kernel still holds dS_row / dS_col in LDS)
     dq_row = torch.empty_like(q_row)
     dq_col = torch.empty_like(q_col)
@@ -481,6 +479,10 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
         d.k_row, d.k_col, d.dq_row, d.dq_col = ptr(k_row), ptr(k_col), ptr(dq_row), ptr(dq_col)
     if fuse_dk:
         d.q_row, d.q_col, d.dk_row, d.dk_col = ptr(q_row), ptr(q_col), ptr(dk_row), ptr(dk_col)
+        ds_row = ds_col = None                     # the logit gradients never leave the chip
+    else:
+        ds_row, ds_col = torch.empty_like(a_row), torch.empty_like(a_col)
+        d.ds_row, d.ds_col = ptr(ds_row), ptr(ds_col)
     with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32)):
         check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
     # two-level batch (image x head): one launch per contraction for the whole batch of images

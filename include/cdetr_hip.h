@@ -200,7 +200,8 @@ typedef struct {
     float* ds_row; float* ds_col; float* d_v;
     const float* k_row; const float* k_col;
     float* dq_row; float* dq_col;
-    const float* q_row; const float* q_col;   /* optional, with dq_*: also ACCUMULATE the key gradients                        */
+    const float* q_row; const float* q_col;   /* optional, with dq_*: also ACCUMULATE the key gradients; ds_row / ds_col may then  */
+                                              /* both be NULL (the logit gradients never leave the chip)                        */
     float* dk_row; float* dk_col;             /* dk_row[n][w] += sum_q ds_row[q][w] q_row[q] (per head; caller zeroes them)    */
 } cdetr_rcda_bwd_desc;
 int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* d, void* stream);

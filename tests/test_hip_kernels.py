@@ -201,6 +201,29 @@ def test_rcda_core(N, L, H, W, masked, precision):
         close(a.grad, b.grad, msg=name, rtol=5e-4, atol_scale=tol(precision)["atol_scale"])
 
 
+@pytest.mark.parametrize("fuse_dq,fuse_dk", [(False, False), (True, False), (True, True)])
+def test_rcda_backward_fusion_levels_agree(fuse_dq, fuse_dk, monkeypatch, precision):
+    """The attention backward with the query / key gradients computed by separate GEMM / weight-gradient launches from the saved
+    logit gradients, with dq fused into the dS kernel, and with dq and dk fused (logit gradients never written): same gradients."""
+    from counting_detr_amd import ops
+    N, L, H, W = 2, 300, 25, 38
+    nh, E = 8, 256
+    mk = lambda *s, seed: torch.randn(*s, generator=g(seed))
+    q_row, q_col = mk(N, L, E, seed=1), mk(N, L, E, seed=2)
+    k_row, k_col, v = mk(N, W, E, seed=3), mk(N, H, E, seed=4), mk(N, H, W, E, seed=5)
+    args = [t.to(DEV) for t in (q_row, q_col, k_row, k_col, v)]
+    dO = mk(N, L, E, seed=6).to(DEV)
+    o, a_row, a_col = ops.rcda_fwd_raw(*args, None, None, nh)
+    monkeypatch.setattr(ops, "FUSE_RCDA_DQ", True)
+    monkeypatch.setattr(ops, "FUSE_RCDA_DK", True)
+    ref = ops.rcda_bwd_raw(dO, *args, a_row, a_col, nh)
+    monkeypatch.setattr(ops, "FUSE_RCDA_DQ", fuse_dq)
+    monkeypatch.setattr(ops, "FUSE_RCDA_DK", fuse_dk)
+    got = ops.rcda_bwd_raw(dO, *args, a_row, a_col, nh)
+    for name, a, b in zip(("dq_row", "dq_col", "dk_row", "dk_col", "dv"), got, ref):
+        close(a, b, msg=name, rtol=2e-4, atol_scale=6e-5)
+
+
 def test_multihead_rcda_module_vs_oracle(precision):
     """Full module (projections + core + out_proj) against the oracle restatement, both mask branches."""
     from counting_detr_amd.transformer import MultiheadRCDA
