@@ -6,6 +6,8 @@ rects=rects)` returns `({"pred_logits","pred_boxes","pred_vars"}, reference_poin
 returns the dict of 0-dim losses and exposes `.weight_dict` / `.matcher`.  The criterion is sync-free: the matcher
 runs on the device and matched pairs are consumed as device index tensors.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -15,6 +17,9 @@ from .backbone import build_backbone
 from .matcher import build_matcher
 from .misc import NestedTensor, get_world_size, is_dist_avail_and_initialized, nested_tensor_from_tensor_list
 from .transformer import build_transformer
+
+
+CONCAT_FREE = os.environ.get("CDETR_CONCAT_FREE", "1") != "0"     # fold the exemplar product into the projection weight (ops.AggrProjFn)
 
 
 class _Conv1x1(nn.Module):
@@ -37,7 +42,11 @@ class _ProjGN(nn.Sequential):
         super().__init__(_Conv1x1(cin, d), nn.GroupNorm(32, d))
 
     def forward(self, x_nhwc):
-        y = self[0](x_nhwc)                                           # [B,h,w,d]
+        if isinstance(x_nhwc, tuple):                                 # (features, exemplar feature): concat-free projection
+            x, pf = x_nhwc
+            y = ops.AggrProjFn.apply(x, pf, self[0].weight, self[0].bias)
+        else:
+            y = self[0](x_nhwc)                                       # [B,h,w,d]
         gn = self[1]
         # GroupNorm statistics over (8 channels x h x w); evaluated on the NHWC tensor through a channels-first view
         y = F.group_norm(y.permute(0, 3, 1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)
@@ -64,7 +73,11 @@ class AnchorDETR(nn.Module):
         if not isinstance(samples, NestedTensor):
             samples = nested_tensor_from_tensor_list(samples)
         images, mask = samples.decompose()
-        feat, m = self.backbone.extract_feature(images, mask, rects)         # NHWC [B,h,w,4096]
+        prev, self.backbone.lazy_concat = self.backbone.lazy_concat, (CONCAT_FREE and images.is_cuda)
+        try:     # NHWC [B,h,w,4096] features, or (x [B,h,w,2048], exemplar feature [B,2048]) for the concat-free projection
+            feat, m = self.backbone.extract_feature(images, mask, rects)
+        finally:
+            self.backbone.lazy_concat = prev
         src = self.aggr_input_proj[0](feat)                                   # NHWC [B,h,w,256]
         (outputs_class, outputs_coord, outputs_var), reference_points = self.transformer(src, m, points)
         out = {"pred_logits": outputs_class[-1], "pred_boxes": outputs_coord[-1], "pred_vars": outputs_var[-1]}

@@ -261,6 +261,7 @@ class BackboneAgg(nn.Module):
                 p.requires_grad_(False)                                   # :93-95
         self.strides = [16 if dilation else 32]
         self.num_channels = [2048]
+        self.lazy_concat = False       # set by AnchorDETR: return (features, exemplar feature) instead of their concatenation
 
     def extract_feature(self, images, mask, rects):
         """images [B,3,H,W], mask bool [B,H,W], rects [B,K,4] normalised xyxy (device) ->
@@ -271,8 +272,10 @@ class BackboneAgg(nn.Module):
         xc = ((r[:, 0] * w + r[:, 2] * w) / 2).to(torch.int64)            # int() truncation (:126-127)
         yc = ((r[:, 1] * h + r[:, 3] * h) / 2).to(torch.int64)
         pf = x[:, yc, xc, :].mean(1)                                      # [B, 2048]
-        feat = torch.cat([x, x * pf[:, None, None, :]], dim=-1)
         m = nn.functional.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]   # nearest (:143)
+        if self.lazy_concat:
+            return (x, pf), m          # the consumer folds the product into its projection (ops.AggrProjFn): no [B,h,w,4096] tensor
+        feat = torch.cat([x, x * pf[:, None, None, :]], dim=-1)
         return feat, m
 
 
