@@ -483,7 +483,10 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
     constexpr int F4R = BKF / 4;             // float4 per k-row (8 or 16)
     constexpr int RPP = NT / F4R;            // rows covered by one pass of the workgroup's threads
-    constexpr int A_SLOTS = BM / RPP, B_SLOTS = (BL == 0) ? BN / RPP : BKF * BN / (4 * NT);
+    // B rows per staging pass: normally every thread takes part (RPP rows); when the thread count does not divide BN (the 12-wave
+    // 96x128 tile) only the first 64 * F4R threads stage B, 64 rows per pass -- the others re-read rows they do not keep
+    constexpr int RPPB = (BN % RPP == 0) ? RPP : 64;
+    constexpr int A_SLOTS = BM / RPP, B_SLOTS = (BL == 0) ? BN / RPPB : BKF * BN / (4 * NT);
     constexpr int LDN = BN + 4;
     constexpr int A_TILE = BM * LDK;
     // PREC == 1: the tile is split into bf16 hi / lo ONCE while it is staged; an LDS row holds [hi k0..BKF-1 | lo k0..BKF-1 | pad]
@@ -498,7 +501,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     constexpr int NV = (EB >= 16) ? 4 : 2;             // n-width of one transposing block
     constexpr int NBLK = EB / (4 * NV);
     static_assert(!TRB || (NBLK >= 1 && NBLK * 4 * NV == EB), "transposing fetch mapping");
-    static_assert(BM % RPP == 0 && (BL != 0 || BN % RPP == 0) && (BKF * BN) % (4 * NT) == 0, "tile / thread mapping");
+    static_assert(BM % RPP == 0 && (BL != 0 || BN % RPPB == 0) && (BL == 0 || (BKF * BN) % (4 * NT) == 0), "tile / thread mapping");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * A_TILE;
@@ -524,6 +527,8 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     const int nkt = (K / BKF) * taps;
 
     const int kq = tid % F4R, r8 = tid / F4R;
+    const int r8b = (RPPB == RPP) ? r8 : r8 % RPPB;
+    const bool b_on = (RPPB == RPP) || r8 < RPPB;
     // Every global load of the pipeline is UNCONDITIONAL: a predicated load sits in its own basic block, the compiler then
     // loses track of the outstanding-load count and drains vmcnt(0) before every LDS stash, which serialises the two tiles
     // in flight (measured: ~1.2 us per k-tile).  Rows that do not exist (conv padding, m >= M, n >= N) are redirected to
@@ -547,7 +552,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     if (BL == 0) {
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i) {
-            const int n = min(n0 + r8 + RPP * i, d.N - 1);
+            const int n = min(n0 + r8b + RPPB * i, d.N - 1);
             bp[i] = B + (long)n * d.ldb + kq * 4;
             bscale0[i] = (d.w_scale && !BRAW) ? d.w_scale[n] : 1.f;
         }
@@ -624,12 +629,13 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
             }
             if constexpr (BL == 0 && (ABL >= 3 || BRAW)) {
 #pragma unroll
-                for (int i = 0; i < B_SLOTS; ++i) *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = qb[i];    // ablation
+                for (int i = 0; i < B_SLOTS; ++i)
+                    if (b_on) *reinterpret_cast<float4*>(bs + (r8b + RPPB * i) * LDK + kq * 4) = qb[i];    // pre-split operand (or ablation): plain copy
             } else if constexpr (BL == 0) {
 #pragma unroll
                 for (int i = 0; i < B_SLOTS; ++i) {
                     const float s = bscale0[i];
-                    stash_split4(reinterpret_cast<__bf16*>(bs + (r8 + RPP * i) * LDK) + KPOS(kq * 4), 32, qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
+                    if (b_on) stash_split4(reinterpret_cast<__bf16*>(bs + (r8b + RPPB * i) * LDK) + KPOS(kq * 4), 32, qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
                 }
             } else {
 #pragma unroll
@@ -652,7 +658,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
 #pragma unroll
             for (int i = 0; i < B_SLOTS; ++i) {
                 const float s = bscale0[i];
-                *reinterpret_cast<float4*>(bs + (r8 + RPP * i) * LDK + kq * 4) = make_float4(qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
+                if (b_on) *reinterpret_cast<float4*>(bs + (r8b + RPPB * i) * LDK + kq * 4) = make_float4(qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
             }
         } else {
 #pragma unroll
@@ -1631,6 +1637,9 @@ int launch_gemm_fast_pd(const cdetr_gemm_desc& d, hipStream_t st) {
         const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
         if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL, PD>, bytes, "cdetr_gemm"))) return rc;
         hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL, PD>), grid, block, bytes, st, d, tilesM);
+    } else if constexpr ((BKF * BN) % (4 * 64 * WM * WN) != 0) {
+        cdetr_set_error("cdetr_gemm: this tile variant has no n-contiguous (b_layout 1) form");
+        return CDETR_ERR_UNSUPPORTED;
     } else {
         // the staging-split variant of the n-contiguous operand needs >= 8 elements per thread (4k x 2n blocks)
         constexpr int P0 = (PREC == 3) ? 2 : PREC;          // pre-split B only exists for the k-contiguous layout
@@ -1730,6 +1739,7 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     if (force == 8 && fast_ok) return launch_gemm_fast<4, 2, 1, 1, 32>(d, st);                 // 128x64, 8 waves of 32x32
     if (force == 9 && fast_ok) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);                 // 64x128, 8 waves of 32x32
     if (force == 10 && fast_ok) return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);                // 128x128, 16 waves of 32x32
+    if (force == 13 && fast_ok && d.b_layout == 0) return launch_gemm_fast<3, 4, 1, 1, 32>(d, st);   // 96x128, 12 waves of 32x32
     if (force == 11 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<4, 4, 1, 1, 64>(d, st);   // same, BK 64
     if (force == 12 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<2, 4, 1, 1, 64>(d, st);   // 64x128 on 8 waves, BK 64
     if (force >= 1 && force <= 4 && fast_ok) {
@@ -1766,7 +1776,13 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         // the fp32-MFMA rate); BK = 64 only pays when the grid is too small to give every CU two workgroups.
         // bf16x3 with a long reduction is bound by L2->CU operand delivery (~8 TB/s measured, tools/split_sweep.py): a
         // 128x128 tile shared by 16 waves of 32x32 halves that traffic at the same per-wave structure and occupancy.
-        if (gemm_is_f44(d)) return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
+        if (gemm_is_f44(d)) {
+            // 128x128 tiles that leave > 1/8 of the CUs idle in a single round: 96x128 tiles (12 waves) when those still fit one round --
+            // 5000 x 512 outputs are 160 workgroups of 128 rows but 212 of 96 (each 3/4 of the work)
+            static const int t96 = getenv("CDETR_GEMM_T96") ? atoi(getenv("CDETR_GEMM_T96")) : 1;
+            if (t96 && blocks(128, 128) < 224 && blocks(96, 128) <= 256) return launch_gemm_fast<3, 4, 1, 1, 32>(d, st);
+            return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
+        }
         // small grids (< 2 workgroups of 4 waves per CU): a 64x128 tile shared by 8 waves keeps the wave count and halves the
         // A-operand traffic (tools/split_sweep.py: 6-11 % over 64x64 BK64 on the N = 256 encoder linears)
         if (gemm_is_f24(d)) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);

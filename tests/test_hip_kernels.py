@@ -525,7 +525,7 @@ def test_weight_mirror_and_dgrad(precision):
     close(b2, dy.double().cpu() @ wl[32:96].double().cpu(), **tol(precision))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 3, 4, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 3, 4, 8, 9, 10, 13])
 def test_gemm_variants_ragged_shapes(variant, monkeypatch):
     """Every tile variant of the implicit-GEMM kernel (CDETR_GEMM_VARIANT), bf16x3, on shapes whose M / N / K are NOT multiples
     of the tile (clamped-load tails), k-contiguous and n-contiguous weight operands, dense and 3x3 (strided / dilated) rows,

@@ -7,7 +7,7 @@ ops.PRECISION = 1
 dev = "cuda"
 SH = [(5000, 1024, 256, True), (5000, 256, 1024, True), (5000, 256, 256, True), (20000, 512, 128, True), (20000, 128, 512, False),
       (5000, 2048, 512, True), (5000, 512, 2048, False), (80000, 256, 64, True), (80000, 64, 256, False), (20000, 512, 256, True), (5000, 512, 1024, False)]
-VARS = {0: "auto", 4: "64x64", 3: "64x64k64", 9: "64x128w8", 8: "128x64w8", 10: "128x128w16"}
+VARS = {0: "auto", 4: "64x64", 9: "64x128w8", 10: "128x128w16", 13: "96x128w12"}
 print("%-26s" % "M,N,K,resid" + "".join("%14s" % v for v in VARS.values()))
 for (M, N, K, res) in SH:
     W = torch.randn(N, K, device=dev) / K ** 0.5
