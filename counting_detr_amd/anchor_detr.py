@@ -48,6 +48,8 @@ class _ProjGN(nn.Sequential):
         else:
             y = self[0](x_nhwc)                                       # [B,h,w,d]
         gn = self[1]
+        if y.is_cuda and (y.shape[-1] // gn.num_groups) % 4 == 0 and y.shape[-1] // gn.num_groups <= 64:
+            return ops.GroupNormNHWCFn.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps)      # statistics over (8 channels x h x w), NHWC
         # GroupNorm statistics over (8 channels x h x w); evaluated on the NHWC tensor through a channels-first view
         y = F.group_norm(y.permute(0, 3, 1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)
         return y.permute(0, 2, 3, 1).contiguous()

@@ -145,7 +145,7 @@ class _TrunkFn(torch.autograd.Function):
     def backward(ctx, d_out):
         blocks, saved = ctx.blocks, ctx.saved_acts
         out_last = saved[-1][3]
-        dz = torch.where(out_last > 0, d_out.contiguous(), torch.zeros((), device=d_out.device))
+        dz = ops.relu_mask(out_last, d_out)          # gradient through the last block's ReLU: one pass
         hook = _BACKWARD_HOOK
         if hook is not None:
             hook(0)          # autograd runs this node last: every gradient above the backbone is final

@@ -609,6 +609,37 @@ def mha_core(qk, v, nh):
 
 
 # ----------------------------------------------------------------------------------------------------- layer norm & glue
+class GroupNormNHWCFn(torch.autograd.Function):
+    """nn.GroupNorm(G, C) on an NHWC activation [B,h,w,C] (A2/models/anchor_detr.py:86-92) -- fwd / bwd are one kernel each, no layout
+    round trip; dgamma / dbeta accumulate straight into the parameters' gradient buffers."""
+
+    @staticmethod
+    def forward(ctx, x, wparam, bparam, G, eps):
+        B, h, w, Cc = x.shape
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mean = torch.empty(B * G, device=x.device, dtype=torch.float32)
+        rstd = torch.empty(B * G, device=x.device, dtype=torch.float32)
+        check(lib().cdetr_groupnorm_fwd(ptr(x), ptr(wparam.detach()), ptr(bparam.detach()), ptr(y), ptr(mean), ptr(rstd), B, h * w, Cc, G,
+                                        eps, stream_ptr()), "cdetr_groupnorm_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.wparam, ctx.bparam, ctx.G = wparam, bparam, G
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        B, h, w, Cc = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        wparam, bparam = ctx.wparam, ctx.bparam
+        gw = grad_buffer(wparam) if wparam.requires_grad else torch.zeros_like(wparam)
+        gb = grad_buffer(bparam) if bparam.requires_grad else torch.zeros_like(bparam)
+        check(lib().cdetr_groupnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(wparam.detach()), ptr(dx), ptr(gw), ptr(gb), B, h * w,
+                                        Cc, ctx.G, stream_ptr()), "cdetr_groupnorm_bwd")
+        return dx, None, None, None, None
+
+
 def ln_fwd_raw(x2d, weight, bias, eps=1e-5):
     rows, Cc = x2d.shape
     y = torch.empty_like(x2d)

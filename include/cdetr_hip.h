@@ -126,6 +126,14 @@ int cdetr_relu_mask(const float* y, const float* dy, float* dz, int64_t n, float
  * cdetr_hw_reduce: Or[n,x,:] = sr * sum_y Xr[n,y,x,:] (+ Ar), Oc[n,y,:] = sc * sum_x Xc[n,y,x,:] (+ Ac)
  *                  (forward: the mean-before-project key inputs; backward: sums of gradient maps over the broadcast axis).
  * cdetr_bcast_add2: out = T + sr * Br[n,x,:] + sc * Bc[n,y,:]                                                   */
+/* nn.GroupNorm(G, C) on the NHWC activation x [B][P][C] (P = h*w; C / G a multiple of 4, <= 64): fwd saves mean / rstd [B*G];
+ * bwd writes dx and ACCUMULATES dgamma / dbeta [C].  Replaces: GroupNorm(32, 256) of the input projection,
+ * A2/models/anchor_detr.py:86-92 (evaluated there on an NCHW tensor).                                                       */
+int cdetr_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int32_t B, int32_t P, int32_t C, int32_t G, float eps, void* stream);
+int cdetr_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                        float* dgamma, float* dbeta, int32_t B, int32_t P, int32_t C, int32_t G, void* stream);
+
 int cdetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int32_t rows, int32_t C, float eps, void* stream);
 int cdetr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,

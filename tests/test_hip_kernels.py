@@ -643,6 +643,27 @@ def test_stem_row_packed_equals_per_tap_form(H, W, precision):
     close(y_rows.permute(0, 3, 1, 2), ref, msg="row-packed stem", **tol(precision))
 
 
+@pytest.mark.parametrize("B,h,w,C,G", [(2, 50, 50, 256, 32), (1, 7, 9, 64, 16), (3, 13, 5, 256, 4), (2, 20, 30, 96, 8)])
+def test_groupnorm_nhwc(B, h, w, C, G):
+    """cdetr_groupnorm_fwd / bwd on NHWC == F.group_norm on the channels-first view (fp64), incl. dgamma / dbeta accumulation."""
+    from counting_detr_amd import ops
+    x = torch.randn(B, h, w, C, generator=g(1)) * 2 + 0.5
+    gm, bt = torch.randn(C, generator=g(2)), torch.randn(C, generator=g(3))
+    dy = torch.randn(B, h, w, C, generator=g(4))
+    xd = x.to(DEV).requires_grad_(True)
+    wp, bp = torch.nn.Parameter(gm.to(DEV)), torch.nn.Parameter(bt.to(DEV))
+    y = ops.GroupNormNHWCFn.apply(xd, wp, bp, G, 1e-5)
+    y.backward(dy.to(DEV))
+    x64 = x.double().requires_grad_(True)
+    g64, b64 = gm.double().requires_grad_(True), bt.double().requires_grad_(True)
+    r = F.group_norm(x64.permute(0, 3, 1, 2), G, g64, b64, 1e-5).permute(0, 2, 3, 1)
+    r.backward(dy.double())
+    close(y, r, rtol=1e-4, msg="gn y")
+    close(xd.grad, x64.grad, rtol=2e-4, msg="gn dx")
+    close(wp.grad, g64.grad, rtol=2e-4, msg="gn dgamma")
+    close(bp.grad, b64.grad, rtol=2e-4, msg="gn dbeta")
+
+
 def test_gemm_group_matches_individual_calls(precision):
     """cdetr_gemm_group (ops.gemm_queue): few-row problems of three k-lengths, the 64x128 class with a pre-split weight image,
     a data-gradient operand (n-contiguous weight), epilogues (bias, residual, ReLU, gate) and 14 problems of one class (two
