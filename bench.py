@@ -132,14 +132,19 @@ def main():
             barrier()
             return (time.perf_counter() - t) / n
         te = timed(eager_step)
-        trainer.capture(images, rects, targets, warmup=1)
-        tg = timed(trainer.replay)
+        try:
+            trainer.capture(images, rects, targets, warmup=1)
+            tg = timed(trainer.replay)
+        except Exception as ex:      # a capture problem must not cost the run: the stream-ordered step is always available
+            print(f"[bench] graph mode unavailable ({type(ex).__name__}: {ex}); using the eager step", file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            tg = float("inf")
         tt = torch.tensor([te, tg], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
         te, tg = float(tt[0]), float(tt[1])
         mode = "eager" if te <= tg else "graph"
-        probe = {"eager_ms": te * 1e3, "graph_ms": tg * 1e3}
+        probe = {"eager_ms": te * 1e3, "graph_ms": tg * 1e3 if tg != float("inf") else None}
     elif mode == "graph":
         trainer.capture(images, rects, targets, warmup=1)
     a.no_graph = (mode == "eager")
