@@ -2036,7 +2036,8 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             const cdetr_wgrad_desc& d = descs[tr64[c0 + k]];
             work += (long)((d.Nout + 63) / 64) * ((d.Cin + 63) / 64) * d.taps * d.batch * ((d.P + 31) / 32);
         }
-        long per_all = (work + 767) / 768;
+        static const long gtarget = getenv("CDETR_WGRAD_GROUP_TARGET") ? atol(getenv("CDETR_WGRAD_GROUP_TARGET")) : 768;
+        long per_all = (work + gtarget - 1) / gtarget;
         if (per_all < 4) per_all = 4;
         for (int k = 0; k < m; ++k) {
             WgradGroupItem& it = g.it[k];
