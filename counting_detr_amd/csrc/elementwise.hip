@@ -315,7 +315,9 @@ constexpr int LN_MAXV = 4;   // float4 per lane: C <= 64 * 4 * 4 = 1024
 // y = (x - mean) * rstd * gamma + beta ; saves mean / rstd per row (A2/models/transformer.py norm1 / norm2 / ffn.norm2)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float* __restrict__ y,
-                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, int C, float eps) {
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int rows, int C, float eps,
+                                                     const float* __restrict__ a1, const float* __restrict__ a2,
+                                                     float* __restrict__ o1, float* __restrict__ o2) {
     const int lane = threadIdx.x & 63;
     const int nv = C >> 8;   // float4 per lane (C multiple of 256) -- checked on the host
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
@@ -336,6 +338,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
         const float rs = rsqrtf(wave_sum(q) / C + eps);
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
         float4* yr = reinterpret_cast<float4*>(y + (long)row * C);
+        // optional fused consumers: o1 = y + a1, o2 = y + a2 (the positional adds that follow a LayerNorm in the decoder); their operands
+        // are requested before the normalised row is formed
+        float4 p1[LN_MAXV], p2[LN_MAXV];
+        if (a1) {
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i)
+                if (i < nv) p1[i] = reinterpret_cast<const float4*>(a1 + (long)row * C)[lane + 64 * i];
+        }
+        if (a2) {
+#pragma unroll
+            for (int i = 0; i < LN_MAXV; ++i)
+                if (i < nv) p2[i] = reinterpret_cast<const float4*>(a2 + (long)row * C)[lane + 64 * i];
+        }
 #pragma unroll
         for (int i = 0; i < LN_MAXV; ++i)
             if (i < nv) {
@@ -345,6 +360,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                 o.x = (v[i].x - mu) * rs * g4.x + b4.x; o.y = (v[i].y - mu) * rs * g4.y + b4.y;
                 o.z = (v[i].z - mu) * rs * g4.z + b4.z; o.w = (v[i].w - mu) * rs * g4.w + b4.w;
                 yr[lane + 64 * i] = o;
+                if (a1) reinterpret_cast<float4*>(o1 + (long)row * C)[lane + 64 * i] = make_float4(o.x + p1[i].x, o.y + p1[i].y, o.z + p1[i].z, o.w + p1[i].w);
+                if (a2) reinterpret_cast<float4*>(o2 + (long)row * C)[lane + 64 * i] = make_float4(o.x + p2[i].x, o.y + p2[i].y, o.z + p2[i].z, o.w + p2[i].w);
             }
     }
 }
@@ -596,8 +613,22 @@ extern "C" int cdetr_layernorm_fwd(const float* x, const float* gamma, const flo
     int blocks = (rows + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gamma, beta, y, mean,
-                       rstd, rows, C, eps);
+                       rstd, rows, C, eps, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     return cdetr_launch_status("cdetr_layernorm_fwd");
+}
+
+extern "C" int cdetr_layernorm_fwd_add(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                       const float* a1, const float* a2, float* o1, float* o2, int32_t rows, int32_t C, float eps,
+                                       void* stream) {
+    CDETR_CHECK_ARG(x && gamma && beta && y && mean && rstd && rows >= 0, "cdetr_layernorm_fwd_add: null pointer");
+    CDETR_CHECK_ARG(a1 && o1 && (!a2 == !o2), "cdetr_layernorm_fwd_add: a1 / o1 are required, a2 / o2 come as a pair");
+    CDETR_CHECK_ARG(C > 0 && (C & 255) == 0 && C <= 1024, "cdetr_layernorm_fwd_add: C must be a multiple of 256, <= 1024 (got %d)", C);
+    if (rows == 0) return CDETR_OK;
+    int blocks = (rows + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, gamma, beta, y, mean,
+                       rstd, rows, C, eps, a1, a2, o1, o2);
+    return cdetr_launch_status("cdetr_layernorm_fwd_add");
 }
 
 extern "C" int cdetr_groupnorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,

@@ -650,6 +650,19 @@ def ln_fwd_raw(x2d, weight, bias, eps=1e-5):
     return y, mean, rstd
 
 
+def ln_fwd_add_raw(x2d, weight, bias, eps, a1, a2=None):
+    """LayerNorm forward that also returns y + a1 (and y + a2): -> (y, mean, rstd, y + a1, y + a2 or None)."""
+    rows, Cc = x2d.shape
+    y = torch.empty_like(x2d)
+    o1 = torch.empty_like(x2d)
+    o2 = torch.empty_like(x2d) if a2 is not None else None
+    mean = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x2d.device, dtype=torch.float32)
+    check(lib().cdetr_layernorm_fwd_add(ptr(x2d), ptr(weight), ptr(bias), ptr(y), ptr(mean), ptr(rstd), ptr(a1), ptr(a2), ptr(o1), ptr(o2),
+                                        rows, Cc, eps, stream_ptr()), "cdetr_layernorm_fwd_add")
+    return y, mean, rstd, o1, o2
+
+
 def ln_bwd_raw(dy2d, x2d, mean, rstd, weight, gw, gb, add=None):
     """dx (+ add); dgamma / dbeta accumulate into gw / gb."""
     rows, Cc = x2d.shape
@@ -844,19 +857,23 @@ class DecoderStackFn(torch.autograd.Function):
                 mem_side.append((linear_fwd(krm2, Wc[2 * E:3 * E], bc[2 * E:3 * E]).view(N, W, E),
                                  linear_fwd(kcm2, Wc[3 * E:4 * E], bc[3 * E:4 * E]).view(N, H, E),
                                  linear_fwd(mem2, Wc[4 * E:5 * E], bc[4 * E:5 * E]).view(N, H, W, E)))
+        a1_next = None
         for li, layer in enumerate(layers):
             sa, ca, f = layer.self_attn, layer.cross_attn, layer.ffn
             nh = sa.num_heads
             Ws, bs = sa.in_proj_weight.detach(), sa.in_proj_bias.detach()
             Wc, bc = ca.in_proj_weight.detach(), ca.in_proj_bias.detach()
-            a1, _ = add2(x, qpos.view(M, E))
+            if a1_next is None:
+                a1, _ = add2(x, qpos.view(M, E))
+            else:
+                a1 = a1_next          # written by the previous layer's last LayerNorm
             with gemm_queue():
                 qk = linear_fwd(a1, Ws[0:2 * E], bs[0:2 * E])
                 vs = linear_fwd(x, Ws[2 * E:3 * E], bs[2 * E:3 * E])
             o1, lse = mha_fwd_raw(qk.view(N, L, 2 * E), vs.view(N, L, E), nh)
             Y2 = linear_fwd(o1.view(M, E), sa.out_proj.weight.detach(), sa.out_proj.bias.detach(), resid=x)
-            T1, mu2, rs2 = ln_fwd_raw(Y2, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps)
-            qr_in, qc_in = add2(T1, qx.view(M, E), qy.view(M, E))
+            T1, mu2, rs2, qr_in, qc_in = ln_fwd_add_raw(Y2, layer.norm2.weight.detach(), layer.norm2.bias.detach(), layer.norm2.eps,
+                                                        qx.view(M, E), qy.view(M, E))
             with gemm_queue():
                 q_row = linear_fwd(qr_in, Wc[0:E], bc[0:E]).view(N, L, E)
                 q_col = linear_fwd(qc_in, Wc[E:2 * E], bc[E:2 * E]).view(N, L, E)
@@ -866,7 +883,10 @@ class DecoderStackFn(torch.autograd.Function):
             T2, mu1, rs1 = ln_fwd_raw(Y1, layer.norm1.weight.detach(), layer.norm1.bias.detach(), layer.norm1.eps)
             Hd = linear_fwd(T2, f.linear1.weight.detach(), f.linear1.bias.detach(), relu=True)
             Y3 = linear_fwd(Hd, f.linear2.weight.detach(), f.linear2.bias.detach(), resid=T2)
-            out, mu3, rs3 = ln_fwd_raw(Y3, f.norm2.weight.detach(), f.norm2.bias.detach(), f.norm2.eps)
+            if li + 1 < len(layers):      # the next layer's tgt + query_pos comes out of this LayerNorm's pass
+                out, mu3, rs3, a1_next, _ = ln_fwd_add_raw(Y3, f.norm2.weight.detach(), f.norm2.bias.detach(), f.norm2.eps, qpos.view(M, E))
+            else:
+                out, mu3, rs3 = ln_fwd_raw(Y3, f.norm2.weight.detach(), f.norm2.bias.detach(), f.norm2.eps)
             outs.append(out.view(N, L, E))
             saved.append((x, a1, qk, vs, o1, lse, Y2, mu2, rs2, T1, qr_in, qc_in, q_row, q_col, k_row, k_col, v, a_row, a_col, o2,
                           Y1, mu1, rs1, T2, Hd, Y3, mu3, rs3))

@@ -136,6 +136,10 @@ int cdetr_groupnorm_bwd(const float* dy, const float* x, const float* mean, cons
 
 int cdetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int32_t rows, int32_t C, float eps, void* stream);
+/* the same forward, plus o1 = y + a1 and (optional pair) o2 = y + a2 in the same pass: the positional adds that consume a decoder
+ * LayerNorm's output (tgt + query_pos_x / tgt + query_pos_y, A2/models/transformer.py:385-389; next layer's tgt + query_pos, :369) */
+int cdetr_layernorm_fwd_add(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                            const float* a1, const float* a2, float* o1, float* o2, int32_t rows, int32_t C, float eps, void* stream);
 int cdetr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                         const float* add, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, void* stream);
 int cdetr_posadd2(const float* X, const float* Prow, const float* Pcol, float* Qr, float* Qc, int32_t N, int32_t H, int32_t W,
