@@ -305,13 +305,139 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
 //     per-lane scalar (the form with A_col*A_row as the MFMA operand needs a multiply + bf16 split per element per h);
 //   * V tiles are prefetched PD = 4 iterations ahead (8 registers per tile per thread): an iteration is never bound by
 //     the global-load latency, which is what limited the one-tile-ahead pipeline of rcda_fwd_kernel.
+constexpr int KSTR = 36;      // LDS row stride (floats) of the projected keys in rcda_scores_mfma: 36 / 4 odd -> conflict-free ds_read_b128
+
+// Score phase on the matrix pipe (split-bf16, H <= 64, W <= 64): S^T = K Q^T per 32-key tile -- A = the projected keys (row = key,
+// k-slot j of step s <-> channel 16s + 8g + j, read from LDS), B = this wave's 32 projected queries (column = query i32, same channel
+// slots, straight from global).  The accumulator of a tile holds, for query i32, the logits of keys 32t + (r&3) + 8(r>>2) + 4g: the
+// softmax over keys is an in-lane reduction over registers plus one exchange between the two lane halves.  Replaces the VALU loop of
+// rcda_scores (50 keys x (8 LDS reads + 32 FMAs) per lane: 9 of the forward kernel's 43 us at the decoder shape).
+// Leaves A_row / A_col in the wave's LDS tiles and saves them, like rcda_scores; ends with the key tiles dead.
+template <int NT, int TW, int TH>
+__device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, const FwdSmem& sm, float* smem, float* Srow, float* Scol,
+                                                 int tid, int lane, int i32, int g, int n, int head, int qbase, int q, bool qvalid) {
+    const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
+    const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
+    float* Krow = smem + sm.off_k;             // [W][KSTR]
+    float* Kcol = Krow + W * KSTR;             // [H][KSTR]
+    {   // stage the projected keys of (n, head): batches of 4 unconditional loads per thread (clamped key, masked store)
+        const int nk8 = (W + H) * 8;
+        for (int base = 0; base < nk8; base += 4 * NT) {
+            float4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = min(base + tid + NT * u, nk8 - 1);
+                const int key = idx >> 3, c4 = idx & 7;
+                const float* src = (key < W) ? d.k_row + ((long)n * W + key) * E + head * D + c4 * 4
+                                             : d.k_col + ((long)n * H + (key - W)) * E + head * D + c4 * 4;
+                t[u] = ld4(src);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + tid + NT * u;
+                if (idx < nk8) *reinterpret_cast<float4*>(Krow + (idx >> 3) * KSTR + (idx & 7) * 4) = t[u];
+            }
+        }
+    }
+    // B operands: this lane's query, channels 16s + 8g .. + 7 of q_row and of q_col
+    bf16x8 qh[2][2], ql[2][2];
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        const float* qp = (side == 0 ? d.q_row : d.q_col) + ((long)n * L + (qvalid ? q : 0)) * E + head * D + 8 * g;
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            float4 t0 = ld4(qp + 16 * st), t1 = ld4(qp + 16 * st + 4);
+            if (!qvalid) { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
+            const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+            split_bf16x8(x, qh[side][st], ql[side][st]);
+        }
+    }
+    // key-padding masks as bit sets (one ballot per 64 keys)
+    unsigned long long mrow = 0ull, mcol0 = 0ull;
+    if (d.mask_row) {
+        const uint8_t* mr = d.mask_row + (long)n * W;
+        const uint8_t* mc = d.mask_col + (long)n * H;
+        mrow = __ballot(lane < W && mr[min(lane, W - 1)] != 0);
+        mcol0 = __ballot(lane < H && mc[min(lane, H - 1)] != 0);
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int side = 0; side < 2; ++side) {
+        constexpr int TMAX = TW > TH ? TW : TH;
+        const int nt = side == 0 ? TW : TH;
+        const int nkeys = side == 0 ? W : H, npad = side == 0 ? Wp : Hp;
+        const float* Ks = side == 0 ? Krow : Kcol;
+        const unsigned long long mbits = side == 0 ? mrow : mcol0;
+        float* S = side == 0 ? Srow + i32 * sm.sw : Scol + i32 * sm.sh;
+        float sv[TMAX][16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t >= nt) break;
+            const int kc = min(32 * t + i32, nkeys - 1);
+            f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const float4 t0 = *reinterpret_cast<const float4*>(Ks + kc * KSTR + 16 * st + 8 * g);
+                const float4 t1 = *reinterpret_cast<const float4*>(Ks + kc * KSTR + 16 * st + 8 * g + 4);
+                const float x[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+                bf16x8 ah, al;
+                split_bf16x8(x, ah, al);
+                acc = mfma_bf16x3(ah, al, qh[side][st], ql[side][st], acc);
+            }
+            mfma_drain(acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
+                float v = acc[r] * d.scale;
+                if (key >= nkeys || ((mbits >> (key & 63)) & 1ull)) v = -INFINITY;
+                sv[t][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t >= nt) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = expf(sv[t][r] - mx);
+                sv[t][r] = e;
+                sum += e;
+            }
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t >= nt) break;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (key < npad) S[key] = sv[t][r] * inv;          // keys in [nkeys, npad) carry exp(-inf) = 0
+            }
+        }
+    }
+    __syncthreads();   // all waves done with the key tiles (the V buffers overlay them); the LDS rows are visible to the whole wave
+
+    {
+        const int nq = min(QW, L - qbase);   // may be <= 0 for tail waves
+        if (nq > 0) {
+            save_rows(Srow, sm.sw, d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
+            save_rows(Scol, sm.sh, d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
+        }
+    }
+}
+
 struct Fwd2Smem { int off_v, vts, total; };
 __host__ __device__ inline Fwd2Smem fwd2_smem(const FwdSmem& sm, int H, int W, int KS) {
     Fwd2Smem s;
     s.off_v = sm.off_k;
     s.vts = 32 * KS + 8;                                   // bf16 per V^T row: [hi 16KS | lo 16KS | pad 8] -> odd multiple of 16 bytes
     const int vfloats = 2 * 32 * s.vts / 2;                // two buffers of 32 channel rows
-    const int kfloats = (W + H) * D;
+    const int kfloats = (W + H) * KSTR;                    // key tiles of the score phase, padded rows (see rcda_scores_mfma)
     s.total = sm.off_k + (kfloats > vfloats ? kfloats : vfloats);
     return s;
 }
@@ -334,7 +460,8 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
     const bool qvalid = q < L;
     float* Srow = smem + sm.off_srow + wid * QW * sm.sw;
     float* Scol = smem + sm.off_scol + wid * QW * sm.sh;
-    rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
+    if (H <= 64) rcda_scores_mfma<NT, (KS + 1) / 2, 2>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
+    else rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
 
     // ---- hoisted B operand: this lane's A_row row, k-slot j of step s <-> w = 16s + 8g + j
     bf16x8 bh[KS], bl[KS];
