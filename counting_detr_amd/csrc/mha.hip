@@ -394,10 +394,10 @@ __global__ __launch_bounds__(NTF) void fwd_kernel(const float* __restrict__ qk, 
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mn = fmaxf(m, mx);
-        const float corr = expf(m - mn);
+        const float corr = __expf(m - mn);
         float ls = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { S[r] = expf(S[r] - mn); ls += S[r]; }
+        for (int r = 0; r < 16; ++r) { S[r] = __expf(S[r] - mn); ls += S[r]; }
         ls += __shfl_xor(ls, 32, 64);
         l = l * corr + ls;
         m = mn;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(NTF) void bwd_q_kernel(const float* __restrict__ qk
         const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, dh, dl);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = (t * 32 + reg_row(r, g) < L) ? expf(S[r] - li) : 0.f;
+            const float p = (t * 32 + reg_row(r, g) < L) ? __expf(S[r] - li) : 0.f;
             S[r] = p * (dP[r] - Di);
         }
         bf16x8 sh[2], sl[2];
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
             const float lsv[4] = {ls4.x, ls4.y, ls4.z, ls4.w}, dvv[4] = {d4.x, d4.y, d4.z, d4.w};
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const float p = expf(S[4 * jj + b] - lsv[b]);
+                const float p = __expf(S[4 * jj + b] - lsv[b]);
                 P[4 * jj + b] = p;
                 S[4 * jj + b] = p * (dP[4 * jj + b] - dvv[b]);
             }
