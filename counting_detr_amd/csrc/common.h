@@ -90,13 +90,28 @@ __device__ __forceinline__ f32x16 mfma_bf16x3(const bf16x8& ah, const bf16x8& al
     return acc;
 }
 
+// Wave-wide reductions on DPP lane permutes (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror inside the rows of 16, row_bcast 15 /
+// 31 across them; lane 63 ends up with the total, v_readlane broadcasts it): ~6 VALU-latency steps instead of 6 ds_bpermute round
+// trips through the LDS pipe (a LayerNorm row does two reductions: they were most of its time).  The result is wave-uniform.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_pull(float x, float fill) {     // lanes the permute does not write read `fill`
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(fill), __float_as_int(x), CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_pull<0xB1, 0xf>(v, 0.f);      // quad_perm [1,0,3,2]
+    v += dpp_pull<0x4E, 0xf>(v, 0.f);      // quad_perm [2,3,0,1]
+    v += dpp_pull<0x141, 0xf>(v, 0.f);     // row_half_mirror
+    v += dpp_pull<0x140, 0xf>(v, 0.f);     // row_mirror: every lane of a row holds the row's sum
+    v += dpp_pull<0x142, 0xa>(v, 0.f);     // row_bcast:15 into rows 1 and 3
+    v += dpp_pull<0x143, 0xc>(v, 0.f);     // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_pull<0xB1, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_pull<0x4E, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_pull<0x141, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_pull<0x140, 0xf>(v, -INFINITY));
+    v = fmaxf(v, dpp_pull<0x142, 0xa>(v, -INFINITY));
+    v = fmaxf(v, dpp_pull<0x143, 0xc>(v, -INFINITY));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
