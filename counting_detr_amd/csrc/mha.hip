@@ -385,27 +385,29 @@ __global__ __launch_bounds__(NTF) void fwd_kernel(const float* __restrict__ qk, 
         // steps past the last tile run on a re-read of it with every row masked: numerically a no-op, and the ring stays branch-free
         const int buf = t & 1;
         fetch(cur.k, cur.v, t + PD);                                           // `cur` (tile t) was staged one step ago
-        f32x16 S = mma_tile(zero16(), lds + buf * 2 * TILE, i32, g, qh, ql);
-        float mx = -INFINITY;
+        if (t < ntile) {           // workgroup-uniform: the (up to PD - 1) surplus steps of the last ring turn only stage and synchronise
+            f32x16 S = mma_tile(zero16(), lds + buf * 2 * TILE, i32, g, qh, ql);
+            float mx = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (t * 32 + reg_row(r, g) >= L) S[r] = -INFINITY;
-            mx = fmaxf(mx, S[r]);
+            for (int r = 0; r < 16; ++r) {
+                if (t * 32 + reg_row(r, g) >= L) S[r] = -INFINITY;
+                mx = fmaxf(mx, S[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const float corr = __expf(m - mn);
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { S[r] = __expf(S[r] - mn); ls += S[r]; }
+            ls += __shfl_xor(ls, 32, 64);
+            l = l * corr + ls;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) OT[r] *= corr;
+            bf16x8 ph[2], pl[2];
+            reg_frag(S, ph, pl);
+            OT = mma_tile(OT, lds + buf * 2 * TILE + TILE, i32, g, ph, pl);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float corr = __expf(m - mn);
-        float ls = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { S[r] = __expf(S[r] - mn); ls += S[r]; }
-        ls += __shfl_xor(ls, 32, 64);
-        l = l * corr + ls;
-        m = mn;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) OT[r] *= corr;
-        bf16x8 ph[2], pl[2];
-        reg_frag(S, ph, pl);
-        OT = mma_tile(OT, lds + buf * 2 * TILE + TILE, i32, g, ph, pl);
         stash(nxt.k, nxt.v, buf ^ 1);                                          // tile t + 1
         __syncthreads();
     };
@@ -468,16 +470,18 @@ __global__ __launch_bounds__(NTF) void bwd_q_kernel(const float* __restrict__ qk
         const int buf = t & 1;
         fetch(cur.k, cur.v, cur.kt, t + PD);
         const __bf16* base = lds + buf * 3 * TILE;
-        f32x16 S = mma_tile(zero16(), base, i32, g, qh, ql);
-        const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, dh, dl);
+        if (t < ntile) {           // workgroup-uniform: surplus steps of the last ring turn only stage and synchronise
+            f32x16 S = mma_tile(zero16(), base, i32, g, qh, ql);
+            const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, dh, dl);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = (t * 32 + reg_row(r, g) < L) ? __expf(S[r] - li) : 0.f;
-            S[r] = p * (dP[r] - Di);
+            for (int r = 0; r < 16; ++r) {
+                const float p = (t * 32 + reg_row(r, g) < L) ? __expf(S[r] - li) : 0.f;
+                S[r] = p * (dP[r] - Di);
+            }
+            bf16x8 sh[2], sl[2];
+            reg_frag(S, sh, sl);
+            dQT = mma_tile(dQT, base + 2 * TILE, i32, g, sh, sl);
         }
-        bf16x8 sh[2], sl[2];
-        reg_frag(S, sh, sl);
-        dQT = mma_tile(dQT, base + 2 * TILE, i32, g, sh, sl);
         stash(nxt.k, nxt.v, nxt.kt, buf ^ 1);
         __syncthreads();
     };
@@ -539,6 +543,7 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
         const int buf = t & 1;
         fetch(cur.q, cur.d, cur.t, cur.s, t + PD);
         const __bf16* base = lds + buf * 4 * TILE;
+        if (t < ntile) {           // workgroup-uniform: surplus steps of the last ring turn only stage and synchronise
         f32x16 S = mma_tile(zero16(), base, i32, g, kh, kl);                   // S^T[q, key]
         const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, vh, vl);     // dP^T[q, key]
         f32x16 P;
@@ -559,6 +564,7 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
         dVT = mma_tile(dVT, base + 3 * TILE, i32, g, ph, pl);                  // dV^T[c, key] += dO^T[c, q] P[q, key]
         reg_frag(S, sh, sl);
         dKT = mma_tile(dKT, base + 2 * TILE, i32, g, sh, sl);                  // dK^T[c, key] += Q^T[c, q] dS[q, key]
+        }
         stash(nxt.q, nxt.d, nxt.t, nxt.s, buf ^ 1);
         __syncthreads();
     };
