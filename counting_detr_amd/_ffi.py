@@ -150,7 +150,14 @@ def check(rc, what):
         raise RuntimeError(f"{what} failed (rc={rc}): {msg}")
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """hipStream_t of torch's current stream on the current device.  The raw accessor costs ~0.3 us; torch.cuda.current_stream()
+    builds a Stream object and resolves the device index in Python (~9 us, i.e. ~6 ms of host time over the ~700 launches of a step)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -236,6 +236,7 @@ class WeightMirror:
         self.f_entries.sort()
         self._tb = [e[0] for e in self.t_entries]
         self._fb = [e[0] for e in self.f_entries]
+        self._memo_t, self._memo_f = {}, {}
 
     def refresh(self):
         check(lib().cdetr_weight_mirror(ptr(self.items_dev), self.n, self.total_tiles, stream_ptr()), "cdetr_weight_mirror")
@@ -255,20 +256,34 @@ class WeightMirror:
 
     def lookup(self, w, scale=None):
         """data-gradient operand of `w` (or of a row slice of it) -> (fp32 mirror view, ldb, pre-split view or None) or None"""
+        key = (w.data_ptr(), scale.data_ptr() if scale is not None else 0)
+        hit = self._memo_t.get(key, False)
+        if hit is not False:
+            return hit
         r = self._find(self.t_entries, self._tb, w, scale)
         if r is None:
-            return None
-        (base, nbytes, off, R, Cc, taps, sptr, has_split), row0 = r
-        sp = self.flat_ts[off + row0:] if (has_split and row0 % 32 == 0) else None
-        return self.flat[off + row0:], taps * R, sp
+            out = None
+        else:
+            (base, nbytes, off, R, Cc, taps, sptr, has_split), row0 = r
+            sp = self.flat_ts[off + row0:] if (has_split and row0 % 32 == 0) else None
+            out = (self.flat[off + row0:], taps * R, sp)
+        self._memo_t[key] = out        # the images never move: the answer for a given operand address is fixed
+        return out
 
     def lookup_fwd(self, w, scale=None):
         """pre-split forward operand of `w` (or of a row slice of it) or None"""
+        key = (w.data_ptr(), scale.data_ptr() if scale is not None else 0)
+        hit = self._memo_f.get(key, False)
+        if hit is not False:
+            return hit
         r = self._find(self.f_entries, self._fb, w, scale)
         if r is None:
-            return None
-        (base, nbytes, off, R, Cc, taps, sptr, _), row0 = r
-        return self.flat_fs[off + row0 * Cc * taps:]
+            out = None
+        else:
+            (base, nbytes, off, R, Cc, taps, sptr, _), row0 = r
+            out = self.flat_fs[off + row0 * Cc * taps:]
+        self._memo_f[key] = out
+        return out
 
 
 MIRROR = None      # set by engine.Trainer; None -> data gradients read the weight itself as the n-contiguous operand
