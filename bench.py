@@ -132,13 +132,18 @@ def main():
             barrier()
             return (time.perf_counter() - t) / n
         te = timed(eager_step)
+        ok = 1.0
         try:
             trainer.capture(images, rects, targets, warmup=1)
-            tg = timed(trainer.replay)
         except Exception as ex:      # a capture problem must not cost the run: the stream-ordered step is always available
             print(f"[bench] graph mode unavailable ({type(ex).__name__}: {ex}); using the eager step", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
-            tg = float("inf")
+            ok = 0.0
+        if world > 1:                # every rank times the replay or none does (the replay contains a collective)
+            okt = torch.tensor([ok], dtype=torch.float64, device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            ok = float(okt[0])
+        tg = timed(trainer.replay) if ok > 0 else float("inf")
         tt = torch.tensor([te, tg], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # every rank takes the same decision
