@@ -1,0 +1,39 @@
+import os, sys
+sys.path.insert(0, '.')
+import torch
+from counting_detr_amd import ops
+ops.PRECISION = 1
+dev = "cuda"
+SH = [(600, 256, 1024, True), (600, 1024, 256, False), (600, 256, 256, True), (600, 512, 256, False)]
+VARS = {0: "auto", 5: "direct", 4: "64x64", 3: "64x64k64", 9: "64x128w8", 7: "32x64"}
+print("%-22s" % "M,N,K,resid" + "".join("%12s" % v for v in VARS.values()))
+for (M, N, K, res) in SH:
+    W = torch.randn(N, K, device=dev) / K ** 0.5
+    mirror = ops.WeightMirror([], [(W, None)]); mirror.refresh()
+    sp = mirror.lookup_fwd(W)
+    b = torch.randn(N, device=dev)
+    ns = 64
+    As = [torch.randn(M, K, device=dev) for _ in range(ns)]
+    Rs = [torch.randn(M, N, device=dev) for _ in range(ns)]
+    Cs = [torch.empty(M, N, device=dev) for _ in range(ns)]
+    row = "%-22s" % ("%d,%d,%d,%s" % (M, N, K, "r" if res else "-"))
+    for v in VARS:
+        os.environ["CDETR_GEMM_VARIANT"] = str(v)
+        def call(i):
+            ops.gemm_raw(As[i], K, W, K, Cs[i], N, M, N, K, bias=b, relu=False, resid=Rs[i] if res else None, ldr=N, B_split=sp)
+        for i in range(ns): call(i)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for i in range(8): call(i)
+        torch.cuda.current_stream().wait_stream(s); torch.cuda.synchronize()
+        with torch.cuda.graph(g):
+            for i in range(ns): call(i)
+        g.replay(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5): g.replay()
+        e1.record(); torch.cuda.synchronize()
+        row += "%10.1fus" % (e0.elapsed_time(e1) / (5 * ns) * 1e3)
+    print(row, flush=True)
