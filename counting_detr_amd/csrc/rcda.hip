@@ -403,7 +403,7 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
             if (t >= nt) break;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = expf(sv[t][r] - mx);
+                const float e = __expf(sv[t][r] - mx);
                 sv[t][r] = e;
                 sum += e;
             }
