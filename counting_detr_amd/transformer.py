@@ -16,6 +16,10 @@ from torch import nn
 from . import ops
 
 
+def _stack(xs):
+    return xs[0].unsqueeze(0) if len(xs) == 1 else torch.stack(xs)
+
+
 def inverse_sigmoid(x, eps=1e-5):
     """A2/util/misc.py:475-479."""
     x = x.clamp(min=0, max=1)
@@ -342,8 +346,7 @@ class Transformer(nn.Module):
             outputs_coords.append(tmp.sigmoid())
             if self.stage == 2:
                 outputs_vars.append(var)
-        out = (torch.stack(outputs_classes), torch.stack(outputs_coords),
-               torch.stack(outputs_vars) if self.stage == 2 else None)
+        out = (_stack(outputs_classes), _stack(outputs_coords), _stack(outputs_vars) if self.stage == 2 else None)
         return out, reference_points
 
 
