@@ -89,11 +89,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Counting-DETR HIP path has no CPU fallback")
+    # CDETR_BENCH_SHARE_GPU=1: rehearsal of the N>1 control flow on a ONE-GPU box (ranks share the device, gloo carries the
+    # collectives through the host).  Never a measurement: the line it prints is tagged "rehearsal".
+    share = os.environ.get("CDETR_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", world_size=world, rank=rank)   # RCCL over xGMI
+        dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://", world_size=world, rank=rank)   # RCCL over xGMI
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
     import counting_detr_amd
@@ -232,7 +237,7 @@ def main():
     res = {"metric": "images/sec FSCD-147 2nd-stage train step", "value": value, "unit": "images/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": ("fp32" if a.precision == "fp32" else "bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"),
-           "data": "synthetic",
+           "data": "synthetic" if not share else "synthetic (REHEARSAL: ranks share one GPU, gloo -- not a measurement)",
            "config": {"workload": f"FSCD-147 2nd-stage train step (ResNet-50-DC5 + RCDA enc6/dec6, Q={a.queries} learned, "
                                   f"{H}x{W}, T={list(Ts)}), fwd+matcher+loss+bwd+clip+AdamW",
                       "images_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",

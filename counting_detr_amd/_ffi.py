@@ -92,7 +92,7 @@ def lib():
         L.cdetr_colsum.restype = C.c_int
         L.cdetr_colsum.argtypes = [_p, C.c_int64, C.c_int32, C.c_int32, _p, _p]
         L.cdetr_sumsq.restype = C.c_int
-        L.cdetr_sumsq.argtypes = [_p, C.c_int64, _p, _p]
+        L.cdetr_sumsq.argtypes = [_p, C.c_int64, _p, _p, _p]
         L.cdetr_adamw_step.restype = C.c_int
         L.cdetr_adamw_step.argtypes = [_p, _p, _p, _p, _p, C.c_int64, _p, _p] + [C.c_float] * 6 + [_p]
         L.cdetr_relu_mask.restype = C.c_int

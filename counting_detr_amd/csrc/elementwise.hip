@@ -11,7 +11,10 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out) {
+// Bit-reproducible: every block parks its partial sum in ws[block], the block that draws the last ticket adds the partials
+// in index order.  (An atomicAdd per block would make the clip coefficient -- and with it the parameters -- depend on the
+// arrival order: data-parallel ranks holding the same reduced gradient would drift apart by an ulp per step.)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out, float* __restrict__ ws) {
     float s = 0.f;
     const long n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -23,9 +26,28 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
         for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
     s = wave_sum(s);
     __shared__ float part[4];
+    __shared__ int last;
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    unsigned* ticket = reinterpret_cast<unsigned*>(ws + CDETR_SUMSQ_MAX_BLOCKS);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ws + blockIdx.x, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float t = 0.f;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __hip_atomic_load(ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = wave_sum(t);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = (part[0] + part[1]) + (part[2] + part[3]);
+        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // armed for the next call
+    }
 }
 
 // state[0] = step count t (float, incremented here by block 0), state[1] = lr scale (StepLR factor),
@@ -96,6 +118,7 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
 
 inline int grid_for(long n4) {
     long b = (n4 + 255) / 256;
+    static_assert(CDETR_SUMSQ_MAX_BLOCKS == 2048, "cdetr_sumsq's workspace holds one partial per block of this grid");
     if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
@@ -273,12 +296,10 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
 
 }  // namespace
 
-extern "C" int cdetr_sumsq(const float* g, int64_t n, float* out, void* stream) {
-    CDETR_CHECK_ARG(g && out && n >= 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "cdetr_sumsq: bad args");
+extern "C" int cdetr_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream) {
+    CDETR_CHECK_ARG(g && out && workspace && n >= 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "cdetr_sumsq: bad args");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
-    if (e != hipSuccess) { cdetr_set_error("cdetr_sumsq: memset: %s", hipGetErrorString(e)); return CDETR_ERR_LAUNCH; }
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, st, g, (long)n, out);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, st, g, (long)n, out, workspace);
     return cdetr_launch_status("cdetr_sumsq");
 }
 

@@ -107,6 +107,7 @@ class Trainer:
         # device-resident optimizer scalars (graph-replay safe): [step count, StepLR factor, last grad norm, spare]
         self.opt_state = torch.tensor([0.0, 1.0, 0.0, 0.0], device=self.device)
         self.sumsq = torch.zeros(1, device=self.device)
+        self.sumsq_ws = torch.zeros(2049, device=self.device)       # CDETR_SUMSQ_WS_FLOATS: block partials + arrival ticket
         self.epoch = 0
         self._graph = None
         self._static = None
@@ -170,7 +171,7 @@ class Trainer:
         n = self.flat_p.numel()
         b1, b2 = self.betas
         st = _ffi.stream_ptr()
-        _ffi.check(_ffi.lib().cdetr_sumsq(self.flat_g.data_ptr(), n, self.sumsq.data_ptr(), st), "cdetr_sumsq")
+        _ffi.check(_ffi.lib().cdetr_sumsq(self.flat_g.data_ptr(), n, self.sumsq.data_ptr(), self.sumsq_ws.data_ptr(), st), "cdetr_sumsq")
         _ffi.check(_ffi.lib().cdetr_adamw_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
                                                self.exp_avg_sq.data_ptr(), self.lr_vec.data_ptr(), n, self.sumsq.data_ptr(),
                                                self.opt_state.data_ptr(), float(self.max_norm), b1, b2, self.eps, self.wd,
@@ -268,6 +269,14 @@ class Trainer:
         st["num_boxes"] = nb0.clone() if torch.is_tensor(nb0) else nb0
         hook = _bb._BACKWARD_HOOK
         _bb.set_backward_hook(None)                # no collectives inside the capture
+        try:
+            g_a, g_b, out = self._capture_graphs(st, world, warmup)
+        finally:                                   # a failed capture must leave the stream-ordered step intact
+            _bb.set_backward_hook(hook)
+        self._graph, self._graph_b, self._static, self._static_out = g_a, g_b, st, out
+        return out
+
+    def _capture_graphs(self, st, world, warmup):
         self._dry_run(st)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -291,9 +300,7 @@ class Trainer:
             g_b = torch.cuda.CUDAGraph()           # (capturing records work, it does not run it)
             with torch.cuda.graph(g_b, pool=g_a.pool()):
                 out["grad_norm"] = self._optimizer_step()
-        _bb.set_backward_hook(hook)
-        self._graph, self._graph_b, self._static, self._static_out = g_a, g_b, st, out
-        return out
+        return g_a, g_b, out
 
     def replay(self, samples=None, rects=None, targets=None):
         st = self._static

@@ -764,3 +764,22 @@ def test_sine_embed_matches_reference_formula():
     np.testing.assert_allclose(e2.detach().cpu().numpy(), f2.detach().numpy(), rtol=0, atol=2e-5)
     close(a1.grad, r1.grad, rtol=1e-4, msg="dpos 1d")
     close(a2.grad, r2.grad, rtol=1e-4, msg="dpos 2d")
+
+
+# ------------------------------------------------------------------------------------------------------- optimizer tail
+@pytest.mark.parametrize("n", [1, 7, 1024, 262147, 37449312])
+def test_sumsq_value_and_bit_reproducibility(n):
+    """cdetr_sumsq (global gradient norm of clip_grad_norm_, A2/engine.py:54-57): value against a float64 sum, and the
+    SAME bits on every call -- data-parallel ranks holding the same reduced gradient must clip identically."""
+    from counting_detr_amd import _ffi
+    gvec = (torch.randn(n, generator=g(11)) * 0.3).to(DEV)
+    out = torch.empty(1, device=DEV)
+    ws = torch.zeros(2049, device=DEV)
+    seen = set()
+    for _ in range(6):
+        _ffi.check(_ffi.lib().cdetr_sumsq(gvec.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _ffi.stream_ptr()), "cdetr_sumsq")
+        seen.add(out.cpu().numpy().tobytes())
+    assert len(seen) == 1, "sum of squares changes from call to call"
+    ref = float((gvec.double() ** 2).sum())
+    assert abs(float(out[0]) - ref) <= 2e-6 * ref + 1e-30
+    assert int(ws[2048].view(torch.int32)) == 0, "arrival ticket not re-armed"
