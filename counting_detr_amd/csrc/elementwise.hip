@@ -11,10 +11,11 @@
 
 namespace {
 
-// Bit-reproducible: every block parks its partial sum in ws[block], the block that draws the last ticket adds the partials
-// in index order.  (An atomicAdd per block would make the clip coefficient -- and with it the parameters -- depend on the
-// arrival order: data-parallel ranks holding the same reduced gradient would drift apart by an ulp per step.)
-__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ out, float* __restrict__ ws) {
+// Bit-reproducible: every block parks its partial sum in ws[block]; a one-block second kernel adds the partials in index
+// order.  (An atomicAdd per block would make the clip coefficient -- and with it the parameters -- depend on the arrival
+// order: data-parallel ranks holding the same reduced gradient would drift apart by an ulp per step.  A last-arriving-block
+// epilogue inside the same kernel needs a device-scope release per block: measured 74 us against 46 + 3 us for two launches.)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long n, float* __restrict__ ws) {
     float s = 0.f;
     const long n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -26,28 +27,19 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
         for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
     s = wave_sum(s);
     __shared__ float part[4];
-    __shared__ int last;
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
     __syncthreads();
-    unsigned* ticket = reinterpret_cast<unsigned*>(ws + CDETR_SUMSQ_MAX_BLOCKS);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(ws + blockIdx.x, (part[0] + part[1]) + (part[2] + part[3]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last = (atomicAdd(ticket, 1u) == gridDim.x - 1);
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
+    if (threadIdx.x == 0) ws[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ ws, int nblocks, float* __restrict__ out) {
     float t = 0.f;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += 256) t += __hip_atomic_load(ws + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = threadIdx.x; i < nblocks; i += 256) t += ws[i];
     t = wave_sum(t);
-    __syncthreads();
+    __shared__ float part[4];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = t;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        out[0] = (part[0] + part[1]) + (part[2] + part[3]);
-        __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // armed for the next call
-    }
+    if (threadIdx.x == 0) out[0] = (part[0] + part[1]) + (part[2] + part[3]);
 }
 
 // state[0] = step count t (float, incremented here by block 0), state[1] = lr scale (StepLR factor),
@@ -144,14 +136,23 @@ __global__ __launch_bounds__(256) void weight_mirror_kernel(const cdetr_mirror_i
     const int r0 = (t / tilesC) * 32, c0 = (t % tilesC) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     __bf16* sp = reinterpret_cast<__bf16*>(it.dst_split);
+    // the four rows of a thread are fetched as one batch of unconditional loads (clamped address, masked use): a load under a
+    // per-element condition is its own basic block and costs one memory round trip each
+    float vin[4], sin_[4];
+    const int cc = min(c0 + tx, it.C - 1);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) vin[p] = it.src[((long)min(r0 + ty + 8 * p, it.R - 1) * it.taps + tap) * it.C + cc];
+    if (it.scale) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sin_[p] = it.scale[min(r0 + ty + 8 * p, it.R - 1)];
+    } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) sin_[p] = 1.f;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const int r = r0 + ty + 8 * p, c = c0 + tx;
-        float v = 0.f;
-        if (r < it.R && c < it.C) {
-            v = it.src[((long)r * it.taps + tap) * it.C + c];
-            if (it.scale) v *= it.scale[r];
-        }
+        const float v = (r < it.R && c < it.C) ? (it.scale ? vin[p] * sin_[p] : vin[p]) : 0.f;
         tile[ty + 8 * p][tx] = v;
         if (!it.transpose && sp && r < it.R && c < it.C) {      // forward image: row r, k = tap*C + c (C % 32 == 0: one group per tile row)
             const __bf16 h = (__bf16)v;
@@ -299,7 +300,9 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
 extern "C" int cdetr_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream) {
     CDETR_CHECK_ARG(g && out && workspace && n >= 0 && (reinterpret_cast<uintptr_t>(g) & 15) == 0, "cdetr_sumsq: bad args");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, st, g, (long)n, out, workspace);
+    const int nb = grid_for(n >> 2);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, st, g, (long)n, workspace);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, st, workspace, nb, out);
     return cdetr_launch_status("cdetr_sumsq");
 }
 

@@ -107,7 +107,7 @@ class Trainer:
         # device-resident optimizer scalars (graph-replay safe): [step count, StepLR factor, last grad norm, spare]
         self.opt_state = torch.tensor([0.0, 1.0, 0.0, 0.0], device=self.device)
         self.sumsq = torch.zeros(1, device=self.device)
-        self.sumsq_ws = torch.zeros(2049, device=self.device)       # CDETR_SUMSQ_WS_FLOATS: block partials + arrival ticket
+        self.sumsq_ws = torch.zeros(2048, device=self.device)       # CDETR_SUMSQ_WS_FLOATS: per-block partial sums
         self.epoch = 0
         self._graph = None
         self._static = None

@@ -109,14 +109,14 @@ int cdetr_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, 
 /* ---- fused optimizer tail over the flat arenas (A2/engine.py:54-57 clip_grad_norm_(0.1) + torch.optim.AdamW) ------
  * cdetr_sumsq:      out[0] = sum_i g[i]^2, bit-reproducible (fixed summation order: data-parallel ranks holding the same
  *                   reduced gradient must compute the same clip coefficient, or their parameters drift apart).
- *                   workspace: CDETR_SUMSQ_WS_FLOATS device floats, zeroed ONCE by the caller before the first call
- *                   (per-block partials + an arrival ticket that the kernel re-arms itself).
+ *                   workspace: CDETR_SUMSQ_WS_FLOATS device floats of scratch (per-block partial sums; a second one-block
+ *                   launch adds them in index order).
  * cdetr_adamw_step: g' = g * grad_div; coef = min(max_norm / (||g'|| + 1e-6), 1) (max_norm <= 0: no clip);
  *                   p *= 1 - lr*wd; m = b1 m + (1-b1) g'coef; v = b2 v + (1-b2)(g'coef)^2;
  *                   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  lr = lr[i] * state[1], t = state[0] + 1.
  *                   state (device float[4]): [0] step count (incremented), [1] lr scale (StepLR), [2] <- ||g'|| (logging).   */
 #define CDETR_SUMSQ_MAX_BLOCKS 2048
-#define CDETR_SUMSQ_WS_FLOATS (CDETR_SUMSQ_MAX_BLOCKS + 1)
+#define CDETR_SUMSQ_WS_FLOATS CDETR_SUMSQ_MAX_BLOCKS
 int cdetr_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream);
 int cdetr_adamw_step(float* p, const float* g, float* m, float* v, const float* lr, int64_t n, const float* sumsq,
                      float* state, float max_norm, float beta1, float beta2, float eps, float weight_decay, float grad_div,

@@ -774,7 +774,7 @@ def test_sumsq_value_and_bit_reproducibility(n):
     from counting_detr_amd import _ffi
     gvec = (torch.randn(n, generator=g(11)) * 0.3).to(DEV)
     out = torch.empty(1, device=DEV)
-    ws = torch.zeros(2049, device=DEV)
+    ws = torch.empty(2048, device=DEV)
     seen = set()
     for _ in range(6):
         _ffi.check(_ffi.lib().cdetr_sumsq(gvec.data_ptr(), n, out.data_ptr(), ws.data_ptr(), _ffi.stream_ptr()), "cdetr_sumsq")
@@ -782,4 +782,3 @@ def test_sumsq_value_and_bit_reproducibility(n):
     assert len(seen) == 1, "sum of squares changes from call to call"
     ref = float((gvec.double() ** 2).sum())
     assert abs(float(out[0]) - ref) <= 2e-6 * ref + 1e-30
-    assert int(ws[2048].view(torch.int32)) == 0, "arrival ticket not re-armed"
