@@ -1,19 +1,23 @@
 """bench.py -- images/sec of one FSCD-147 2nd-stage Counting-DETR training step on N MI355X (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+  python bench.py --gpus N --steps 20 --warmup 5          (N > 1: re-launches itself as N ranks, one per GPU, over RCCL)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = forward + device Hungarian matcher + SetCriterion + backward + clip_grad_norm(0.1) + AdamW on a synthetic
 batch of 2 images 800x800 per GPU (Q=300 learned anchors, T=(37,120) targets -- BASELINE.json configs[1]),
 inputs resident in HBM, random-init (name-seeded) weights.  Weak scaling: per-GPU batch fixed, gradients averaged over
-ranks by RCCL.  The step is replayed from a HIP graph (N=1: one graph; N>1: graph / flat all-reduce / graph).
-Prints ONE JSON line on rank 0 with the extra objects `roofline` (fp32-MFMA family of implicit-GEMM kernels, timed with
-HIP events on the launch stream in an instrumented eager pass of the same step) and, at N=1, `cpu_baseline` (the oracle's
-CPU restatement of the same step on the host cores, bounded sample).
+ranks by RCCL in four buckets that leave while the backbone's backward is still running (stream-ordered step: from hooks in
+the backward; graph replay: between the five captured sub-graphs).
+Prints ONE JSON line on rank 0 with the extra objects `roofline` (implicit-GEMM family timed with HIP events on the launch
+stream in an instrumented eager pass of the same step), `step_ms` (median / p10 / p90 of the timed steps, HIP events),
+`extra_shapes` (the shipped script's grid-576 shape and a 384x576 image), at N>1 `allreduce_exposed_ms`, and at N=1
+`cpu_baseline` (the oracle's CPU restatement of the same step on the host's physical cores, bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,7 +30,24 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense bf16 MFMA; the split-bf16 mode spends 3 bf16 MFMAs per algorithmic product
 PRECISIONS = {"bf16x3": 1, "fp32": 0}
-STEP_GFLOP_PER_IMAGE = 616.0         # 800x800, Q=300, reduced form (mean-before-project keys)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_traffic.json")
+
+
+def step_gflop_per_image(H, W, Q):
+    """algorithmic work of one train step per image, reduced form (mean-before-project keys):
+    616 GFLOP at 800x800 / Q=300, 643 at Q=576, 212 at 384x576 / Q=300."""
+    C, nh, d, dff = 256, 8, 32, 1024
+    px, h, w = H * W, H // 16, W // 16
+    n = h * w
+    backbone = 123697.0 * px
+    proj = 4096.0 * 256 * n
+    lo, hi = min(h, w), max(h, w)
+    enc = n * C * C * 6 + nh * n * (w + h) * d + nh * n * lo * hi * d + nh * n * hi * d + 2 * n * C * dff
+    dec = (4 * Q * C * C + 2 * nh * Q * Q * d) + (2 * Q * C * C + 3 * n * C * C + nh * Q * (w + h) * d + nh * Q * lo * hi * d
+                                                  + nh * Q * hi * d + Q * C * C) + 6 * Q * C * C + Q * (4 * C * C + 8 * C) + 2 * Q * C * dff
+    fwd = backbone + proj + 6 * enc + 6 * dec - 12 * 2 * (n - (w + h) / 2.0) * C * C
+    frozen = 10.02e9 * px / 640000.0
+    return 2.0 * (fwd + 2.0 * (fwd - frozen)) / 1e9
 
 
 def synthetic_batch(B, H, W, Ts, seed, device):
@@ -43,30 +64,152 @@ def synthetic_batch(B, H, W, Ts, seed, device):
     return images.to(device), rects.to(device), targets
 
 
-def cpu_baseline(B, H, W, Ts, steps=2, warmup=1):
-    """The oracle (CPU restatement of the reference step, parity-pinned against the real reference) on the host cores."""
-    from oracle.step import OracleTrainer, synthetic_batch as sb
-    cores = os.cpu_count() or 1
+def physical_cores():
+    """Physical cores of the host (unique (physical id, core id) pairs of /proc/cpuinfo), not os.cpu_count()'s SMT threads."""
     try:
-        import psutil
-        cores = psutil.cpu_count(logical=False) or cores
+        pairs, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if pairs:
+            n = len(pairs)
+            try:
+                n = min(n, len(os.sched_getaffinity(0)))      # a container may pin fewer CPUs than the host has
+            except Exception:
+                pass
+            return max(n, 1)
     except Exception:
         pass
-    torch.set_num_threads(cores)
+    return max((os.cpu_count() or 2) // 2, 1)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(B, H, W, Ts, steps=3, warmup=2):
+    """The oracle (CPU restatement of the reference step, parity-pinned against the real reference) on the host cores:
+    one step per candidate thread count (8 / 16 / 32 / 64 / all physical cores), then `warmup` + `steps` timed steps at the best
+    one (>= 3 timed steps after 2 warm-ups, physical cores)."""
+    from oracle.step import OracleTrainer, synthetic_batch as sb
+    phys = physical_cores()
     tr = OracleTrainer(num_position=300)
     images, rects, targets = sb(B=B, H=H, W=W, Ts=Ts)
-    for _ in range(warmup):
+    cands = sorted({c for c in (8, 16, 32, 64, phys) if c <= phys} or {phys})
+    torch.set_num_threads(cands[-1])
+    tr.step(images, rects, targets)                      # first touch: allocator / oneDNN primitive caches
+    sweep = {}
+    for c in cands:
+        torch.set_num_threads(c)
+        t0 = time.perf_counter()
         tr.step(images, rects, targets)
-    t0 = time.perf_counter()
+        sweep[c] = time.perf_counter() - t0
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    for _ in range(max(warmup - 1, 0)):                  # the sweep step at `best` already was a warm-up at this thread count
+        tr.step(images, rects, targets)
+    ts = []
     for _ in range(steps):
+        t0 = time.perf_counter()
         tr.step(images, rects, targets)
-    dt = (time.perf_counter() - t0) / steps
-    return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{steps} timed steps (+{warmup} warm-up) of the same B={B} {H}x{W} Q=300 T={list(Ts)} step, oracle fp32 on CPU",
-            "ms_per_step": dt * 1e3}
+        ts.append(time.perf_counter() - t0)
+    dt = sum(ts) / len(ts)
+    return {"value": B / dt, "unit": "images/s", "cores": best, "kind": "port", "physical_cores": phys, "cpu": cpu_model(),
+            "sample": f"{steps} timed steps (+{warmup} warm-ups) of the same B={B} {H}x{W} Q=300 T={list(Ts)} step, oracle fp32 on "
+                      f"CPU at the best of {cands} threads",
+            "ms_per_step": dt * 1e3, "thread_sweep_ms": {str(k): v * 1e3 for k, v in sweep.items()}}
 
 
-def main():
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become the launcher -- N ranks of this same command line under
+    torch.distributed.run, one per GPU, rendezvous on 127.0.0.1.  Output and exit code are the ranks'."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def percentiles(xs):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    pick = lambda q: xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]     # noqa: E731
+    return {"median": pick(0.5), "p10": pick(0.1), "p90": pick(0.9), "min": xs[0], "max": xs[-1], "n": len(xs)}
+
+
+def timed_steps(step, n, barrier):
+    """EXACTLY n steps between two barrier + device-sync brackets (host clock), plus one HIP event per step boundary for the
+    per-step distribution (recording an event does not synchronise anything)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    evs[0].record()
+    out = None
+    for i in range(n):
+        out = step()
+        evs[i + 1].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(n)], out
+
+
+def build_trainer(dev, queries, prior, precision):
+    import counting_detr_amd
+    from counting_detr_amd import ops
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.engine import Trainer
+    from counting_detr_amd.init import seeded_init_
+    ops.PRECISION = PRECISIONS[precision]
+    args = default_args(device=str(dev), num_query_position=queries, spatial_prior=prior)
+    model, crit, _ = counting_detr_amd.build_model(args)
+    seeded_init_(model)          # deterministic name-seeded random weights (no checkpoints in this environment)
+    model.to(dev).train()
+    crit.train()
+    return Trainer(model, crit, args, device=dev)
+
+
+def extra_shape(dev, H, W, queries, prior, Ts, batch, precision, steps=10):
+    """A short graph-replay run of another shape (single GPU): capture, 3 warm-up replays, `steps` timed."""
+    tr = build_trainer(dev, queries, prior, precision)
+    images, rects, targets = synthetic_batch(batch, H, W, Ts, seed=0, device=dev)
+    tr.capture(images, rects, targets, warmup=1)
+    for _ in range(3):
+        tr.replay()
+
+    def bar():
+        torch.cuda.synchronize()
+    dt, per, out = timed_steps(tr.replay, steps, bar)
+    q = out["loss"]
+    Q = tr.model.transformer.num_position * tr.model.transformer.num_pattern
+    return {"image": [H, W], "queries": Q, "spatial_prior": prior, "targets": list(Ts), "images_per_gpu": batch,
+            "value": batch * steps / dt, "unit": "images/s", "ms_per_step": dt / steps * 1e3, "step_ms": percentiles(per),
+            "steps": steps, "whole_step_tflops": step_gflop_per_image(H, W, Q) * batch / (dt / steps * 1e3), "final_loss": float(q)}
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -74,48 +217,48 @@ def main():
     ap.add_argument("--size", type=int, nargs=2, default=[800, 800])
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--queries", type=int, default=300)
+    ap.add_argument("--prior", choices=["learned", "grid"], default="learned")
     ap.add_argument("--mode", choices=["auto", "eager", "graph"], default="auto",
-                    help="eager = stream-ordered launches (bucketed all-reduce overlapped with backward); graph = HIP-graph replay of the "
-                         "sync-free step; auto (default) times 3 steps of each after a short warm-up and keeps the faster one")
+                    help="eager = stream-ordered launches; graph = HIP-graph replay of the sync-free step (N > 1: five sub-graphs with "
+                         "the bucketed all-reduce between them); auto (default) times 3 steps of each after a short warm-up and keeps "
+                         "the faster one.  Both overlap the gradient exchange with the backbone's backward")
     ap.add_argument("--no-graph", action="store_true", help="same as --mode eager")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=list(PRECISIONS), default="bf16x3",
                     help="matrix-core arithmetic of the GEMM kernels: split-bf16 x3 (default, ~5e-6 rel) or fp32 MFMA (exact products)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other precision mode")
-    a = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra shapes (grid-576 queries, 384x576 image)")
+    a = ap.parse_args(argv)
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Counting-DETR HIP path has no CPU fallback")
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world} (launch N ranks, or run `python bench.py --gpus N` and "
+                         "let it launch them)")
     # CDETR_BENCH_SHARE_GPU=1: rehearsal of the N>1 control flow on a ONE-GPU box (ranks share the device, gloo carries the
     # collectives through the host).  Never a measurement: the line it prints is tagged "rehearsal".
     share = os.environ.get("CDETR_BENCH_SHARE_GPU", "0") == "1"
     if share:
         local_rank %= torch.cuda.device_count()
+    elif world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo" if share else "nccl", init_method="env://", world_size=world, rank=rank)   # RCCL over xGMI
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
-    import counting_detr_amd
     from counting_detr_amd import ops
-    from counting_detr_amd.args import default_args
-    from counting_detr_amd.engine import Trainer
-    from counting_detr_amd.init import seeded_init_
-
-    ops.PRECISION = PRECISIONS[a.precision]
     H, W = a.size
     Ts = (37, 120)
-    args = default_args(device=str(dev), num_query_position=a.queries)
-    model, crit, _ = counting_detr_amd.build_model(args)
-    seeded_init_(model)          # deterministic name-seeded random weights (no checkpoints in this environment)
-    model.to(dev).train()
-    crit.train()
-    trainer = Trainer(model, crit, args, device=dev)
+    trainer = build_trainer(dev, a.queries, a.prior, a.precision)
+    Q = a.queries if a.prior == "learned" else int(round(a.queries ** 0.5)) ** 2
     images, rects, targets = synthetic_batch(a.batch, H, W, Ts, seed=1000 * rank, device=dev)
 
     def barrier():
@@ -144,7 +287,7 @@ def main():
             print(f"[bench] graph mode unavailable ({type(ex).__name__}: {ex}); using the eager step", file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             ok = 0.0
-        if world > 1:                # every rank times the replay or none does (the replay contains a collective)
+        if world > 1:                # every rank times the replay or none does (the replay contains collectives)
             okt = torch.tensor([ok], dtype=torch.float64, device=dev)
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             ok = float(okt[0])
@@ -161,12 +304,11 @@ def main():
     step = eager_step if mode == "eager" else trainer.replay
     for _ in range(a.warmup):
         out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    if world > 1:
+        trainer.exchange.probe = []                        # (compute, comm) event pair per timed step -> exposed all-reduce time
+    dt, per_step, out = timed_steps(step, a.steps, barrier)
+    exposed = trainer.exchange.exposed_ms() if world > 1 else None
+    trainer.exchange.probe = None
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -189,21 +331,15 @@ def main():
     torch.cuda.synchronize()
     fam = {}
     shapes = {}
-    ig_alg_bytes = 0.0
-    for family, flops, e0, e1, tag in ops.PROFILE:
-        if family == "igemm" and tag is not None and tag[0] == "group":
-            ig_alg_bytes += tag[1]           # grouped launch: the sum over its problems (ops.gemm_queue)
-        elif family == "igemm" and tag is not None:
-            M_, N_, K_, taps_ = tag[0], tag[1], tag[2], tag[3]
-            # compulsory fp32 bytes of one launch: input rows once (a strided/dilated conv reads <= M*K of them), weights, output
-            ig_alg_bytes += 4.0 * (M_ * K_ + N_ * K_ * taps_ + M_ * N_) * max(tag[5], 1)
+    for family, flops, e0, e1, tag, nbytes in ops.PROFILE:
         if tag is not None:
             sh = shapes.setdefault((family,) + tuple(tag), [0.0, 0.0, 0])
             sh[0] += flops; sh[1] += e0.elapsed_time(e1) * 1e-3; sh[2] += 1
-        f = fam.setdefault(family, [0.0, 0.0, 0])
+        f = fam.setdefault(family, [0.0, 0.0, 0, 0.0])
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 1
+        f[3] += nbytes
     ops.PROFILE = None
     if os.environ.get("CDETR_BENCH_SHAPES") and rank == 0:
         rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
@@ -212,37 +348,55 @@ def main():
             for k, v in rows:
                 f.write(",".join(str(x) for x in k) + f",{v[2] // reps},{v[1] / v[2] * 1e6:.1f},{v[1] / reps * 1e3:.3f},{v[0] / v[1] / 1e12:.1f}\n")
     bb.set_backward_hook(hook)
-    kern = {k: {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / reps * 1e3, "launches_per_step": v[2] // reps,
-                "gflop_per_step": v[0] / reps / 1e9} for k, v in fam.items() if v[1] > 0}
-    ig = fam.get("igemm", [0.0, 1.0, 1])
+    # HBM traffic per launch: PMC counters need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE cannot share one), so the
+    # figures are read from the committed summary of those passes (tools/run_meas.sh -> profiles/r2_traffic.json)
+    tj = None
+    if os.path.exists(TRAFFIC_JSON) and (H, W, a.queries, a.batch, a.precision, a.prior) == (800, 800, 300, 2, "bf16x3", "learned"):
+        with open(TRAFFIC_JSON) as f:
+            tj = json.load(f)
+    kern = {}
+    for k, v in fam.items():
+        if v[1] <= 0:
+            continue
+        kern[k] = {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / reps * 1e3, "launches_per_step": v[2] // reps,
+                   "gflop_per_step": v[0] / reps / 1e9, "algorithmic_bytes_per_launch": v[3] / max(v[2], 1),
+                   "traffic_bytes_per_launch": (tj or {}).get("families", {}).get(k)}
+    ig = fam.get("igemm", [0.0, 1.0, 1, 0.0])
     achieved = ig[0] / ig[1] / 1e12
     peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
-    # HBM traffic per launch of the same family: PMC counters need their own rocprofv3 passes (FETCH_SIZE and WRITE_SIZE
-    # cannot share one), so the figure is read from the committed summary of those passes (tools/run_meas.sh).
-    traffic = traffic_src = None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_traffic.json")
-    if os.path.exists(tpath) and (H, W, a.queries, a.batch, a.precision) == (800, 800, 300, 2, "bf16x3"):
-        with open(tpath) as f:
-            tj = json.load(f)
-        traffic, traffic_src = tj["bytes_per_launch"], tj["source"]
+    gflop_img = step_gflop_per_image(H, W, Q)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": ig_alg_bytes / max(ig[2], 1),
+                "frac": achieved / peak, "traffic": (tj or {}).get("families", {}).get("igemm"), "traffic_unit": "bytes/launch",
+                "traffic_source": (tj or {}).get("source"),
+                "algorithmic_bytes_per_launch": ig[3] / max(ig[2], 1),
                 "peak_note": ("fp32 MFMA v_mfma_f32_32x32x2_f32" if a.precision == "fp32" else
-                              "2500 TF dense bf16 MFMA / 3 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi)"),
+                              "2500 TF dense bf16 MFMA / 3 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi); "
+                              "frac_of_dense_bf16 prices the same FLOPs against the full 2500 TF"),
+                "frac_of_dense_bf16": achieved / PEAK_BF16_MFMA_TFLOPS,
                 "kernel": "igemm_fast_kernel (conv fwd / dgrad / linear) -- algorithmic FLOPs 2*M*N*K*taps per launch",
                 "avg_launch_us": ig[1] / max(ig[2], 1) * 1e6, "families": kern,
-                "whole_step_tflops": STEP_GFLOP_PER_IMAGE * a.batch / ms_per_step if (H, W, a.queries) == (800, 800, 300) else None}
+                "whole_step_tflops": gflop_img * a.batch / ms_per_step, "step_gflop_per_image": gflop_img,
+                "pmc": (tj or {}).get("pmc")}
 
     res = {"metric": "images/sec FSCD-147 2nd-stage train step", "value": value, "unit": "images/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": ("fp32" if a.precision == "fp32" else "bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"),
            "data": "synthetic" if not share else "synthetic (REHEARSAL: ranks share one GPU, gloo -- not a measurement)",
-           "config": {"workload": f"FSCD-147 2nd-stage train step (ResNet-50-DC5 + RCDA enc6/dec6, Q={a.queries} learned, "
+           "config": {"workload": f"FSCD-147 2nd-stage train step (ResNet-50-DC5 + RCDA enc6/dec6, Q={Q} {a.prior}, "
                                   f"{H}x{W}, T={list(Ts)}), fwd+matcher+loss+bwd+clip+AdamW",
                       "images_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                       "graph": not a.no_graph, "mode_probe_ms": probe, "precision": a.precision, "final_loss": loss},
+           "step_ms": percentiles(per_step),
            "roofline": roofline}
+    if world > 1:
+        ex = torch.tensor([sum(exposed) / max(len(exposed), 1) if exposed else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        res["allreduce_exposed_ms"] = {"mean_max_over_ranks": float(ex[0]), "rank0": percentiles(exposed or []),
+                                       "bytes_per_step": int(trainer.flat_g.numel() * 4),
+                                       "buckets_bytes": [int((trainer.seg_bounds[i + 1] - trainer.seg_bounds[i]) * 4) for i in range(4)],
+                                       "backend": "gloo (rehearsal)" if share else "nccl (RCCL over xGMI)",
+                                       "note": "time the compute stream waits for the last gradient bucket before clip + AdamW "
+                                               "(HIP events on the compute and exchange streams); 0 = fully hidden behind backward"}
     if world == 1 and not a.no_alt:
         # the same step in the other arithmetic mode (short run, same launch mode), for transparency
         alt = "fp32" if a.precision != "fp32" else "bf16x3"
@@ -262,13 +416,22 @@ def main():
         dta = (time.perf_counter() - t1) / 5
         res["alt_precision"] = {"precision": alt, "value": a.batch / dta, "unit": "images/s", "ms_per_step": dta * 1e3, "steps": 5}
         ops.PRECISION = PRECISIONS[a.precision]
+    if world == 1 and not a.no_extra:
+        del trainer
+        torch.cuda.empty_cache()
+        res["extra_shapes"] = [
+            # the shipped training script: --spatial_prior grid --num_query_position 600 -> 24 x 24 = 576 anchors (A2/scripts/var_wh_laplace_600.sh)
+            extra_shape(dev, 800, 800, 600, "grid", Ts, a.batch, a.precision),
+            # a typical FSC-147 image after the resize rule (A2/data/fsc147.py:75-77)
+            extra_shape(dev, 384, 576, 300, "learned", Ts, a.batch, a.precision)]
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.batch, H, W, Ts)
     if rank == 0:
-        print(json.dumps(res))
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":

@@ -48,11 +48,11 @@ class _ProjGN(nn.Sequential):
         else:
             y = self[0](x_nhwc)                                       # [B,h,w,d]
         gn = self[1]
-        if y.is_cuda and (y.shape[-1] // gn.num_groups) % 4 == 0 and y.shape[-1] // gn.num_groups <= 64:
-            return ops.GroupNormNHWCFn.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps)      # statistics over (8 channels x h x w), NHWC
-        # GroupNorm statistics over (8 channels x h x w); evaluated on the NHWC tensor through a channels-first view
-        y = F.group_norm(y.permute(0, 3, 1, 2), gn.num_groups, gn.weight, gn.bias, gn.eps)
-        return y.permute(0, 2, 3, 1).contiguous()
+        cpg = y.shape[-1] // gn.num_groups
+        if not (y.is_cuda and cpg % 4 == 0 and cpg <= 64):        # no fallback: the product path is the HIP kernel or nothing
+            raise RuntimeError(f"GroupNorm({gn.num_groups}, {y.shape[-1]}) on {y.device}: cdetr_groupnorm_fwd needs a GPU tensor with "
+                               "channels-per-group a multiple of 4 and <= 64")
+        return ops.GroupNormNHWCFn.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps)          # statistics over (8 channels x h x w), NHWC
 
 
 class AnchorDETR(nn.Module):
@@ -70,6 +70,8 @@ class AnchorDETR(nn.Module):
         self.aux_loss = aux_loss
         self.transformer.all_layer_heads = bool(aux_loss)
         self.aggr_input_proj = nn.ModuleList([_ProjGN(backbone.num_channels[0] * 2, hidden_dim)])
+        self.taps = None      # a dict: forward() leaves the intermediates there (layer4 features, projected source, every encoder /
+        #                       decoder layer's output) -- the full-size parity tests compare their digests with the reference's
 
     def forward(self, samples, points=None, rects=None):
         if not isinstance(samples, NestedTensor):
@@ -81,10 +83,18 @@ class AnchorDETR(nn.Module):
         finally:
             self.backbone.lazy_concat = prev
         src = self.aggr_input_proj[0](feat)                                   # NHWC [B,h,w,256]
+        self.transformer.taps = self.taps
+        if self.taps is not None:
+            self.taps["layer4"] = (feat[0] if isinstance(feat, tuple) else feat[..., : feat.shape[-1] // 2]).detach()
+            self.taps["proj"] = src.detach()
         (outputs_class, outputs_coord, outputs_var), reference_points = self.transformer(src, m, points)
         out = {"pred_logits": outputs_class[-1], "pred_boxes": outputs_coord[-1], "pred_vars": outputs_var[-1]}
         if self.aux_loss:
-            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b} for a, b in zip(outputs_class[:-1], outputs_coord[:-1])]
+            # A2/models/anchor_detr.py:129-140.  The reference's _set_aux_loss leaves pred_vars out and its criterion then raises
+            # KeyError in loss_variance on the first aux layer (the shipped scripts all pass --no_aux_loss); the variances of the
+            # intermediate layers are added here so that aux_loss=True trains.
+            out["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b, "pred_vars": c}
+                                  for a, b, c in zip(outputs_class[:-1], outputs_coord[:-1], outputs_var[:-1])]
         return out, reference_points
 
 
@@ -123,17 +133,25 @@ class SetCriterion(nn.Module):
 
     def forward(self, outputs, targets, num_boxes=None):
         """`num_boxes`: optional precomputed normaliser (device scalar) -- the data-parallel trainer all-reduces the target
-        count BEFORE the (graph-captured) step; otherwise it is computed here as in the reference (:321-325)."""
+        count BEFORE the (graph-captured) step; otherwise it is computed here as in the reference (:321-325).
+        With `aux_outputs` (aux_loss=True, :334-350) every intermediate decoder layer gets its own Hungarian matching and the
+        same losses under the key suffix `_i`; the matchings of all layers are ONE cost launch + ONE assignment launch
+        (layers x images independent problems, one wavefront each), then one fused loss launch per layer."""
         out = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "enc_outputs")}
         logits = out["pred_logits"]
         B, Q = logits.shape[:2]
-        key = (tuple(len(t["boxes"]) for t in targets), Q, str(logits.device))
-        plan = self._plans.get(key)
-        if plan is None:
-            if len(self._plans) > 256:          # real data: a new plan per distinct tuple of target counts
-                self._plans.clear()
-            plan = self._plans[key] = ops.MatchPlan(key[0], Q, logits.device)
-        idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan)
+        sizes = tuple(len(t["boxes"]) for t in targets)
+        plan = self._plan(sizes, Q, logits.device)
+        aux = outputs.get("aux_outputs")
+        if aux:
+            layers = list(aux) + [out]
+            L = len(layers)
+            plan_all = self._plan(sizes * L, Q, logits.device)
+            stacked = {k: torch.cat([l[k] for l in layers]) for k in ("pred_logits", "pred_boxes")}       # [L*B, Q, .]
+            idx_i, idx_j, status, _ = self.matcher.match_device(stacked, list(targets) * L, plan_all)
+        else:
+            layers, L = [out], 1
+            idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan)
         if self.check_status and bool((status != 0).any()):
             raise ValueError("invalid or infeasible matching cost matrix")
         if num_boxes is not None:
@@ -148,7 +166,9 @@ class SetCriterion(nn.Module):
             num_boxes = max(float(sum(plan.sizes)), 1.0)                      # :321-325
         tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
         tgt_labels_all = torch.cat([t["labels"] for t in targets])
-        if self.fused and logits.is_cuda and list(self.losses) == ["labels", "boxes", "cardinality", "vars"] and "aux_outputs" not in outputs:
+        fused = self.fused and logits.is_cuda and list(self.losses) == ["labels", "boxes", "cardinality", "vars"]
+        nbt = None
+        if fused:
             if not torch.is_tensor(num_boxes):
                 nbt = self._nb_cache.get((float(num_boxes), str(logits.device)))
                 if nbt is None:
@@ -157,20 +177,38 @@ class SetCriterion(nn.Module):
                     nbt = self._nb_cache[(float(num_boxes), str(logits.device))] = torch.full((1,), float(num_boxes), device=logits.device)
             else:
                 nbt = num_boxes.reshape(-1)[:1].to(torch.float32)
-            vec = ops.CriterionFn.apply(logits, out["pred_boxes"], out["pred_vars"], tgt_boxes_all, tgt_labels_all.to(torch.int64), plan,
-                                        idx_i, idx_j, nbt, self.num_classes, self.focal_alpha)
-            self.last_vec = vec     # [loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, loss_variance]
-            return {"loss_ce": vec[0], "class_error": vec[1].detach(), "cardinality_error": vec[2].detach(), "loss_bbox": vec[3],
-                    "loss_giou": vec[4], "loss_variance": vec[5]}
-        self.last_vec = None
-        bidx, sidx, tidx = self._matched(idx_i, idx_j, plan)
         losses = {}
-        for loss in self.losses:
-            losses.update(getattr(self, "loss_" + loss)(out, plan, bidx, sidx, tidx, tgt_boxes_all, tgt_labels_all, num_boxes))
-        if "aux_outputs" in outputs:
-            raise NotImplementedError("aux losses need pred_vars in aux outputs (a reference bug: the shipped configs "
-                                      "run --no_aux_loss, A2/models/anchor_detr.py:136-140,268)")
+        self.last_vec = None
+        for li, lo in enumerate(layers):
+            ii, jj = idx_i[li * B:(li + 1) * B], idx_j[li * B:(li + 1) * B]
+            last = li == L - 1
+            if fused:
+                vec = ops.CriterionFn.apply(lo["pred_logits"], lo["pred_boxes"], lo["pred_vars"], tgt_boxes_all, tgt_labels_all.to(torch.int64),
+                                            plan, ii, jj, nbt, self.num_classes, self.focal_alpha)
+                d = {"loss_ce": vec[0], "class_error": vec[1].detach(), "cardinality_error": vec[2].detach(), "loss_bbox": vec[3],
+                     "loss_giou": vec[4], "loss_variance": vec[5]}
+                if last and L == 1:
+                    self.last_vec = vec     # [loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, loss_variance]
+            else:
+                bidx, sidx, tidx = self._matched(ii, jj, plan)
+                d = {}
+                for loss in self.losses:
+                    d.update(getattr(self, "loss_" + loss)(lo, plan, bidx, sidx, tidx, tgt_boxes_all, tgt_labels_all, num_boxes))
+            if last:
+                losses.update(d)
+            else:
+                d.pop("class_error", None)          # logged for the last layer only (log=False, :343-345)
+                losses.update({k + f"_{li}": v for k, v in d.items()})
         return losses
+
+    def _plan(self, sizes, Q, device):
+        key = (tuple(sizes), Q, str(device))
+        plan = self._plans.get(key)
+        if plan is None:
+            if len(self._plans) > 256:          # real data: a new plan per distinct tuple of target counts
+                self._plans.clear()
+            plan = self._plans[key] = ops.MatchPlan(key[0], Q, device)
+        return plan
 
     def loss_labels(self, out, plan, bidx, sidx, tidx, tb, tl, num_boxes):
         src_logits = out["pred_logits"]                                       # :166-197

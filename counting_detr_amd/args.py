@@ -61,6 +61,16 @@ def get_args_parser():
     p.add_argument("--images_per_gpu", default=2, type=int, help="local batch of the data-parallel trainer")
     p.add_argument("--synthetic", action="store_true", help="train on seeded synthetic tensors (no dataset needed)")
     p.add_argument("--steps_per_epoch", default=20, type=int, help="synthetic mode only")
+    p.add_argument("--synthetic_size", default=[800, 800], type=int, nargs=2, help="synthetic mode only: image H W")
+    p.add_argument("--pretrained_backbone", default="", type=str,
+                   help="torchvision-layout ResNet-50 state dict (the reference hard-codes pretrained_models/resnet50-0676ba61.pth)")
+    p.add_argument("--resume_skip_mismatch", action="store_true",
+                   help="--resume: drop checkpoint keys whose shape differs (e.g. an Anchor-DETR COCO class head) instead of raising")
+    p.add_argument("--no_resume_optimizer", dest="resume_optimizer", action="store_false",
+                   help="--resume: model weights only, like the reference (default: also restore AdamW moments / epoch when present)")
+    p.add_argument("--exemplar_mode", default="per_image", choices=["per_image", "reference"],
+                   help="per_image: image b is conditioned on its own exemplars; reference: rects[0] for the whole batch "
+                        "(A2/models/backbone.py:122 -- exact only at batch 1)")
     return p
 
 

@@ -120,6 +120,7 @@ class Bottleneck(nn.Module):
 
 
 _BACKWARD_HOOK = None
+_DEFER = None      # a list while the trainer wants the trunk's backward as an explicit object (TrunkBackward) instead of inline
 
 
 def set_backward_hook(fn):
@@ -127,6 +128,40 @@ def set_backward_hook(fn):
     backbone, 1 / 2 / 3 = layer4 / layer3 / layer2 (used by the trainer to launch bucketed all-reduces early)."""
     global _BACKWARD_HOOK
     _BACKWARD_HOOK = fn
+
+
+class defer_trunk_backward:
+    """Context manager: inside it `_TrunkFn.backward` only applies the last ReLU mask and parks the rest of its work as a
+    `TrunkBackward` in `.pending`; the caller then runs `pending[0].run(segment)` for segment 1 (layer4), 2 (layer3),
+    3 (layer2) itself, on its own thread.  The data-parallel graph replay needs this: each segment is captured as its own HIP
+    graph so that the RCCL all-reduce of a finished gradient bucket can be issued BETWEEN two graph launches, on a side
+    stream, and overlap the remaining segments (a collective cannot sit inside a captured graph, and stream capture cannot
+    be ended / restarted from the autograd engine's thread in the middle of a backward)."""
+
+    def __enter__(self):
+        global _DEFER
+        assert _DEFER is None
+        self.pending = _DEFER = []
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER
+        _DEFER = None
+        return False
+
+
+class TrunkBackward:
+    def __init__(self, blocks, saved, dz):
+        self.blocks, self.saved, self.dz = blocks, saved, dz
+        n2, n3 = RESNET50_LAYERS[1], RESNET50_LAYERS[2]
+        n = len(blocks)
+        self.ranges = {1: (n - 1, n2 + n3), 2: (n2 + n3 - 1, n2), 3: (n2 - 1, 0)}      # block indices, high -> low inclusive
+
+    def run(self, seg):
+        hi, lo = self.ranges[seg]
+        for k in range(hi, lo - 1, -1):
+            self.dz = self.blocks[k].backward_fused(self.saved[k], self.dz, need_dx=(k > 0))
+            self.saved[k] = None
 
 
 class _TrunkFn(torch.autograd.Function):
@@ -146,20 +181,18 @@ class _TrunkFn(torch.autograd.Function):
         blocks, saved = ctx.blocks, ctx.saved_acts
         out_last = saved[-1][3]
         dz = ops.relu_mask(out_last, d_out)          # gradient through the last block's ReLU: one pass
+        if _DEFER is not None:                       # the trainer runs the segments itself (graph replay with bucketed exchange)
+            _DEFER.append(TrunkBackward(blocks, saved, dz))
+            ctx.saved_acts = None
+            return None, None, None
         hook = _BACKWARD_HOOK
         if hook is not None:
             hook(0)          # autograd runs this node last: every gradient above the backbone is final
-        n2, n3 = RESNET50_LAYERS[1], RESNET50_LAYERS[2]
-        for k in range(len(blocks) - 1, -1, -1):
-            dz = blocks[k].backward_fused(saved[k], dz, need_dx=(k > 0))
-            saved[k] = None
+        tb = TrunkBackward(blocks, saved, dz)
+        for seg in (1, 2, 3):
+            tb.run(seg)
             if hook is not None:
-                if k == n2 + n3:
-                    hook(1)  # layer4 done
-                elif k == n2:
-                    hook(2)  # layer3 done
-                elif k == 0:
-                    hook(3)  # layer2 done
+                hook(seg)    # layer4 / layer3 / layer2 done
         ctx.saved_acts = None
         return None, None, None
 
@@ -262,17 +295,31 @@ class BackboneAgg(nn.Module):
         self.strides = [16 if dilation else 32]
         self.num_channels = [2048]
         self.lazy_concat = False       # set by AnchorDETR: return (features, exemplar feature) instead of their concatenation
+        # "per_image" (default): image b is conditioned on rects[b], scaled by ITS un-padded extent -- what a batched trainer
+        # needs.  "reference": A2/models/backbone.py:122 verbatim -- rects[0] for the whole batch, scaled by the padded map
+        # (the reference only ever runs batch 1, where the two coincide; the golden vector `b2_pad` pins this mode).
+        self.exemplar_mode = "per_image"
 
     def extract_feature(self, images, mask, rects):
-        """images [B,3,H,W], mask bool [B,H,W], rects [B,K,4] normalised xyxy (device) ->
+        """images [B,3,H,W], mask bool [B,H,W], rects [B,K,4] normalised xyxy (device; rows with x2 < 0 = absent exemplar) ->
         (features NHWC [B,h,w,4096], mask [B,h,w])."""
         x = self.body.forward_nhwc(images)
         B, h, w, Cc = x.shape
-        r = rects[0].to(torch.float32)                                    # only image 0's exemplars (:122)
-        xc = ((r[:, 0] * w + r[:, 2] * w) / 2).to(torch.int64)            # int() truncation (:126-127)
-        yc = ((r[:, 1] * h + r[:, 3] * h) / 2).to(torch.int64)
-        pf = x[:, yc, xc, :].mean(1)                                      # [B, 2048]
         m = nn.functional.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]   # nearest (:143)
+        if self.exemplar_mode == "reference":
+            r = rects[0].to(torch.float32)                                # only image 0's exemplars (:122)
+            xc = ((r[:, 0] * w + r[:, 2] * w) / 2).to(torch.int64)        # int() truncation (:126-127)
+            yc = ((r[:, 1] * h + r[:, 3] * h) / 2).to(torch.int64)
+            pf = x[:, yc, xc, :].mean(1)                                  # [B, 2048]
+        else:
+            r = rects.to(torch.float32)                                   # [B, K, 4]
+            hv = (~m[:, :, 0]).sum(1).to(torch.float32)[:, None]          # un-padded rows / columns of each image, in cells
+            wv = (~m[:, 0, :]).sum(1).to(torch.float32)[:, None]
+            ok = r[..., 2] >= 0
+            xc = ((r[..., 0] * wv + r[..., 2] * wv) / 2).to(torch.int64).clamp(0, w - 1)
+            yc = ((r[..., 1] * hv + r[..., 3] * hv) / 2).to(torch.int64).clamp(0, h - 1)
+            g = x[torch.arange(B, device=x.device)[:, None], yc, xc, :]   # [B, K, 2048]
+            pf = (g * ok[..., None]).sum(1) / ok.sum(1).clamp(min=1)[:, None]
         if self.lazy_concat:
             return (x, pf), m          # the consumer folds the product into its projection (ops.AggrProjFn): no [B,h,w,4096] tensor
         feat = torch.cat([x, x * pf[:, None, None, :]], dim=-1)
@@ -283,4 +330,6 @@ def build_backbone(args):
     train_backbone = args.lr_backbone > 0
     assert not (args.masks or args.num_feature_levels > 1), "only the single-level 2nd-stage path is built"
     assert args.backbone == "resnet50"
-    return BackboneAgg(train_backbone, args.dilation)
+    bb = BackboneAgg(train_backbone, args.dilation)
+    bb.exemplar_mode = getattr(args, "exemplar_mode", "per_image")
+    return bb

@@ -51,6 +51,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float t = state[0] + 1.f;
     const float lr_scale = state[1];
     const float total_norm = sqrtf(sumsq[0]) * grad_div;
+    // a non-finite gradient (NaN / Inf loss, A2/engine.py:44-49) must not reach the parameters or the moments: the whole update is
+    // skipped (grid-uniform branch) and adamw_finish_kernel latches the event in state[3] for the host to read when it next looks
+    if (!(fabsf(total_norm) <= 3.0e38f)) return;
     float coef = 1.f;
     if (max_norm > 0.f) coef = fminf(max_norm / (total_norm + 1e-6f), 1.f);
     coef *= grad_div;                      // grad_div = 1 / world_size folds the data-parallel average into the same pass
@@ -88,8 +91,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 
 __global__ void adamw_finish_kernel(const float* __restrict__ sumsq, float* __restrict__ state, float grad_div) {
-    state[2] = sqrtf(sumsq[0]) * grad_div;   // total gradient norm (of the averaged gradient), for logging
-    state[0] += 1.f;
+    const float total_norm = sqrtf(sumsq[0]) * grad_div;
+    state[2] = total_norm;                   // total gradient norm (of the averaged gradient), for logging
+    if (fabsf(total_norm) <= 3.0e38f) state[0] += 1.f;
+    else state[3] += 1.f;                    // skipped (non-finite) steps since the host last cleared it
 }
 
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ y, const float* __restrict__ dy,

@@ -197,7 +197,9 @@ def collate(samples):
         image[b, :, :h, :w] = s["image"]
         mask[b, :h, :w] = False
     rk = "ex_rects" if "ex_rects" in samples[0] else "exemplar_boxes"
-    rects = torch.stack([torch.as_tensor(s[rk], dtype=torch.float32)[:3] for s in samples])
+    rl = [torch.as_tensor(s[rk], dtype=torch.float32).reshape(-1, 4)[:3] for s in samples]
+    # FSCD-LVIS has "at most 3" exemplars (L2/data/fscd_lvis.py:53): absent rows are marked with -1 (backbone per_image mode skips them)
+    rects = torch.stack([torch.cat([r, torch.full((3 - r.shape[0], 4), -1.0)]) if r.shape[0] < 3 else r for r in rl])
     targets = [{"boxes": torch.as_tensor(s["boxes"], dtype=torch.float32).reshape(-1, 4),
                 "labels": torch.as_tensor(s["labels"], dtype=torch.int64).reshape(-1)} for s in samples]
     out = {"image": image, "mask": mask, "ex_rects": rects, "targets": targets,

@@ -41,6 +41,7 @@ class FlatGradExchange:
         self.flat_g, self.seg_bounds = flat_g, list(seg_bounds)
         self.stream = torch.cuda.Stream() if (flat_g.is_cuda and is_dist_avail_and_initialized()) else None
         self.launched = []
+        self.probe = None       # a list: finish() appends (compute-side event, comm-side event) per step -> exposed_ms()
 
     def segment_done(self, seg):
         lo, hi = self.seg_bounds[seg], self.seg_bounds[seg + 1]
@@ -65,7 +66,19 @@ class FlatGradExchange:
                 self.segment_done(seg)
         self.launched = []
         if self.stream is not None:
+            if self.probe is not None:      # how long the compute stream has to wait for the last bucket = exposed communication
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(torch.cuda.current_stream())
+                eb.record(self.stream)
+                self.probe.append((ea, eb))
             torch.cuda.current_stream().wait_stream(self.stream)
+
+    def exposed_ms(self):
+        """Per-step time the compute stream waited on the gradient exchange (0 = fully hidden behind backward); call after a
+        device synchronisation.  None when nothing was probed."""
+        if not self.probe:
+            return None
+        return [max(0.0, ea.elapsed_time(eb)) for ea, eb in self.probe]
 
 
 class Trainer:
@@ -88,8 +101,10 @@ class Trainer:
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.lr_vec = torch.zeros(total, device=self.device, dtype=torch.float32)   # per-element base lr
         self.seg_bounds = [0, 0, 0, 0, 0]
+        self.offsets = {}
         off = 0
         for (n, p), sz in zip(named, sizes):
+            self.offsets[n] = (off, sz)
             pv = self._view_like(self.flat_p[off:off + sz], p)
             pv.copy_(p.data)
             p.data = pv
@@ -109,13 +124,40 @@ class Trainer:
         self.sumsq = torch.zeros(1, device=self.device)
         self.sumsq_ws = torch.zeros(2048, device=self.device)       # CDETR_SUMSQ_WS_FLOATS: per-block partial sums
         self.epoch = 0
-        self._graph = None
-        self._static = None
+        self._graph = self._graph_b = self._static = self._static_out = None
+        self._seg_graphs = None
         order = ("loss_ce", "class_error", "cardinality_error", "loss_bbox", "loss_giou", "loss_variance")
         self._w6 = torch.tensor([float(criterion.weight_dict.get(k, 0.0)) for k in order], device=self.device)
         self.mirror = self._build_mirror(named)
         self.exchange = FlatGradExchange(self.flat_g, self.seg_bounds)
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
+        self.sync_replicas()
+
+    def sync_replicas(self, src=0):
+        """Data-parallel replicas must start from (and after --resume, return to) identical weights: rank `src`'s trainable
+        arena, frozen parameters and buffers are broadcast to every rank -- what DistributedDataParallel does at construction
+        (A1/main.py:206-208).  Only gradients are exchanged afterwards, so replicas that start equal stay bit-equal."""
+        if get_world_size() < 2:
+            return
+        dist.broadcast(self.flat_p, src=src)
+        in_arena = set(self.names)
+        rest = [p.data for n, p in self.model.named_parameters() if n not in in_arena]
+        rest += [b for _, b in self.model.named_buffers() if b.is_floating_point()]
+        seen, uniq = set(), []
+        for t in rest:
+            if t.data_ptr() not in seen and t.numel():
+                seen.add(t.data_ptr())
+                uniq.append(t)
+        if uniq:
+            flat = torch.cat([t.detach().reshape(-1).to(torch.float32) for t in uniq])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in uniq:
+                t.copy_(flat[off:off + t.numel()].view(t.shape))
+                off += t.numel()
+        for m in self.model.modules():          # cached FrozenBN folds / stem images depend on what was just overwritten
+            if hasattr(m, "_cache"):
+                m._cache = None
 
     def _build_mirror(self, named):
         """Weight images (ops.WeightMirror), rewritten once per step: k-contiguous transposes of every trainable matrix that
@@ -178,18 +220,88 @@ class Trainer:
                                                1.0 / get_world_size(), st), "cdetr_adamw_step")
         return self.opt_state[2]
 
-    def state_dict(self):
-        """Optimizer state in a self-describing form (flat moments + names/offsets) for the checkpoint's "optimizer" key."""
-        sizes = [dict(self.model.named_parameters())[n].numel() for n in self.names]
-        return {"names": self.names, "sizes": sizes, "exp_avg": self.exp_avg.detach().cpu(),
-                "exp_avg_sq": self.exp_avg_sq.detach().cpu(), "state": self.opt_state.detach().cpu(), "epoch": self.epoch}
+    def _torch_param_order(self):
+        """Parameter order of the reference's optimizer (A2/main.py:157-183): three groups over model.named_parameters() --
+        [neither backbone nor linear_proj names | backbone names | linear_proj names], requires_grad only."""
+        a = self.args
+        bb = lambda n: any(k in n for k in a.lr_backbone_names)            # noqa: E731
+        lp = lambda n: any(k in n for k in a.lr_linear_proj_names)         # noqa: E731
+        named = [(n, p) for n, p in self.model.named_parameters() if p.requires_grad]
+        return [[n for n, _ in named if not bb(n) and not lp(n)], [n for n, _ in named if bb(n)], [n for n, _ in named if lp(n)]], \
+               [a.lr, a.lr_backbone, a.lr * a.lr_linear_proj_mult]
 
-    def load_state_dict(self, sd):
-        assert sd["names"] == self.names, "optimizer state does not match this model's parameter layout"
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.opt_state.copy_(sd["state"])
-        self.epoch = int(sd["epoch"])
+    def state_dict(self):
+        """The checkpoint's "optimizer" entry in torch.optim.AdamW's own state_dict layout (what the reference writes,
+        A2/main.py:228-231): {"state": {index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} with the reference's
+        three groups and parameter numbering; parameters that never receive a gradient (`input_proj.*`) have no state entry,
+        as in torch.  Tools written against the reference's checkpoints read it unchanged; `load_state_dict` reads it back."""
+        groups, lrs = self._torch_param_order()
+        params = dict(self.model.named_parameters())
+        factor = float(self.opt_state[1])
+        step = float(self.opt_state[0])
+        state, pgs, idx = {}, [], 0
+        m_cpu, v_cpu = self.exp_avg.detach().cpu(), self.exp_avg_sq.detach().cpu()
+        for names, lr in zip(groups, lrs):
+            ids = []
+            for n in names:
+                if n in self.offsets and step > 0:
+                    off, sz = self.offsets[n]
+                    p = params[n]
+                    state[idx] = {"step": torch.tensor(step), "exp_avg": self._view_like(m_cpu[off:off + sz], p).clone(),
+                                  "exp_avg_sq": self._view_like(v_cpu[off:off + sz], p).clone()}
+                ids.append(idx)
+                idx += 1
+            pgs.append({"lr": lr * factor, "betas": self.betas, "eps": self.eps, "weight_decay": self.wd, "amsgrad": False,
+                        "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                        "initial_lr": lr, "params": ids})
+        return {"state": state, "param_groups": pgs}
+
+    def lr_scheduler_state_dict(self):
+        """torch.optim.lr_scheduler.StepLR.state_dict() of the reference's scheduler (A2/main.py:189,232)."""
+        _, lrs = self._torch_param_order()
+        f = 0.1 ** (self.epoch // self.args.lr_drop)
+        return {"step_size": self.args.lr_drop, "gamma": 0.1, "base_lrs": list(lrs), "last_epoch": self.epoch,
+                "_step_count": self.epoch + 1, "_get_lr_called_within_step": False, "_last_lr": [lr * f for lr in lrs]}
+
+    def load_state_dict(self, sd, lr_scheduler=None):
+        """Restore moments / step count from a checkpoint's "optimizer" entry (torch AdamW layout, from this trainer or from the
+        reference) and the epoch / StepLR factor from its "lr_scheduler" entry."""
+        if "param_groups" in sd:
+            groups, _ = self._torch_param_order()
+            order = [n for g in groups for n in g]
+            ids = [i for g in sd["param_groups"] for i in g["params"]]
+            assert len(ids) == len(order), "optimizer state does not match this model's parameter list"
+            params = dict(self.model.named_parameters())
+            step = 0.0
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
+            for i, n in zip(ids, order):
+                st = sd["state"].get(i)
+                if st is None or n not in self.offsets:
+                    continue
+                off, sz = self.offsets[n]
+                self._view_like(self.exp_avg[off:off + sz], params[n]).copy_(st["exp_avg"])
+                self._view_like(self.exp_avg_sq[off:off + sz], params[n]).copy_(st["exp_avg_sq"])
+                step = max(step, float(st["step"]))
+            self.opt_state[0] = step
+        else:                                   # round-1 format: flat moments + names
+            assert sd["names"] == self.names, "optimizer state does not match this model's parameter layout"
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.opt_state.copy_(sd["state"])
+            self.epoch = int(sd["epoch"])
+        if lr_scheduler is not None:
+            self.epoch = int(lr_scheduler.get("last_epoch", self.epoch))
+        self.opt_state[1] = 0.1 ** (self.epoch // self.args.lr_drop)
+        self.opt_state[3] = 0.0
+
+    def nonfinite_steps(self, clear=True):
+        """Number of steps whose gradient norm was NaN / Inf since the last call (host sync).  Such a step leaves parameters,
+        moments and step count untouched (cdetr_adamw_step), so nothing is polluted before the host notices."""
+        n = int(self.opt_state[3])
+        if clear and n:
+            self.opt_state[3] = 0.0
+        return n
 
     def lr_scheduler_step(self):
         """StepLR(step=lr_drop, gamma=0.1), stepped once per epoch (A2/main.py:189,219)."""
@@ -207,7 +319,10 @@ class Trainer:
             return torch.clamp(t / get_world_size(), min=1)[0]
         return max(nb, 1.0)
 
-    def _fwd_bwd(self, images, mask, rects, targets, num_boxes):
+    def _fwd_bwd(self, images, mask, rects, targets, num_boxes, defer_trunk=False):
+        """zero-grad + weight images + forward + criterion + backward.  `defer_trunk`: stop the backward at the backbone (the
+        gradient w.r.t. layer4's output is parked in `self._trunk_pending`, a backbone.TrunkBackward) -- the caller runs the
+        three backbone segments itself (`_trunk_segment`)."""
         from .misc import NestedTensor
         from . import ops
         self.flat_g.zero_()
@@ -225,12 +340,30 @@ class Trainer:
             else:
                 losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
             with ops.wgrad_queue():      # small parameter gradients outside the fused layer nodes (heads, positional MLPs): grouped
-                losses.backward()
+                if defer_trunk:
+                    with _bb.defer_trunk_backward() as d:
+                        losses.backward()
+                    self._trunk_pending = d.pending[0] if d.pending else None
+                else:
+                    losses.backward()
         finally:
-            ops.MIRROR = None
+            if not defer_trunk:
+                ops.MIRROR = None
         out = dict(loss_dict)
         out["loss"] = losses.detach()
         return out
+
+    def _trunk_segment(self, seg, last=False):
+        """Backward of one backbone segment (1 = layer4, 2 = layer3, 3 = layer2) of a deferred trunk backward."""
+        from . import ops
+        try:
+            if self._trunk_pending is not None:
+                with ops.wgrad_queue():
+                    self._trunk_pending.run(seg)
+        finally:
+            if last:
+                ops.MIRROR = None
+                self._trunk_pending = None
 
     def _step_impl(self, images, mask, rects, targets, num_boxes):
         out = self._fwd_bwd(images, mask, rects, targets, num_boxes)
@@ -258,8 +391,11 @@ class Trainer:
     def capture(self, samples, rects, targets, warmup=0):
         """Capture (record, not run) the step for fixed shapes / target counts; `replay()` executes it.
         world_size == 1: ONE graph = zero-grad + forward + device matcher + losses + backward + clip + AdamW.
-        world_size  > 1: graph A = everything up to the gradients, then ONE eager flat all-reduce (RCCL) on the compute
-        stream, then graph B = clip + AdamW (no collective inside a capture)."""
+        world_size  > 1: FIVE graphs -- [everything down to the gradient w.r.t. layer4's output] [layer4 backward] [layer3
+        backward] [layer2 backward] [clip + AdamW].  A collective cannot sit inside a captured graph, so the gradient exchange
+        lives BETWEEN the graph launches: after graph i, the all-reduce (RCCL) of the arena segment it completed is issued on the
+        side stream and overlaps graphs i+1.. on the compute stream; graph 5 waits for the last bucket.  Same buckets, same
+        order, same overlap as the stream-ordered step."""
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
         images, mask = nt.decompose()
         st = {"images": images.clone(), "mask": mask.clone(), "rects": rects.clone(),
@@ -270,10 +406,10 @@ class Trainer:
         hook = _bb._BACKWARD_HOOK
         _bb.set_backward_hook(None)                # no collectives inside the capture
         try:
-            g_a, g_b, out = self._capture_graphs(st, world, warmup)
+            g_a, segs, g_b, out = self._capture_graphs(st, world, warmup)
         finally:                                   # a failed capture must leave the stream-ordered step intact
             _bb.set_backward_hook(hook)
-        self._graph, self._graph_b, self._static, self._static_out = g_a, g_b, st, out
+        self._graph, self._seg_graphs, self._graph_b, self._static, self._static_out = g_a, segs, g_b, st, out
         return out
 
     def _capture_graphs(self, st, world, warmup):
@@ -289,20 +425,29 @@ class Trainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g_a = torch.cuda.CUDAGraph()
+        segs = None
         if world == 1:
             with torch.cuda.graph(g_a):
                 out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
                 out["grad_norm"] = self._optimizer_step()
             g_b = None
-        else:
+        else:                                      # (capturing records work, it does not run it)
             with torch.cuda.graph(g_a):
-                out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
-            g_b = torch.cuda.CUDAGraph()           # (capturing records work, it does not run it)
+                out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"], defer_trunk=True)
+            segs = []
+            for seg in (1, 2, 3):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=g_a.pool()):
+                    self._trunk_segment(seg, last=(seg == 3))
+                segs.append(g)
+            g_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_b, pool=g_a.pool()):
                 out["grad_norm"] = self._optimizer_step()
-        return g_a, g_b, out
+        return g_a, segs, g_b, out
 
     def replay(self, samples=None, rects=None, targets=None):
+        """Run the captured step; with arguments, on a NEW batch of the captured shapes / target counts (copied into the
+        graph's static inputs first)."""
         st = self._static
         if samples is not None:
             nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
@@ -317,43 +462,70 @@ class Trainer:
                 st["num_boxes"].copy_(self._num_boxes(targets))
         self._graph.replay()
         if self._graph_b is not None:
-            dist.all_reduce(self.flat_g)
+            self.exchange.segment_done(0)          # everything above the backbone is final: first bucket leaves now
+            for seg, g in zip((1, 2, 3), self._seg_graphs):
+                g.replay()
+                self.exchange.segment_done(seg)
+            self.exchange.finish()
             self._graph_b.replay()
         return self._static_out
 
 
 def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
-    """A2/engine.py:14-67: iterate, step, abort on a non-finite loss.  The loss is read back every `print_freq`
-    iterations only (the reference syncs every step with .item())."""
+    """A2/engine.py:14-67: iterate, step, abort on a non-finite loss.  The reference reads the loss back with .item() every
+    step; here the step stays asynchronous: a step whose gradient is NaN / Inf changes nothing on the device and latches a
+    flag (cdetr_adamw_step), the loss statistics accumulate on the device every step, and the host looks at both every
+    `print_freq` iterations (and at the end of the epoch) -- so no polluted update is ever applied, and the abort happens at
+    most `print_freq` no-op steps later."""
     trainer.model.train()
     trainer.criterion.train()
-    stats = {}
-    n = 0
+    keys, acc, n = None, None, 0
+
+    def check(it, vals=None):
+        bad = trainer.nonfinite_steps()
+        if bad or (vals is not None and not math.isfinite(vals["loss"])):
+            v = "nan" if vals is None else vals["loss"]
+            log("Loss is {}, stopping training".format(v))
+            log({"nonfinite_steps": bad, "iteration": it, **(vals or {})})
+            sys.exit(1)
+
+    it = -1
     for it, ret in enumerate(data_loader):
         samples = NestedTensor(ret["image"], ret["mask"]) if "mask" in ret else ret["image"]     # data.collate pads + masks
         out = trainer.train_step(samples, ret["ex_rects"], ret["targets"])
+        if keys is None:
+            keys = sorted(k for k, v in out.items() if torch.is_tensor(v))
+            acc = torch.zeros(len(keys), device=trainer.device, dtype=torch.float32)
+        acc += torch.stack([out[k].detach().float().reshape(()) for k in keys])
+        n += 1
         if it % print_freq == 0:
-            red = reduce_dict({k: v for k, v in out.items() if torch.is_tensor(v)})
+            red = reduce_dict({k: out[k] for k in keys})
             vals = {k: float(v) for k, v in red.items()}
-            if not math.isfinite(vals["loss"]):
-                log("Loss is {}, stopping training".format(vals["loss"]))
-                log(vals)
-                sys.exit(1)
-            for k, v in vals.items():
-                stats[k] = stats.get(k, 0.0) + v
-            n += 1
+            check(it, vals)
             log(f"Epoch: [{epoch}] it {it} " + "  ".join(f"{k}: {v:.4f}" for k, v in vals.items()))
-    return {k: v / max(n, 1) for k, v in stats.items()}
+    if keys is None:
+        return {}
+    check(it)
+    red = reduce_dict({k: acc[i] / n for i, k in enumerate(keys)})
+    return {k: float(v) for k, v in red.items()}
+
+
+@torch.no_grad()
+def count_from_logits(pred_logits, threshold=0.5):
+    """The counting rule of A2/infer.py:75-81 on `pred_logits` [B,Q,2]: a query counts when sigmoid(logit[..., 0]) >= threshold
+    (>=: a probability of exactly 0.5 counts).  -> (counts [B] int64, keep [B,Q] bool, prob [B,Q])."""
+    prob = pred_logits.sigmoid()[..., 0]
+    keep = prob >= threshold
+    return keep.sum(-1), keep, prob
 
 
 @torch.no_grad()
 def count_objects(model, samples, rects, threshold=0.5):
-    """The counting rule of A2/infer.py:75-81: #queries with sigmoid(logit[...,0]) >= 0.5; also returns the kept boxes."""
+    """Forward + the counting rule; also returns the kept-query mask, the raw outputs and the reference points."""
     model.eval()
     outputs, ref_points = model(samples, rects=rects)
-    prob = outputs["pred_logits"].sigmoid()[..., 0]
-    keep = prob >= threshold
-    return keep.sum(-1), keep, outputs, ref_points
+    counts, keep, _ = count_from_logits(outputs["pred_logits"], threshold)
+    return counts, keep, outputs, ref_points
 
 
 def counting_metrics(pred_counts, gt_counts):
@@ -364,6 +536,6 @@ def counting_metrics(pred_counts, gt_counts):
         err = abs(float(g) - float(p))
         sae += err
         sse += err ** 2
-        nae += err / g
-        sre += err ** 2 / g
+        nae += err / g if g else 0.0            # an image without objects has no relative error
+        sre += err ** 2 / g if g else 0.0
     return {"MAE": sae / cnt, "RMSE": (sse / cnt) ** 0.5, "NAE": nae / cnt, "SRE": (sre / cnt) ** 0.5}

@@ -28,8 +28,8 @@ PRECISION = int(_os.environ.get("CDETR_PRECISION", "1"))
 
 
 class _Timed:
-    def __init__(self, family, flops, tag=None):
-        self.family, self.flops, self.tag = family, flops, tag
+    def __init__(self, family, flops, tag=None, nbytes=0.0):
+        self.family, self.flops, self.tag, self.nbytes = family, flops, tag, nbytes     # nbytes: compulsory (algorithmic) HBM bytes of the launch
 
     def __enter__(self):
         if PROFILE is not None:
@@ -41,7 +41,7 @@ class _Timed:
         if PROFILE is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
-            PROFILE.append((self.family, self.flops, self.t0, t1, self.tag))
+            PROFILE.append((self.family, self.flops, self.t0, t1, self.tag, self.nbytes))
         return False
 
 
@@ -68,7 +68,8 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
         _GEMM_QUEUE.append((d, 2.0 * M * N * K * taps * batch, 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
                             (A, B, Cout, bias, w_scale, resid, gate, B_split)))
         return
-    with _Timed("igemm", 2.0 * M * N * K * taps * batch, (M, N, K, taps, b_layout, batch)):
+    # compulsory fp32 bytes: input rows once (a strided / dilated conv reads <= M*K of them), weights, output
+    with _Timed("igemm", 2.0 * M * N * K * taps * batch, (M, N, K, taps, b_layout, batch), 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1)):
         check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
 
 
@@ -92,7 +93,7 @@ class gemm_queue:
         q, _GEMM_QUEUE = _GEMM_QUEUE, None
         if et is None and q:
             arr = (GemmDesc * len(q))(*[e[0] for e in q])
-            with _Timed("igemm", sum(e[1] for e in q), ("group", sum(e[2] for e in q), len(q), 0, -1, 0)):
+            with _Timed("igemm", sum(e[1] for e in q), ("group", sum(e[2] for e in q), len(q), 0, -1, 0), sum(e[2] for e in q)):
                 check(lib().cdetr_gemm_group(arr, len(q), stream_ptr()), "cdetr_gemm_group")
         return False
 
@@ -110,9 +111,10 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
     d.dbias = ptr(dbias)
     d.g = geom if geom is not None else _geom()
     if may_defer and _WG_QUEUE is not None:       # inside wgrad_queue(): submitted together by its exit (cdetr_wgrad_group)
-        _WG_QUEUE.append((d, 2.0 * P * Nout * Cin * taps * batch, (dY, X, dW, w_scale, dbias)))
+        _WG_QUEUE.append((d, 2.0 * P * Nout * Cin * taps * batch, (dY, X, dW, w_scale, dbias), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1)))
         return
-    with _Timed("wgrad", 2.0 * P * Nout * Cin * taps * batch, (P, Nout, Cin, taps, -1, batch)):
+    # compulsory bytes: dY and X once, dW read + written (accumulation into the gradient arena)
+    with _Timed("wgrad", 2.0 * P * Nout * Cin * taps * batch, (P, Nout, Cin, taps, -1, batch), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1)):
         check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
 
 
@@ -145,7 +147,7 @@ def wgrad_flush():
     q = _WG_QUEUE
     if q:
         arr = (WgradDesc * len(q))(*[e[0] for e in q])
-        with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0)):
+        with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0), sum(e[3] for e in q)):
             check(lib().cdetr_wgrad_group(arr, len(q), stream_ptr()), "cdetr_wgrad_group")
         del q[:]
 
@@ -507,7 +509,9 @@ def rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
     d.q_row, d.q_col, d.k_row, d.k_col, d.v = ptr(q_row), ptr(q_col), ptr(k_row), ptr(k_col), ptr(v)
     d.mask_row, d.mask_col = ptr(mask_row), ptr(mask_col)
     d.out, d.a_row, d.a_col = ptr(out), ptr(a_row), ptr(a_col)
-    with _Timed("rcda_fwd", 2.0 * N * nh * L * (H * W * 32 + (H + W) * 32)):
+    # compulsory bytes: both query sets, both key sets, V, the output and the two saved attention maps
+    with _Timed("rcda_fwd", 2.0 * N * nh * L * (H * W * 32 + (H + W) * 32), None,
+                4.0 * N * (3 * L * E + (H + W) * E + H * W * E + nh * L * (Hp + Wp))):
         check(lib().cdetr_rcda_fwd(C.byref(d), stream_ptr()), "cdetr_rcda_fwd")
     return out, a_row, a_col
 
@@ -541,7 +545,9 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
     else:
         ds_row, ds_col = torch.empty_like(a_row), torch.empty_like(a_col)
         d.ds_row, d.ds_col = ptr(ds_row), ptr(ds_col)
-    with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32)):
+    # compulsory bytes: d_out, attention maps, V, queries / keys in; dq (x2), dk (x2), dV out
+    with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32), None,
+                4.0 * N * (5 * L * E + 2 * (H + W) * E + 2 * H * W * E + nh * L * (Hp + Wp))):
         check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
     # two-level batch (image x head): one launch per contraction for the whole batch of images
     if not fuse_dq:

@@ -238,6 +238,7 @@ class Transformer(nn.Module):
         assert num_feature_levels == 1 and attention_type == "RCDA" and dropout == 0.0 and activation == "relu"
         self.d_model, self.nhead, self.stage = d_model, nhead, stage
         self.all_layer_heads = True     # AnchorDETR sets this to its aux_loss flag
+        self.taps = None                # see AnchorDETR.taps
         import os
         self.fused_decoder = os.environ.get("CDETR_FUSED_DECODER", "1") != "0"   # all decoder layers as one autograd node (ops.DecoderStackFn); False = op-by-op autograd
         self.encoder_layers = nn.ModuleList(
@@ -311,8 +312,10 @@ class Transformer(nn.Module):
         mask_col = mask[:, :, 0].to(torch.uint8).contiguous()
 
         x = src
-        for layer in self.encoder_layers:
+        for li, layer in enumerate(self.encoder_layers):
             x = layer(x, mask_row, mask_col, posemb_row, posemb_col)
+            if self.taps is not None:
+                self.taps[f"enc{li}"] = x.detach()
         memory = x
         k_row_mean = memory.mean(1) + posemb_row                          # shared by the 6 decoder layers
         k_col_mean = memory.mean(2) + posemb_col
@@ -321,7 +324,6 @@ class Transformer(nn.Module):
         query_pos = self.adapt_pos2d(pos2posemb2d(reference_points))
         reference = inverse_sigmoid(reference_points)
 
-        outputs_classes, outputs_coords, outputs_vars = [], [], []
         last = len(self.decoder_layers) - 1
         if self.fused_decoder and torch.is_grad_enabled():
             layer_outs = ops.DecoderStackFn.apply(tgt, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean,
@@ -331,23 +333,24 @@ class Transformer(nn.Module):
             for layer in self.decoder_layers:
                 output = layer(output, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean, mask_row, mask_col)
                 layer_outs.append(output)
-        for lid in range(len(self.decoder_layers)):
-            output = layer_outs[lid]
-            if not (self.all_layer_heads or lid == last):
-                continue     # the heads of layers 0..4 only feed the aux losses (the reference computes and drops them)
-            if self.stage == 2:
-                outputs_class, tmp, var = mlps_levelwise([self.cls_embed[lid], self.bbox_embed[lid], self.bbox_variance[lid]], output)
-            else:
-                ce = self.cls_embed[lid]
-                outputs_class = ops.linear(output, ce.weight, None) + ce.bias
-                tmp = self.bbox_embed[lid](output)
-            tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], dim=-1)                     # :200
-            outputs_classes.append(outputs_class)
-            outputs_coords.append(tmp.sigmoid())
-            if self.stage == 2:
-                outputs_vars.append(var)
-        out = (_stack(outputs_classes), _stack(outputs_coords), _stack(outputs_vars) if self.stage == 2 else None)
-        return out, reference_points
+        if self.taps is not None:
+            for lid, o in enumerate(layer_outs):
+                self.taps[f"hs{lid}"] = o.detach()
+        # the heads are ONE module aliased over the layers (:104-107): with aux losses all layers go through them in one pass
+        lids = list(range(len(self.decoder_layers))) if self.all_layer_heads else [last]
+        output = layer_outs[last] if len(lids) == 1 else torch.stack([layer_outs[i] for i in lids])      # [(Ld,) B, Q, C]
+        if self.stage == 2:
+            outputs_class, tmp, var = mlps_levelwise([self.cls_embed[last], self.bbox_embed[last], self.bbox_variance[last]], output)
+        else:
+            ce = self.cls_embed[last]
+            outputs_class = ops.linear(output, ce.weight, None) + ce.bias
+            tmp = self.bbox_embed[last](output)
+        tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], dim=-1)                         # :200
+        coord = tmp.sigmoid()
+        if len(lids) == 1:
+            outputs_class, coord = outputs_class.unsqueeze(0), coord.unsqueeze(0)
+            var = var.unsqueeze(0) if self.stage == 2 else None
+        return (outputs_class, coord, var if self.stage == 2 else None), reference_points
 
 
 def build_transformer(args):

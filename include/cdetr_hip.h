@@ -114,7 +114,9 @@ int cdetr_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, float* out, 
  * cdetr_adamw_step: g' = g * grad_div; coef = min(max_norm / (||g'|| + 1e-6), 1) (max_norm <= 0: no clip);
  *                   p *= 1 - lr*wd; m = b1 m + (1-b1) g'coef; v = b2 v + (1-b2)(g'coef)^2;
  *                   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps),  lr = lr[i] * state[1], t = state[0] + 1.
- *                   state (device float[4]): [0] step count (incremented), [1] lr scale (StepLR), [2] <- ||g'|| (logging).   */
+ *                   state (device float[4]): [0] step count (incremented), [1] lr scale (StepLR), [2] <- ||g'|| (logging),
+ *                   [3] += 1 when ||g'|| is NaN / Inf: that step changes neither p, m, v nor the step count (the reference
+ *                   aborts on a non-finite loss BEFORE its optimizer step, A2/engine.py:44-49).                               */
 #define CDETR_SUMSQ_MAX_BLOCKS 2048
 #define CDETR_SUMSQ_WS_FLOATS CDETR_SUMSQ_MAX_BLOCKS
 int cdetr_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream);

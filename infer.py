@@ -16,7 +16,7 @@ import torch
 import counting_detr_amd
 from counting_detr_amd import data
 from counting_detr_amd.args import get_args_parser
-from counting_detr_amd.engine import counting_metrics
+from counting_detr_amd.engine import count_from_logits, counting_metrics
 from counting_detr_amd.misc import NestedTensor
 
 
@@ -39,8 +39,7 @@ def infer(model, criterion, data_loader, device, output_dir, split="test", thres
         loss_dict = criterion(outputs, targets)
         for k, v in loss_dict.items():
             loss_sum[k] = loss_sum.get(k, 0.0) + float(v) * len(targets)
-        prob = outputs["pred_logits"].sigmoid()[..., 0]                      # :75-81
-        keep = prob >= threshold
+        _, keep, prob = count_from_logits(outputs["pred_logits"], threshold)  # :75-81
         for b in range(image.shape[0]):
             ori_h, ori_w = [int(x) for x in ret["orig_size"][b]]
             image_id = int(ret["image_id"][b]) if "image_id" in ret else n_img
@@ -63,7 +62,7 @@ def infer(model, criterion, data_loader, device, output_dir, split="test", thres
     with open(output_path, "w") as handle:
         json.dump(predictions, handle)
     metrics = {k: v / max(n_img, 1) for k, v in loss_sum.items()}
-    if n_img and all(g > 0 for g in gt_counts):
+    if n_img:       # images without objects contribute to MAE / RMSE only (the reference divides by the count, A2/eval_all.py:264-265)
         metrics.update(counting_metrics(pred_counts, gt_counts))
     metrics["images"] = n_img
     return metrics, predictions

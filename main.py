@@ -19,6 +19,7 @@ from pathlib import Path
 import torch
 
 import counting_detr_amd
+from counting_detr_amd import checkpoint as ckpt_io
 from counting_detr_amd import misc as utils
 from counting_detr_amd.args import get_args_parser
 from counting_detr_amd.engine import Trainer, count_objects, counting_metrics, train_one_epoch
@@ -52,28 +53,32 @@ def main(args):
     utils.init_distributed_mode(args)
     os.makedirs(args.output_dir, exist_ok=True)
     device = torch.device(args.device if not getattr(args, "distributed", False) else f"cuda:{args.gpu}")
-    torch.manual_seed(args.seed + utils.get_rank())
+    # every rank builds the SAME initial weights (the init draws from the global RNG); only the data order is rank-specific.
+    # Trainer additionally broadcasts rank 0's parameters and buffers (what DistributedDataParallel does at construction).
+    torch.manual_seed(args.seed)
     model, criterion, _ = counting_detr_amd.build_model(args)
     model.to(device)
+    if args.pretrained_backbone:                                        # A2/models/backbone.py:153-155 -> resnet.py:292-297
+        n = ckpt_io.load_backbone_pretrained(model, args.pretrained_backbone)
+        print(f"backbone: {n} tensors from {args.pretrained_backbone}")
 
+    checkpoint = None
     if args.resume:                                                     # A2/main.py:195-209
-        checkpoint = torch.load(args.resume, map_location="cpu", weights_only=False)
-        sd = model.state_dict()
-        pretrained = {k: v for k, v in checkpoint["model"].items() if k in sd and "transformer.pattern." not in k}
-        missing, unexpected = model.load_state_dict(pretrained, strict=False)
-        if missing:
-            print("Missing Keys: {}".format(missing))
-        if unexpected:
-            print("Unexpected Keys: {}".format(unexpected))
+        checkpoint, _, _ = ckpt_io.resume_model(model, args.resume, skip_mismatch=args.resume_skip_mismatch)
 
-    trainer = Trainer(model, criterion, args, device=device)           # 3 lr groups + flat AdamW (A2/main.py:157-189)
+    trainer = Trainer(model, criterion, args, device=device)           # 3 lr groups + flat AdamW (A2/main.py:157-189); syncs replicas
+    if checkpoint is not None and args.resume_optimizer and checkpoint.get("optimizer"):
+        trainer.load_state_dict(checkpoint["optimizer"], checkpoint.get("lr_scheduler"))
+        args.start_epoch = max(args.start_epoch, int(checkpoint.get("epoch", -1)) + 1)
+    torch.manual_seed(args.seed + 1 + utils.get_rank())                 # data-side RNG (synthetic batches, augmentation)
+    sampler = None
     if args.synthetic:
-        loader = SyntheticLoader(args, device, args.steps_per_epoch)
+        loader = SyntheticLoader(args, device, args.steps_per_epoch, size=tuple(args.synthetic_size))
     else:                                                               # A2/main.py:146-147 (+ batching, sharding, prefetch)
         from torch.utils.data import DataLoader, DistributedSampler
         from counting_detr_amd import data
         ds = data.build_dataset(args)
-        sampler = DistributedSampler(ds, shuffle=True) if getattr(args, "distributed", False) else None
+        sampler = DistributedSampler(ds, shuffle=True, seed=args.seed) if getattr(args, "distributed", False) else None
         dl = DataLoader(ds, batch_size=args.images_per_gpu, shuffle=(sampler is None), sampler=sampler, collate_fn=data.collate,
                         num_workers=args.num_workers, drop_last=True, pin_memory=False)
         loader = data.Prefetcher(dl, device)
@@ -81,6 +86,8 @@ def main(args):
     start = time.time()
     output_dir = Path(args.output_dir)
     for epoch in range(args.start_epoch, args.epochs):
+        if sampler is not None:
+            sampler.set_epoch(epoch)           # a different shuffle (and rank sharding) every epoch
         stats = train_one_epoch(trainer, loader, epoch, print_freq=10)
         trainer.lr_scheduler_step()
         paths = [output_dir / "detr_retrain.pth"]
@@ -88,13 +95,13 @@ def main(args):
             paths.append(output_dir / f"detr_retrain_{epoch:04}.pth")
         for p in paths:
             utils.save_on_master({"model": model.state_dict(), "optimizer": trainer.state_dict(),
-                                  "lr_scheduler": {"last_epoch": trainer.epoch, "step_size": args.lr_drop, "gamma": 0.1},
+                                  "lr_scheduler": trainer.lr_scheduler_state_dict(),
                                   "epoch": epoch, "args": args}, p)
         if utils.is_main_process():
             with (output_dir / "detr_retrain.txt").open("a") as f:
                 f.write(json.dumps({**{f"train_{k}": v for k, v in stats.items()}, "epoch": epoch}) + "\n")
     print("time: ", time.time() - start)
-    if args.eval:                                                       # counting rule + MAE on the synthetic shard
+    if args.eval and args.synthetic:                                    # counting rule + MAE on the synthetic shard
         pred, gt = [], []
         for ret in SyntheticLoader(args, device, 2):
             counts, _, _, _ = count_objects(model, ret["image"], ret["ex_rects"])

@@ -108,6 +108,33 @@ def set_criterion(outputs, targets, indices=None, num_classes=1, world_size=1, n
     return losses, indices
 
 
+def set_criterion_aux(outputs, targets, world_size=1):
+    """A2/models/anchor_detr.py:308-350 with aux_loss=True: the last layer's losses plus, for every intermediate decoder layer
+    i, its OWN Hungarian matching and the same losses under the key suffix `_i` (class_error is logged for the last layer only,
+    `log=False` :343-345).  `aux_outputs` must carry pred_vars (the reference's `_set_aux_loss` :136-140 omits it and its
+    loss_variance then raises KeyError -- the golden generator patches that one line).  -> (losses, [indices per layer])."""
+    main = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "all_layers", "memory")}
+    losses, idx = set_criterion(main, targets, world_size=world_size)
+    all_idx = []
+    for i, aux in enumerate(outputs["aux_outputs"]):
+        l_i, idx_i = set_criterion(aux, targets, world_size=world_size)
+        l_i.pop("class_error")
+        losses.update({k + f"_{i}": v for k, v in l_i.items()})
+        all_idx.append(idx_i)
+    all_idx.append(idx)
+    return losses, all_idx
+
+
+def aux_weight_dict(dec_layers=6, base=None):
+    """A2/models/anchor_detr.py:419-428."""
+    base = dict(base or WEIGHT_DICT)
+    wd = dict(base)
+    for i in range(dec_layers - 1):
+        wd.update({k + f"_{i}": v for k, v in base.items()})
+    wd.update({k + "_enc": v for k, v in base.items()})
+    return wd
+
+
 WEIGHT_DICT = {"loss_ce": 2.0, "loss_bbox": 5.0, "loss_giou": 2.0, "loss_variance": 2.0}  # A2/main.py:105-120
 
 

@@ -1,0 +1,150 @@
+"""Generate tests/golden/g10_full.npz by RUNNING THE REAL REFERENCE at the sizes BASELINE.json quotes (TEST INFRA).
+
+    python -m oracle.gen_golden_full [case ...]      # needs /root/reference; a few minutes of CPU
+
+Cases:
+  cfg2       BASELINE configs[1]/[2]: B=2, 800x800, Q=300 learned, T=(37,120) -- exactly bench.py's batch (seed 0);
+  shipped576 the shipped script's shape: --spatial_prior grid --num_query_position 600 -> 576 anchors, one 384x576 image
+             (A2/scripts/var_wh_laplace_600.sh; the reference trains at batch 1);
+  small_b2   B=2 with two image sizes (padding mask), 128x160 / 96x128;
+  aux        aux_loss=True on B=2 128x160: six Hungarian matchings per step.  The reference's `_set_aux_loss`
+             (A2/models/anchor_detr.py:136-140) forgets pred_vars, so its own loss_variance raises KeyError on the aux outputs;
+             the generator patches that ONE method on the instance (adds pred_vars of the intermediate layers) and runs the
+             reference's SetCriterion.forward :334-350 unchanged.
+Inputs are NOT stored (15 MB per 800x800 batch): both sides regenerate them from the seeds recorded here with
+oracle.step.synthetic_batch / synthetic_images.  Weights: oracle.weights.seeded_state_dict(heads="wide") -- head weights of
+O(1/sqrt(d)), so outputs are driven by the trunk and not by the biases.  Stored: outputs, reference points, Hungarian indices,
+losses, total and per-parameter (clipped) gradient norms, parameter sums after the AdamW step, and strided digests of the
+intermediates (layer4 features, projected + GroupNormed source, every encoder layer's output, every decoder layer's state)
+captured with forward hooks on the reference's own modules.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+from oracle import gen_golden as G
+from oracle.step import synthetic_batch, synthetic_images
+
+OUT = G.OUT
+
+CASES = {
+    "cfg2": dict(sizes=[(800, 800)] * 2, Ts=(37, 120), prior="learned", nq=300, seed=0, aux=False),
+    "shipped576": dict(sizes=[(384, 576)], Ts=(56,), prior="grid", nq=600, seed=11, aux=False),
+    "small_b2": dict(sizes=[(128, 160), (96, 128)], Ts=(7, 13), prior="learned", nq=300, seed=21, aux=False),
+    "aux": dict(sizes=[(128, 160)] * 2, Ts=(7, 13), prior="learned", nq=100, seed=31, aux=True),
+}
+
+
+def make_inputs(c):
+    sizes = c["sizes"]
+    if len(set(sizes)) == 1:
+        images, rects, targets = synthetic_batch(B=len(sizes), H=sizes[0][0], W=sizes[0][1], Ts=c["Ts"], seed=c["seed"])
+        return images, rects, targets
+    return synthetic_images(sizes, c["Ts"], c["seed"])
+
+
+def run_case(name, c, d):
+    from models import build_model
+    from oracle.weights import model_schema, seeded_state_dict
+    args = G.ref_args(spatial_prior=c["prior"], num_query_position=c["nq"], aux_loss=c["aux"])
+    model, crit, _ = build_model(args)
+    nq_eff = c["nq"] if c["prior"] == "learned" else int(round(c["nq"] ** 0.5)) ** 2
+    sd = seeded_state_dict(model_schema(num_position=c["nq"], spatial_prior=c["prior"]), heads="wide")
+    model.load_state_dict(sd, strict=True)
+    model.train(); crit.train()
+    images, rects, tg = make_inputs(c)
+    B = len(c["sizes"])
+    taps = {}
+
+    def hook(key, pick=lambda o: o):
+        def fn(mod, inp, out):
+            taps[key] = pick(out).detach()
+        return fn
+    hs = [model.backbone.body.register_forward_hook(hook("layer4", lambda o: o["0"])),
+          model.aggr_input_proj[0].register_forward_hook(hook("proj"))]
+    for i, lyr in enumerate(model.transformer.encoder_layers):
+        hs.append(lyr.register_forward_hook(hook(f"enc{i}")))
+    for i, lyr in enumerate(model.transformer.decoder_layers):
+        hs.append(lyr.register_forward_hook(hook(f"hs{i}")))
+    if c["aux"]:
+        stash = {}
+        orig_tf = model.transformer.forward
+
+        def tf(*a, **k):
+            out = orig_tf(*a, **k)
+            stash["vars"] = out[0][2]
+            return out
+        model.transformer.forward = tf
+        model._set_aux_loss = lambda oc, ob: [{"pred_logits": a, "pred_boxes": b, "pred_vars": v}
+                                              for a, b, v in zip(oc[:-1], ob[:-1], stash["vars"][:-1])]
+    out, ref = model(images, rects=rects)
+    for h in hs:
+        h.remove()
+    assert bool((out["pred_vars"] > 0).all()), "variance head went non-positive: loss would be NaN"
+    losses = crit(out, tg)
+    wd = crit.weight_dict
+    total = sum(losses[k] * wd[k] for k in losses if k in wd)
+    opt = torch.optim.AdamW([{"params": [p for n, p in model.named_parameters() if "backbone" not in n and p.requires_grad], "lr": 1e-4},
+                             {"params": [p for n, p in model.named_parameters() if "backbone" in n and p.requires_grad], "lr": 1e-5}],
+                            lr=1e-4, weight_decay=1e-4)
+    opt.zero_grad()
+    total.backward()
+    gnorm_raw = np.array([(p.grad.norm().item() if p.grad is not None else -1.0) for n, p in model.named_parameters()])
+    gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+    main_out = {k: v for k, v in out.items() if k != "aux_outputs"}
+    idx = crit.matcher(main_out, tg)
+    names = [n for n, p in model.named_parameters()]
+    opt.step()
+    psum = np.array([p.detach().double().sum().item() for n, p in model.named_parameters()])
+    G.put(d, f"{name}/cfg", np.array([B, c["nq"], int(c["prior"] == "grid"), c["seed"], int(c["aux"]), nq_eff]))
+    G.put(d, f"{name}/sizes", np.array(c["sizes"]))
+    G.put(d, f"{name}/Ts", np.array(c["Ts"]))
+    G.put(d, f"{name}/rects", rects)
+    for b, t in enumerate(tg):
+        G.put(d, f"{name}/tgt{b}", t["boxes"])
+        G.put(d, f"{name}/idx_i{b}", idx[b][0]); G.put(d, f"{name}/idx_j{b}", idx[b][1])
+    for k, v in main_out.items():
+        G.put(d, f"{name}/{k}", v)
+    if c["aux"]:
+        for i, aux in enumerate(out["aux_outputs"]):
+            ia = crit.matcher(aux, tg)
+            for k, v in aux.items():
+                G.put(d, f"{name}/aux{i}/{k}", v)
+            for b in range(B):
+                G.put(d, f"{name}/aux{i}/idx_i{b}", ia[b][0]); G.put(d, f"{name}/aux{i}/idx_j{b}", ia[b][1])
+    G.put(d, f"{name}/ref", ref)
+    for k, v in losses.items():
+        G.put(d, f"{name}/L_{k}", v)
+    G.put(d, f"{name}/loss_total", total)
+    G.put(d, f"{name}/grad_total_norm", gn)
+    G.put(d, f"{name}/param_names", np.array(names))
+    G.put(d, f"{name}/grad_norms", gnorm_raw)
+    G.put(d, f"{name}/param_sums_after_step", psum)
+    for k, v in taps.items():
+        G.put(d, f"{name}/tap_{k}", G.digest(v, full_max=4096, nsamp=2048))
+        G.put(d, f"{name}/tap_{k}/shape", np.array(v.shape))
+    print(name, {k: round(float(v), 6) for k, v in losses.items() if "_" not in k[-2:]}, "gn", float(gn),
+          "logit range", float(out["pred_logits"].min()), float(out["pred_logits"].max()),
+          "var range", float(out["pred_vars"].min()), float(out["pred_vars"].max()), flush=True)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    G.install_stubs()
+    torch.manual_seed(0)
+    which = sys.argv[1:] or list(CASES)
+    path = os.path.join(OUT, "g10_full.npz")
+    d = {}
+    if os.path.exists(path):                       # regenerate a subset without losing the other cases
+        with np.load(path, allow_pickle=False) as z:
+            d = {k: z[k] for k in z.files if k.split("/")[0] not in which}
+    for name in which:
+        run_case(name, CASES[name], d)
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

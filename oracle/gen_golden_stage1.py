@@ -48,7 +48,37 @@ def main():
             G.put(d, f"{name}/L_{k}", v)
         G.put(d, f"{name}/param_names", np.array(names)); G.put(d, f"{name}/grad_norms", gn)
         print(name, {k: float(v) for k, v in losses.items()})
-    np.savez_compressed(os.path.join(OUT, "g7_stage1.npz"), **d)
+    if "--keep-g7" not in sys.argv:
+        np.savez_compressed(os.path.join(OUT, "g7_stage1.npz"), **d)
+    # BASELINE config 5 at its stated size: 900 `defined` anchor points on one 800x800 image (A1/models/transformer.py:114-121),
+    # forward + BoundingBoxCriterion + backward.  Inputs are regenerated from the seed on both sides (never stored).
+    d = {}
+    model, crit, _ = build_model(args)
+    model.load_state_dict(seeded_state_dict(stage1_schema()), strict=True)
+    model.train()
+    from oracle.step import stage1_inputs
+    img, pts, whs = stage1_inputs(800, 800, 900, seed=1900)
+    taps = {}
+    hk = [model.transformer.decoder_layers[i].register_forward_hook(lambda m, i_, o, k=i: taps.__setitem__(f"hs{k}", o.detach()))
+          for i in range(6)]
+    out = model(img, pts)
+    for h in hk:
+        h.remove()
+    losses = crit(out, {"points": pts, "whs": whs})
+    total = sum(losses[k] * crit.weight_dict[k] for k in losses)
+    total.backward()
+    names = [n for n, p in model.named_parameters()]
+    gn = np.array([(p.grad.norm().item() if p.grad is not None else -1.0) for n, p in model.named_parameters()])
+    G.put(d, "n900/cfg", np.array([800, 800, 900, 1900]))
+    for k, v in out.items():
+        G.put(d, f"n900/{k}", v)
+    for k, v in losses.items():
+        G.put(d, f"n900/L_{k}", v)
+    for k, v in taps.items():
+        G.put(d, f"n900/tap_{k}", G.digest(v, full_max=4096, nsamp=2048))
+    G.put(d, "n900/param_names", np.array(names)); G.put(d, "n900/grad_norms", gn)
+    print("n900", {k: float(v) for k, v in losses.items()})
+    np.savez_compressed(os.path.join(OUT, "g11_stage1_n900.npz"), **d)
 
 
 if __name__ == "__main__":

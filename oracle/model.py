@@ -61,14 +61,32 @@ def exemplar_centres(rects0, h, w):
     return out
 
 
-def extract_feature(images, mask, rects, sd, dilation=True):
-    """A2/models/backbone.py:116-145.  NB only `rects[0]` (image 0's exemplars) is used for the whole batch."""
+def extract_feature(images, mask, rects, sd, dilation=True, exemplar_mode="reference"):
+    """A2/models/backbone.py:116-145.  exemplar_mode "reference": only `rects[0]` (image 0's exemplars) is used for the whole
+    batch, scaled by the PADDED feature-map size -- what the reference does (it only ever runs batch 1, where this is exact).
+    exemplar_mode "per_image" (the batched trainer's rule): image b is conditioned on ITS exemplars `rects[b]`, whose
+    normalised coordinates are scaled by that image's own un-padded extent in feature cells (rows / columns of the
+    down-sampled padding mask that are not padding); rows with x2 < 0 are absent exemplars (FSCD-LVIS has "at most 3").
+    Identical to "reference" for a batch of one un-padded image."""
     x = resnet50_dc5(images, sd, dilation)
     h, w = x.shape[-2:]
-    pfs = [x[:, :, yc, xc][:, :, None, None] for (yc, xc) in exemplar_centres(rects[0], h, w)]
-    pf = torch.stack(pfs).mean(0)
-    feat = torch.cat([x, x * pf], dim=1)
     m = F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]
+    if exemplar_mode == "reference":
+        pfs = [x[:, :, yc, xc][:, :, None, None] for (yc, xc) in exemplar_centres(rects[0], h, w)]
+        pf = torch.stack(pfs).mean(0)
+    else:
+        assert exemplar_mode == "per_image"
+        rows = []
+        for b in range(x.shape[0]):
+            hv, wv = int((~m[b, :, 0]).sum()), int((~m[b, 0, :]).sum())
+            rb = rects[b][rects[b][:, 2] >= 0]
+            cs = exemplar_centres(rb, hv, wv)
+            acc = x[b, :, cs[0][0], cs[0][1]]
+            for (yc, xc) in cs[1:]:
+                acc = acc + x[b, :, yc, xc]
+            rows.append(acc / len(cs))
+        pf = torch.stack(rows)[:, :, None, None]
+    feat = torch.cat([x, x * pf], dim=1)
     return feat, m
 
 
@@ -231,7 +249,7 @@ def reference_points(sd, bs, spatial_prior, num_position, num_pattern, points=No
 
 
 def transformer(src, mask, sd, spatial_prior="learned", num_position=300, num_pattern=1, enc=6, dec=6,
-                points=None, all_layers=False, stage=2):
+                points=None, all_layers=False, stage=2, taps=None):
     """A2/models/transformer.py:109-215 for num_feature_levels == 1.  src: [N,C,H,W]."""
     N, C, H, W = src.shape
     t = "transformer"
@@ -245,12 +263,16 @@ def transformer(src, mask, sd, spatial_prior="learned", num_position=300, num_pa
     x = src.permute(0, 2, 3, 1)
     for i in range(enc):
         x = encoder_layer(x, mask, posemb_row, posemb_col, sd, f"{t}.encoder_layers.{i}")
+        if taps is not None:
+            taps[f"enc{i}"] = x.permute(0, 3, 1, 2)          # NCHW like the reference's encoder layer output
     memory = x
     outs = []
     out = tgt
     inv_ref = inverse_sigmoid(ref)
     for i in range(dec):
         out = decoder_layer(out, ref, memory, mask, posemb_row, posemb_col, sd, f"{t}.decoder_layers.{i}")
+        if taps is not None:
+            taps[f"hs{i}"] = out
         logits = F.linear(out, sd[f"{t}.cls_embed.{i}.weight"], sd[f"{t}.cls_embed.{i}.bias"])
         tmp = mlp3(out, sd, f"{t}.bbox_embed.{i}")
         tmp = torch.cat([tmp[..., :2] + inv_ref, tmp[..., 2:]], -1)                     # :200
@@ -258,8 +280,9 @@ def transformer(src, mask, sd, spatial_prior="learned", num_position=300, num_pa
         var = mlp3(out, sd, f"{t}.bbox_variance.{i}") if stage == 2 else None
         outs.append((logits, boxes, var))
     res = {"pred_logits": outs[-1][0], "pred_boxes": outs[-1][1], "pred_vars": outs[-1][2]}
-    if all_layers:
+    if all_layers:       # aux_loss=True (A2/models/anchor_detr.py:129-140) -- with pred_vars added, which the reference forgets
         res["all_layers"] = outs
+        res["aux_outputs"] = [{"pred_logits": a, "pred_boxes": b, "pred_vars": c} for a, b, c in outs[:-1]]
     res["memory"] = memory
     return res, ref
 
@@ -282,8 +305,12 @@ def forward(images, rects, sd, mask=None, **kw):
     """AnchorDETR.forward, A2/models/anchor_detr.py:94-133 -> (out dict, reference_points)."""
     if mask is None:
         images, mask = nested(images)
-    feat, m = extract_feature(images, mask, rects, sd)
+    feat, m = extract_feature(images, mask, rects, sd, exemplar_mode=kw.pop("exemplar_mode", "reference"))
     src = aggr_input_proj(feat, sd)
+    taps = kw.get("taps")
+    if taps is not None:
+        taps["layer4"] = feat[:, : feat.shape[1] // 2]
+        taps["proj"] = src
     return transformer(src, m, sd, **kw)
 
 

@@ -79,3 +79,28 @@ def synthetic_batch(B=2, H=800, W=800, Ts=(37, 120), seed=0):
         wh = torch.rand(T, 2, generator=g1) * 0.10 + 0.02
         targets.append({"boxes": torch.cat([cxcy, wh], 1), "labels": torch.zeros(T, dtype=torch.int64)})
     return images, rects, targets
+
+
+def synthetic_images(sizes, Ts, seed):
+    """A batch of images of DIFFERENT sizes (list of [3,h,w]; the model pads them and builds the mask) with per-image exemplar
+    rectangles and targets -- seeded like synthetic_batch, so golden inputs never have to be stored."""
+    g0 = torch.Generator().manual_seed(seed)
+    images = [torch.randn(3, h, w, generator=g0) for h, w in sizes]
+    base = torch.tensor([[.10, .10, .20, .20], [.40, .40, .50, .55], [.70, .20, .80, .30]])
+    rects = torch.stack([(base + 0.07 * b).clamp(max=0.95) for b in range(len(sizes))])
+    g1 = torch.Generator().manual_seed(seed + 1)
+    targets = []
+    for b in range(len(sizes)):
+        T = Ts[b % len(Ts)]
+        cxcy = torch.rand(T, 2, generator=g1) * 0.8 + 0.1
+        wh = torch.rand(T, 2, generator=g1) * 0.10 + 0.02
+        targets.append({"boxes": torch.cat([cxcy, wh], 1), "labels": torch.zeros(T, dtype=torch.int64)})
+    return images, rects, targets
+
+
+def stage1_inputs(H, W, npts, seed):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randn(1, 3, H, W, generator=g)
+    pts = torch.rand(1, npts, 2, generator=g) * 0.8 + 0.1
+    whs = torch.rand(1, npts, 2, generator=g) * 0.1 + 0.02
+    return img, pts, whs

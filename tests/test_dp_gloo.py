@@ -103,3 +103,32 @@ def _equiv(rank, world):
 def test_dp_gradient_equals_large_batch():
     out = run2(_equiv)
     assert out[0] and out[1]
+
+
+def _replicas(rank, world):
+    """Ranks that build their model from DIFFERENT RNG streams (what main.py used to do) hold identical parameters, frozen
+    weights and buffers once the trainer exists (DistributedDataParallel's construction-time broadcast, A1/main.py:206-208)."""
+    import hashlib
+    from counting_detr_amd import build_model
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.engine import Trainer
+    args = default_args()
+    args.device = "cpu"
+    torch.manual_seed(1234 + rank)
+    model, crit, _ = build_model(args)
+    with torch.no_grad():
+        model.backbone.body.bn1.running_mean.add_(float(rank))          # a buffer and a frozen weight that differ per rank
+        model.backbone.body.layer1[0].conv1.weight.add_(float(rank))
+    tr = Trainer(model, crit, args, device="cpu")
+    h = hashlib.sha256()
+    h.update(tr.flat_p.numpy().tobytes())
+    for k, v in sorted(model.state_dict().items()):
+        h.update(v.detach().contiguous().numpy().tobytes())
+    s1, b1 = model.backbone.body.bn1.affine()
+    return h.hexdigest(), float(model.backbone.body.bn1.running_mean[0]), float(b1[0])
+
+
+def test_trainer_broadcasts_rank0_weights_to_every_replica():
+    out = run2(_replicas)
+    assert out[0][0] == out[1][0], "replicas start from different weights"
+    assert out[0][1] == out[1][1] and out[0][2] == out[1][2]

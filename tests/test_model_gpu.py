@@ -28,6 +28,7 @@ def build(nq=300, prior="learned"):
     args = default_args(device=DEV, num_query_position=nq, spatial_prior=prior)
     model, crit, _ = counting_detr_amd.build_model(args)
     model.load_state_dict(seeded_state_dict(model_schema(num_position=nq, spatial_prior=prior)), strict=True)
+    model.backbone.exemplar_mode = "reference"      # the golden vectors are the reference's: rects[0] for the whole batch
     return model.to(DEV), crit, args
 
 
@@ -228,3 +229,170 @@ def test_stage1_to_stage2_handoff(tmp_path):
     w0, h0 = Image.open(root / "images_384_VarV2" / "7.jpg").size
     want = np.array([a["bbox"] for a in ann["annotations"] if a["image_id"] == 1], dtype=np.float32) / np.array([w0, h0, w0, h0], dtype=np.float32)
     np.testing.assert_allclose(s0["boxes"], want, rtol=0, atol=1e-7)
+
+
+def _dev_batch(B, H, W, Ts, seed):
+    from oracle.step import synthetic_batch
+    images, rects, targets = synthetic_batch(B=B, H=H, W=W, Ts=Ts, seed=seed)
+    return images.to(DEV), rects.to(DEV), [{k: v.to(DEV) for k, v in t.items()} for t in targets]
+
+
+def test_graph_replay_with_new_inputs_equals_eager_step():
+    """`Trainer.replay(samples, rects, targets)` on a batch the graph was NOT captured with == the stream-ordered step on that
+    batch from the same weights: losses, gradient norm and every parameter after the update."""
+    from counting_detr_amd.engine import Trainer
+    cap = _dev_batch(2, 128, 160, (7, 13), seed=0)
+    new = _dev_batch(2, 128, 160, (7, 13), seed=5)              # same shapes / target counts, different pixels and boxes
+    new[1][:, 1] = torch.tensor([0.55, 0.20, 0.75, 0.50], device=DEV)      # and other exemplars
+    res, params = [], []
+    for use_graph in (False, True):
+        model, crit, args = build()
+        model.train()
+        tr = Trainer(model, crit, args, device=DEV)
+        if use_graph:
+            tr.capture(*cap, warmup=0)                          # recorded with the OTHER batch; weights untouched
+            out = tr.replay(*new)
+        else:
+            out = tr.train_step(*new)
+        torch.cuda.synchronize()
+        res.append({k: float(v) for k, v in out.items()})
+        params.append(tr.flat_p.detach().clone())
+    for k in res[0]:
+        np.testing.assert_allclose(res[1][k], res[0][k], rtol=1e-4, atol=1e-6, err_msg=k)
+    assert float((params[0] - params[1]).abs().max()) <= 2e-6    # one AdamW step moves a weight by <= lr = 1e-4
+    ref = _dev_batch(2, 128, 160, (7, 13), seed=0)
+    model, crit, args = build()
+    tr = Trainer(model, crit, args, device=DEV)
+    out0 = tr.train_step(*ref)
+    assert abs(float(out0["loss"]) - res[0]["loss"]) > 1e-4      # the two batches really differ
+
+
+def test_per_image_exemplars_vs_oracle(precision):
+    """exemplar_mode "per_image" (the batched trainer's rule): image b is conditioned on rects[b], scaled by its own un-padded
+    extent.  B=2 with different image sizes (padding mask) and different exemplars vs the oracle's restatement; and it equals the
+    reference rule when the batch is one un-padded image."""
+    from oracle import model as OM
+    from oracle.weights import model_schema, seeded_state_dict
+    g = torch.Generator().manual_seed(3)
+    imgs = [torch.randn(3, 96, 128, generator=g), torch.randn(3, 64, 96, generator=g)]
+    rects = torch.tensor([[[.10, .10, .20, .20], [.40, .40, .50, .55], [.70, .20, .80, .30]],
+                          [[.55, .60, .70, .80], [.05, .30, .20, .45], [-1., -1., -1., -1.]]])     # image 1 has two exemplars
+    sd = seeded_state_dict(model_schema())
+    o_out, _ = OM.forward(imgs, rects, sd, exemplar_mode="per_image")
+    model, crit, args = build()
+    model.backbone.exemplar_mode = "per_image"
+    model.eval()
+    with torch.no_grad():
+        out, _ = model([i.to(DEV) for i in imgs], rects=rects.to(DEV))
+    for k in ("pred_logits", "pred_boxes", "pred_vars"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), o_out[k].detach().numpy(), rtol=1e-3, atol=1e-5, err_msg=k)
+    # conditioning really is per image: swapping image 1's exemplars changes image 1 only
+    r2 = rects.clone()
+    r2[1, 0] = torch.tensor([.30, .10, .45, .25])
+    with torch.no_grad():
+        out2, _ = model([i.to(DEV) for i in imgs], rects=r2.to(DEV))
+    assert torch.equal(out2["pred_logits"][0], out["pred_logits"][0])
+    assert not torch.equal(out2["pred_logits"][1], out["pred_logits"][1])
+    # batch of one un-padded image: identical to the reference rule
+    with torch.no_grad():
+        a, _ = model(imgs[0][None].to(DEV), rects=rects[:1].to(DEV))
+        model.backbone.exemplar_mode = "reference"
+        b, _ = model(imgs[0][None].to(DEV), rects=rects[:1].to(DEV))
+    for k in ("pred_logits", "pred_boxes", "pred_vars"):
+        np.testing.assert_allclose(a[k].cpu().numpy(), b[k].cpu().numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+def test_infer_counts_match_the_golden_count_rule(golden, tmp_path):
+    """SURVEY a14 through the product's inference driver: infer.infer() fed the G8 logits (a stand-in model returns them) writes
+    one annotation per counted query and reports the golden counts / MAE / RMSE / NAE / SRE (A2/infer.py:75-81, eval_all.py:252-270)."""
+    import json
+    import infer as infer_mod
+    z = golden("g8_count.npz")
+    logits = torch.from_numpy(z["logits"]).to(DEV)
+    gt = [int(v) for v in z["gt"]]
+    n_img, Q = logits.shape[:2]
+
+    class Stub(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.i = 0
+
+        def forward(self, samples, rects=None):
+            i, self.i = self.i, self.i + 1
+            boxes = torch.rand(1, Q, 4, device=DEV) * 0.5 + 0.1
+            return ({"pred_logits": logits[i:i + 1], "pred_boxes": boxes, "pred_vars": torch.ones(1, Q, 2, device=DEV)},
+                    torch.rand(1, Q, 2, device=DEV))
+
+    class Crit(torch.nn.Module):
+        def forward(self, outputs, targets):
+            return {"loss_ce": torch.zeros((), device=DEV)}
+
+    def loader():
+        for i in range(n_img):
+            yield {"image": torch.zeros(1, 3, 64, 64), "mask": torch.zeros(1, 64, 64, dtype=torch.bool), "ex_rects": torch.zeros(1, 3, 4),
+                   "targets": [{"boxes": torch.zeros(gt[i], 4), "labels": torch.zeros(gt[i], dtype=torch.int64)}],
+                   "orig_size": torch.tensor([[480, 640]]), "image_id": torch.tensor([100 + i])}
+
+    metrics, pred = infer_mod.infer(Stub(), Crit(), loader(), torch.device(DEV), str(tmp_path), split="val")
+    per_image = [sum(1 for a in pred["annotations"] if a["image_id"] == 100 + i) for i in range(n_img)]
+    assert per_image == [int(c) for c in z["counts"]]
+    np.testing.assert_allclose([metrics["MAE"], metrics["RMSE"], metrics["NAE"], metrics["SRE"]], z["metrics"], rtol=1e-12)
+    pj = json.load(open(tmp_path / "predictions_val.json"))
+    assert len(pj["annotations"]) == int(z["counts"].sum()) and all(a["score"] >= 0.5 for a in pj["annotations"])
+
+
+def test_main_resume_and_pretrained_backbone_end_to_end(tmp_path):
+    """SURVEY 8f row 3 through main.py: start from a torchvision-layout backbone file + an Anchor-DETR-COCO-shaped detector
+    checkpoint (--resume --resume_skip_mismatch), train, write the reference's checkpoint dict, and resume THAT (model,
+    AdamW moments, epoch) into a second run (A2/main.py:195-236)."""
+    import main as main_mod
+    from counting_detr_amd.args import get_args_parser
+    from test_checkpoint import _torchvision_resnet50_state_dict
+    tv = _torchvision_resnet50_state_dict()
+    torch.save(tv, tmp_path / "resnet50.pth")
+    base = ["--synthetic", "--no_aux_loss", "--num_query_pattern", "1", "--num_query_position", "100", "--steps_per_epoch", "2",
+            "--images_per_gpu", "2", "--device", DEV, "--synthetic_size", "128", "160"]
+    a = get_args_parser().parse_args(base + ["--epochs", "1", "-o", str(tmp_path / "run1"), "--pretrained_backbone",
+                                             str(tmp_path / "resnet50.pth")])
+    main_mod.main(a)
+    ck = torch.load(tmp_path / "run1" / "detr_retrain.pth", map_location="cpu", weights_only=False)
+    assert set(ck) == {"model", "optimizer", "lr_scheduler", "epoch", "args"} and ck["epoch"] == 0
+    assert set(ck["optimizer"]) == {"state", "param_groups"} and len(ck["optimizer"]["param_groups"]) == 3
+    assert torch.equal(ck["model"]["backbone.body.conv1.weight"], tv["conv1.weight"])          # frozen stem: the pretrained values
+    assert not torch.equal(ck["model"]["backbone.body.layer4.2.conv3.weight"], tv["layer4.2.conv3.weight"])   # trained
+    a2 = get_args_parser().parse_args(base + ["--epochs", "2", "-o", str(tmp_path / "run2"), "--resume",
+                                              str(tmp_path / "run1" / "detr_retrain.pth")])
+    main_mod.main(a2)
+    ck2 = torch.load(tmp_path / "run2" / "detr_retrain.pth", map_location="cpu", weights_only=False)
+    assert ck2["epoch"] == 1                                                                    # continued at epoch 1, not 0
+    st1 = ck["optimizer"]["state"]
+    st2 = ck2["optimizer"]["state"]
+    k = sorted(st1)[0]
+    assert float(st2[k]["step"]) == float(st1[k]["step"]) + 2                                   # moments / step count were restored
+    lines = open(tmp_path / "run2" / "detr_retrain.txt").read().strip().splitlines()
+    assert len(lines) == 1 and '"epoch": 1' in lines[0]
+
+
+def test_bench_self_launches_two_ranks_rehearsal():
+    """`python bench.py --gpus 2` with no launcher around it spawns the two ranks itself (torch.distributed.run, 127.0.0.1) and
+    prints ONE line for the whole job.  On this one-GPU box the ranks share the device and gloo carries the collectives
+    (CDETR_BENCH_SHARE_GPU=1 -- the line is tagged as a rehearsal); the control flow -- self-launch, replica sync, five-graph
+    replay with the bucketed exchange between the graphs, exposed all-reduce time -- is the one the 8-GPU run takes."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CDETR_BENCH_SHARE_GPU="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    for mode in ("graph", "eager"):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "256", "256",
+                            "--queries", "100", "--mode", mode, "--no-cpu-baseline", "--no-alt", "--no-extra"],
+                           env=env, cwd=root, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        r = json.loads(lines[0])
+        assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"
+        assert r["config"]["graph"] == (mode == "graph") and "REHEARSAL" in r["data"]
+        ex = r["allreduce_exposed_ms"]
+        assert ex["mean_max_over_ranks"] >= 0 and ex["rank0"]["n"] == 3 and sum(ex["buckets_bytes"]) == ex["bytes_per_step"]
+        assert r["value"] > 0 and r["step_ms"]["n"] == 3 and r["roofline"]["achieved"] > 0

@@ -219,3 +219,71 @@ def test_g7_stage1(golden, name):
             assert sd[n].grad is None, n
         else:
             np.testing.assert_allclose(sd[n].grad.norm().item(), r, rtol=5e-3, atol=1e-7, err_msg=n)
+
+
+# ------------------------------------------------------------------------------------------------ full-size vectors (G10, G11)
+@pytest.mark.parametrize("name", ["small_b2", "aux", "shipped576", "cfg2"])
+def test_g10_full_size_reference_runs(golden, name):
+    """The oracle vs the real reference at BASELINE's sizes (cfg2 = B=2 800x800 Q=300 T=(37,120), bench.py's batch), the shipped
+    script's grid-576 shape, a padded batch and aux_loss=True: outputs, Hungarian indices (incl. every aux layer's), losses, total
+    gradient norm and the digests of every intermediate (layer4, projection, 6 encoder outputs, 6 decoder states)."""
+    from fullsize import TAP_KEYS, case_inputs, check_tap, rel_err
+    from oracle.step import trainable_names
+    z = golden("g10_full.npz")
+    c = case_inputs(z, name)
+    sd = seeded_state_dict(model_schema(num_position=c["nq"], spatial_prior=c["prior"]), heads="wide")
+    names = trainable_names(sd)
+    for n in names:
+        sd[n].requires_grad_(True)
+    for n in list(sd):
+        for fam in ("cls_embed", "bbox_embed", "bbox_variance"):
+            if f"transformer.{fam}.0." in n:
+                for i in range(1, 6):
+                    sd[n.replace(f"{fam}.0.", f"{fam}.{i}.")] = sd[n]
+    taps = {}
+    out, ref = OM.forward(c["images"], c["rects"], sd, spatial_prior=c["prior"], num_position=c["nq"], all_layers=c["aux"], taps=taps)
+    for k in ("pred_logits", "pred_boxes", "pred_vars"):
+        assert rel_err(out[k].detach().numpy(), z[f"{name}/{k}"]) < 1e-4, k
+    np.testing.assert_allclose(ref.detach().numpy(), z[f"{name}/ref"], rtol=1e-6)
+    for k in TAP_KEYS:
+        check_tap(z, f"{name}/tap_{k}", taps[k], 2e-4)
+    if c["aux"]:
+        losses, all_idx = OC.set_criterion_aux(out, c["targets"])
+        wd = OC.aux_weight_dict()
+        for i in range(5):
+            for b in range(c["B"]):
+                assert np.array_equal(all_idx[i][b][0].numpy(), z[f"{name}/aux{i}/idx_i{b}"])
+                assert np.array_equal(all_idx[i][b][1].numpy(), z[f"{name}/aux{i}/idx_j{b}"])
+        idx = all_idx[-1]
+    else:
+        losses, idx = OC.set_criterion(out, c["targets"])
+        wd = OC.WEIGHT_DICT
+    for b in range(c["B"]):
+        assert np.array_equal(idx[b][0].numpy(), z[f"{name}/idx_i{b}"]) and np.array_equal(idx[b][1].numpy(), z[f"{name}/idx_j{b}"])
+    lkeys = [k[len(name) + 3:] for k in z.files if k.startswith(f"{name}/L_")]
+    assert sorted(lkeys) == sorted(losses), (sorted(lkeys), sorted(losses))
+    for k in lkeys:
+        np.testing.assert_allclose(losses[k].item(), z[f"{name}/L_{k}"], rtol=2e-4, atol=1e-6, err_msg=k)
+    total = OC.total_loss(losses, wd)
+    np.testing.assert_allclose(total.item(), z[f"{name}/loss_total"], rtol=2e-4)
+    total.backward()
+    gn = torch.norm(torch.stack([sd[n].grad.norm() for n in names if sd[n].grad is not None]))
+    np.testing.assert_allclose(gn.item(), z[f"{name}/grad_total_norm"], rtol=2e-3)
+
+
+def test_g11_stage1_900_points(golden):
+    """BASELINE config 5 at its stated size: the 1st-stage forward with 900 `defined` anchor points on an 800x800 image."""
+    from fullsize import check_tap, rel_err
+    from oracle.step import stage1_inputs
+    from oracle.weights import stage1_schema
+    z = golden("g11_stage1_n900.npz")
+    H, W, n, seed = [int(v) for v in z["n900/cfg"]]
+    img, pts, whs = stage1_inputs(H, W, n, seed)
+    sd = seeded_state_dict(stage1_schema())
+    with torch.no_grad():
+        out = OM.forward_stage1(img, pts, sd)
+    for k in ("pred_logits", "pred_wh", "pred_points"):
+        assert rel_err(out[k].numpy(), z[f"n900/{k}"]) < 1e-4, k
+    losses = OC.bbox_criterion(out, {"points": pts, "whs": whs})
+    for k in ("loss_wh", "loss_giou"):
+        np.testing.assert_allclose(losses[k].item(), z[f"n900/L_{k}"], rtol=1e-4, err_msg=k)
