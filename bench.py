@@ -50,6 +50,17 @@ def step_gflop_per_image(H, W, Q):
     return 2.0 * (fwd + 2.0 * (fwd - frozen)) / 1e9
 
 
+def dtype_string(precision):
+    """The arithmetic the step computes in, pass by pass (never a narrower claim than what runs)."""
+    if precision == "fp32":
+        return "fp32 (fp32 MFMA, exact products; fp32 storage)"
+    from counting_detr_amd import ops
+    bwd = {1: "bf16x3", 2: "bf16x2 (weight / activation operand rounded to bf16, incoming gradient split hi+lo, 2 MFMAs per product)",
+           3: "bf16 (both operands rounded to bf16, 1 MFMA per product)"}[ops.PRECISION_BWD]
+    return ("forward bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs per product); data / weight gradients " + bwd +
+            "; fp32 accumulate, fp32 storage, fp32 attention softmax / norms / losses / optimizer")
+
+
 def synthetic_batch(B, H, W, Ts, seed, device):
     g0 = torch.Generator().manual_seed(seed)
     images = torch.randn(B, 3, H, W, generator=g0)
@@ -380,12 +391,14 @@ def main(argv=None):
 
     res = {"metric": "images/sec FSCD-147 2nd-stage train step", "value": value, "unit": "images/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": ("fp32" if a.precision == "fp32" else "bf16x3 (fp32 operands split hi+lo, 3 bf16 MFMAs per product, fp32 accumulate; fp32 storage)"),
+           "vs_baseline": None, "dtype": dtype_string(a.precision),
            "data": "synthetic" if not share else "synthetic (REHEARSAL: ranks share one GPU, gloo -- not a measurement)",
            "config": {"workload": f"FSCD-147 2nd-stage train step (ResNet-50-DC5 + RCDA enc6/dec6, Q={Q} {a.prior}, "
                                   f"{H}x{W}, T={list(Ts)}), fwd+matcher+loss+bwd+clip+AdamW",
                       "images_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
-                      "graph": not a.no_graph, "mode_probe_ms": probe, "precision": a.precision, "final_loss": loss},
+                      "graph": not a.no_graph, "mode_probe_ms": probe, "precision": a.precision,
+                      "precision_backward": ({1: "bf16x3", 2: "bf16x2", 3: "bf16"}[ops.PRECISION_BWD] if a.precision != "fp32" else "fp32"),
+                      "final_loss": loss},
            "step_ms": percentiles(per_step),
            "roofline": roofline}
     if world > 1:

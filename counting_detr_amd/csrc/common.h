@@ -83,6 +83,14 @@ __device__ __forceinline__ void stash_split4(__bf16* dst, int lo_off, float x0, 
     *reinterpret_cast<uint2*>(dst) = h;
     *reinterpret_cast<uint2*>(dst + lo_off) = l;
 }
+// four consecutive-k fp32 values -> their bf16 roundings (8 bytes) at dst: the plain-bf16 products never read a lo plane
+__device__ __forceinline__ void stash_hi4(__bf16* dst, float x0, float x1, float x2, float x3) {
+    const f32x2 v0 = {x0, x1}, v1 = {x2, x3};
+    uint2 h;
+    h.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16x2));
+    h.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16x2));
+    *reinterpret_cast<uint2*>(dst) = h;
+}
 __device__ __forceinline__ f32x16 mfma_bf16x3(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);    // small terms first
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);

@@ -475,9 +475,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 // split-plane LDS rows are groups of 32 k-values, [hi 32 | lo 32] each (= the byte layout of cdetr_gemm_desc.B_split): position
 // of k inside a row, in bf16 units; the lo plane of the same k sits 32 further.
 #define KPOS(k) ((((k) >> 5) << 6) + ((k) & 31))
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds; PD: k-tiles in flight in registers
+// TERMS (split-bf16 staging modes only): bf16 MFMAs per algorithmic product -- 3 = hi*hi + hi*lo + lo*hi ("bf16x3", ~5e-6 relative),
+// 2 = hi*hi + lo*hi (the B operand rounded to bf16, A exact to 2^-17: "bf16x2"), 1 = hi*hi (both rounded: plain bf16).  Fewer terms
+// skip the MFMAs, the LDS reads of the unused lo planes and (TERMS 1) the lo half of the staging split of A.
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2, int TERMS = 3>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds; PD: k-tiles in flight in registers
 __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const int tilesM, const int bx, const int bz) {
     static_assert(PD == 2 || PD == 4, "register ring depth");
+    static_assert(TERMS == 3 || ((PREC == 2 || PREC == 3) && BL == 0 && ABL == 0), "reduced-term products exist for the staging-split k-contiguous forms");
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
@@ -625,6 +629,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
                 if constexpr (ABL == 4) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = qa[i];      // ablation: no split
+                else if constexpr (TERMS == 1) stash_hi4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + KPOS(kq * 4), qa[i].x, qa[i].y, qa[i].z, qa[i].w);
                 else stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + KPOS(kq * 4), 32, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
             }
             if constexpr (BL == 0 && (ABL >= 3 || BRAW)) {
@@ -756,17 +761,23 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     #pragma unroll
                     for (int a = 0; a < FM; ++a) {
                         ah[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + KPOS(hp * 16));
-                        al[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + KPOS(hp * 16) + 32);
+                        if constexpr (TERMS >= 2) al[a] = *reinterpret_cast<const bf16x8*>(a16 + a * 32 * 2 * LDK + KPOS(hp * 16) + 32);
                     }
     #pragma unroll
                     for (int b = 0; b < FN; ++b) {
                         bh[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + KPOS(hp * 16));
-                        bl[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + KPOS(hp * 16) + 32);
+                        if constexpr (TERMS == 3) bl[b] = *reinterpret_cast<const bf16x8*>(b16 + b * 32 * 2 * LDK + KPOS(hp * 16) + 32);
                     }
     #pragma unroll
                     for (int a = 0; a < FM; ++a)
     #pragma unroll
-                        for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+                        for (int b = 0; b < FN; ++b) {
+                            if constexpr (TERMS == 3) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+                            else {
+                                if constexpr (TERMS == 2) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                            }
+                        }
                 }
             }
         }
@@ -875,9 +886,9 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
 }
 
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2>
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2, int TERMS = 3>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
-    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, ABL, PD>(d, tilesM, blockIdx.x, blockIdx.z);
+    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, ABL, PD, TERMS>(d, tilesM, blockIdx.x, blockIdx.z);
 }
 
 // Grouped launch of up to GG_MAX independent GEMMs of one kernel class (same idea as WgradGroupArgs below): the problems'
@@ -1137,7 +1148,8 @@ __device__ __forceinline__ bf16x8 lds_tr8(const __bf16* p0, const __bf16* p1) {
     return __builtin_bit_cast(bf16x8, c);
 }
 
-template <int BI, int BJ>
+// TERMS: bf16 MFMAs per product, as in igemm_fast_body (3 = bf16x3; 2 = X rounded to bf16, dY split; 1 = plain bf16).
+template <int BI, int BJ, int TERMS = 3>
 __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const int tilesI, const int tilesJ, const int kt_per_slice,
                                               float* __restrict__ dbias, const int bx, const int by, const int bz, const bool single) {
     constexpr int BKF = 32;
@@ -1225,13 +1237,15 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) {
             const float4 v = (qf & 1u) ? qa[s] : zero4();
-            stash_split4(wbase + buf * BUF + s * BLK, PLANE_A, v.x, v.y, v.z, v.w);
+            if constexpr (TERMS == 1) stash_hi4(wbase + buf * BUF + s * BLK, v.x, v.y, v.z, v.w);
+            else stash_split4(wbase + buf * BUF + s * BLK, PLANE_A, v.x, v.y, v.z, v.w);
             if (do_bias) { bsum[s].x += v.x; bsum[s].y += v.y; bsum[s].z += v.z; bsum[s].w += v.w; }
         }
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) {
             const float4 v = (qf & 2u) ? qb[s] : zero4();
-            stash_split4(wbase + buf * BUF + 2 * PLANE_A + s * BLK, PLANE_B, v.x, v.y, v.z, v.w);
+            if constexpr (TERMS < 3) stash_hi4(wbase + buf * BUF + 2 * PLANE_A + s * BLK, v.x, v.y, v.z, v.w);
+            else stash_split4(wbase + buf * BUF + 2 * PLANE_A + s * BLK, PLANE_B, v.x, v.y, v.z, v.w);
         }
     };
 
@@ -1258,17 +1272,23 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
 #pragma unroll
             for (int a = 0; a < FM; ++a) {
                 ah[a] = lds_tr8(as + a * BLK + hp * 512, as + a * BLK + hp * 512 + 128);
-                al[a] = lds_tr8(as + PLANE_A + a * BLK + hp * 512, as + PLANE_A + a * BLK + hp * 512 + 128);
+                if constexpr (TERMS >= 2) al[a] = lds_tr8(as + PLANE_A + a * BLK + hp * 512, as + PLANE_A + a * BLK + hp * 512 + 128);
             }
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
                 bh[b] = lds_tr8(bs + b * BLK + hp * 512, bs + b * BLK + hp * 512 + 128);
-                bl[b] = lds_tr8(bs + PLANE_B + b * BLK + hp * 512, bs + PLANE_B + b * BLK + hp * 512 + 128);
+                if constexpr (TERMS == 3) bl[b] = lds_tr8(bs + PLANE_B + b * BLK + hp * 512, bs + PLANE_B + b * BLK + hp * 512 + 128);
             }
 #pragma unroll
             for (int a = 0; a < FM; ++a)
 #pragma unroll
-                for (int b = 0; b < FN; ++b) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+                for (int b = 0; b < FN; ++b) {
+                    if constexpr (TERMS == 3) acc[a][b] = mfma_bf16x3(ah[a], al[a], bh[b], bl[b], acc[a][b]);
+                    else {
+                        if constexpr (TERMS == 2) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                    }
+                }
         }
     };
 
@@ -1329,10 +1349,10 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
     }
 }
 
-template <int BI, int BJ>
+template <int BI, int BJ, int TERMS = 3>
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
                                                        const int kt_per_slice, float* __restrict__ dbias) {
-    wgrad_tr_body<BI, BJ>(d, tilesI, tilesJ, kt_per_slice, dbias, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
+    wgrad_tr_body<BI, BJ, TERMS>(d, tilesI, tilesJ, kt_per_slice, dbias, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
 }
 
 // Grouped launch: up to WG_MAX independent weight-gradient problems (arbitrary pointers / shapes, same kernel variant) in ONE
@@ -1344,14 +1364,14 @@ struct WgradGroupItem { cdetr_wgrad_desc d; int tilesI, tilesJ, per, nx, ny; int
 struct WgradGroupArgs { int n; int blk0[WG_MAX + 1]; WgradGroupItem it[WG_MAX]; };
 static_assert(sizeof(WgradGroupArgs) <= 4000, "grouped launch arguments must fit the kernel-argument segment");
 
-template <int BI, int BJ>
+template <int BI, int BJ, int TERMS = 3>
 __global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const WgradGroupArgs g) {
     int p = 0;
     while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
     const WgradGroupItem& it = g.it[p];
     const int lb = blockIdx.x - g.blk0[p];
     const int bx = lb % it.nx, r = lb / it.nx;
-    wgrad_tr_body<BI, BJ>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, bx, r % it.ny, r / it.ny, false);
+    wgrad_tr_body<BI, BJ, TERMS>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, bx, r % it.ny, r / it.ny, false);
 }
 
 // ------------------------------------------------------------------------------------------------ direct small GEMMs
@@ -1635,6 +1655,18 @@ int launch_gemm_fast_pd(const cdetr_gemm_desc& d, hipStream_t st) {
     int rc;
     if (d.b_layout == 0) {
         const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
+        if constexpr ((PREC == 2 || PREC == 3) && ABL == 0 && PD == 2 && FM == 1 && FN == 1) {
+            if (d.precision == 2) {      // bf16x2: B rounded to bf16
+                if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 0, 2, 2>, bytes, "cdetr_gemm"))) return rc;
+                hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 0, 2, 2>), grid, block, bytes, st, d, tilesM);
+                return cdetr_launch_status("cdetr_gemm");
+            }
+            if (d.precision == 3) {      // plain bf16
+                if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 0, 2, 1>, bytes, "cdetr_gemm"))) return rc;
+                hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 0, 2, 1>), grid, block, bytes, st, d, tilesM);
+                return cdetr_launch_status("cdetr_gemm");
+            }
+        }
         if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL, PD>, bytes, "cdetr_gemm"))) return rc;
         hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL, PD>), grid, block, bytes, st, d, tilesM);
     } else if constexpr ((BKF * BN) % (4 * 64 * WM * WN) != 0) {
@@ -1663,8 +1695,8 @@ int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
 
 template <int WM, int WN, int FM, int FN, int BKF, int ABL = 0>
 int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
-    if (ABL == 0 && d.precision == 1) {
-        // bf16x3: k-contiguous operands (b_layout 0) are split once while they are staged into LDS; the n-contiguous operand
+    if (ABL == 0 && d.precision >= 1) {
+        // bf16x3 (precision 1; 2 / 3 = the reduced-term forms, launch_gemm_fast_pd): k-contiguous operands (b_layout 0) are split once while they are staged into LDS; the n-contiguous operand
         // keeps the per-fragment split (its staging transpose costs more than it saves -- tools/split_sweep.py).
         // CDETR_GEMM_SPLIT: 0 = per-fragment everywhere, 2 = staging split everywhere.
         static const int split_mode = getenv("CDETR_GEMM_SPLIT") ? atoi(getenv("CDETR_GEMM_SPLIT")) : 1;
@@ -1697,12 +1729,12 @@ bool gemm_is_direct(const cdetr_gemm_desc& d, int vecA, int vecB) {
 // bf16x3 with a long reduction is bound by L2->CU operand delivery (~8 TB/s measured, tools/split_sweep.py): a
 // 128x128 tile shared by 16 waves of 32x32 halves that traffic at the same per-wave structure and occupancy.
 bool gemm_is_f44(const cdetr_gemm_desc& d) {
-    return d.precision == 1 && d.b_layout == 0 && (long)d.K * d.taps >= 1024 && (d.N % 128) == 0 && gemm_blocks(d, 128, 128) >= 150;
+    return d.precision >= 1 && d.b_layout == 0 && (long)d.K * d.taps >= 1024 && (d.N % 128) == 0 && gemm_blocks(d, 128, 128) >= 150;
 }
 // small grids (< 2 workgroups of 4 waves per CU): a 64x128 tile shared by 8 waves keeps the wave count and halves the
 // A-operand traffic (tools/split_sweep.py: 6-11 % over 64x64 BK64 on the N = 256 encoder linears)
 bool gemm_is_f24(const cdetr_gemm_desc& d) {
-    return d.precision == 1 && d.b_layout == 0 && (d.N % 128) == 0 && gemm_blocks(d, 64, 64) < 512;
+    return d.precision >= 1 && d.b_layout == 0 && (d.N % 128) == 0 && gemm_blocks(d, 64, 64) < 512;
 }
 int check_gemm_desc(const cdetr_gemm_desc& d) {
     CDETR_CHECK_ARG(d.M >= 0 && d.N > 0 && d.K > 0 && d.taps > 0 && d.batch > 0, "cdetr_gemm: bad sizes M=%d N=%d K=%d taps=%d batch=%d",
@@ -1917,11 +1949,19 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             // split-bf16: the transpose-read kernel is 7-20 % faster than the per-fragment split on every shape of this model
             // (profiles/r1_gemm_sweep.txt); CDETR_WGRAD_TR=0 keeps the older kernel reachable for A/B runs
             const int use_tr = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
-            if (d.precision == 1 && use_tr) {
+            if (d.precision >= 1 && use_tr) {
                 const int tbytes = 2 * 2 * (BI + BJ) * 32 * 2;
-                if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
-                hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
-            } else if (d.precision == 1) {
+                if (d.precision == 2) {
+                    if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ, 2>, tbytes, "cdetr_wgrad"))) return;
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 2>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
+                } else if (d.precision == 3) {
+                    if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ, 1>, tbytes, "cdetr_wgrad"))) return;
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 1>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
+                } else {
+                    if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
+                }
+            } else if (d.precision >= 1) {
                 if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 1>, bytes, "cdetr_wgrad"))) return;
                 hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ, 1>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
             } else {
@@ -1941,7 +1981,7 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
         const int use_tr_sel = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
         if (d.taps > 1 && d.Nout >= 512 && d.Cin >= 512)
             launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
-        else if (d.precision == 1 && use_tr_sel) {
+        else if (d.precision >= 1 && use_tr_sel) {
             // transpose-read kernel (profiles/r1_gemm_sweep.txt, wgrad section): 64x128 once the weight has >= 1M elements, else 64x64
             if (d.taps == 1 && (long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128)
                 launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 128>{});
@@ -2004,7 +2044,7 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
         if (int rcv = check_wgrad_desc(d)) return rcv;
         if (d.P == 0) continue;
         if (grouping && wgrad_is_direct(d)) direct.push_back(i);
-        else if (grouping && wgrad_is_fast(d) && d.precision == 1 && use_tr && !forced &&
+        else if (grouping && wgrad_is_fast(d) && d.precision >= 1 && use_tr && !forced &&
                  !(d.taps > 1 && d.Nout >= 512 && d.Cin >= 512) && !(d.taps == 1 && (long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128))
             tr64.push_back(i);                               // = the shapes cdetr_wgrad gives to wgrad_tr_kernel<64, 64>
         else if (int rc1 = cdetr_wgrad(&d, stream)) return rc1;
@@ -2048,7 +2088,11 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             it.nx = it.tilesI * it.tilesJ * it.d.taps; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
             g.blk0[k + 1] = g.blk0[k] + it.nx * it.ny * it.d.batch;
         }
-        hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
+        // one precision per grouped launch: the group's members come from one backward pass, the first member decides
+        const int gprec = g.it[0].d.precision;
+        if (gprec == 2) hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64, 2>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
+        else if (gprec == 3) hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64, 1>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
+        else hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
         if (int rcl = cdetr_launch_status("cdetr_wgrad_group")) return rcl;
     }
     return CDETR_OK;

@@ -349,7 +349,9 @@ class Trainer:
         finally:
             if not defer_trunk:
                 ops.MIRROR = None
-        out = dict(loss_dict)
+        # detached: a returned loss that still references the autograd graph keeps its AccumulateGrad nodes (and their stream) alive
+        # into the next step -- a later graph capture on another stream then records a cross-stream dependency and fails
+        out = {k: v.detach() for k, v in loss_dict.items()}
         out["loss"] = losses.detach()
         return out
 

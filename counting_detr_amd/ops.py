@@ -25,6 +25,15 @@ PROFILE = None
 # 0 = fp32 MFMA (exact fp32 products).  Both modes pass the same parity suite (1e-3 rel, bit-exact Hungarian indices).
 import os as _os
 PRECISION = int(_os.environ.get("CDETR_PRECISION", "1"))
+# Arithmetic of the BACKWARD contractions (data gradients and weight gradients) when PRECISION == 1: 1 = bf16x3 like the forward,
+# 2 = "bf16x2" (the weight / activation operand rounded to bf16, the incoming gradient split hi+lo: 2 MFMAs per product),
+# 3 = plain bf16 (1 MFMA).  The forward always runs bf16x3: its 1e-3 / bit-exact-assignment contract has no room for a bf16
+# rounding per product (~1e-2 end to end), gradients have (per-parameter norms within 1e-2 of the reference).  DESIGN.md section 3.
+PRECISION_BWD = int(_os.environ.get("CDETR_PRECISION_BWD", "3"))
+
+
+def bwd_precision():
+    return PRECISION_BWD if PRECISION == 1 else PRECISION
 
 
 class _Timed:
@@ -51,11 +60,11 @@ def _geom(mode=_ffi.ROWS_DENSE, Ha=0, Wa=0, Hc=0, Wc=0, kh=1, kw=1, stride=1, pa
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
-             batch_inner=0, sA2=0, sB2=0, sC2=0):
+             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None):
     d = GemmDesc()
     d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
-    d.precision = PRECISION
+    d.precision = PRECISION if precision is None else precision
     d.A, d.lda, d.sA = ptr(A), lda, sA
     d.B, d.ldb, d.sB = ptr(B), ldb, sB
     d.B_split = ptr(B_split)
@@ -103,7 +112,7 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
     d = WgradDesc()
     d.batch_inner, d.sY2, d.sX2, d.sW2 = batch_inner, sY2, sX2, sW2
     d.P, d.Nout, d.Cin, d.taps, d.batch = P, Nout, Cin, taps, batch
-    d.precision = PRECISION
+    d.precision = bwd_precision()
     d.dY, d.ldy, d.sY = ptr(dY), ldy, sY
     d.X, d.ldx, d.sX = ptr(X), ldx, sX
     d.dW, d.ldw, d.sW = ptr(dW), ldw, sW
@@ -311,11 +320,11 @@ def linear_dgrad(dy2d, weight, gate=None, resid=None):
     if m is not None:
         gemm_raw(dy2d, dy2d.stride(0), m[0], m[1], dx, K, M, K, N, b_layout=0,
                  gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
-                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0), B_split=m[2])
+                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0), B_split=m[2], precision=bwd_precision())
         return dx
     gemm_raw(dy2d, dy2d.stride(0), weight, weight.stride(0), dx, K, M, K, N, b_layout=1,
              gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
-             resid=resid, ldr=(resid.stride(0) if resid is not None else 0))
+             resid=resid, ldr=(resid.stride(0) if resid is not None else 0), precision=bwd_precision())
     return dx
 
 
@@ -412,7 +421,7 @@ class AggrProjFn(torch.autograd.Function):
         dy = dy.contiguous()
         WeffT = Weff.transpose(1, 2).contiguous()                          # [B, C, d]: k-contiguous operand of the data gradient
         dx = torch.empty_like(x)
-        gemm_raw(dy, d, WeffT, d, dx, Cc, h * w, Cc, d, batch=B, sA=h * w * d, sB=Cc * d, sC=h * w * Cc)
+        gemm_raw(dy, d, WeffT, d, dx, Cc, h * w, Cc, d, batch=B, sA=h * w * d, sB=Cc * d, sC=h * w * Cc, precision=bwd_precision())
         dWeff = torch.zeros((B, d, Cc), device=x.device, dtype=torch.float32)
         gb = grad_buffer(bparam) if bparam.requires_grad else None
         wgrad_raw(dy, d, x, Cc, dWeff, Cc, h * w, d, Cc, batch=B, sY=h * w * d, sX=h * w * Cc, sW=d * Cc, dbias=gb)
@@ -459,10 +468,10 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
-                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2])
+                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], precision=bwd_precision())
         return dx
     gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
-             gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g)
+             gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, precision=bwd_precision())
     return dx
 
 

@@ -52,7 +52,10 @@ typedef struct {
     int32_t batch; /* grid.z; per-batch element strides sA/sB/sC (0 = shared); see batch_inner for two-level batches */
     int32_t b_layout;
     int32_t relu;
-    int32_t precision; /* 0 = fp32 MFMA (exact fp32 products), 1 = split-bf16 x3 on the bf16 matrix pipe (~1e-5 rel) */
+    int32_t precision; /* 0 = fp32 MFMA (exact fp32 products), 1 = split-bf16 x3 on the bf16 matrix pipe (~1e-5 rel);
+                          2 = "bf16x2": B rounded to bf16, A split hi+lo, 2 MFMAs per product (~2^-9 rel per product, random);
+                          3 = plain bf16: both operands rounded, 1 MFMA.  2 / 3 are meant for the BACKWARD passes (data / weight
+                          gradients); kernels without a reduced-term form (few-row GEMMs, n-contiguous operands) run them as 1. */
     float out_scale;
     const float* A; int64_t lda, sA;
     const float* B; int64_t ldb, sB;

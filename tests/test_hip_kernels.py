@@ -19,6 +19,18 @@ def precision(request):
     ops.PRECISION = old
 
 
+@pytest.fixture(autouse=True)
+def _bf16x3_backward():
+    """The kernel-level tests pin the backward contractions to the forward's arithmetic (bf16x3 / fp32): their 2e-4 bars are the
+    bars of those kernels.  The reduced-term backward forms (ops.PRECISION_BWD 2 / 3, the library default) have their own test
+    below, and the end-to-end tests run with the default."""
+    from counting_detr_amd import ops
+    old = ops.PRECISION_BWD
+    ops.PRECISION_BWD = 1
+    yield
+    ops.PRECISION_BWD = old
+
+
 def tol(precision):
     return dict(rtol=2e-4, atol_scale=2e-5) if precision == 0 else dict(rtol=2e-4, atol_scale=6e-5)
 
@@ -782,3 +794,41 @@ def test_sumsq_value_and_bit_reproducibility(n):
     assert len(seen) == 1, "sum of squares changes from call to call"
     ref = float((gvec.double() ** 2).sum())
     assert abs(float(out[0]) - ref) <= 2e-6 * ref + 1e-30
+
+
+@pytest.mark.parametrize("bwd,lim", [(2, 3e-3), (3, 5e-3)])
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,dil,H,W", [(256, 256, 3, 1, 1, 1, 50, 50), (512, 2048, 1, 1, 0, 1, 50, 50), (128, 128, 3, 2, 1, 1, 100, 100),
+                                                        (512, 512, 3, 1, 2, 2, 50, 50)])
+def test_reduced_term_backward_kernels(Cin, Cout, k, stride, pad, dil, H, W, bwd, lim):
+    """ops.PRECISION_BWD 2 ("bf16x2": weights / activations rounded to bf16, the incoming gradient split) and 3 (plain bf16): data
+    and weight gradients of a convolution through the weight mirror vs fp64.  A product then carries a 2^-9 rounding; over a
+    K-term sum the error stays below ~1e-3 of the result's scale (bar 2.5e-3); the forward is untouched (bf16x3, 2e-4)."""
+    from counting_detr_amd import ops
+    ops.PRECISION, old = 1, ops.PRECISION
+    ops.PRECISION_BWD = bwd
+    try:
+        B = 2
+        x = torch.randn(B, Cin, H, W, generator=g(11))
+        w = torch.randn(Cout, Cin, k, k, generator=g(12)) / (Cin * k * k) ** 0.5
+        sc = torch.rand(Cout, generator=g(13)) + 0.5
+        xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        wd = torch.nn.Parameter(w.contiguous(memory_format=torch.channels_last).to(DEV))
+        wd.grad = torch.zeros_like(wd)
+        scd, bd = sc.to(DEV), torch.zeros(Cout, device=DEV)
+        mirror = ops.WeightMirror([(wd.data, scd)], [(wd.data, scd)] if Cin % 32 == 0 else [])
+        mirror.refresh()
+        ops.MIRROR = mirror
+        y = ops.conv_fwd(xd, wd.data, scd, bd, stride=stride, pad=pad, dil=dil)
+        gy = torch.randn(y.shape, generator=g(14)).to(DEV)
+        dx = ops.conv_dgrad(gy, wd.data, scd, (H, W), stride=stride, pad=pad, dil=dil)
+        ops.conv_wgrad_(gy, xd, wd, scd, stride=stride, pad=pad, dil=dil)
+        x64 = x.double().requires_grad_(True)
+        w64 = w.double().requires_grad_(True)
+        y64 = F.conv2d(x64, w64 * sc.double().view(-1, 1, 1, 1), None, stride, pad, dil)
+        y64.backward(gy.double().cpu().permute(0, 3, 1, 2))
+        close(y.permute(0, 3, 1, 2), y64, msg="y (forward stays bf16x3)", rtol=2e-4, atol_scale=6e-5)
+        close(dx.permute(0, 3, 1, 2), x64.grad, msg=f"dx bwd={bwd}", rtol=lim, atol_scale=0.0)
+        close(wd.grad, w64.grad, msg=f"dW bwd={bwd}", rtol=lim, atol_scale=0.0)
+    finally:
+        ops.MIRROR = None
+        ops.PRECISION = old

@@ -92,7 +92,11 @@ def test_train_step_matches_reference_adamw(golden, precision):
     sums = z[f"{name}/param_sums_after_step"]
     params = dict(model.named_parameters())
     for n, s in zip(names, sums):
-        np.testing.assert_allclose(params[n].detach().double().sum().item(), s, rtol=1e-4, atol=5e-3, err_msg=n)
+        # the first AdamW step moves every element by lr * sign(g): an element whose (near-zero) gradient changes sign under the
+        # kernels' rounding moves the sum by 2 lr -- budget 1 % of the elements, on top of the absolute / relative bar
+        p = params[n]
+        lr = 1e-5 if "backbone" in n else 1e-4
+        np.testing.assert_allclose(p.detach().double().sum().item(), s, rtol=1e-4, atol=5e-3 + 0.02 * lr * p.numel(), err_msg=n)
 
 
 def test_graph_replay_equals_eager():
