@@ -57,7 +57,7 @@ class CriterionDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("Q", C.c_int32), ("C", C.c_int32), ("num_classes", C.c_int32), ("Mmax", C.c_int32), ("alpha", C.c_float),
                 ("logits", _p), ("boxes", _p), ("vars", _p), ("tgt_boxes", _p), ("tgt_labels", _p), ("tgt_off", _p), ("idx_i", _p),
                 ("idx_j", _p), ("num_boxes", _p), ("losses", _p), ("g_logits", _p), ("g_l1", _p), ("g_giou", _p), ("g_var_box", _p),
-                ("g_vars", _p)]
+                ("g_vars", _p), ("loss_weights", _p)]
 
 
 class MirrorItem(C.Structure):
@@ -67,7 +67,8 @@ class MirrorItem(C.Structure):
 
 EXPORTS = ["cdetr_gemm", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
            "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
-           "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
+           "cdetr_mask_prep", "cdetr_stem_pack", "cdetr_exemplar_fwd", "cdetr_exemplar_bwd", "cdetr_aggr_weight_fwd", "cdetr_aggr_weight_bwd",
+           "cdetr_box_head_fwd", "cdetr_box_head_bwd", "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
 
 _lib = None
 
@@ -114,7 +115,7 @@ def lib():
         L.cdetr_criterion_fwd.restype = C.c_int
         L.cdetr_criterion_fwd.argtypes = [_p, _p]
         L.cdetr_criterion_bwd.restype = C.c_int
-        L.cdetr_criterion_bwd.argtypes = [_p] * 9 + [C.c_int32, C.c_int32, _p]
+        L.cdetr_criterion_bwd.argtypes = [_p] * 11 + [C.c_int32, C.c_int32, _p]
         L.cdetr_sine_embed.restype = C.c_int
         L.cdetr_sine_embed.argtypes = [_p, C.c_int32, _p, C.c_int64, C.c_int32, C.c_int32, C.c_float, _p]
         L.cdetr_sine_embed_bwd.restype = C.c_int
@@ -138,6 +139,16 @@ def lib():
                                        C.c_float, _p, _p]
         L.cdetr_lsap.restype = C.c_int
         L.cdetr_lsap.argtypes = [_p, _p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p, _p, _p, _p]
+        for name, args in (("cdetr_mask_prep", [_p] + [C.c_int32] * 5 + [_p] * 7),
+                           ("cdetr_stem_pack", [_p, _p] + [C.c_int32] * 7 + [_p]),
+                           ("cdetr_exemplar_fwd", [_p, _p, _p] + [C.c_int32] * 6 + [_p] * 4),
+                           ("cdetr_exemplar_bwd", [_p] * 4 + [C.c_int32] * 4 + [_p]),
+                           ("cdetr_aggr_weight_fwd", [_p] * 4 + [C.c_int32] * 3 + [_p]),
+                           ("cdetr_aggr_weight_bwd", [_p] * 5 + [C.c_int32] * 3 + [_p]),
+                           ("cdetr_box_head_fwd", [_p] * 3 + [C.c_int32] * 2 + [_p]),
+                           ("cdetr_box_head_bwd", [_p] * 5 + [C.c_int32] * 2 + [_p])):
+            getattr(L, name).restype = C.c_int
+            getattr(L, name).argtypes = args
         if L.cdetr_abi_version() != 1:
             raise RuntimeError("libcdetr_hip.so ABI version mismatch")
         _lib = L

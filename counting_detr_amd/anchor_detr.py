@@ -42,9 +42,9 @@ class _ProjGN(nn.Sequential):
         super().__init__(_Conv1x1(cin, d), nn.GroupNorm(32, d))
 
     def forward(self, x_nhwc):
-        if isinstance(x_nhwc, tuple):                                 # (features, exemplar feature): concat-free projection
-            x, pf = x_nhwc
-            y = ops.AggrProjFn.apply(x, pf, self[0].weight, self[0].bias)
+        if isinstance(x_nhwc, tuple):                                 # (features, rects, extents, per-image flag): concat-free projection
+            x, rects, extent, per_image = x_nhwc
+            y = ops.AggrProjFn.apply(x, rects, extent, per_image, self[0].weight, self[0].bias)
         else:
             y = self[0](x_nhwc)                                       # [B,h,w,d]
         gn = self[1]
@@ -77,17 +77,18 @@ class AnchorDETR(nn.Module):
         if not isinstance(samples, NestedTensor):
             samples = nested_tensor_from_tensor_list(samples)
         images, mask = samples.decompose()
-        prev, self.backbone.lazy_concat = self.backbone.lazy_concat, (CONCAT_FREE and images.is_cuda)
-        try:     # NHWC [B,h,w,4096] features, or (x [B,h,w,2048], exemplar feature [B,2048]) for the concat-free projection
-            feat, m = self.backbone.extract_feature(images, mask, rects)
-        finally:
-            self.backbone.lazy_concat = prev
-        src = self.aggr_input_proj[0](feat)                                   # NHWC [B,h,w,256]
+        x, mi = self.backbone.features(images, mask)                          # NHWC [B,h,w,2048] + everything derived from the mask
+        per_image = self.backbone.exemplar_mode == "per_image"
+        if CONCAT_FREE:     # the exemplar product folds into the projection weight: no [B,h,w,4096] tensor
+            src = self.aggr_input_proj[0]((x, rects, mi.extent, per_image))
+        else:
+            pf = ops.ExemplarFeatureFn.apply(x, rects, mi.extent, per_image)
+            src = self.aggr_input_proj[0](torch.cat([x, x * pf[:, None, None, :]], dim=-1))
         self.transformer.taps = self.taps
         if self.taps is not None:
-            self.taps["layer4"] = (feat[0] if isinstance(feat, tuple) else feat[..., : feat.shape[-1] // 2]).detach()
+            self.taps["layer4"] = x.detach()
             self.taps["proj"] = src.detach()
-        (outputs_class, outputs_coord, outputs_var), reference_points = self.transformer(src, m, points)
+        (outputs_class, outputs_coord, outputs_var), reference_points = self.transformer(src, mi, points)
         out = {"pred_logits": outputs_class[-1], "pred_boxes": outputs_coord[-1], "pred_vars": outputs_var[-1]}
         if self.aux_loss:
             # A2/models/anchor_detr.py:129-140.  The reference's _set_aux_loss leaves pred_vars out and its criterion then raises
@@ -121,6 +122,7 @@ class SetCriterion(nn.Module):
         import os
         self.fused = os.environ.get("CDETR_FUSED_CRITERION", "1") != "0"   # losses + their gradients in one kernel (ops.CriterionFn); False = tensor-op composition
         self._nb_cache = {}
+        self._w6_cache = {}
         self._plans = {}            # (target counts, Q, device) -> MatchPlan (device offset tables built once: graph-safe)
 
     # -- matched (batch, query, target-row) index tensors on the device
@@ -142,16 +144,18 @@ class SetCriterion(nn.Module):
         B, Q = logits.shape[:2]
         sizes = tuple(len(t["boxes"]) for t in targets)
         plan = self._plan(sizes, Q, logits.device)
+        tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
+        tgt_labels_all = torch.cat([t["labels"] for t in targets])
         aux = outputs.get("aux_outputs")
         if aux:
             layers = list(aux) + [out]
             L = len(layers)
             plan_all = self._plan(sizes * L, Q, logits.device)
             stacked = {k: torch.cat([l[k] for l in layers]) for k in ("pred_logits", "pred_boxes")}       # [L*B, Q, .]
-            idx_i, idx_j, status, _ = self.matcher.match_device(stacked, list(targets) * L, plan_all)
+            idx_i, idx_j, status, _ = self.matcher.match_device(stacked, None, plan_all, tgt_boxes=tgt_boxes_all.repeat(L, 1))
         else:
             layers, L = [out], 1
-            idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan)
+            idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan, tgt_boxes=tgt_boxes_all)
         if self.check_status and bool((status != 0).any()):
             raise ValueError("invalid or infeasible matching cost matrix")
         if num_boxes is not None:
@@ -164,8 +168,6 @@ class SetCriterion(nn.Module):
             num_boxes = torch.clamp(num_boxes, min=1)[0]                      # stays on the device (no .item())
         else:
             num_boxes = max(float(sum(plan.sizes)), 1.0)                      # :321-325
-        tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
-        tgt_labels_all = torch.cat([t["labels"] for t in targets])
         fused = self.fused and logits.is_cuda and list(self.losses) == ["labels", "boxes", "cardinality", "vars"]
         nbt = None
         if fused:
@@ -178,17 +180,18 @@ class SetCriterion(nn.Module):
             else:
                 nbt = num_boxes.reshape(-1)[:1].to(torch.float32)
         losses = {}
-        self.last_vec = None
+        self.last_total = None      # weighted total (A2/engine.py:37) when the fused kernel produced it: the trainer backpropagates this
+        totals = []
         for li, lo in enumerate(layers):
             ii, jj = idx_i[li * B:(li + 1) * B], idx_j[li * B:(li + 1) * B]
             last = li == L - 1
             if fused:
-                vec = ops.CriterionFn.apply(lo["pred_logits"], lo["pred_boxes"], lo["pred_vars"], tgt_boxes_all, tgt_labels_all.to(torch.int64),
-                                            plan, ii, jj, nbt, self.num_classes, self.focal_alpha)
+                vec, tot = ops.CriterionFn.apply(lo["pred_logits"], lo["pred_boxes"], lo["pred_vars"], tgt_boxes_all,
+                                                 tgt_labels_all.to(torch.int64), plan, ii, jj, nbt, self.num_classes, self.focal_alpha,
+                                                 self._weights6(logits.device, None if last else li))
+                totals.append(tot)
                 d = {"loss_ce": vec[0], "class_error": vec[1].detach(), "cardinality_error": vec[2].detach(), "loss_bbox": vec[3],
                      "loss_giou": vec[4], "loss_variance": vec[5]}
-                if last and L == 1:
-                    self.last_vec = vec     # [loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, loss_variance]
             else:
                 bidx, sidx, tidx = self._matched(ii, jj, plan)
                 d = {}
@@ -199,7 +202,19 @@ class SetCriterion(nn.Module):
             else:
                 d.pop("class_error", None)          # logged for the last layer only (log=False, :343-345)
                 losses.update({k + f"_{li}": v for k, v in d.items()})
+        if totals:
+            self.last_total = totals[0] if len(totals) == 1 else torch.stack(totals).sum()
         return losses
+
+    def _weights6(self, device, layer):
+        """weight_dict entries of one layer's six scalars, in the fused kernel's order (0 for the logged-only ones), on the device."""
+        key = (str(device), layer)
+        w = self._w6_cache.get(key)
+        if w is None:
+            suf = "" if layer is None else f"_{layer}"
+            order = ("loss_ce", "class_error", "cardinality_error", "loss_bbox", "loss_giou", "loss_variance")
+            w = self._w6_cache[key] = torch.tensor([float(self.weight_dict.get(k + suf, 0.0)) for k in order], device=device)
+        return w
 
     def _plan(self, sizes, Q, device):
         key = (tuple(sizes), Q, str(device))

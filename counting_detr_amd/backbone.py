@@ -250,8 +250,8 @@ class ResNetBody(nn.Module):
         B, _, H, W = images.shape
         Ho, Wo = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
         Ha, Wa = H + 6, W + 8 + (W & 1)
-        xp = torch.zeros((B, Ha, Wa, 4), device=images.device, dtype=torch.float32)
-        xp[:, 3:3 + H, 3:3 + W, :3] = images.permute(0, 2, 3, 1)
+        xp = torch.empty((B, Ha, Wa, 4), device=images.device, dtype=torch.float32)
+        ops.check(ops.lib().cdetr_stem_pack(ops.ptr(images.contiguous()), ops.ptr(xp), B, H, W, Ha, Wa, 3, 3, ops.stream_ptr()), "cdetr_stem_pack")
         s, b = self.bn1.affine()
         wr = self.stem_weight_rows()
         y = torch.empty((B, Ho, Wo, 64), device=images.device, dtype=torch.float32)
@@ -294,36 +294,23 @@ class BackboneAgg(nn.Module):
                 p.requires_grad_(False)                                   # :93-95
         self.strides = [16 if dilation else 32]
         self.num_channels = [2048]
-        self.lazy_concat = False       # set by AnchorDETR: return (features, exemplar feature) instead of their concatenation
         # "per_image" (default): image b is conditioned on rects[b], scaled by ITS un-padded extent -- what a batched trainer
         # needs.  "reference": A2/models/backbone.py:122 verbatim -- rects[0] for the whole batch, scaled by the padded map
         # (the reference only ever runs batch 1, where the two coincide; the golden vector `b2_pad` pins this mode).
         self.exemplar_mode = "per_image"
 
+    def features(self, images, mask):
+        """images [B,3,H,W], mask bool [B,H,W] -> (layer4 features NHWC [B,h,w,2048], ops.MaskInfo of the down-sampled mask)."""
+        x = self.body.forward_nhwc(images)
+        return x, ops.mask_prep(mask, x.shape[1], x.shape[2])
+
     def extract_feature(self, images, mask, rects):
         """images [B,3,H,W], mask bool [B,H,W], rects [B,K,4] normalised xyxy (device; rows with x2 < 0 = absent exemplar) ->
-        (features NHWC [B,h,w,4096], mask [B,h,w])."""
-        x = self.body.forward_nhwc(images)
-        B, h, w, Cc = x.shape
-        m = nn.functional.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]   # nearest (:143)
-        if self.exemplar_mode == "reference":
-            r = rects[0].to(torch.float32)                                # only image 0's exemplars (:122)
-            xc = ((r[:, 0] * w + r[:, 2] * w) / 2).to(torch.int64)        # int() truncation (:126-127)
-            yc = ((r[:, 1] * h + r[:, 3] * h) / 2).to(torch.int64)
-            pf = x[:, yc, xc, :].mean(1)                                  # [B, 2048]
-        else:
-            r = rects.to(torch.float32)                                   # [B, K, 4]
-            hv = (~m[:, :, 0]).sum(1).to(torch.float32)[:, None]          # un-padded rows / columns of each image, in cells
-            wv = (~m[:, 0, :]).sum(1).to(torch.float32)[:, None]
-            ok = r[..., 2] >= 0
-            xc = ((r[..., 0] * wv + r[..., 2] * wv) / 2).to(torch.int64).clamp(0, w - 1)
-            yc = ((r[..., 1] * hv + r[..., 3] * hv) / 2).to(torch.int64).clamp(0, h - 1)
-            g = x[torch.arange(B, device=x.device)[:, None], yc, xc, :]   # [B, K, 2048]
-            pf = (g * ok[..., None]).sum(1) / ok.sum(1).clamp(min=1)[:, None]
-        if self.lazy_concat:
-            return (x, pf), m          # the consumer folds the product into its projection (ops.AggrProjFn): no [B,h,w,4096] tensor
-        feat = torch.cat([x, x * pf[:, None, None, :]], dim=-1)
-        return feat, m
+        (features NHWC [B,h,w,4096] = cat([x, x * exemplar feature]), mask [B,h,w])   (A2/models/backbone.py:116-145).
+        The model itself never builds this tensor: AnchorDETR folds the product into its projection (ops.AggrProjFn)."""
+        x, mi = self.features(images, mask)
+        pf = ops.ExemplarFeatureFn.apply(x, rects, mi.extent, self.exemplar_mode == "per_image")
+        return torch.cat([x, x * pf[:, None, None, :]], dim=-1), mi.m
 
 
 def build_backbone(args):

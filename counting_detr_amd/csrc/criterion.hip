@@ -190,16 +190,24 @@ __global__ __launch_bounds__(256) void criterion_fwd_kernel(const cdetr_criterio
         d.losses[3] = red[R_L1] * inv_nb;
         d.losses[4] = red[R_GIOU] * inv_nb;
         d.losses[5] = K > 0 ? (mw * red[R_IW] + mh * red[R_IH] + red[R_LOGS]) * inv_nb : 0.f;
+        if (d.loss_weights) {                          // the weighted total (A2/engine.py:37): one more element, no extra launches
+            float t = 0.f;
+            for (int k = 0; k < 6; ++k) t += d.loss_weights[k] != 0.f ? d.loss_weights[k] * d.losses[k] : 0.f;
+            d.losses[6] = t;
+        }
     }
 }
 
 // d_logits = g[0] * G_ce ; d_boxes = g[3] * G_l1 + g[4] * G_giou + g[5] * G_varbox ; d_vars = g[5] * G_vars
-__global__ __launch_bounds__(256) void criterion_bwd_kernel(const float* __restrict__ g, const float* __restrict__ g_logits,
+__global__ __launch_bounds__(256) void criterion_bwd_kernel(const float* __restrict__ g6, const float* __restrict__ gt,
+                                                            const float* __restrict__ lw, const float* __restrict__ g_logits,
                                                             const float* __restrict__ g_l1, const float* __restrict__ g_giou,
                                                             const float* __restrict__ g_vb, const float* __restrict__ g_vars,
                                                             float* __restrict__ d_logits, float* __restrict__ d_boxes,
                                                             float* __restrict__ d_vars, const int BQ, const int C) {
-    const float gce = g[0], gl1 = g[3], ggi = g[4], gva = g[5];
+    const float t = (gt && lw) ? gt[0] : 0.f;
+    auto eff = [&](int k) { return (g6 ? g6[k] : 0.f) + ((gt && lw) ? t * lw[k] : 0.f); };
+    const float gce = eff(0), gl1 = eff(3), ggi = eff(4), gva = eff(5);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < BQ * C; i += gridDim.x * 256) d_logits[i] = gce * g_logits[i];
     for (int i = blockIdx.x * 256 + threadIdx.x; i < BQ * 4; i += gridDim.x * 256)
         d_boxes[i] = gl1 * g_l1[i] + ggi * g_giou[i] + gva * g_vb[i];
@@ -227,14 +235,14 @@ extern "C" int cdetr_criterion_fwd(const cdetr_criterion_desc* dp, void* stream)
     return cdetr_launch_status("cdetr_criterion_fwd");
 }
 
-extern "C" int cdetr_criterion_bwd(const float* g6, const float* g_logits, const float* g_l1, const float* g_giou, const float* g_var_box,
-                                   const float* g_vars, float* d_logits, float* d_boxes, float* d_vars, int32_t BQ, int32_t C,
-                                   void* stream) {
-    CDETR_CHECK_ARG(g6 && g_logits && g_l1 && g_giou && g_var_box && g_vars && d_logits && d_boxes && d_vars && BQ > 0 && C > 0,
+extern "C" int cdetr_criterion_bwd(const float* g6, const float* g_total, const float* loss_weights, const float* g_logits, const float* g_l1,
+                                   const float* g_giou, const float* g_var_box, const float* g_vars, float* d_logits, float* d_boxes,
+                                   float* d_vars, int32_t BQ, int32_t C, void* stream) {
+    CDETR_CHECK_ARG((g6 || (g_total && loss_weights)) && g_logits && g_l1 && g_giou && g_var_box && g_vars && d_logits && d_boxes && d_vars && BQ > 0 && C > 0,
                     "cdetr_criterion_bwd: bad args");
     int blocks = (BQ * 4 + 255) / 256;
     if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(criterion_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g6, g_logits, g_l1,
-                       g_giou, g_var_box, g_vars, d_logits, d_boxes, d_vars, BQ, C);
+    hipLaunchKernelGGL(criterion_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), g6, g_total, loss_weights,
+                       g_logits, g_l1, g_giou, g_var_box, g_vars, d_logits, d_boxes, d_vars, BQ, C);
     return cdetr_launch_status("cdetr_criterion_bwd");
 }

@@ -98,6 +98,8 @@ __global__ __launch_bounds__(NT) void lsap_kernel(const float* __restrict__ cost
     const int tid = threadIdx.x;
     int64_t* oi = idx_i + (long)b * Mmax;
     int64_t* oj = idx_j + (long)b * Mmax;
+    for (int i = tid; i < Mmax; i += NT) { oi[i] = 0; oj[i] = 0; }     // rows are valid (in range) on every exit path; the caller does not pre-fill
+    __syncthreads();
     if (nr == 0) { if (tid == 0) status[b] = 0; return; }
 
     // LDS carve (nc_cap >= nc >= nr): v, spc, u f64 | path, row4col, remaining, col4row i32 | SC, SR u8
@@ -304,6 +306,7 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
     const int lane = threadIdx.x;
     int64_t* oi = idx_i + (long)b * Mmax;
     int64_t* oj = idx_j + (long)b * Mmax;
+    for (int i = lane; i < Mmax; i += 64) { oi[i] = 0; oj[i] = 0; }    // rows are valid (in range) on every exit path; the caller does not pre-fill
     if (nr == 0) { if (lane == 0) status[b] = 0; return; }
 
     // LDS carve: u[nr] f64 | col4row[nr] | row4col[nc] | remaining[nc] | path[nc] | cost[nr*nc] f32 (optional)

@@ -121,13 +121,12 @@ class Trainer:
             self.seg_bounds[i] = max(self.seg_bounds[i], self.seg_bounds[i - 1])
         # device-resident optimizer scalars (graph-replay safe): [step count, StepLR factor, last grad norm, spare]
         self.opt_state = torch.tensor([0.0, 1.0, 0.0, 0.0], device=self.device)
+        self._one = torch.ones((), device=self.device)
         self.sumsq = torch.zeros(1, device=self.device)
         self.sumsq_ws = torch.zeros(2048, device=self.device)       # CDETR_SUMSQ_WS_FLOATS: per-block partial sums
         self.epoch = 0
         self._graph = self._graph_b = self._static = self._static_out = None
         self._seg_graphs = None
-        order = ("loss_ce", "class_error", "cardinality_error", "loss_bbox", "loss_giou", "loss_variance")
-        self._w6 = torch.tensor([float(criterion.weight_dict.get(k, 0.0)) for k in order], device=self.device)
         self.mirror = self._build_mirror(named)
         self.exchange = FlatGradExchange(self.flat_g, self.seg_bounds)
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
@@ -334,18 +333,16 @@ class Trainer:
             outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
             loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
             wd = self.criterion.weight_dict
-            vec = getattr(self.criterion, "last_vec", None)
-            if vec is not None:          # fused criterion: one weighted reduction of its loss vector
-                losses = (vec * self._w6).sum()                                       # A2/engine.py:37
-            else:
-                losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)
+            losses = getattr(self.criterion, "last_total", None)       # fused criterion: the weighted total came out of the same launch
+            if losses is None:
+                losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)      # A2/engine.py:37
             with ops.wgrad_queue():      # small parameter gradients outside the fused layer nodes (heads, positional MLPs): grouped
                 if defer_trunk:
                     with _bb.defer_trunk_backward() as d:
-                        losses.backward()
+                        losses.backward(self._one)      # explicit root gradient: autograd would launch a fill for its ones_like
                     self._trunk_pending = d.pending[0] if d.pending else None
                 else:
-                    losses.backward()
+                    losses.backward(self._one)
         finally:
             if not defer_trunk:
                 ops.MIRROR = None

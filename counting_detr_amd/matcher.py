@@ -16,13 +16,14 @@ class OriginalHungarianMatcher(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
     @torch.no_grad()
-    def match_device(self, outputs, targets, plan=None):
-        """-> (idx_i [B,Mmax], idx_j [B,Mmax] int64 device, status [B] int32 device, plan)."""
+    def match_device(self, outputs, targets, plan=None, tgt_boxes=None):
+        """-> (idx_i [B,Mmax], idx_j [B,Mmax] int64 device, status [B] int32 device, plan).  `tgt_boxes`: the targets' boxes already
+        concatenated in plan order (the criterion needs the same tensor: one concatenation per step instead of two)."""
         logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
         B, Q = logits.shape[:2]
         if plan is None:
             plan = ops.MatchPlan([len(t["boxes"]) for t in targets], Q, logits.device)
-        tgt = torch.cat([t["boxes"] for t in targets]).to(torch.float32) if plan.tgt_off is not None else None
+        tgt = tgt_boxes if tgt_boxes is not None else torch.cat([t["boxes"] for t in targets]).to(torch.float32)
         cost = ops.match_cost(logits.detach().float(), boxes.detach().float(), tgt, plan, float(self.cost_class),
                               float(self.cost_bbox), float(self.cost_giou))
         idx_i, idx_j, status = ops.lsap(cost, plan)

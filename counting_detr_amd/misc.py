@@ -22,11 +22,20 @@ class NestedTensor(object):
         return str(self.tensors)
 
 
+_NO_PADDING = {}
+
+
 def nested_tensor_from_tensor_list(tensor_list):
     """Zero-pad a list of [3,h,w] images (or the rows of a [B,3,H,W] tensor) to a common size + bool padding mask."""
     if isinstance(tensor_list, torch.Tensor):
         b, c, h, w = tensor_list.shape
-        return NestedTensor(tensor_list, torch.zeros((b, h, w), dtype=torch.bool, device=tensor_list.device))
+        key = (b, h, w, str(tensor_list.device))
+        m = _NO_PADDING.get(key)           # a batch given as ONE tensor has no padding: the all-false mask is built once per shape
+        if m is None:
+            if len(_NO_PADDING) > 16:
+                _NO_PADDING.clear()
+            m = _NO_PADDING[key] = torch.zeros((b, h, w), dtype=torch.bool, device=tensor_list.device)
+        return NestedTensor(tensor_list, m)
     if tensor_list[0].ndim != 3:
         raise ValueError("not supported")
     hh = max(img.shape[1] for img in tensor_list)

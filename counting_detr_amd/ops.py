@@ -391,47 +391,134 @@ def linear(x, weight, bias=None, relu=False, resid=None, out_scale=1.0, rows=Non
     return LinearFn.apply(x, weight, bias, lo, hi, relu, resid, out_scale)
 
 
-class AggrProjFn(torch.autograd.Function):
-    """y[b] = [x[b], x[b] * pf[b]] W^T + bias  (the exemplar aggregation + 1x1 projection of A2/models/backbone.py:146-150 and
-    anchor_detr.py:120) WITHOUT materialising the concatenated [.., 2C] feature map: the channel-wise product folds into a per-image
-    effective weight  W_eff[b] = W[:, :C] + W[:, C:] * pf[b]  (2 MB), so the projection is one batched GEMM with K = C instead of 2C
-    (half the FLOPs, no 82 MB concat, no x * pf pass) and its backward one batched data gradient + one batched weight gradient of
-    the same half size; dW[:, :C] = sum_b dW_eff[b], dW[:, C:] = sum_b dW_eff[b] * pf[b], dpf[b] = sum_o dW_eff[b] * W[:, C:]."""
+class MaskInfo:
+    """Everything the step derives from the padding mask, produced by ONE launch (cdetr_mask_prep): `m` bool [B,h,w] (nearest
+    down-sampling, A2/models/backbone.py:143), `mask_row` [B,w] / `mask_col` [B,h] uint8 (first row / column: the RCDA key masks),
+    `pos_row` [B,w] / `pos_col` [B,h] (mask2pos, A2/models/transformer.py:497-503), `extent` [B,2] = un-padded (rows, columns)."""
+    __slots__ = ("m", "mask_row", "mask_col", "pos_row", "pos_col", "extent")
+
+
+def mask_prep(mask, h, w):
+    B, H, W = mask.shape
+    mask = mask.contiguous()
+    dev = mask.device
+    u8 = torch.empty(B * h * w + B * w + B * h, device=dev, dtype=torch.uint8)
+    f = torch.empty(B * (w + h + 2), device=dev, dtype=torch.float32)
+    mi = MaskInfo()
+    m8 = u8[:B * h * w].view(B, h, w)
+    mi.mask_row = u8[B * h * w:B * h * w + B * w].view(B, w)
+    mi.mask_col = u8[B * h * w + B * w:].view(B, h)
+    mi.pos_row, mi.pos_col, mi.extent = f[:B * w].view(B, w), f[B * w:B * (w + h)].view(B, h), f[B * (w + h):].view(B, 2)
+    check(lib().cdetr_mask_prep(mask.data_ptr(), B, H, W, h, w, ptr(m8), ptr(mi.mask_row), ptr(mi.mask_col), ptr(mi.pos_row),
+                                ptr(mi.pos_col), ptr(mi.extent), stream_ptr()), "cdetr_mask_prep")
+    mi.m = m8.view(torch.bool)
+    return mi
+
+
+def exemplar_fwd_raw(x, rects, extent, per_image):
+    B, h, w, Cc = x.shape
+    K = rects.shape[1]
+    idx = torch.empty((B, K), device=x.device, dtype=torch.int32)
+    inv_cnt = torch.empty(B, device=x.device, dtype=torch.float32)
+    pf = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    check(lib().cdetr_exemplar_fwd(ptr(x), ptr(rects), ptr(extent), int(per_image), B, h, w, Cc, K, ptr(idx), ptr(inv_cnt), ptr(pf),
+                                   stream_ptr()), "cdetr_exemplar_fwd")
+    return pf, idx, inv_cnt
+
+
+class ExemplarFeatureFn(torch.autograd.Function):
+    """pf[b] = mean_k x[b, cell(b, k)]: the exemplar feature of A2/models/backbone.py:116-131 (`per_image`: image b is conditioned on
+    rects[b] scaled by its un-padded extent; else the reference's rects[0]-for-the-whole-batch rule).  x NHWC [B,h,w,C] -> [B,C]."""
 
     @staticmethod
-    def forward(ctx, x, pf, wparam, bparam):
+    def forward(ctx, x, rects, extent, per_image):
+        x = x.contiguous()
+        pf, idx, inv_cnt = exemplar_fwd_raw(x, rects.contiguous().to(torch.float32), extent, per_image)
+        ctx.save_for_backward(idx, inv_cnt)
+        ctx.shape = x.shape
+        return pf
+
+    @staticmethod
+    def backward(ctx, dpf):
+        idx, inv_cnt = ctx.saved_tensors
+        B, h, w, Cc = ctx.shape
+        dx = torch.zeros(ctx.shape, device=dpf.device, dtype=torch.float32)
+        check(lib().cdetr_exemplar_bwd(ptr(dpf.contiguous()), ptr(idx), ptr(inv_cnt), ptr(dx), B, h * w, Cc, idx.shape[1], stream_ptr()),
+              "cdetr_exemplar_bwd")
+        return dx, None, None, None
+
+
+class AggrProjFn(torch.autograd.Function):
+    """y[b] = [x[b], x[b] * pf[b]] W^T + bias with pf[b] = the exemplar feature of image b -- exemplar aggregation + 1x1 projection
+    (A2/models/backbone.py:116-136, anchor_detr.py:119) WITHOUT the concatenated [.., 2C] feature map: the channel-wise product
+    folds into a per-image effective weight  W_eff[b] = W[:, :C] + W[:, C:] * pf[b]  (2 MB), so the projection is one batched GEMM
+    with K = C instead of 2C (half the FLOPs, no 82 MB concat, no x * pf pass).  Five launches forward (exemplar gather, effective
+    weight + its transpose, GEMM), six backward (data gradient, zero-fill, weight gradient, weight / exemplar-feature gradients,
+    exemplar scatter into dx): dW[:, :C] = sum_b dW_eff[b], dW[:, C:] = sum_b dW_eff[b] * pf[b], dpf[b] = sum_o dW_eff[b] * W[:, C:],
+    dx[b, cell] += dpf[b] / K."""
+
+    @staticmethod
+    def forward(ctx, x, rects, extent, per_image, wparam, bparam):
         B, h, w, Cc = x.shape
         W2d = wparam.detach().reshape(wparam.shape[0], -1)                 # [d, 2C]
+        assert W2d.is_contiguous() and W2d.shape[1] == 2 * Cc
         d = W2d.shape[0]
         x = x.contiguous()
-        Weff = (W2d[:, :Cc].unsqueeze(0) + W2d[:, Cc:].unsqueeze(0) * pf.unsqueeze(1)).contiguous()      # [B, d, C]
+        pf, idx, inv_cnt = exemplar_fwd_raw(x, rects.contiguous().to(torch.float32), extent, per_image)
+        Weff = torch.empty((B, d, Cc), device=x.device, dtype=torch.float32)
+        WeffT = torch.empty((B, Cc, d), device=x.device, dtype=torch.float32)
+        check(lib().cdetr_aggr_weight_fwd(ptr(W2d), ptr(pf), ptr(Weff), ptr(WeffT), B, d, Cc, stream_ptr()), "cdetr_aggr_weight_fwd")
         y = torch.empty((B, h, w, d), device=x.device, dtype=torch.float32)
         # the bias pointer is shared by the batch items
         gemm_raw(x, Cc, Weff, Cc, y, d, h * w, d, Cc, bias=bparam.detach(), batch=B, sA=h * w * Cc, sB=d * Cc, sC=h * w * d)
-        ctx.save_for_backward(x, pf, Weff)
-        ctx.wparam, ctx.bparam = wparam, bparam
+        ctx.save_for_backward(x, pf, WeffT, idx, inv_cnt)
+        ctx.wparam, ctx.bparam, ctx.d = wparam, bparam, d
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, pf, Weff = ctx.saved_tensors
-        wparam, bparam = ctx.wparam, ctx.bparam
+        x, pf, WeffT, idx, inv_cnt = ctx.saved_tensors
+        wparam, bparam, d = ctx.wparam, ctx.bparam, ctx.d
         B, h, w, Cc = x.shape
-        d = Weff.shape[1]
         dy = dy.contiguous()
-        WeffT = Weff.transpose(1, 2).contiguous()                          # [B, C, d]: k-contiguous operand of the data gradient
         dx = torch.empty_like(x)
         gemm_raw(dy, d, WeffT, d, dx, Cc, h * w, Cc, d, batch=B, sA=h * w * d, sB=Cc * d, sC=h * w * Cc, precision=bwd_precision())
-        dWeff = torch.zeros((B, d, Cc), device=x.device, dtype=torch.float32)
+        z = torch.zeros(B * d * Cc + B * Cc, device=x.device, dtype=torch.float32)      # dW_eff and dpf: one fill
+        dWeff, dpf = z[:B * d * Cc].view(B, d, Cc), z[B * d * Cc:].view(B, Cc)
         gb = grad_buffer(bparam) if bparam.requires_grad else None
         wgrad_raw(dy, d, x, Cc, dWeff, Cc, h * w, d, Cc, batch=B, sY=h * w * d, sX=h * w * Cc, sW=d * Cc, dbias=gb)
-        W2 = wparam.detach().reshape(d, -1)[:, Cc:]
-        if wparam.requires_grad:
-            gw = grad_buffer(wparam).reshape(d, -1)
-            gw[:, :Cc] += dWeff.sum(0)
-            gw[:, Cc:] += (dWeff * pf.unsqueeze(1)).sum(0)
-        dpf = (dWeff * W2.unsqueeze(0)).sum(1)                             # [B, C]
-        return dx, dpf, None, None
+        W2d = wparam.detach().reshape(d, -1)
+        gw = grad_buffer(wparam).reshape(d, -1) if wparam.requires_grad else None
+        check(lib().cdetr_aggr_weight_bwd(ptr(dWeff), ptr(pf), ptr(W2d), ptr(gw), ptr(dpf), B, d, Cc, stream_ptr()), "cdetr_aggr_weight_bwd")
+        check(lib().cdetr_exemplar_bwd(ptr(dpf), ptr(idx), ptr(inv_cnt), ptr(dx), B, h * w, Cc, idx.shape[1], stream_ptr()), "cdetr_exemplar_bwd")
+        return dx, None, None, None, None, None
+
+
+class BoxHeadFn(torch.autograd.Function):
+    """boxes = sigmoid(tmp + [inverse_sigmoid(ref), 0, 0]) -- the tail of the box head (A2/models/transformer.py:193-203,
+    A2/util/misc.py:475-479) as one launch forward and one backward instead of ~12 + ~25 tensor launches (clamp x3, rsub, div, log,
+    add, cat, sigmoid and their autograd mirrors).  tmp [..., 4] with leading dims (L,) B, Q; ref [B, Q, 2]."""
+
+    @staticmethod
+    def forward(ctx, tmp, ref):
+        tmp, ref = tmp.contiguous(), ref.contiguous()
+        M, R = tmp.numel() // 4, ref.numel() // 2
+        boxes = torch.empty_like(tmp)
+        check(lib().cdetr_box_head_fwd(ptr(tmp), ptr(ref), ptr(boxes), M, R, stream_ptr()), "cdetr_box_head_fwd")
+        ctx.save_for_backward(boxes, ref)
+        return boxes
+
+    @staticmethod
+    def backward(ctx, d_boxes):
+        boxes, ref = ctx.saved_tensors
+        M, R = boxes.numel() // 4, ref.numel() // 2
+        d_boxes = d_boxes.contiguous()
+        d_tmp = torch.empty_like(boxes)
+        d_ref = None
+        if ctx.needs_input_grad[1]:
+            d_ref = torch.empty_like(ref) if M == R else torch.zeros_like(ref)
+        check(lib().cdetr_box_head_bwd(ptr(d_boxes), ptr(boxes), ptr(ref), ptr(d_tmp), ptr(d_ref), M, R, stream_ptr()), "cdetr_box_head_bwd")
+        return d_tmp, d_ref
 
 
 # ----------------------------------------------------------------------------------------------------- conv
@@ -525,14 +612,19 @@ def rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
     return out, a_row, a_col
 
 
-def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh):
-    """-> (dq_row, dq_col, dk_row, dk_col, dv)."""
+def rcda_zero_numel(v, k_row, k_col):
+    return v.numel() + k_row.numel() + k_col.numel()
+
+
+def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh, zbuf=None):
+    """-> (dq_row, dq_col, dk_row, dk_col, dv).  `zbuf`: a ZEROED fp32 buffer of rcda_zero_numel(...) elements for everything the
+    backward accumulates into atomically (dV and both key gradients) -- a stack of layers zero-fills one arena for all its calls."""
     N, L, E = q_row.shape
     H, W = v.shape[1:3]
     Hp, Wp = rcda_pads(H, W)
     d_out = d_out.contiguous()
-    # one fill for everything the backward accumulates into atomically: dV and both key gradients
-    zbuf = torch.zeros(v.numel() + k_row.numel() + k_col.numel(), device=v.device, dtype=torch.float32)
+    if zbuf is None:
+        zbuf = torch.zeros(rcda_zero_numel(v, k_row, k_col), device=v.device, dtype=torch.float32)
     d_v = zbuf[:v.numel()].view(v.shape)
     d = RcdaBwdDesc()
     d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
@@ -799,7 +891,9 @@ class EncoderLayerFn(torch.autograd.Function):
             return EncoderLayerFn._backward(ctx, dX2)
 
     @staticmethod
-    def _backward(ctx, dX2):
+    def _backward(ctx, dX2, accR=None, accC=None, zbuf=None):
+        """accR / accC: d(posemb_row) / d(posemb_col) accumulated by the layers ABOVE (EncoderStackFn): added inside the data-gradient
+        epilogues, the returned d(posemb) then already contain them."""
         (X, Qr, Qc, Kr, Kc, q_row, q_col, k_row, k_col, v, a_row, a_col, o, Y1, mu1, rs1, X1, Hd, Y2, mu2, rs2) = ctx.saved_tensors
         layer = ctx.layer
         N, H, W, Cc, E, nh = ctx.dims
@@ -819,7 +913,7 @@ class EncoderLayerFn(torch.autograd.Function):
         o2d = o.view(R, E)
         _wg(dY1, o2d, att.out_proj.weight, att.out_proj.bias, 0, Cc)
         dO = linear_dgrad(dY1, att.out_proj.weight.detach()).view(N, H * W, E)
-        dq_row, dq_col, dk_row, dk_col, dv = rcda_bwd_raw(dO, q_row, q_col, k_row, k_col, v, a_row, a_col, nh)
+        dq_row, dq_col, dk_row, dk_col, dv = rcda_bwd_raw(dO, q_row, q_col, k_row, k_col, v, a_row, a_col, nh, zbuf)
         dq_row2, dq_col2, dv2 = dq_row.view(R, E), dq_col.view(R, E), dv.view(R, E)
         dk_row2, dk_col2 = dk_row.view(N * W, E), dk_col.view(N * H, E)
         _wg(dq_row2, Qr.view(R, Cc), Wip, bip, 0, E)
@@ -834,13 +928,62 @@ class EncoderLayerFn(torch.autograd.Function):
         with gemm_queue():
             dKr = linear_dgrad(dk_row2, Wi[2 * E:3 * E])                           # [N*W, C]
             dKc = linear_dgrad(dk_col2, Wi[3 * E:4 * E])                           # [N*H, C]
+            # the same two (tiny) products once more with the accumulated d(posemb) of the layers above in the epilogue: they ride in
+            # the same grouped launch, and the accumulation costs no launch of its own
+            dKrA = linear_dgrad(dk_row2, Wi[2 * E:3 * E], resid=accR.reshape(N * W, Cc)) if accR is not None else dKr
+            dKcA = linear_dgrad(dk_col2, Wi[3 * E:4 * E], resid=accC.reshape(N * H, Cc)) if accC is not None else dKc
         dX = bcast_add2(t.view(N, H, W, Cc), dKr, dKc, 1.0 / H, 1.0 / W)
         # ---- d(posemb): sum over the broadcast axis BEFORE projecting back (linearity) + the key-mean terms
         sr, sc = hw_reduce(dq_row.view(N, H, W, E), dq_col.view(N, H, W, E), None, None, 1.0, 1.0)
         with gemm_queue():
-            dProw = linear_dgrad(sr.view(N * W, E), Wi[0:E], resid=dKr).view(N, W, Cc)
-            dPcol = linear_dgrad(sc.view(N * H, E), Wi[E:2 * E], resid=dKc).view(N, H, Cc)
+            dProw = linear_dgrad(sr.view(N * W, E), Wi[0:E], resid=dKrA).view(N, W, Cc)
+            dPcol = linear_dgrad(sc.view(N * H, E), Wi[E:2 * E], resid=dKcA).view(N, H, Cc)
         return dX, dProw, dPcol, None, None, None, None
+
+
+class EncoderStackFn(torch.autograd.Function):
+    """ALL encoder layers (A2/models/transformer.py:162-163, 242-279) as ONE autograd node: the per-layer forward / backward of
+    EncoderLayerFn, plus what only a whole-stack node can do -- the gradients of the two positional embeddings, which every layer
+    consumes, are accumulated across the layers inside GEMM epilogues (no autograd accumulation launches: the stack used to cost 12
+    tensor adds), and the parameter gradients of all layers leave in a few grouped launches at the end of the stack's backward."""
+
+    @staticmethod
+    def forward(ctx, src, posemb_row, posemb_col, mask_row, mask_col, layers, anchor, taps):
+        x = src
+        ctxs = []
+        for li, layer in enumerate(layers):
+            c = _Ctx()
+            x = EncoderLayerFn.forward(c, x, posemb_row, posemb_col, mask_row, mask_col, layer, None)
+            ctxs.append(c)
+            if taps is not None:
+                taps[f"enc{li}"] = x.detach()
+        ctx.ctxs = ctxs
+        return x
+
+    @staticmethod
+    def backward(ctx, dX):
+        accR = accC = None
+        c0 = ctx.ctxs[0]
+        N, H, W, Cc, E, nh = c0.dims
+        zn = N * H * W * E + N * W * E + N * H * E                  # per layer: dV + both key gradients (rcda_zero_numel)
+        zall = torch.zeros(len(ctx.ctxs) * zn, device=dX.device, dtype=torch.float32)      # ONE fill for the whole stack
+        with wgrad_queue():
+            for li in range(len(ctx.ctxs) - 1, -1, -1):
+                c = ctx.ctxs[li]
+                dX, accR, accC = EncoderLayerFn._backward(c, dX, accR, accC, zall[li * zn:(li + 1) * zn])[:3]
+                c.saved_tensors = None
+        ctx.ctxs = None
+        return dX, accR, accC, None, None, None, None, None
+
+
+class _Ctx:
+    """Stand-in for an autograd ctx when a Function's forward / backward bodies are driven by an enclosing node."""
+
+    def save_for_backward(self, *ts):
+        self.saved_tensors = ts
+
+    def set_materialize_grads(self, flag):
+        pass
 
 
 def add2(T, A, B=None):
@@ -868,12 +1011,19 @@ class DecoderStackFn(torch.autograd.Function):
     autograd never runs an accumulation kernel for them."""
 
     @staticmethod
-    def forward(ctx, tgt, qpos, qx, qy, memory, krm, kcm, mask_row, mask_col, layers, anchor):
+    def forward(ctx, tgt, qpos, qx, qy, memory, krm, kcm, mask_row, mask_col, layers, anchor, posemb_row=None, posemb_col=None):
+        """krm / kcm: the key means mean_H(memory) + posemb_row, mean_W(memory) + posemb_col -- or None with posemb_row / posemb_col
+        given: then they are formed here (one launch) and their backward folds into the memory gradient (one launch) instead of
+        four tensor launches each way."""
         N, L, E = tgt.shape
         _, H, W, _ = memory.shape
         M = N * L
         tgt, qpos, qx, qy = tgt.contiguous(), qpos.contiguous(), qx.contiguous(), qy.contiguous()
-        mem2 = memory.contiguous().view(N * H * W, E)
+        memory = memory.contiguous()
+        mem2 = memory.view(N * H * W, E)
+        ctx.own_means = krm is None
+        if ctx.own_means:
+            krm, kcm = hw_reduce(memory, memory, posemb_row.contiguous(), posemb_col.contiguous(), 1.0 / H, 1.0 / W)
         krm2, kcm2 = krm.contiguous().view(N * W, E), kcm.contiguous().view(N * H, E)
         outs = []
         saved = []
@@ -938,7 +1088,9 @@ class DecoderStackFn(torch.autograd.Function):
         mem2, krm2, kcm2 = ctx.shared
         M = N * L
         dev = mem2.device
-        acc = torch.zeros((3, M, E), device=dev, dtype=torch.float32)          # d(query_pos), d(query_pos_x), d(query_pos_y)
+        zn = N * H * W * E + N * W * E + N * H * E                              # per layer: dV + both key gradients (rcda_zero_numel)
+        zall = torch.zeros(3 * M * E + len(layers) * zn, device=dev, dtype=torch.float32)     # ONE fill for the whole stack's accumulators
+        acc = zall[:3 * M * E].view(3, M, E)                                    # d(query_pos), d(query_pos_x), d(query_pos_y)
         acc_p, acc_x, acc_y = acc[0], acc[1], acc[2]
         dMem = dKrm = dKcm = None
         dx = None                                                               # gradient flowing into the layer output
@@ -966,7 +1118,8 @@ class DecoderStackFn(torch.autograd.Function):
             dY1 = ln_bwd_raw(dT2, Y1, mu1, rs1, layer.norm1.weight.detach(), grad_buffer(layer.norm1.weight), grad_buffer(layer.norm1.bias))
             _wg(dY1, o2.view(M, E), ca.out_proj.weight, ca.out_proj.bias, 0, E)
             dO2 = linear_dgrad(dY1, ca.out_proj.weight.detach()).view(N, L, E)
-            dq_row, dq_col, dk_row, dk_col, dv = rcda_bwd_raw(dO2, q_row, q_col, k_row, k_col, v, a_row, a_col, ca.num_heads)
+            dq_row, dq_col, dk_row, dk_col, dv = rcda_bwd_raw(dO2, q_row, q_col, k_row, k_col, v, a_row, a_col, ca.num_heads,
+                                                              zall[3 * M * E + li * zn:3 * M * E + (li + 1) * zn])
             dq_row2, dq_col2 = dq_row.view(M, E), dq_col.view(M, E)
             dk_row2, dk_col2, dv2 = dk_row.view(N * W, E), dk_col.view(N * H, E), dv.view(N * H * W, E)
             Wcp, bcp = ca.in_proj_weight, ca.in_proj_bias
@@ -994,8 +1147,12 @@ class DecoderStackFn(torch.autograd.Function):
                 ga1 = linear_dgrad(dqk.view(M, 2 * E), Ws[0:2 * E])
                 t = linear_dgrad(dvs.view(M, E), Ws[2 * E:3 * E], resid=dY2)
             dx = grad_merge(t, ga1, None, acc_p, None)                         # d(x) = residual + v-path + q/k-path; d(qpos) += ga1
+        if ctx.own_means:        # memory also fed the two key means: broadcast their gradients back in the same pass
+            dMem = bcast_add2(dMem.view(N, H, W, E), dKrm, dKcm, 1.0 / H, 1.0 / W)
+            return (dx.view(N, L, E), acc_p.view(N, L, E), acc_x.view(N, L, E), acc_y.view(N, L, E), dMem, None, None, None, None, None,
+                    None, dKrm.view(N, W, E), dKcm.view(N, H, E))
         return (dx.view(N, L, E), acc_p.view(N, L, E), acc_x.view(N, L, E), acc_y.view(N, L, E), dMem.view(N, H, W, E),
-                dKrm.view(N, W, E), dKcm.view(N, H, E), None, None, None, None)
+                dKrm.view(N, W, E), dKcm.view(N, H, E), None, None, None, None, None, None)
 
 
 # ----------------------------------------------------------------------------------------------------- matcher
@@ -1036,25 +1193,26 @@ def match_cost(logits, boxes, tgt_boxes, plan, w_class=2.0, w_bbox=5.0, w_giou=2
 
 def lsap(cost, plan):
     dev = cost.device
-    idx_i = torch.zeros((plan.B, plan.Mmax), dtype=torch.int64, device=dev)
-    idx_j = torch.zeros((plan.B, plan.Mmax), dtype=torch.int64, device=dev)
-    status = torch.zeros(plan.B, dtype=torch.int32, device=dev)
+    idx = torch.empty((2, plan.B, plan.Mmax), dtype=torch.int64, device=dev)     # cleared by the kernels themselves
+    idx_i, idx_j = idx[0], idx[1]
+    status = torch.empty(plan.B, dtype=torch.int32, device=dev)
     check(lib().cdetr_lsap(ptr(cost), ptr(plan.cost_off), ptr(plan.tgt_off), plan.B, plan.Q, plan.nc_max, plan.Mmax,
                            ptr(idx_i), ptr(idx_j), ptr(status), stream_ptr()), "cdetr_lsap")
     return idx_i, idx_j, status
 
 
 class CriterionFn(torch.autograd.Function):
-    """SetCriterion's six scalars in one launch (cdetr_criterion_fwd); returns the vector
-    [loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, loss_variance].  The forward kernel already leaves the
-    gradient of every loss w.r.t. logits / boxes / vars, so backward is one scaled sum (cdetr_criterion_bwd)."""
+    """SetCriterion's six scalars in one launch (cdetr_criterion_fwd); returns (vec, total) with
+    vec = [loss_ce, class_error, cardinality_error, loss_bbox, loss_giou, loss_variance] and total = sum_k w6[k] vec[k] (the weighted
+    loss of A2/engine.py:37, formed by the same launch; None without `w6`).  The forward kernel already leaves the gradient of every
+    loss w.r.t. logits / boxes / vars, so backward is one scaled sum (cdetr_criterion_bwd) of whichever of (vec, total) was used."""
 
     @staticmethod
-    def forward(ctx, logits, boxes, pvars, tgt_boxes, tgt_labels, plan, idx_i, idx_j, num_boxes, num_classes, alpha):
+    def forward(ctx, logits, boxes, pvars, tgt_boxes, tgt_labels, plan, idx_i, idx_j, num_boxes, num_classes, alpha, w6=None):
         B, Q, Cc = logits.shape
         logits, boxes, pvars = logits.contiguous(), boxes.contiguous(), pvars.contiguous()
         dev = logits.device
-        losses = torch.empty(6, device=dev, dtype=torch.float32)
+        losses = torch.empty(7, device=dev, dtype=torch.float32)
         g = torch.empty(B * Q * (Cc + 14), device=dev, dtype=torch.float32)
         n = B * Q
         g_logits, g_l1, g_giou, g_vb, g_vars = (g[:n * Cc], g[n * Cc:n * (Cc + 4)], g[n * (Cc + 4):n * (Cc + 8)],
@@ -1066,22 +1224,30 @@ class CriterionFn(torch.autograd.Function):
         d.tgt_labels = ptr(tgt_labels) if tgt_labels.numel() else ptr(losses)
         d.tgt_off, d.idx_i, d.idx_j, d.num_boxes, d.losses = ptr(plan.tgt_off), ptr(idx_i), ptr(idx_j), ptr(num_boxes), ptr(losses)
         d.g_logits, d.g_l1, d.g_giou, d.g_var_box, d.g_vars = ptr(g_logits), ptr(g_l1), ptr(g_giou), ptr(g_vb), ptr(g_vars)
+        d.loss_weights = ptr(w6)
         check(lib().cdetr_criterion_fwd(C.byref(d), stream_ptr()), "cdetr_criterion_fwd")
-        ctx.g, ctx.dims = (g_logits, g_l1, g_giou, g_vb, g_vars), (B, Q, Cc)
-        return losses
+        ctx.g, ctx.dims, ctx.w6 = (g_logits, g_l1, g_giou, g_vb, g_vars), (B, Q, Cc), w6
+        ctx.set_materialize_grads(False)
+        vec = losses[:6]
+        if w6 is None:
+            return vec, None
+        return vec, losses[6]
 
     @staticmethod
-    def backward(ctx, g6):
+    def backward(ctx, g6, gt):
         B, Q, Cc = ctx.dims
         g_logits, g_l1, g_giou, g_vb, g_vars = ctx.g
-        g6 = g6.contiguous()
-        dev = g6.device
+        dev = g_logits.device
         d_logits = torch.empty((B, Q, Cc), device=dev, dtype=torch.float32)
         d_boxes = torch.empty((B, Q, 4), device=dev, dtype=torch.float32)
         d_vars = torch.empty((B, Q, 2), device=dev, dtype=torch.float32)
-        check(lib().cdetr_criterion_bwd(ptr(g6), ptr(g_logits), ptr(g_l1), ptr(g_giou), ptr(g_vb), ptr(g_vars), ptr(d_logits),
-                                        ptr(d_boxes), ptr(d_vars), B * Q, Cc, stream_ptr()), "cdetr_criterion_bwd")
-        return d_logits, d_boxes, d_vars, None, None, None, None, None, None, None, None
+        g6 = g6.contiguous() if g6 is not None else None
+        gt = gt.reshape(1).contiguous() if gt is not None else None
+        if g6 is None and gt is None:
+            return (None,) * 12
+        check(lib().cdetr_criterion_bwd(ptr(g6), ptr(gt), ptr(ctx.w6), ptr(g_logits), ptr(g_l1), ptr(g_giou), ptr(g_vb), ptr(g_vars),
+                                        ptr(d_logits), ptr(d_boxes), ptr(d_vars), B * Q, Cc, stream_ptr()), "cdetr_criterion_bwd")
+        return (d_logits, d_boxes, d_vars) + (None,) * 9
 
 
 class SineEmbedFn(torch.autograd.Function):
@@ -1125,3 +1291,38 @@ class SineEmbedFn(torch.autograd.Function):
 
 def sine_embed(pos, nfeat, temperature=10000.0, two_d=False):
     return SineEmbedFn.apply(pos, nfeat, float(temperature), two_d)
+
+
+class SineEmbedXYFn(torch.autograd.Function):
+    """(pos2posemb1d(p[..., 0]), pos2posemb1d(p[..., 1])) for points p [..., 2] (A2/models/transformer.py:378-379) read in place with
+    an element stride of 2: no `p[..., 0].contiguous()` copies forward, and the backward writes both coordinates' gradients
+    straight into one [..., 2] tensor (no select_backward zero-fill + copy + add)."""
+
+    @staticmethod
+    def forward(ctx, pos, nfeat, temperature):
+        p = pos.contiguous().to(torch.float32)
+        rows = p.numel() // 2
+        ex = torch.empty(tuple(p.shape[:-1]) + (nfeat,), device=p.device, dtype=torch.float32)
+        ey = torch.empty_like(ex)
+        check(lib().cdetr_sine_embed(p.data_ptr(), 2, ptr(ex), nfeat, rows, nfeat, temperature, stream_ptr()), "cdetr_sine_embed")
+        check(lib().cdetr_sine_embed(p.data_ptr() + 4, 2, ptr(ey), nfeat, rows, nfeat, temperature, stream_ptr()), "cdetr_sine_embed")
+        ctx.save_for_backward(p)
+        ctx.cfg = (rows, nfeat, temperature, pos.shape)
+        return ex, ey
+
+    @staticmethod
+    def backward(ctx, dex, dey):
+        (p,) = ctx.saved_tensors
+        rows, nfeat, temperature, shape = ctx.cfg
+        dp = torch.empty_like(p) if (dex is not None and dey is not None) else torch.zeros_like(p)
+        if dex is not None:
+            check(lib().cdetr_sine_embed_bwd(p.data_ptr(), 2, ptr(dex.contiguous()), nfeat, dp.data_ptr(), 2, rows, nfeat, temperature, 0,
+                                             stream_ptr()), "cdetr_sine_embed_bwd")
+        if dey is not None:
+            check(lib().cdetr_sine_embed_bwd(p.data_ptr() + 4, 2, ptr(dey.contiguous()), nfeat, dp.data_ptr() + 4, 2, rows, nfeat, temperature, 0,
+                                             stream_ptr()), "cdetr_sine_embed_bwd")
+        return dp.view(shape), None, None
+
+
+def sine_embed_xy(points, nfeat, temperature=10000.0):
+    return SineEmbedXYFn.apply(points, nfeat, float(temperature))

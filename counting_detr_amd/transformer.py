@@ -296,39 +296,49 @@ class Transformer(nn.Module):
         raise ValueError(f"unknown {self.spatial_prior} spatial prior")
 
     def forward(self, src, mask, points=None):
-        """src: NHWC [B,h,w,C] (the product path keeps NHWC); mask bool [B,h,w].
-        Returns ((classes [Ld,B,Q,ncls], coords [Ld,B,Q,4], vars [Ld,B,Q,2]), reference_points [B,Q,2])."""
+        """src: NHWC [B,h,w,C] (the product path keeps NHWC); mask: bool [B,h,w] or the ops.MaskInfo the model derived from the
+        image-level padding mask.  Returns (([classes [B,Q,ncls]] , [coords [B,Q,4]], [vars [B,Q,2]]) -- one entry per decoder layer
+        whose heads are evaluated (all with aux losses, else the last) --, reference_points [B,Q,2])."""
         bs, h, w, c = src.shape
+        mi = mask if isinstance(mask, ops.MaskInfo) else ops.mask_prep(mask, h, w)
         reference_points = self.reference_points(bs, src.device, points)
         pattern = self.pattern if self.stage == 2 else self.modify_pattern
         tgt = (pattern.weight.reshape(1, self.num_pattern, 1, c).repeat(bs, 1, self.num_position, 1)
                .reshape(bs, self.num_pattern * self.num_position, c))
-        pos_col, pos_row = mask2pos(mask)
-        # the four 1-d positional MLP applications (key rows / columns here, query x / y below) run level by level, grouped
+        # the four 1-d positional MLP applications (key rows / columns, query x / y) run level by level, grouped
+        emb_x, emb_y = ops.sine_embed_xy(reference_points, c)
         posemb_row, posemb_col, query_pos_x, query_pos_y = pos_mlp_many(
-            self.adapt_pos1d, [pos2posemb1d(pos_row), pos2posemb1d(pos_col),                    # [B,w,C], [B,h,C]
-                               pos2posemb1d(reference_points[..., 0]), pos2posemb1d(reference_points[..., 1])])
-        mask_row = mask[:, 0, :].to(torch.uint8).contiguous()
-        mask_col = mask[:, :, 0].to(torch.uint8).contiguous()
+            self.adapt_pos1d, [pos2posemb1d(mi.pos_row), pos2posemb1d(mi.pos_col), emb_x, emb_y])          # [B,w,C], [B,h,C], 2 x [B,Q,C]
+        mask_row, mask_col = mi.mask_row, mi.mask_col
+        grad = torch.is_grad_enabled()
 
-        x = src
-        for li, layer in enumerate(self.encoder_layers):
-            x = layer(x, mask_row, mask_col, posemb_row, posemb_col)
-            if self.taps is not None:
-                self.taps[f"enc{li}"] = x.detach()
-        memory = x
-        k_row_mean = memory.mean(1) + posemb_row                          # shared by the 6 decoder layers
-        k_col_mean = memory.mean(2) + posemb_col
+        enc = list(self.encoder_layers)
+        if enc and enc[0].fused and src.is_cuda:
+            if grad:
+                memory = ops.EncoderStackFn.apply(src, posemb_row, posemb_col, mask_row, mask_col, enc, enc[0].norm1.weight, self.taps)
+            else:       # inference: the same fused forward bodies, nothing saved
+                memory = src
+                for li, layer in enumerate(enc):
+                    memory = ops.EncoderLayerFn.forward(ops._Ctx(), memory, posemb_row, posemb_col, mask_row, mask_col, layer, None)
+                    if self.taps is not None:
+                        self.taps[f"enc{li}"] = memory
+        else:
+            memory = src
+            for li, layer in enumerate(enc):
+                memory = layer(memory, mask_row, mask_col, posemb_row, posemb_col)
+                if self.taps is not None:
+                    self.taps[f"enc{li}"] = memory.detach()
 
         # query positional terms do not depend on the layer (the reference recomputes them in every layer, :366-379)
         query_pos = self.adapt_pos2d(pos2posemb2d(reference_points))
-        reference = inverse_sigmoid(reference_points)
-
         last = len(self.decoder_layers) - 1
-        if self.fused_decoder and torch.is_grad_enabled():
-            layer_outs = ops.DecoderStackFn.apply(tgt, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean,
-                                                  mask_row, mask_col, list(self.decoder_layers), self.pattern.weight if self.stage == 2 else self.modify_pattern.weight)
+        if self.fused_decoder and src.is_cuda:
+            args = (tgt, query_pos, query_pos_x, query_pos_y, memory, None, None, mask_row, mask_col, list(self.decoder_layers),
+                    pattern.weight, posemb_row, posemb_col)
+            layer_outs = ops.DecoderStackFn.apply(*args) if grad else ops.DecoderStackFn.forward(ops._Ctx(), *args)
         else:
+            k_row_mean = memory.mean(1) + posemb_row                      # shared by the 6 decoder layers
+            k_col_mean = memory.mean(2) + posemb_col
             layer_outs, output = [], tgt
             for layer in self.decoder_layers:
                 output = layer(output, query_pos, query_pos_x, query_pos_y, memory, k_row_mean, k_col_mean, mask_row, mask_col)
@@ -344,13 +354,11 @@ class Transformer(nn.Module):
         else:
             ce = self.cls_embed[last]
             outputs_class = ops.linear(output, ce.weight, None) + ce.bias
-            tmp = self.bbox_embed[last](output)
-        tmp = torch.cat([tmp[..., :2] + reference, tmp[..., 2:]], dim=-1)                         # :200
-        coord = tmp.sigmoid()
+            tmp, var = self.bbox_embed[last](output), None
+        coord = ops.BoxHeadFn.apply(tmp, reference_points)               # sigmoid(tmp + [inverse_sigmoid(ref), 0, 0])   (:193-203)
         if len(lids) == 1:
-            outputs_class, coord = outputs_class.unsqueeze(0), coord.unsqueeze(0)
-            var = var.unsqueeze(0) if self.stage == 2 else None
-        return (outputs_class, coord, var if self.stage == 2 else None), reference_points
+            return ([outputs_class], [coord], [var] if self.stage == 2 else None), reference_points
+        return (list(outputs_class.unbind(0)), list(coord.unbind(0)), list(var.unbind(0)) if self.stage == 2 else None), reference_points
 
 
 def build_transformer(args):

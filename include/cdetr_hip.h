@@ -261,8 +261,8 @@ int cdetr_lsap(const float* cost, const int64_t* cost_off, const int32_t* tgt_of
  * and the gradient of every differentiable loss w.r.t. its inputs:
  *   g_logits [B,Q,C] = d loss_ce / d logits;  g_l1 / g_giou / g_var_box [B,Q,4] = d {loss_bbox, loss_giou, loss_variance} / d boxes;
  *   g_vars [B,Q,2] = d loss_variance / d vars.   num_boxes is a DEVICE scalar (the data-parallel normaliser).
- * cdetr_criterion_bwd: d_logits = g6[0] g_logits; d_boxes = g6[3] g_l1 + g6[4] g_giou + g6[5] g_var_box; d_vars = g6[5] g_vars
- * (g6 = upstream gradient of the six scalars, device).                                                                   */
+ * cdetr_criterion_bwd: d_logits = g[0] g_logits; d_boxes = g[3] g_l1 + g[4] g_giou + g[5] g_var_box; d_vars = g[5] g_vars
+ * (g = upstream gradient of the six scalars, device; see the prototype for how it is formed).                              */
 typedef struct {
     int32_t B, Q, C, num_classes, Mmax;
     float alpha;
@@ -281,13 +281,52 @@ typedef struct {
     float* g_giou;
     float* g_var_box;
     float* g_vars;
+    const float* loss_weights;  /* optional [6] (NULL = absent): losses[6] <- sum_k loss_weights[k] * losses[k], the weighted total of
+                                   A2/engine.py:37 (losses then has 7 elements) */
 } cdetr_criterion_desc;
 int cdetr_criterion_fwd(const cdetr_criterion_desc* d, void* stream);
-int cdetr_criterion_bwd(const float* g6, const float* g_logits, const float* g_l1, const float* g_giou, const float* g_var_box,
-                        const float* g_vars, float* d_logits, float* d_boxes, float* d_vars, int32_t BQ, int32_t C, void* stream);
+/* g6 (upstream gradient of the six scalars) and g_total (upstream gradient of the weighted total, with loss_weights) may each be
+ * NULL = zero: the effective gradient of loss k is g6[k] + g_total[0] * loss_weights[k]. */
+int cdetr_criterion_bwd(const float* g6, const float* g_total, const float* loss_weights, const float* g_logits, const float* g_l1,
+                        const float* g_giou, const float* g_var_box, const float* g_vars, float* d_logits, float* d_boxes, float* d_vars,
+                        int32_t BQ, int32_t C, void* stream);
 
 const char* cdetr_last_error(void);
 int cdetr_abi_version(void);
+
+/* ---- glue (csrc/glue.hip): the small steps between the GEMMs, one launch each -------------------------------------------------
+ * cdetr_mask_prep: padding mask [B][H][W] (bytes, non-zero = padding) -> m [B][h][w] (nearest-neighbour down-sampling,
+ *   A2/models/backbone.py:143), mask_row [B][w] = m[:, 0, :], mask_col [B][h] = m[:, :, 0] (the RCDA key masks,
+ *   row_column_decoupled_attention.py:238-249), pos_row [B][w] / pos_col [B][h] = mask2pos (A2/models/transformer.py:497-503),
+ *   extent [B][2] = un-padded (rows, columns) of each image in feature cells.
+ * cdetr_stem_pack: images NCHW [B][3][H][W] -> xp [B][Ha][Wa][4] NHWC, image at (pad_y, pad_x), zeros elsewhere, 4th channel 0
+ *   (input of the row-packed 7x7 stem, A2/models/resnet.py:178-180).
+ * cdetr_exemplar_fwd: pf[b][c] = mean over the present exemplars k of x[b][cell(b,k)][c] with x [B][h*w][C] NHWC, rects [B][K][4]
+ *   normalised xyxy (x2 < 0: absent), cell = centre of the box in feature cells, truncated (A2/models/backbone.py:122-131);
+ *   per_image: image b uses rects[b] and extent[b]; else rects[0] scaled by (h, w) for every image (the reference's rule).
+ *   Writes idx [B][K] (cell or -1) and inv_cnt [B] for the backward.   cdetr_exemplar_bwd: dx[b][cell][c] += dpf[b][c] * inv_cnt[b].
+ * cdetr_aggr_weight_fwd: Weff[b] = W[:, :C] + W[:, C:] * pf[b] ([B][d][C]) and its transpose WeffT [B][C][d]; W is [d][2C]
+ *   (A2/models/backbone.py:132-136 + anchor_detr.py:119 with the concatenation folded into the weight).
+ * cdetr_aggr_weight_bwd: from dWeff [B][d][C]: gW[:, :C] += sum_b dWeff[b]; gW[:, C:] += sum_b dWeff[b] * pf[b] (gW may be NULL);
+ *   dpf[b][c] += sum_o dWeff[b][o][c] * W[o][C + c]  (dpf must be zeroed by the caller).  B <= 16.
+ * cdetr_box_head_fwd: boxes[m] = sigmoid(tmp[m] + [inverse_sigmoid(ref[m % R]), 0, 0]); tmp / boxes [M][4], ref [R][2], M % R == 0
+ *   (A2/models/transformer.py:193-203, A2/util/misc.py:475-479).  cdetr_box_head_bwd: d_tmp = d_boxes * s (1 - s) and, when d_ref is
+ *   not NULL, d_ref[m % R] (+)= d_tmp[:2] * d inverse_sigmoid (torch's clamp-backward rule; plain store when M == R, else atomic
+ *   accumulation into a caller-zeroed buffer).                                                                                  */
+int cdetr_mask_prep(const uint8_t* mask, int32_t B, int32_t H, int32_t W, int32_t h, int32_t w, uint8_t* m, uint8_t* mask_row,
+                    uint8_t* mask_col, float* pos_row, float* pos_col, float* extent, void* stream);
+int cdetr_stem_pack(const float* images, float* xp, int32_t B, int32_t H, int32_t W, int32_t Ha, int32_t Wa, int32_t pad_y, int32_t pad_x,
+                    void* stream);
+int cdetr_exemplar_fwd(const float* x, const float* rects, const float* extent, int32_t per_image, int32_t B, int32_t h, int32_t w,
+                       int32_t C, int32_t K, int32_t* idx, float* inv_cnt, float* pf, void* stream);
+int cdetr_exemplar_bwd(const float* dpf, const int32_t* idx, const float* inv_cnt, float* dx, int32_t B, int32_t P, int32_t C, int32_t K,
+                       void* stream);
+int cdetr_aggr_weight_fwd(const float* W, const float* pf, float* Weff, float* WeffT, int32_t B, int32_t d, int32_t C, void* stream);
+int cdetr_aggr_weight_bwd(const float* dWeff, const float* pf, const float* W, float* gW, float* dpf, int32_t B, int32_t d, int32_t C,
+                          void* stream);
+int cdetr_box_head_fwd(const float* tmp, const float* ref, float* boxes, int32_t M, int32_t R, void* stream);
+int cdetr_box_head_bwd(const float* d_boxes, const float* boxes, const float* ref, float* d_tmp, float* d_ref, int32_t M, int32_t R,
+                       void* stream);
 
 #ifdef __cplusplus
 }

@@ -303,7 +303,7 @@ def test_criterion_golden(golden, name, fused):
     crit = SetCriterion(1, OriginalHungarianMatcher(2, 5, 2), wd, ["labels", "boxes", "cardinality", "vars"], focal_alpha=0.25)
     crit.fused = fused
     losses = crit(outs, tg)
-    assert (crit.last_vec is not None) == fused
+    assert (crit.last_total is not None) == fused
     for k in ("loss_ce", "class_error", "cardinality_error", "loss_bbox", "loss_giou", "loss_variance"):
         np.testing.assert_allclose(float(losses[k]), float(z[f"{name}/L_{k}"]), rtol=1e-4, atol=1e-6, err_msg=k, equal_nan=True)
     if f"{name}/g_pred_logits" in z.files:
@@ -832,3 +832,112 @@ def test_reduced_term_backward_kernels(Cin, Cout, k, stride, pad, dil, H, W, bwd
     finally:
         ops.MIRROR = None
         ops.PRECISION = old
+
+
+# ----------------------------------------------------------------------------------------------------- glue kernels (csrc/glue.hip)
+@pytest.mark.parametrize("B,H,W,h,w", [(2, 800, 800, 50, 50), (3, 128, 160, 8, 10), (2, 96, 75, 6, 5), (1, 37, 53, 3, 4)])
+def test_mask_prep_matches_the_tensor_composition(B, H, W, h, w):
+    """cdetr_mask_prep == F.interpolate(nearest) + first row / column + mask2pos (A2/models/backbone.py:143, transformer.py:497-503)."""
+    from counting_detr_amd import ops
+    from counting_detr_amd.transformer import mask2pos
+    mask = torch.ones(B, H, W, dtype=torch.bool)
+    gg = g(5)
+    for b in range(B):
+        hh = int(torch.randint(H // 2, H + 1, (1,), generator=gg)) if b else H
+        ww = int(torch.randint(W // 2, W + 1, (1,), generator=gg)) if b else W
+        mask[b, :hh, :ww] = False
+    mi = ops.mask_prep(mask.to(DEV), h, w)
+    m = F.interpolate(mask[None].float(), size=(h, w)).to(torch.bool)[0]
+    assert torch.equal(mi.m.cpu(), m)
+    assert torch.equal(mi.mask_row.cpu().bool(), m[:, 0, :]) and torch.equal(mi.mask_col.cpu().bool(), m[:, :, 0])
+    pc, pr = mask2pos(m)
+    np.testing.assert_allclose(mi.pos_col.cpu().numpy(), pc.numpy(), rtol=1e-6)
+    np.testing.assert_allclose(mi.pos_row.cpu().numpy(), pr.numpy(), rtol=1e-6)
+    ext = torch.stack([(~m[:, :, 0]).sum(1), (~m[:, 0, :]).sum(1)], 1).float()
+    assert torch.equal(mi.extent.cpu(), ext)
+
+
+@pytest.mark.parametrize("per_image", [True, False])
+def test_exemplar_feature_and_concat_free_projection(per_image, precision):
+    """ops.ExemplarFeatureFn / ops.AggrProjFn vs the reference composition: pf = mean of x at the truncated box centres
+    (A2/models/backbone.py:122-131), y = conv1x1(cat([x, x * pf])) (:132-136 + anchor_detr.py:119): values and every gradient."""
+    from counting_detr_amd import ops
+    B, h, w, Cc, d, K = 2, 9, 7, 64, 32, 3
+    x = torch.randn(B, h, w, Cc, generator=g(1))
+    W = torch.randn(d, 2 * Cc, 1, 1, generator=g(2)) / (2 * Cc) ** 0.5
+    bias = torch.randn(d, generator=g(3))
+    rects = torch.tensor([[[.10, .10, .20, .20], [.40, .40, .50, .55], [.70, .20, .999, .999]],
+                          [[.55, .60, .70, .80], [.05, .30, .20, .45], [-1., -1., -1., -1.]]])
+    extent = torch.tensor([[float(h), float(w)], [6.0, 5.0]])
+    gy = torch.randn(B, h, w, d, generator=g(4))
+    # reference composition in fp64
+    x64, W64, b64 = x.double().requires_grad_(True), W.double().requires_grad_(True), bias.double().requires_grad_(True)
+    pfs = []
+    for b in range(B):
+        rb = rects[b if per_image else 0]
+        hv, wv = (extent[b] if per_image else torch.tensor([float(h), float(w)]))
+        rows = []
+        for r in rb:
+            if r[2] < 0:
+                continue
+            xc = int((r[0] * wv + r[2] * wv) / 2)
+            yc = int((r[1] * hv + r[3] * hv) / 2)
+            rows.append(x64[b, min(yc, h - 1), min(xc, w - 1)])
+        pfs.append(torch.stack(rows).mean(0))
+    pf64 = torch.stack(pfs)
+    feat = torch.cat([x64, x64 * pf64[:, None, None, :]], -1)
+    y64 = feat @ W64.reshape(d, -1).t() + b64
+    y64.backward(gy.double())
+    xd = x.to(DEV).requires_grad_(True)
+    Wd, bd = torch.nn.Parameter(W.to(DEV)), torch.nn.Parameter(bias.to(DEV))
+    y = ops.AggrProjFn.apply(xd, rects.to(DEV), extent.to(DEV), per_image, Wd, bd)
+    y.backward(gy.to(DEV))
+    t = tol(precision)
+    close(y, y64, msg="y", **t)
+    close(xd.grad, x64.grad, msg="dx", **t)
+    close(Wd.grad.reshape(d, -1), W64.grad.reshape(d, -1), msg="dW", **t)
+    close(bd.grad, b64.grad, msg="db", **t)
+    xe = x.to(DEV).requires_grad_(True)
+    pf = ops.ExemplarFeatureFn.apply(xe, rects.to(DEV), extent.to(DEV), per_image)
+    close(pf, pf64, rtol=1e-6, msg="pf")
+    gp = torch.randn(B, Cc, generator=g(6))
+    pf.backward(gp.to(DEV))
+    (gx64,) = torch.autograd.grad(pf64, x64, gp.double())
+    close(xe.grad, gx64, rtol=1e-6, msg="d pf / dx")
+
+
+@pytest.mark.parametrize("L", [1, 3])
+def test_box_head_tail_matches_torch(L):
+    """ops.BoxHeadFn == sigmoid(cat([tmp[..., :2] + inverse_sigmoid(ref), tmp[..., 2:]])) incl. torch's clamp-backward conventions at
+    the edges (reference points exactly 0, 1, 1e-5, below / above the clamps)  (A2/models/transformer.py:193-203, util/misc.py:475-479)."""
+    from counting_detr_amd import ops
+    from counting_detr_amd.transformer import inverse_sigmoid
+    B, Q = 2, 37
+    ref = torch.rand(B, Q, 2, generator=g(1))
+    ref[0, :8, 0] = torch.tensor([0.0, 1.0, 1e-5, 1 - 1e-5, 5e-6, 1 - 5e-6, -0.1, 1.2])
+    tmp = torch.randn(*((L,) if L > 1 else ()), B, Q, 4, generator=g(2))
+    gb = torch.randn(tmp.shape, generator=g(3))
+    r0, t0 = ref.clone().requires_grad_(True), tmp.clone().requires_grad_(True)
+    want = torch.cat([t0[..., :2] + inverse_sigmoid(r0), t0[..., 2:]], -1).sigmoid()
+    want.backward(gb)
+    r1, t1 = ref.to(DEV).requires_grad_(True), tmp.to(DEV).requires_grad_(True)
+    got = ops.BoxHeadFn.apply(t1, r1)
+    got.backward(gb.to(DEV))
+    close(got, want, rtol=1e-6, msg="boxes")
+    close(t1.grad, t0.grad, rtol=1e-6, msg="d tmp")
+    close(r1.grad, r0.grad, rtol=1e-5, msg="d ref")
+
+
+def test_sine_embed_xy_matches_the_one_coordinate_form():
+    from counting_detr_amd import ops
+    p = torch.rand(2, 300, 2, generator=g(1))
+    ge = (torch.randn(2, 300, 256, generator=g(2)).to(DEV), torch.randn(2, 300, 256, generator=g(3)).to(DEV))
+    a = p.to(DEV).requires_grad_(True)
+    ex, ey = ops.sine_embed_xy(a, 256)
+    (ex * ge[0]).sum().backward(retain_graph=True)
+    (ey * ge[1]).sum().backward()
+    b = p.to(DEV).requires_grad_(True)
+    fx, fy = ops.sine_embed(b[..., 0], 256), ops.sine_embed(b[..., 1], 256)
+    ((fx * ge[0]).sum() + (fy * ge[1]).sum()).backward()
+    assert torch.equal(ex, fx) and torch.equal(ey, fy)
+    close(a.grad, b.grad, rtol=1e-6, msg="d points")

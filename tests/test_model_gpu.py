@@ -263,7 +263,10 @@ def test_graph_replay_with_new_inputs_equals_eager_step():
         params.append(tr.flat_p.detach().clone())
     for k in res[0]:
         np.testing.assert_allclose(res[1][k], res[0][k], rtol=1e-4, atol=1e-6, err_msg=k)
-    assert float((params[0] - params[1]).abs().max()) <= 2e-6    # one AdamW step moves a weight by <= lr = 1e-4
+    # one AdamW step moves a weight by lr * g / (|g| + eps'): the two runs add their split-K partial sums in different (atomic) orders,
+    # so an element whose gradient is ~0 may land anywhere in +-lr; everything else agrees to rounding
+    diff = (params[0] - params[1]).abs()
+    assert float(diff.max()) <= 2.1e-4 and float((diff > 2e-6).float().mean()) < 2e-3
     ref = _dev_batch(2, 128, 160, (7, 13), seed=0)
     model, crit, args = build()
     tr = Trainer(model, crit, args, device=DEV)
