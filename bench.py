@@ -369,15 +369,18 @@ def main(argv=None):
     for k, v in fam.items():
         if v[1] <= 0:
             continue
+        tps = (tj or {}).get("families_bytes_per_step", {}).get(k)         # PMC bytes of the family per step (profiles/r2_traffic.json)
         kern[k] = {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / reps * 1e3, "launches_per_step": v[2] // reps,
                    "gflop_per_step": v[0] / reps / 1e9, "algorithmic_bytes_per_launch": v[3] / max(v[2], 1),
-                   "traffic_bytes_per_launch": (tj or {}).get("families", {}).get(k)}
+                   "algorithmic_bytes_per_step": v[3] / reps, "traffic_bytes_per_step": tps,
+                   "traffic_bytes_per_launch": (tps / max(v[2] // reps, 1)) if tps else None,     # per host-side launch (a grouped launch = one)
+                   "traffic_over_algorithmic": (tps / (v[3] / reps)) if (tps and v[3]) else None}
     ig = fam.get("igemm", [0.0, 1.0, 1, 0.0])
     achieved = ig[0] / ig[1] / 1e12
     peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
     gflop_img = step_gflop_per_image(H, W, Q)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": (tj or {}).get("families", {}).get("igemm"), "traffic_unit": "bytes/launch",
+                "frac": achieved / peak, "traffic": kern.get("igemm", {}).get("traffic_bytes_per_launch"), "traffic_unit": "bytes/launch",
                 "traffic_source": (tj or {}).get("source"),
                 "algorithmic_bytes_per_launch": ig[3] / max(ig[2], 1),
                 "peak_note": ("fp32 MFMA v_mfma_f32_32x32x2_f32" if a.precision == "fp32" else

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libcdetr_hip.so")
+LIB_PATH = os.environ.get("CDETR_LIB") or os.path.join(_HERE, "lib", "libcdetr_hip.so")      # CDETR_LIB: experiment builds (tools/)
 
 ROWS_DENSE, ROWS_CONV_FWD, ROWS_CONV_DGRAD = 0, 1, 2
 _p = C.c_void_p

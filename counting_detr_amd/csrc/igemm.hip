@@ -583,6 +583,16 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
     auto fetch = [&](float4 (&qa)[A_SLOTS], BVec (&qb)[B_REGS], float4 (&qs)[TRB ? NBLK : 1], unsigned& qm, int tap, int kc) __attribute__((always_inline)) {
         qm = amask;
+#ifdef CDETR_EXP_HALF_LOADS      // EXPERIMENT (wrong results): what would half the operand bytes per k-tile buy the plain-bf16 forms?
+        if constexpr (TERMS == 1 && A_SLOTS >= 2 && B_SLOTS >= 2 && BL == 0) {
+            const int koff = tap * K + kc;
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; i += 2) { qa[i] = ld4(ap[i] + kc); qa[i + 1] = qa[i]; }
+#pragma unroll
+            for (int i = 0; i < B_SLOTS; i += 2) { qb[i] = ld4(bp[i] + koff); qb[i + 1] = qb[i]; }
+            return;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) qa[i] = ld4(ap[i] + kc);
         if constexpr (BL == 0) {
@@ -1209,6 +1219,18 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
     auto fetch = [&](float4 (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], unsigned& qf) __attribute__((always_inline)) {
         const bool pv = p < d.P;
         const float* yp = dY + (long)(pv ? p : d.P - 1) * d.ldy;
+#ifdef CDETR_EXP_HALF_LOADS
+        if constexpr (TERMS == 1 && A_SLOTS >= 2) {
+#pragma unroll
+            for (int s = 0; s < A_SLOTS; s += 2) { qa[s] = ld4(yp + acol[s]); qa[s + 1] = qa[s]; }
+        } else
+#endif
+#ifdef CDETR_EXP_HALF_LOADS
+        if constexpr (TERMS == 1 && A_SLOTS >= 2) {
+#pragma unroll
+            for (int s = 0; s < A_SLOTS; s += 2) { qa[s] = ld4(yp + acol[s]); qa[s + 1] = qa[s]; }
+        } else
+#endif
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) qa[s] = ld4(yp + acol[s]);
         long row = -1;
@@ -1223,6 +1245,18 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
         qf = ((pv && ft < nk) ? 1u : 0u) | (row >= 0 ? 2u : 0u);
         ++ft;
         const float* xp = X + (row >= 0 ? row : 0) * d.ldx;
+#ifdef CDETR_EXP_HALF_LOADS
+        if constexpr (TERMS == 1 && B_SLOTS >= 2) {
+#pragma unroll
+            for (int s = 0; s < B_SLOTS; s += 2) { qb[s] = ld4(xp + bcol[s]); qb[s + 1] = qb[s]; }
+        } else
+#endif
+#ifdef CDETR_EXP_HALF_LOADS
+        if constexpr (TERMS == 1 && B_SLOTS >= 2) {
+#pragma unroll
+            for (int s = 0; s < B_SLOTS; s += 2) { qb[s] = ld4(xp + bcol[s]); qb[s + 1] = qb[s]; }
+        } else
+#endif
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) qb[s] = ld4(xp + bcol[s]);
         p += BKF;
@@ -1349,9 +1383,26 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
     }
 }
 
+// XCD-aware slice placement (ny % 8 == 0, 1-D grid of nx * ny workgroups per batch item): workgroup b runs on XCD b % 8 (private
+// 4 MiB L2 each), and XCD x is given the pixel slices x, x + 8, ... -- every output tile of one slice back to back.  All tiles of a
+// slice read the SAME pixel rows of dY and X (a few hundred KB), so those rows come from HBM / MALL once per slice and are L2 hits for the
+// other tiles; with tiles dealt round-robin over the XCDs every XCD fetched every slice (PMC: 3.7x the algorithmic bytes, the
+// weight gradients ran at HBM speed).  Placement only affects speed.
+__device__ __forceinline__ void wgrad_xcd_slice(int lid, int nx, int& bx, int& by) {
+    const int xcd = lid & 7, j = lid >> 3;
+    bx = j % nx;
+    by = (j / nx) * 8 + xcd;
+}
+
 template <int BI, int BJ, int TERMS = 3>
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
-                                                       const int kt_per_slice, float* __restrict__ dbias) {
+                                                       const int kt_per_slice, float* __restrict__ dbias, const int nx_xcd) {
+    if (nx_xcd > 0) {      // 1-D grid, XCD-aware slices (never a single slice: ny is a multiple of 8)
+        int bx, by;
+        wgrad_xcd_slice(blockIdx.x, nx_xcd, bx, by);
+        wgrad_tr_body<BI, BJ, TERMS>(d, tilesI, tilesJ, kt_per_slice, dbias, bx, by, blockIdx.z, false);
+        return;
+    }
     wgrad_tr_body<BI, BJ, TERMS>(d, tilesI, tilesJ, kt_per_slice, dbias, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
 }
 
@@ -1370,8 +1421,13 @@ __global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const WgradGroupArg
     while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
     const WgradGroupItem& it = g.it[p];
     const int lb = blockIdx.x - g.blk0[p];
-    const int bx = lb % it.nx, r = lb / it.nx;
-    wgrad_tr_body<BI, BJ, TERMS>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, bx, r % it.ny, r / it.ny, false);
+    const int per_z = it.nx * it.ny;
+    const int z = lb / per_z, l = lb - z * per_z;
+    if (z >= it.d.batch) return;                           // padding blocks (every item's count is rounded up to a multiple of 8)
+    int bx, by;
+    if ((it.ny & 7) == 0) wgrad_xcd_slice(l, it.nx, bx, by);   // blk0 and per_z are multiples of 8: l % 8 == blockIdx.x % 8 == the XCD
+    else { bx = l % it.nx; by = l / it.nx; }
+    wgrad_tr_body<BI, BJ, TERMS>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, bx, by, z, false);
 }
 
 // ------------------------------------------------------------------------------------------------ direct small GEMMs
@@ -1942,10 +1998,20 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             if (slices > max_slices) slices = max_slices;
             if (slices < 1) slices = 1;
             if (slices > 65535) slices = 65535;
-            const int per = (int)((nktf + slices - 1) / slices);
-            slices = (nktf + per - 1) / per;
+            // XCD-aware slices (wgrad_tr_kernel; CDETR_WGRAD_XCD=1): a multiple of 8 slices whenever >= 8 slices of >= 4 k-tiles exist (empty
+            // trailing slices exit at once).  MEASURED (profiles/r2_notes.txt): the step's weight gradients 2.04 -> 2.08 ms, i.e. nothing --
+            // the re-reads the counters show (3.7x the algorithmic bytes) are served by the 256 MB Infinity Cache at a rate that does not
+            // bound the kernel; kept off by default, reachable for A/B runs
+            static const int xcd_on = getenv("CDETR_WGRAD_XCD") ? atoi(getenv("CDETR_WGRAD_XCD")) : 0;
+            const int use_tr0 = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
+            const bool xcd = xcd_on && use_tr0 && d.precision >= 1 && max_slices >= 8;
+            if (xcd) slices = std::max<long>(8, (slices + 7) / 8 * 8);
+            int per = (int)((nktf + slices - 1) / slices);
+            if (!xcd) slices = (nktf + per - 1) / per;
             const int bytes = (2 * 32 * (BI + 4) + 2 * 32 * (BJ + 4)) * 4;
+            const int nx_xcd = xcd ? tilesI * tilesJ * d.taps : 0;
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
+            if (xcd) grid = dim3((unsigned)(nx_xcd * slices), 1, d.batch);
             // split-bf16: the transpose-read kernel is 7-20 % faster than the per-fragment split on every shape of this model
             // (profiles/r1_gemm_sweep.txt); CDETR_WGRAD_TR=0 keeps the older kernel reachable for A/B runs
             const int use_tr = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
@@ -1953,13 +2019,13 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
                 const int tbytes = 2 * 2 * (BI + BJ) * 32 * 2;
                 if (d.precision == 2) {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ, 2>, tbytes, "cdetr_wgrad"))) return;
-                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 2>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 2>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias, nx_xcd);
                 } else if (d.precision == 3) {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ, 1>, tbytes, "cdetr_wgrad"))) return;
-                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 1>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 1>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias, nx_xcd);
                 } else {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
-                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias, nx_xcd);
                 }
             } else if (d.precision >= 1) {
                 if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 1>, bytes, "cdetr_wgrad"))) return;
@@ -2086,7 +2152,12 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             it.tilesI = (it.d.Nout + 63) / 64; it.tilesJ = (it.d.Cin + 63) / 64;
             it.per = (int)std::min<long>(per_all, nkt);
             it.nx = it.tilesI * it.tilesJ * it.d.taps; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
-            g.blk0[k + 1] = g.blk0[k] + it.nx * it.ny * it.d.batch;
+            static const int xcd_on = getenv("CDETR_WGRAD_XCD") ? atoi(getenv("CDETR_WGRAD_XCD")) : 0;
+            if (xcd_on && it.ny >= 6 && (nkt + 3) / 4 >= 8) {            // XCD-aware slices: a multiple of 8 (see wgrad_tr_kernel)
+                it.ny = (it.ny + 7) / 8 * 8;
+                it.per = (nkt + it.ny - 1) / it.ny;
+            }
+            g.blk0[k + 1] = g.blk0[k] + (it.nx * it.ny * it.d.batch + 7) / 8 * 8;
         }
         // one precision per grouped launch: the group's members come from one backward pass, the first member decides
         const int gprec = g.it[0].d.precision;

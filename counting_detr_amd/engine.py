@@ -122,6 +122,7 @@ class Trainer:
         # device-resident optimizer scalars (graph-replay safe): [step count, StepLR factor, last grad norm, spare]
         self.opt_state = torch.tensor([0.0, 1.0, 0.0, 0.0], device=self.device)
         self._one = torch.ones((), device=self.device)
+        self._side = None
         self.sumsq = torch.zeros(1, device=self.device)
         self.sumsq_ws = torch.zeros(2048, device=self.device)       # CDETR_SUMSQ_WS_FLOATS: per-block partial sums
         self.epoch = 0
@@ -324,14 +325,28 @@ class Trainer:
         three backbone segments itself (`_trunk_segment`)."""
         from .misc import NestedTensor
         from . import ops
-        self.flat_g.zero_()
-        # weight images (transposes for the data gradients, pre-split operands for both passes): one launch, armed for this step only
+        # weight images, armed for this step only: the forward operands now; the data-gradient operands and the gradient arena's
+        # zero-fill are not needed before the backward starts, so they run on a side stream UNDER the criterion -- the Hungarian solve
+        # is one wavefront per image for ~0.3 ms, the rest of the chip is idle there (in a captured step: a parallel graph branch)
         if self.mirror is not None:
-            self.mirror.refresh()
+            self.mirror.refresh("fwd")
         ops.MIRROR = self.mirror
         try:
             outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
+            main = torch.cuda.current_stream() if self.flat_g.is_cuda else None
+            if main is not None:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self.flat_g.zero_()
+                    if self.mirror is not None:
+                        self.mirror.refresh("bwd")
+            else:
+                self.flat_g.zero_()
             loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
+            if main is not None:
+                main.wait_stream(self._side)
             wd = self.criterion.weight_dict
             losses = getattr(self.criterion, "last_total", None)       # fused criterion: the weighted total came out of the same launch
             if losses is None:

@@ -205,6 +205,7 @@ class WeightMirror:
         items = (MirrorItem * (len(entries) + len(fwd_entries)))()
         self.t_entries, self.f_entries = [], []
         tile0 = 0
+        self.nT = len(entries)
 
         def geom(w):
             R, Cc = w.shape[0], w.shape[1]
@@ -228,6 +229,8 @@ class WeightMirror:
             self._keep.append((w, sc))
             tile0 += ((R + 31) // 32) * ((Cc + 31) // 32) * taps
             off += w.numel()
+        self.tilesT = tile0
+        tile0 = 0            # the forward images are a table (and a launch) of their own: see refresh()
         off = 0
         for j, (w, sc) in enumerate(fwd_entries):
             R, Cc, taps = geom(w)
@@ -240,17 +243,25 @@ class WeightMirror:
             self._keep.append((w, sc))
             tile0 += ((R + 31) // 32) * ((Cc + 31) // 32) * taps
             off += w.numel()
-        self.total_tiles, self.n = tile0, len(entries) + len(fwd_entries)
+        self.tilesF, self.nF = tile0, len(fwd_entries)
         raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
         self.items_dev = torch.from_numpy(raw).to(dev)
+        self.item_bytes = C.sizeof(MirrorItem)
         self.t_entries.sort()
         self.f_entries.sort()
         self._tb = [e[0] for e in self.t_entries]
         self._fb = [e[0] for e in self.f_entries]
         self._memo_t, self._memo_f = {}, {}
 
-    def refresh(self):
-        check(lib().cdetr_weight_mirror(ptr(self.items_dev), self.n, self.total_tiles, stream_ptr()), "cdetr_weight_mirror")
+    def refresh(self, part="all"):
+        """Rewrite the images from the current weights.  part "fwd": the forward operands (needed before the forward pass);
+        "bwd": the transposed data-gradient operands (needed only when the backward starts -- the trainer rewrites them on a side
+        stream under the Hungarian solve); "all": both."""
+        if part in ("all", "fwd") and self.nF:
+            check(lib().cdetr_weight_mirror(self.items_dev.data_ptr() + self.nT * self.item_bytes, self.nF, self.tilesF, stream_ptr()),
+                  "cdetr_weight_mirror")
+        if part in ("all", "bwd") and self.nT:
+            check(lib().cdetr_weight_mirror(self.items_dev.data_ptr(), self.nT, self.tilesT, stream_ptr()), "cdetr_weight_mirror")
 
     def _find(self, table, bases, w, scale):
         p = w.data_ptr()
