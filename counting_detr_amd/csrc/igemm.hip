@@ -478,10 +478,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 // TERMS (split-bf16 staging modes only): bf16 MFMAs per algorithmic product -- 3 = hi*hi + hi*lo + lo*hi ("bf16x3", ~5e-6 relative),
 // 2 = hi*hi + lo*hi (the B operand rounded to bf16, A exact to 2^-17: "bf16x2"), 1 = hi*hi (both rounded: plain bf16).  Fewer terms
 // skip the MFMAs, the LDS reads of the unused lo planes and (TERMS 1) the lo half of the staging split of A.
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2, int TERMS = 3>   // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 (split per fragment), 2 = same, split once at staging; ABL: ablation builds; PD: k-tiles in flight in registers
+// PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 with the split per fragment (the n-contiguous operand form), 2 = split once at staging,
+// 3 = as 2 with B arriving pre-split from HBM.  (Measured dead ends of round 1, no longer built: a 4-deep register ring -- 0-25 % slower
+// at two images per GPU --, a staging-time transpose of the n-contiguous operand, 128-wide tiles on 4 waves, 32x64 / 128x64 tiles.)
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3>
 __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const int tilesM, const int bx, const int bz) {
-    static_assert(PD == 2 || PD == 4, "register ring depth");
-    static_assert(TERMS == 3 || ((PREC == 2 || PREC == 3) && BL == 0 && ABL == 0), "reduced-term products exist for the staging-split k-contiguous forms");
+    constexpr int PD = 2;                    // k-tiles in flight in registers
+    static_assert(TERMS == 3 || ((PREC == 2 || PREC == 3) && BL == 0), "reduced-term products exist for the staging-split k-contiguous forms");
+    static_assert(BL == 0 || PREC <= 1, "the n-contiguous operand has no staging-split form");
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
@@ -493,18 +497,11 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     constexpr int A_SLOTS = BM / RPP, B_SLOTS = (BL == 0) ? BN / RPPB : BKF * BN / (4 * NT);
     constexpr int LDN = BN + 4;
     constexpr int A_TILE = BM * LDK;
-    // PREC == 1: the tile is split into bf16 hi / lo ONCE while it is staged; an LDS row holds [hi k0..BKF-1 | lo k0..BKF-1 | pad]
-    // = the same LDK*4 bytes as the fp32 row, and B is always stored [n][k] (a n-contiguous operand is transposed in
-    // registers: every thread fetches a 4k x NV n block).
+    // PREC >= 2: the tile is split into bf16 hi / lo ONCE while it is staged; an LDS row holds [hi k0..BKF-1 | lo k0..BKF-1 | pad]
+    // = the same LDK*4 bytes as the fp32 row.
     constexpr bool SPL = (PREC == 2 || PREC == 3);     // operands live in LDS as bf16 hi / lo planes
     constexpr bool BRAW = (PREC == 3);                  // B arrives pre-split from HBM (cdetr_gemm_desc.B_split): staged by a plain copy
-    static_assert(!BRAW || BL == 0, "pre-split B is a k-contiguous operand");
-    constexpr bool TRB = (PREC == 2 && BL == 1);
-    constexpr int B_TILE = (BL == 0 || SPL) ? BN * LDK : BKF * LDN;
-    constexpr int EB = BKF * BN / NT;                  // B elements per thread
-    constexpr int NV = (EB >= 16) ? 4 : 2;             // n-width of one transposing block
-    constexpr int NBLK = EB / (4 * NV);
-    static_assert(!TRB || (NBLK >= 1 && NBLK * 4 * NV == EB), "transposing fetch mapping");
+    constexpr int B_TILE = (BL == 0) ? BN * LDK : BKF * LDN;
     static_assert(BM % RPP == 0 && (BL != 0 || BN % RPPB == 0) && (BL == 0 || (BKF * BN) % (4 * NT) == 0), "tile / thread mapping");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -563,55 +560,17 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
     // register sets for the two k-tiles in flight.  Fetches are RAW loads (nothing in fetch() consumes a loaded value, so
     // no s_waitcnt lands between issuing a tile and computing on the previous one); scaling / splitting happens in stash().
-    using BVec = typename std::conditional<TRB && NV == 2, float2, float4>::type;
-    constexpr int B_REGS = TRB ? NBLK * 4 : B_SLOTS;
     float4 ra[PD][A_SLOTS];
     unsigned rm[PD];                           // amask of each register set
-    BVec rb[PD][B_REGS];
-    float4 rs[PD][TRB ? NBLK : 1];             // TRB: per-k-row weight scales of the fetched blocks
-    const float* tb[TRB ? NBLK : 1];           // TRB: this thread's block origin (k-group row, n column) at tap 0, kc 0
-    int tkg[TRB ? NBLK : 1], tng[TRB ? NBLK : 1];
-    if (TRB) {
-#pragma unroll
-        for (int j = 0; j < NBLK; ++j) {
-            const int b = tid + NT * j;
-            tkg[j] = b / (BN / NV);
-            tng[j] = b - tkg[j] * (BN / NV);
-            const int n = min(n0 + tng[j] * NV, d.N - NV);
-            tb[j] = B + (long)(tkg[j] * 4) * taps * d.ldb + n;
-        }
-    }
-    auto fetch = [&](float4 (&qa)[A_SLOTS], BVec (&qb)[B_REGS], float4 (&qs)[TRB ? NBLK : 1], unsigned& qm, int tap, int kc) __attribute__((always_inline)) {
+    float4 rb[PD][B_SLOTS];
+    auto fetch = [&](float4 (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], unsigned& qm, int tap, int kc) __attribute__((always_inline)) {
         qm = amask;
-#ifdef CDETR_EXP_HALF_LOADS      // EXPERIMENT (wrong results): what would half the operand bytes per k-tile buy the plain-bf16 forms?
-        if constexpr (TERMS == 1 && A_SLOTS >= 2 && B_SLOTS >= 2 && BL == 0) {
-            const int koff = tap * K + kc;
-#pragma unroll
-            for (int i = 0; i < A_SLOTS; i += 2) { qa[i] = ld4(ap[i] + kc); qa[i + 1] = qa[i]; }
-#pragma unroll
-            for (int i = 0; i < B_SLOTS; i += 2) { qb[i] = ld4(bp[i] + koff); qb[i + 1] = qb[i]; }
-            return;
-        }
-#endif
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) qa[i] = ld4(ap[i] + kc);
         if constexpr (BL == 0) {
             const int koff = tap * K + kc;
 #pragma unroll
             for (int i = 0; i < B_SLOTS; ++i) qb[i] = ld4(bp[i] + koff);
-        } else if constexpr (TRB) {
-            // 4 consecutive k rows x NV columns per block, raw
-            const long base = ((long)kc * taps + tap) * d.ldb;       // wave-uniform
-            const long rstep = (long)taps * d.ldb;
-#pragma unroll
-            for (int j = 0; j < NBLK; ++j) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    if constexpr (NV == 4) qb[j * 4 + kk] = ld4(tb[j] + base + kk * rstep);
-                    else qb[j * 4 + kk] = *reinterpret_cast<const float2*>(tb[j] + base + kk * rstep);
-                }
-                qs[j] = d.w_scale ? ld4(d.w_scale + kc + tkg[j] * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
-            }
         } else {
 #pragma unroll
             for (int i = 0; i < B_SLOTS; ++i) {
@@ -629,7 +588,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
             }
         }
     };
-    auto stash = [&](const float4 (&qa0)[A_SLOTS], const BVec (&qb)[B_REGS], const float4 (&qs)[TRB ? NBLK : 1], unsigned qm, int buf) __attribute__((always_inline)) {
+    auto stash = [&](const float4 (&qa0)[A_SLOTS], const float4 (&qb)[B_SLOTS], unsigned qm, int buf) __attribute__((always_inline)) {
         float* as = As + buf * A_TILE;
         float* bs = Bs + buf * B_TILE;
         float4 qa[A_SLOTS];
@@ -638,32 +597,18 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
         if constexpr (SPL) {
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
-                if constexpr (ABL == 4) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = qa[i];      // ablation: no split
-                else if constexpr (TERMS == 1) stash_hi4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + KPOS(kq * 4), qa[i].x, qa[i].y, qa[i].z, qa[i].w);
+                if constexpr (TERMS == 1) stash_hi4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + KPOS(kq * 4), qa[i].x, qa[i].y, qa[i].z, qa[i].w);
                 else stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + KPOS(kq * 4), 32, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
             }
-            if constexpr (BL == 0 && (ABL >= 3 || BRAW)) {
+            if constexpr (BRAW) {
 #pragma unroll
                 for (int i = 0; i < B_SLOTS; ++i)
                     if (b_on) *reinterpret_cast<float4*>(bs + (r8b + RPPB * i) * LDK + kq * 4) = qb[i];    // pre-split operand (or ablation): plain copy
-            } else if constexpr (BL == 0) {
+            } else {
 #pragma unroll
                 for (int i = 0; i < B_SLOTS; ++i) {
                     const float s = bscale0[i];
                     if (b_on) stash_split4(reinterpret_cast<__bf16*>(bs + (r8b + RPPB * i) * LDK) + KPOS(kq * 4), 32, qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
-                }
-            } else {
-#pragma unroll
-                for (int j = 0; j < NBLK; ++j) {
-                    __bf16* dst = reinterpret_cast<__bf16*>(bs + (tng[j] * NV) * LDK) + KPOS(tkg[j] * 4);
-                    const BVec &k0 = qb[j * 4], &k1 = qb[j * 4 + 1], &k2 = qb[j * 4 + 2], &k3 = qb[j * 4 + 3];
-                    const float4 sc = qs[j];
-                    stash_split4(dst, 32, k0.x * sc.x, k1.x * sc.y, k2.x * sc.z, k3.x * sc.w);
-                    stash_split4(dst + 2 * LDK, 32, k0.y * sc.x, k1.y * sc.y, k2.y * sc.z, k3.y * sc.w);
-                    if constexpr (NV == 4) {
-                        stash_split4(dst + 4 * LDK, 32, k0.z * sc.x, k1.z * sc.y, k2.z * sc.z, k3.z * sc.w);
-                        stash_split4(dst + 6 * LDK, 32, k0.w * sc.x, k1.w * sc.y, k2.w * sc.z, k3.w * sc.w);
-                    }
                 }
             }
         } else {
@@ -811,34 +756,30 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     auto step = [&](auto sc) __attribute__((always_inline)) {      // tile t (t % PD == S): issue t + PD, compute t, stage t + 1
         constexpr int S = decltype(sc)::value, NX = (S + 1) % PD;
         advance();
-        fetch(ra[S], rb[S], rs[S], rm[S], f_tap, f_kc);
+        fetch(ra[S], rb[S], rm[S], f_tap, f_kc);
         compute(S & 1);
-        stash(ra[NX], rb[NX], rs[NX], rm[NX], NX & 1);
+        stash(ra[NX], rb[NX], rm[NX], NX & 1);
         __syncthreads();
     };
     auto drain_step = [&](auto sc) __attribute__((always_inline)) { // tail: stage tile t (already in registers) and compute it
         constexpr int S = decltype(sc)::value;
-        stash(ra[S], rb[S], rs[S], rm[S], S & 1);
+        stash(ra[S], rb[S], rm[S], S & 1);
         __syncthreads();
         compute(S & 1);
     };
     set_tap(0);
-    fetch(ra[0], rb[0], rs[0], rm[0], 0, 0);
+    fetch(ra[0], rb[0], rm[0], 0, 0);
 #pragma unroll
     for (int j = 1; j < PD; ++j) {
         advance();
-        fetch(ra[j], rb[j], rs[j], rm[j], f_tap, f_kc);
+        fetch(ra[j], rb[j], rm[j], f_tap, f_kc);
     }
-    stash(ra[0], rb[0], rs[0], rm[0], 0);
+    stash(ra[0], rb[0], rm[0], 0);
     __syncthreads();
     int kt = 0;
     for (; kt + PD < nkt; kt += PD) {
         step(std::integral_constant<int, 0>{});
         step(std::integral_constant<int, 1>{});
-        if constexpr (PD == 4) {
-            step(std::integral_constant<int, 2>{});
-            step(std::integral_constant<int, 3>{});
-        }
     }
     // residual / gate operands of this wave's outputs: ONE batch of unconditional loads per fragment (clamped row / column, masked
     // at the store), issued before the last k-tiles are computed so the round trip overlaps them.  (A load inside the per-element
@@ -865,15 +806,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
     const int rem = nkt - kt;                                      // 1 .. PD tiles left: tile kt is staged, the others sit in registers
     compute(0);
-    if (rem > 1) {
-        drain_step(std::integral_constant<int, 1>{});
-        if constexpr (PD == 4) {
-            if (rem > 2) {
-                drain_step(std::integral_constant<int, 2>{});
-                if (rem > 3) drain_step(std::integral_constant<int, 3>{});
-            }
-        }
-    }
+    if (rem > 1) drain_step(std::integral_constant<int, 1>{});
     mfma_drain(acc);
 
 #pragma unroll
@@ -896,9 +829,9 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
 }
 
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int ABL = 0, int PD = 2, int TERMS = 3>
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
-    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, ABL, PD, TERMS>(d, tilesM, blockIdx.x, blockIdx.z);
+    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, TERMS>(d, tilesM, blockIdx.x, blockIdx.z);
 }
 
 // Grouped launch of up to GG_MAX independent GEMMs of one kernel class (same idea as WgradGroupArgs below): the problems'
@@ -914,7 +847,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_group_kernel(const Ge
     while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
     const GemmGroupItem& it = g.it[p];
     const int lb = blockIdx.x - g.blk0[p];             // nx is a multiple of 8: the XCD banding of the body is preserved
-    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, 0, 2>(it.d, it.tilesM, lb % it.nx, lb / it.nx);
+    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC>(it.d, it.tilesM, lb % it.nx, lb / it.nx);
 }
 
 // ------------------------------------------------------------------------------------------------ fast wgrad
@@ -1219,18 +1152,6 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
     auto fetch = [&](float4 (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], unsigned& qf) __attribute__((always_inline)) {
         const bool pv = p < d.P;
         const float* yp = dY + (long)(pv ? p : d.P - 1) * d.ldy;
-#ifdef CDETR_EXP_HALF_LOADS
-        if constexpr (TERMS == 1 && A_SLOTS >= 2) {
-#pragma unroll
-            for (int s = 0; s < A_SLOTS; s += 2) { qa[s] = ld4(yp + acol[s]); qa[s + 1] = qa[s]; }
-        } else
-#endif
-#ifdef CDETR_EXP_HALF_LOADS
-        if constexpr (TERMS == 1 && A_SLOTS >= 2) {
-#pragma unroll
-            for (int s = 0; s < A_SLOTS; s += 2) { qa[s] = ld4(yp + acol[s]); qa[s + 1] = qa[s]; }
-        } else
-#endif
 #pragma unroll
         for (int s = 0; s < A_SLOTS; ++s) qa[s] = ld4(yp + acol[s]);
         long row = -1;
@@ -1245,18 +1166,6 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
         qf = ((pv && ft < nk) ? 1u : 0u) | (row >= 0 ? 2u : 0u);
         ++ft;
         const float* xp = X + (row >= 0 ? row : 0) * d.ldx;
-#ifdef CDETR_EXP_HALF_LOADS
-        if constexpr (TERMS == 1 && B_SLOTS >= 2) {
-#pragma unroll
-            for (int s = 0; s < B_SLOTS; s += 2) { qb[s] = ld4(xp + bcol[s]); qb[s + 1] = qb[s]; }
-        } else
-#endif
-#ifdef CDETR_EXP_HALF_LOADS
-        if constexpr (TERMS == 1 && B_SLOTS >= 2) {
-#pragma unroll
-            for (int s = 0; s < B_SLOTS; s += 2) { qb[s] = ld4(xp + bcol[s]); qb[s + 1] = qb[s]; }
-        } else
-#endif
 #pragma unroll
         for (int s = 0; s < B_SLOTS; ++s) qb[s] = ld4(xp + bcol[s]);
         p += BKF;
@@ -1703,67 +1612,52 @@ int raise_lds(F func, int bytes, const char* what) {
     return CDETR_OK;
 }
 
-template <int WM, int WN, int FM, int FN, int BKF, int PREC, int ABL = 0, int PD = 2>
+template <int WM, int WN, int FM, int FN, int BKF, int PREC>
 int launch_gemm_fast_pd(const cdetr_gemm_desc& d, hipStream_t st) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
     dim3 grid(8 * ((tilesM + 7) / 8) * tilesN, 1, d.batch), block(64 * WM * WN);      // 8 XCD bands (see the kernel)
     int rc;
-    if (d.b_layout == 0) {
+    if constexpr (PREC >= 2) {           // k-contiguous operands, split at staging (3: B pre-split); reduced-term forms by d.precision
         const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
-        if constexpr ((PREC == 2 || PREC == 3) && ABL == 0 && PD == 2 && FM == 1 && FN == 1) {
-            if (d.precision == 2) {      // bf16x2: B rounded to bf16
-                if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 0, 2, 2>, bytes, "cdetr_gemm"))) return rc;
-                hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 0, 2, 2>), grid, block, bytes, st, d, tilesM);
-                return cdetr_launch_status("cdetr_gemm");
-            }
-            if (d.precision == 3) {      // plain bf16
-                if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 0, 2, 1>, bytes, "cdetr_gemm"))) return rc;
-                hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 0, 2, 1>), grid, block, bytes, st, d, tilesM);
-                return cdetr_launch_status("cdetr_gemm");
-            }
+        if (d.precision == 2) {          // bf16x2: B rounded to bf16
+            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 2>, bytes, "cdetr_gemm"))) return rc;
+            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 2>), grid, block, bytes, st, d, tilesM);
+        } else if (d.precision == 3) {   // plain bf16
+            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1>, bytes, "cdetr_gemm"))) return rc;
+            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1>), grid, block, bytes, st, d, tilesM);
+        } else {
+            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC>, bytes, "cdetr_gemm"))) return rc;
+            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC>), grid, block, bytes, st, d, tilesM);
         }
-        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL, PD>, bytes, "cdetr_gemm"))) return rc;
-        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, ABL, PD>), grid, block, bytes, st, d, tilesM);
+    } else if (d.b_layout == 0) {        // fp32 MFMA
+        static_assert(PREC == 0 || PREC == 1, "");
+        const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
+        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC>), grid, block, bytes, st, d, tilesM);
     } else if constexpr ((BKF * BN) % (4 * 64 * WM * WN) != 0) {
         cdetr_set_error("cdetr_gemm: this tile variant has no n-contiguous (b_layout 1) form");
         return CDETR_ERR_UNSUPPORTED;
-    } else {
-        // the staging-split variant of the n-contiguous operand needs >= 8 elements per thread (4k x 2n blocks)
-        constexpr int P0 = (PREC == 3) ? 2 : PREC;          // pre-split B only exists for the k-contiguous layout
-        constexpr int P1 = (P0 == 2 && (BKF * BN) / (64 * WM * WN) < 8) ? 1 : P0;
-        const int bytes = (2 * BM * (BKF + 4) + 2 * (P1 == 2 ? BN * (BKF + 4) : BKF * (BN + 4))) * 4;
-        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL, PD>, bytes, "cdetr_gemm"))) return rc;
-        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, P1, ABL, PD>), grid, block, bytes, st, d, tilesM);
+    } else {                             // n-contiguous operand: fp32 MFMA or the per-fragment split
+        const int bytes = (2 * BM * (BKF + 4) + 2 * BKF * (BN + 4)) * 4;
+        if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC>, bytes, "cdetr_gemm"))) return rc;
+        hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC>), grid, block, bytes, st, d, tilesM);
     }
     return cdetr_launch_status("cdetr_gemm");
 }
 
-template <int WM, int WN, int FM, int FN, int BKF, int PREC, int ABL = 0>
-int launch_gemm_fast_p(const cdetr_gemm_desc& d, hipStream_t st) {
-    // register ring depth (k-tiles in flight): CDETR_GEMM_PD = 2 | 4
-    static const int pd = getenv("CDETR_GEMM_PD") ? atoi(getenv("CDETR_GEMM_PD")) : 2;
-    if constexpr (ABL == 0 && FM == 1 && FN == 1 && BKF == 32) {
-        if (pd == 4) return launch_gemm_fast_pd<WM, WN, FM, FN, BKF, PREC, ABL, 4>(d, st);
-    }
-    return launch_gemm_fast_pd<WM, WN, FM, FN, BKF, PREC, ABL, 2>(d, st);
-}
-
-template <int WM, int WN, int FM, int FN, int BKF, int ABL = 0>
+template <int WM, int WN, int FM, int FN, int BKF>
 int launch_gemm_fast(const cdetr_gemm_desc& d, hipStream_t st) {
-    if (ABL == 0 && d.precision >= 1) {
-        // bf16x3 (precision 1; 2 / 3 = the reduced-term forms, launch_gemm_fast_pd): k-contiguous operands (b_layout 0) are split once while they are staged into LDS; the n-contiguous operand
-        // keeps the per-fragment split (its staging transpose costs more than it saves -- tools/split_sweep.py).
-        // CDETR_GEMM_SPLIT: 0 = per-fragment everywhere, 2 = staging split everywhere.
-        static const int split_mode = getenv("CDETR_GEMM_SPLIT") ? atoi(getenv("CDETR_GEMM_SPLIT")) : 1;
-        static const int presplit = getenv("CDETR_GEMM_PRESPLIT") ? atoi(getenv("CDETR_GEMM_PRESPLIT")) : 1;
-        if (presplit && d.B_split && d.b_layout == 0 && d.batch == 1 && split_mode >= 1)
-            return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 3, 0>(d, st);
-        if (split_mode == 2 || (split_mode == 1 && d.b_layout == 0)) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 2, 0>(d, st);
-        return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 1, 0>(d, st);
+    if (d.precision >= 1) {
+        // bf16x3 (precision 1; 2 / 3 = the reduced-term forms, launch_gemm_fast_pd): k-contiguous operands (b_layout 0) are split once
+        // while they are staged into LDS -- the weight operand arrives pre-split from the step's weight images when there is one
+        // (B_split: a plain copy) --; the n-contiguous operand keeps the per-fragment split (its staging transpose costs more than it
+        // saves, profiles/r1_gemm_sweep.txt).
+        if (d.B_split && d.b_layout == 0 && d.batch == 1) return launch_gemm_fast_pd<WM, WN, FM, FN, BKF, 3>(d, st);
+        if (d.b_layout == 0) return launch_gemm_fast_pd<WM, WN, FM, FN, BKF, 2>(d, st);
+        return launch_gemm_fast_pd<WM, WN, FM, FN, BKF, 1>(d, st);
     }
-    if (ABL >= 3) return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 2, ABL>(d, st);
-    return launch_gemm_fast_p<WM, WN, FM, FN, BKF, 0, ABL>(d, st);
+    return launch_gemm_fast_pd<WM, WN, FM, FN, BKF, 0>(d, st);
 }
 
 }  // namespace
@@ -1823,22 +1717,13 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     const char* force_s = getenv("CDETR_GEMM_VARIANT");
     const int force = force_s ? atoi(force_s) : 0;
     const bool fast_ok = vecA && vecB && (d.K % 32) == 0;
-    if (force == 7 && fast_ok) return launch_gemm_fast<1, 2, 1, 1, 32>(d, st);                 // 32x64, 2 waves
-    if (force == 8 && fast_ok) return launch_gemm_fast<4, 2, 1, 1, 32>(d, st);                 // 128x64, 8 waves of 32x32
-    if (force == 9 && fast_ok) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);                 // 64x128, 8 waves of 32x32
-    if (force == 10 && fast_ok) return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);                // 128x128, 16 waves of 32x32
-    if (force == 13 && fast_ok && d.b_layout == 0) return launch_gemm_fast<3, 4, 1, 1, 32>(d, st);   // 96x128, 12 waves of 32x32
-    if (force == 11 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<4, 4, 1, 1, 64>(d, st);   // same, BK 64
-    if (force == 12 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<2, 4, 1, 1, 64>(d, st);   // 64x128 on 8 waves, BK 64
-    if (force >= 1 && force <= 4 && fast_ok) {
-        if (force == 1) return launch_gemm_fast<2, 2, 2, 2, 32>(d, st);                       // 128x128
-        if (force == 2) return launch_gemm_fast<2, 2, 2, 1, 32>(d, st);                       // 128x64
-        if (force == 3 && (d.K % 64) == 0) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);    // 64x64, BK 64
-        const char* abl = getenv("CDETR_GEMM_ABL");
-        if (abl && atoi(abl) == 3) return launch_gemm_fast<2, 2, 1, 1, 32, 3>(d, st);
-        if (abl && atoi(abl) == 4) return launch_gemm_fast<2, 2, 1, 1, 32, 4>(d, st);
-        return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);                                       // 64x64, BK 32
-    }
+    // CDETR_GEMM_VARIANT (tests / tools/gemm_sweep.py): 3 = 64x64 BK64, 4 = 64x64, 9 = 64x128 (8 waves), 10 = 128x128 (16 waves),
+    // 13 = 96x128 (12 waves) -- the tiles of the default dispatch --, 5 = the few-row kernel, 6 = the generic kernel
+    if (force == 9 && fast_ok) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);
+    if (force == 10 && fast_ok) return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
+    if (force == 13 && fast_ok && d.b_layout == 0) return launch_gemm_fast<3, 4, 1, 1, 32>(d, st);
+    if (force == 3 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);
+    if (force == 4 && fast_ok) return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);
     if (force == 6) {
         if (d.N > 64 && d.M > 64) return launch_gemm<128, 128>(d, st, vecA, vecB);
         return launch_gemm<64, 64>(d, st, vecA, vecB);
@@ -1889,8 +1774,7 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
 extern "C" int cdetr_gemm_group(const cdetr_gemm_desc* descs, int32_t n, void* stream) {
     CDETR_CHECK_ARG(n >= 0 && (descs != nullptr || n == 0), "cdetr_gemm_group: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    static const bool grouping = !(getenv("CDETR_GEMM_GROUP") && atoi(getenv("CDETR_GEMM_GROUP")) == 0) && !getenv("CDETR_GEMM_VARIANT") &&
-                                 !getenv("CDETR_GEMM_SPLIT") && !getenv("CDETR_GEMM_PRESPLIT") && !getenv("CDETR_GEMM_PD") && !getenv("CDETR_GEMM_ABL");
+    static const bool grouping = !(getenv("CDETR_GEMM_GROUP") && atoi(getenv("CDETR_GEMM_GROUP")) == 0) && !getenv("CDETR_GEMM_VARIANT");
     std::vector<int> cls[4];          // direct UB 4 / 8 / 16 (k-contiguous weight), fast 64x128 with a pre-split weight
     for (int i = 0; i < n; ++i) {
         const cdetr_gemm_desc& d = descs[i];
@@ -2002,9 +1886,8 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             // trailing slices exit at once).  MEASURED (profiles/r2_notes.txt): the step's weight gradients 2.04 -> 2.08 ms, i.e. nothing --
             // the re-reads the counters show (3.7x the algorithmic bytes) are served by the 256 MB Infinity Cache at a rate that does not
             // bound the kernel; kept off by default, reachable for A/B runs
-            static const int xcd_on = getenv("CDETR_WGRAD_XCD") ? atoi(getenv("CDETR_WGRAD_XCD")) : 0;
-            const int use_tr0 = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
-            const bool xcd = xcd_on && use_tr0 && d.precision >= 1 && max_slices >= 8;
+            const int xcd_on = getenv("CDETR_WGRAD_XCD") ? atoi(getenv("CDETR_WGRAD_XCD")) : 0;
+            const bool xcd = xcd_on && d.precision >= 1 && max_slices >= 8;
             if (xcd) slices = std::max<long>(8, (slices + 7) / 8 * 8);
             int per = (int)((nktf + slices - 1) / slices);
             if (!xcd) slices = (nktf + per - 1) / per;
@@ -2012,10 +1895,8 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             const int nx_xcd = xcd ? tilesI * tilesJ * d.taps : 0;
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
             if (xcd) grid = dim3((unsigned)(nx_xcd * slices), 1, d.batch);
-            // split-bf16: the transpose-read kernel is 7-20 % faster than the per-fragment split on every shape of this model
-            // (profiles/r1_gemm_sweep.txt); CDETR_WGRAD_TR=0 keeps the older kernel reachable for A/B runs
-            const int use_tr = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
-            if (d.precision >= 1 && use_tr) {
+            // split-bf16: the LDS transpose-read kernel (wgrad_tr_kernel); fp32 MFMA: wgrad_fast_kernel
+            if (d.precision >= 1) {
                 const int tbytes = 2 * 2 * (BI + BJ) * 32 * 2;
                 if (d.precision == 2) {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ, 2>, tbytes, "cdetr_wgrad"))) return;
@@ -2027,9 +1908,6 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
                     hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias, nx_xcd);
                 }
-            } else if (d.precision >= 1) {
-                if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 1>, bytes, "cdetr_wgrad"))) return;
-                hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ, 1>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
             } else {
                 if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 0>, bytes, "cdetr_wgrad"))) return;
                 hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ, 0>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
@@ -2044,10 +1922,9 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
         if (wforce) { if (rcf) return rcf; return cdetr_launch_status("cdetr_wgrad"); }
         // measured (tools/gemm_sweep.py wgrad, profiles/r1_gemm_sweep.txt): 64x64 tiles win for 1x1 / linear layers,
         // 128-wide tiles only for the 3x3 convolutions (9 taps = 9x more output tiles per k-slice)
-        const int use_tr_sel = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
         if (d.taps > 1 && d.Nout >= 512 && d.Cin >= 512)
             launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
-        else if (d.precision >= 1 && use_tr_sel) {
+        else if (d.precision >= 1) {
             // transpose-read kernel (profiles/r1_gemm_sweep.txt, wgrad section): 64x128 once the weight has >= 1M elements, else 64x64
             if (d.taps == 1 && (long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128)
                 launchf(std::integral_constant<int, 64>{}, std::integral_constant<int, 128>{});
@@ -2102,7 +1979,6 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
     CDETR_CHECK_ARG(n >= 0 && (descs != nullptr || n == 0), "cdetr_wgrad_group: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     static const int grouping = getenv("CDETR_WGRAD_GROUP") ? atoi(getenv("CDETR_WGRAD_GROUP")) : 1;
-    const int use_tr = getenv("CDETR_WGRAD_TR") ? atoi(getenv("CDETR_WGRAD_TR")) : 1;
     const bool forced = getenv("CDETR_WGRAD_VARIANT") && atoi(getenv("CDETR_WGRAD_VARIANT")) != 0;
     std::vector<int> direct, tr64;
     for (int i = 0; i < n; ++i) {
@@ -2110,7 +1986,7 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
         if (int rcv = check_wgrad_desc(d)) return rcv;
         if (d.P == 0) continue;
         if (grouping && wgrad_is_direct(d)) direct.push_back(i);
-        else if (grouping && wgrad_is_fast(d) && d.precision >= 1 && use_tr && !forced &&
+        else if (grouping && wgrad_is_fast(d) && d.precision >= 1 && !forced &&
                  !(d.taps > 1 && d.Nout >= 512 && d.Cin >= 512) && !(d.taps == 1 && (long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128))
             tr64.push_back(i);                               // = the shapes cdetr_wgrad gives to wgrad_tr_kernel<64, 64>
         else if (int rc1 = cdetr_wgrad(&d, stream)) return rc1;
@@ -2152,7 +2028,7 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             it.tilesI = (it.d.Nout + 63) / 64; it.tilesJ = (it.d.Cin + 63) / 64;
             it.per = (int)std::min<long>(per_all, nkt);
             it.nx = it.tilesI * it.tilesJ * it.d.taps; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
-            static const int xcd_on = getenv("CDETR_WGRAD_XCD") ? atoi(getenv("CDETR_WGRAD_XCD")) : 0;
+            const int xcd_on = getenv("CDETR_WGRAD_XCD") ? atoi(getenv("CDETR_WGRAD_XCD")) : 0;
             if (xcd_on && it.ny >= 6 && (nkt + 3) / 4 >= 8) {            // XCD-aware slices: a multiple of 8 (see wgrad_tr_kernel)
                 it.ny = (it.ny + 7) / 8 * 8;
                 it.per = (nkt + it.ny - 1) / it.ny;
