@@ -438,6 +438,13 @@ class Trainer:
                 self._optimizer_step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if world > 1:
+            # every collective issued so far has completed AND been retired by the process group's watchdog thread before the capture
+            # starts: the watchdog polls its pending work with event queries, which a capturing process must not see
+            import time
+            dist.barrier()
+            torch.cuda.synchronize()
+            time.sleep(0.5)
         g_a = torch.cuda.CUDAGraph()
         segs = None
         if world == 1:

@@ -505,6 +505,42 @@ class AggrProjFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class TileParamFn(torch.autograd.Function):
+    """A parameter laid out over the batch / query axes, with its gradient accumulated IN PLACE into `.grad` like every other parameter of
+    the path (no autograd AccumulateGrad node: those pin the stream they were first run on, and a later graph capture on another stream
+    would record a cross-stream edge):
+      mode "tile":   w [Q, c] -> out[b, p*Q + q] = w[q]        (reference points: position.weight over batch and patterns, :114-116)
+      mode "repeat": w [P, c] -> out[b, p*Q + q] = w[p]        (tgt: pattern.weight over batch and positions, :137-139)"""
+
+    @staticmethod
+    def forward(ctx, wparam, B, P, Q, mode):
+        w = wparam.detach()
+        if mode == "tile":
+            out = w.unsqueeze(0).unsqueeze(0).expand(B, P, Q, w.shape[-1]).reshape(B, P * Q, w.shape[-1])
+        else:
+            out = w.unsqueeze(0).unsqueeze(2).expand(B, P, Q, w.shape[-1]).reshape(B, P * Q, w.shape[-1])
+        ctx.wparam, ctx.cfg = wparam, (B, P, Q, mode)
+        return out.contiguous()
+
+    @staticmethod
+    def backward(ctx, d):
+        B, P, Q, mode = ctx.cfg
+        wparam = ctx.wparam
+        if wparam.requires_grad:
+            g = grad_buffer(wparam)
+            d = d.contiguous()
+            c = d.shape[-1]
+            if mode == "tile":                      # sum over the B*P slabs of [Q, c]
+                colsum_(d.view(B * P, Q * c), g.view(-1))
+            elif P == 1:
+                colsum_(d.view(B * Q, c), g.view(-1))
+            else:
+                for b in range(B):
+                    for p_ in range(P):
+                        colsum_(d[b, p_ * Q:(p_ + 1) * Q], g[p_])
+        return None, None, None, None, None
+
+
 class BoxHeadFn(torch.autograd.Function):
     """boxes = sigmoid(tmp + [inverse_sigmoid(ref), 0, 0]) -- the tail of the box head (A2/models/transformer.py:193-203,
     A2/util/misc.py:475-479) as one launch forward and one backward instead of ~12 + ~25 tensor launches (clamp x3, rsub, div, log,

@@ -279,6 +279,8 @@ class Transformer(nn.Module):
     def reference_points(self, bs, device, points=None):
         """:114-135."""
         if self.spatial_prior == "learned":
+            if self.position.weight.is_cuda:
+                return ops.TileParamFn.apply(self.position.weight, bs, self.num_pattern, self.num_position, "tile")
             return self.position.weight.unsqueeze(0).repeat(bs, self.num_pattern, 1)
         if self.spatial_prior == "grid":
             nx = ny = round(math.sqrt(self.num_position))
@@ -303,8 +305,11 @@ class Transformer(nn.Module):
         mi = mask if isinstance(mask, ops.MaskInfo) else ops.mask_prep(mask, h, w)
         reference_points = self.reference_points(bs, src.device, points)
         pattern = self.pattern if self.stage == 2 else self.modify_pattern
-        tgt = (pattern.weight.reshape(1, self.num_pattern, 1, c).repeat(bs, 1, self.num_position, 1)
-               .reshape(bs, self.num_pattern * self.num_position, c))
+        if src.is_cuda:
+            tgt = ops.TileParamFn.apply(pattern.weight, bs, self.num_pattern, self.num_position, "repeat")
+        else:
+            tgt = (pattern.weight.reshape(1, self.num_pattern, 1, c).repeat(bs, 1, self.num_position, 1)
+                   .reshape(bs, self.num_pattern * self.num_position, c))
         # the four 1-d positional MLP applications (key rows / columns, query x / y) run level by level, grouped
         emb_x, emb_y = ops.sine_embed_xy(reference_points, c)
         posemb_row, posemb_col, query_pos_x, query_pos_y = pos_mlp_many(

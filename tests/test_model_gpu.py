@@ -390,7 +390,7 @@ def test_bench_self_launches_two_ranks_rehearsal():
     env = dict(os.environ, CDETR_BENCH_SHARE_GPU="1")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    for mode in ("graph", "eager"):
+    for mode in ("auto", "graph", "eager"):
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--size", "256", "256",
                             "--queries", "100", "--mode", mode, "--no-cpu-baseline", "--no-alt", "--no-extra"],
                            env=env, cwd=root, capture_output=True, text=True, timeout=900)
@@ -399,7 +399,62 @@ def test_bench_self_launches_two_ranks_rehearsal():
         assert len(lines) == 1, p.stdout[-2000:]
         r = json.loads(lines[0])
         assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 4 and r["config"]["parallelism"] == "dp2"
-        assert r["config"]["graph"] == (mode == "graph") and "REHEARSAL" in r["data"]
+        assert (mode == "auto" or r["config"]["graph"] == (mode == "graph")) and "REHEARSAL" in r["data"]
         ex = r["allreduce_exposed_ms"]
         assert ex["mean_max_over_ranks"] >= 0 and ex["rank0"]["n"] == 3 and sum(ex["buckets_bytes"]) == ex["bytes_per_step"]
         assert r["value"] > 0 and r["step_ms"]["n"] == 3 and r["roofline"]["achieved"] > 0
+
+
+def test_fscd_lvis_train_epoch_and_infer(tmp_path):
+    """BASELINE config 4 (FSCD-LVIS 2nd stage: the same network on the LVIS readers, L2/data/fscd_lvis.py) end to end on the tiny
+    LVIS-shaped dataset: reader -> collate (different image sizes: padding mask; per-image exemplars, absent rows marked) -> prefetch ->
+    Trainer steps (stream-ordered, then a captured replay on the same shapes) -> inference on the test split with the counting rule."""
+    import os
+    from torch.utils.data import DataLoader
+    from counting_detr_amd import build_model, data
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.engine import Trainer, count_from_logits, train_one_epoch
+    from counting_detr_amd.misc import NestedTensor
+    from oracle.weights import seeded_state_dict
+    here = os.path.dirname(os.path.abspath(__file__))
+    args = default_args(dataset="fscd_lvis")
+    args.data_path = os.path.join(here, "golden", "fscd_lvis_tiny")
+    model, criterion, _ = build_model(args)
+    model.load_state_dict(seeded_state_dict(heads="wide"), strict=True)
+    model.to(DEV); criterion.to(DEV)
+    assert model.backbone.exemplar_mode == "per_image"
+    trainer = Trainer(model, criterion, args, device=DEV)
+    ds = data.build_dataset(args)
+    assert type(ds).__name__ == "FSCDLVISDataset" and len(ds) >= 2
+    dl = DataLoader(ds, batch_size=2, shuffle=False, collate_fn=data.collate)
+    batch = next(iter(dl))
+    assert batch["ex_rects"].shape[1:] == (3, 4) and batch["mask"].dtype == torch.bool
+    logs = []
+    stats = train_one_epoch(trainer, data.Prefetcher(dl, DEV), 0, print_freq=1, log=logs.append)
+    assert np.isfinite(stats["loss"]) and stats["loss"] > 0 and np.isfinite(stats["grad_norm"]) and trainer.nonfinite_steps() == 0
+    # the same padded batch through a captured step == one more stream-ordered step from the same weights
+    dev_b = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items() if k != "targets"}
+    tg = [{k: v.to(DEV) for k, v in t.items()} for t in batch["targets"]]
+    nt = NestedTensor(dev_b["image"], dev_b["mask"])
+    trainer.capture(nt, dev_b["ex_rects"], tg, warmup=0)
+    p0 = trainer.flat_p.clone()
+    m0, v0, st0 = trainer.exp_avg.clone(), trainer.exp_avg_sq.clone(), trainer.opt_state.clone()
+    out_g = {k: float(v) for k, v in trainer.replay().items()}
+    torch.cuda.synchronize()
+    trainer.flat_p.copy_(p0); trainer.exp_avg.copy_(m0); trainer.exp_avg_sq.copy_(v0); trainer.opt_state.copy_(st0)
+    out_e = {k: float(v) for k, v in trainer.train_step(nt, dev_b["ex_rects"], tg).items()}
+    for k in out_e:
+        np.testing.assert_allclose(out_g[k], out_e[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    # test split: exemplars are not clipped there, counts come from the rule of A2/infer.py:75-81
+    te = data.FSCDLVISDataset(args, split="test", test=True)
+    vl = DataLoader(te, batch_size=1, shuffle=False, collate_fn=data.collate)
+    model.eval()
+    n = 0
+    with torch.no_grad():
+        for b in vl:
+            out, ref = model(NestedTensor(b["image"].to(DEV), b["mask"].to(DEV)), rects=b["ex_rects"].to(DEV))
+            counts, keep, prob = count_from_logits(out["pred_logits"])
+            assert out["pred_boxes"].shape == (1, 300, 4) and int(counts[0]) == int(keep.sum()) and 0 <= int(counts[0]) <= 300
+            assert torch.isfinite(out["pred_boxes"]).all() and torch.isfinite(out["pred_vars"]).all()
+            n += 1
+    assert n == len(te) >= 1
