@@ -8,6 +8,7 @@
 // cdetr_relu_mask   : dz = (y > 0) ? dy * scale : 0   (ReLU backward for the linear layers, one pass).
 #include "../../include/cdetr_hip.h"
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -47,7 +48,8 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, const float* __restrict__ lr, long n,
                                                     const float* __restrict__ sumsq, float* __restrict__ state, float max_norm,
-                                                    float beta1, float beta2, float eps, float wd, float grad_div) {
+                                                    float beta1, float beta2, float eps, float wd, float grad_div, float lr0, float lr1,
+                                                    long lr_split) {
     const float t = state[0] + 1.f;
     const float lr_scale = state[1];
     const float total_norm = sqrtf(sumsq[0]) * grad_div;
@@ -75,9 +77,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
         pp -= (l / bc1) * (mm / denom);
     };
+    // lr == NULL: two learning rates split at element lr_split (the arena is ordered [everything else | backbone], A2/main.py:157-183):
+    // one 150 MB stream less than the per-element table (lr_split is a multiple of 4 or the table is used)
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         float4 pp = p4[i], mm = m4[i], vv = v4[i];
-        const float4 gg = g4[i], ll = l4[i];
+        const float4 gg = g4[i];
+        float4 ll;
+        if (lr) ll = l4[i];
+        else { const float l = (4 * i < lr_split) ? lr0 : lr1; ll = make_float4(l, l, l, l); }
         upd(pp.x, gg.x, mm.x, vv.x, ll.x);
         upd(pp.y, gg.y, mm.y, vv.y, ll.y);
         upd(pp.z, gg.z, mm.z, vv.z, ll.z);
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
     }
     if (blockIdx.x == 0)
-        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) upd(p[i], g[i], m[i], v[i], lr[i]);
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) upd(p[i], g[i], m[i], v[i], lr ? lr[i] : (i < lr_split ? lr0 : lr1));
     // every block has read state[0] / sumsq before block 0 writes them only if ... they are written by a SEPARATE tiny
     // kernel (adamw_finish) launched after this one -- see cdetr_adamw_step.
 }
@@ -317,6 +324,20 @@ extern "C" int cdetr_sumsq(const float* g, int64_t n, float* out, float* workspa
     return cdetr_launch_status("cdetr_sumsq");
 }
 
+extern "C" int cdetr_adamw_step2(float* p, const float* g, float* m, float* v, const float* lr, float lr0, float lr1, int64_t lr_split,
+                                 int64_t n, const float* sumsq, float* state, float max_norm, float beta1, float beta2, float eps,
+                                 float weight_decay, float grad_div, void* stream) {
+    CDETR_CHECK_ARG(p && g && m && v && sumsq && state && n >= 0, "cdetr_adamw_step2: null pointer");
+    CDETR_CHECK_ARG(lr || (lr_split >= 0 && (lr_split & 3) == 0), "cdetr_adamw_step2: without a per-element table lr_split must be a multiple of 4");
+    CDETR_CHECK_ARG(((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                      reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(lr)) & 15) == 0, "cdetr_adamw_step2: arenas must be 16-byte aligned");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, st, p, g, m, v, lr, (long)n, sumsq, state, max_norm, beta1, beta2,
+                       eps, weight_decay, grad_div, lr0, lr1, (long)lr_split);
+    hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(1), 0, st, sumsq, state, grad_div);
+    return cdetr_launch_status("cdetr_adamw_step2");
+}
+
 extern "C" int cdetr_adamw_step(float* p, const float* g, float* m, float* v, const float* lr, int64_t n, const float* sumsq,
                                 float* state, float max_norm, float beta1, float beta2, float eps, float weight_decay,
                                 float grad_div, void* stream) {
@@ -326,7 +347,7 @@ extern "C" int cdetr_adamw_step(float* p, const float* g, float* m, float* v, co
                     "cdetr_adamw_step: arenas must be 16-byte aligned");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, st, p, g, m, v, lr, (long)n, sumsq, state, max_norm,
-                       beta1, beta2, eps, weight_decay, grad_div);
+                       beta1, beta2, eps, weight_decay, grad_div, 0.f, 0.f, 0L);
     hipLaunchKernelGGL(adamw_finish_kernel, dim3(1), dim3(1), 0, st, sumsq, state, grad_div);
     return cdetr_launch_status("cdetr_adamw_step");
 }
@@ -689,7 +710,8 @@ extern "C" int cdetr_layernorm_bwd(const float* dy, const float* x, const float*
     if (rows == 0) return CDETR_OK;
     // >= 4 rows per wave amortise the per-workgroup dgamma / dbeta atomics on long inputs; short ones (decoder: 600 rows) are latency
     // bound, one row per wave there
-    int blocks = rows <= 2048 ? (rows + 3) / 4 : (rows + 15) / 16;
+    static const int rpb = getenv("CDETR_LN_BWD_ROWS") ? atoi(getenv("CDETR_LN_BWD_ROWS")) : 32;      // rows per workgroup on long inputs (A/B)
+    int blocks = rows <= 2048 ? (rows + 3) / 4 : (rows + rpb - 1) / rpb;
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma,

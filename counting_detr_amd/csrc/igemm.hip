@@ -1684,6 +1684,8 @@ bool gemm_is_f44(const cdetr_gemm_desc& d) {
 // small grids (< 2 workgroups of 4 waves per CU): a 64x128 tile shared by 8 waves keeps the wave count and halves the
 // A-operand traffic (tools/split_sweep.py: 6-11 % over 64x64 BK64 on the N = 256 encoder linears)
 bool gemm_is_f24(const cdetr_gemm_desc& d) {
+    static const int on = getenv("CDETR_GEMM_F24") ? atoi(getenv("CDETR_GEMM_F24")) : 3;      // A/B: bit 0 = forward (3 terms), bit 1 = reduced-term backward
+    if (!((d.precision == 1 && (on & 1)) || (d.precision >= 2 && (on & 2)))) return false;
     return d.precision >= 1 && d.b_layout == 0 && (d.N % 128) == 0 && gemm_blocks(d, 64, 64) < 512;
 }
 int check_gemm_desc(const cdetr_gemm_desc& d) {
@@ -1848,7 +1850,13 @@ void direct_wgrad_plan(const cdetr_wgrad_desc& d, int& tilesI, int& tilesJ, int&
     per = ((per + 15) / 16) * 16;
     slices = (d.P + per - 1) / per;
 }
-bool wgrad_is_direct(const cdetr_wgrad_desc& d) { return d.g.mode == CDETR_ROWS_DENSE && d.P <= 1024; }
+// few-pixel problems (positional MLPs: P = B*(h+w) rows) take the one-wave-per-16x16-tile kernel; from 256 pixels on (the decoder's B*Q = 600
+// rows) the transpose-read tile kernel is faster -- measured on the step: boundary 1024 / 512 / 256 / 64 pixels -> 11.71 / 11.63 / 11.60 /
+// 11.60 ms (CDETR_WGRAD_DIRECT_MAXP moves it for A/B runs)
+bool wgrad_is_direct(const cdetr_wgrad_desc& d) {
+    static const int maxp = getenv("CDETR_WGRAD_DIRECT_MAXP") ? atoi(getenv("CDETR_WGRAD_DIRECT_MAXP")) : 256;
+    return d.g.mode == CDETR_ROWS_DENSE && (d.P <= maxp || !((d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0)) && d.P <= 1024;
+}
 bool wgrad_is_fast(const cdetr_wgrad_desc& d) { return (d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0; }
 }  // namespace
 

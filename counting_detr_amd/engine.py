@@ -119,6 +119,15 @@ class Trainer:
             self.seg_bounds[_segment_of(n) + 1] = off
         for i in range(1, 5):
             self.seg_bounds[i] = max(self.seg_bounds[i], self.seg_bounds[i - 1])
+        # the reference's learning-rate groups (A2/main.py:157-183) as TWO contiguous ranges of the arena when they are: [lr | lr_backbone]
+        # (the update then streams no per-element table); any other grouping keeps the table
+        lv = self.lr_vec.cpu()
+        chg = (lv[1:] != lv[:-1]).nonzero().flatten() + 1
+        self._lr_two = None
+        if chg.numel() == 0:
+            self._lr_two = (float(lv[0]) if total else 0.0, float(lv[0]) if total else 0.0, 0)
+        elif chg.numel() == 1 and int(chg[0]) % 4 == 0:
+            self._lr_two = (float(lv[0]), float(lv[-1]), int(chg[0]))
         # device-resident optimizer scalars (graph-replay safe): [step count, StepLR factor, last grad norm, spare]
         self.opt_state = torch.tensor([0.0, 1.0, 0.0, 0.0], device=self.device)
         self._one = torch.ones((), device=self.device)
@@ -214,10 +223,11 @@ class Trainer:
         b1, b2 = self.betas
         st = _ffi.stream_ptr()
         _ffi.check(_ffi.lib().cdetr_sumsq(self.flat_g.data_ptr(), n, self.sumsq.data_ptr(), self.sumsq_ws.data_ptr(), st), "cdetr_sumsq")
-        _ffi.check(_ffi.lib().cdetr_adamw_step(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
-                                               self.exp_avg_sq.data_ptr(), self.lr_vec.data_ptr(), n, self.sumsq.data_ptr(),
-                                               self.opt_state.data_ptr(), float(self.max_norm), b1, b2, self.eps, self.wd,
-                                               1.0 / get_world_size(), st), "cdetr_adamw_step")
+        lr_tab, lr0, lr1, split = (None, *self._lr_two) if self._lr_two is not None else (self.lr_vec.data_ptr(), 0.0, 0.0, 0)
+        _ffi.check(_ffi.lib().cdetr_adamw_step2(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), lr_tab, lr0, lr1, split, n, self.sumsq.data_ptr(),
+                                                self.opt_state.data_ptr(), float(self.max_norm), b1, b2, self.eps, self.wd,
+                                                1.0 / get_world_size(), st), "cdetr_adamw_step2")
         return self.opt_state[2]
 
     def _torch_param_order(self):

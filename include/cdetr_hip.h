@@ -126,6 +126,12 @@ int cdetr_sumsq(const float* g, int64_t n, float* out, float* workspace, void* s
 int cdetr_adamw_step(float* p, const float* g, float* m, float* v, const float* lr, int64_t n, const float* sumsq,
                      float* state, float max_norm, float beta1, float beta2, float eps, float weight_decay, float grad_div,
                      void* stream);
+/* cdetr_adamw_step2: the same with the learning rates given as TWO values split at element lr_split when lr == NULL (elements
+ * [0, lr_split) use lr0, the rest lr1; lr_split a multiple of 4): the reference's parameter groups (A2/main.py:157-183) are two
+ * contiguous ranges of the arena, and the per-element table is a 150 MB stream the update does not need.                       */
+int cdetr_adamw_step2(float* p, const float* g, float* m, float* v, const float* lr, float lr0, float lr1, int64_t lr_split, int64_t n,
+                      const float* sumsq, float* state, float max_norm, float beta1, float beta2, float eps, float weight_decay,
+                      float grad_div, void* stream);
 /* dz[i] = y[i] > 0 ? dy[i] * scale : 0      (ReLU backward of the fused linear+ReLU layers) */
 int cdetr_relu_mask(const float* y, const float* dy, float* dz, int64_t n, float scale, void* stream);
 
