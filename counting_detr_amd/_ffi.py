@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
                 ("C", _p), ("ldc", C.c_int64), ("sC", C.c_int64),
                 ("w_scale", _p), ("bias", _p), ("resid", _p), ("ldr", C.c_int64), ("gate", _p), ("ldg", C.c_int64),
                 ("g", ConvGeom), ("B_split", _p), ("batch_inner", C.c_int32), ("pad_", C.c_int32),
-                ("sA2", C.c_int64), ("sB2", C.c_int64), ("sC2", C.c_int64)]
+                ("sA2", C.c_int64), ("sB2", C.c_int64), ("sC2", C.c_int64), ("C16", _p)]
 
 
 class WgradDesc(C.Structure):
@@ -37,7 +37,7 @@ class WgradDesc(C.Structure):
                 ("X", _p), ("ldx", C.c_int64), ("sX", C.c_int64),
                 ("dW", _p), ("ldw", C.c_int64), ("sW", C.c_int64),
                 ("w_scale", _p), ("dbias", _p), ("g", ConvGeom), ("batch_inner", C.c_int32), ("pad_", C.c_int32),
-                ("sY2", C.c_int64), ("sX2", C.c_int64), ("sW2", C.c_int64)]
+                ("sY2", C.c_int64), ("sX2", C.c_int64), ("sW2", C.c_int64), ("dY16", _p), ("X16", _p)]
 
 
 class RcdaFwdDesc(C.Structure):
@@ -65,7 +65,7 @@ class MirrorItem(C.Structure):
                 ("tile0", C.c_int32), ("transpose", C.c_int32), ("pad_", C.c_int32)]
 
 
-EXPORTS = ["cdetr_gemm", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
+EXPORTS = ["cdetr_gemm", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
            "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_mask_prep", "cdetr_stem_pack", "cdetr_exemplar_fwd", "cdetr_exemplar_bwd", "cdetr_aggr_weight_fwd", "cdetr_aggr_weight_bwd",
            "cdetr_box_head_fwd", "cdetr_box_head_bwd", "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
@@ -100,6 +100,8 @@ def lib():
         L.cdetr_adamw_step2.argtypes = [_p] * 5 + [C.c_float, C.c_float, C.c_int64, C.c_int64, _p, _p] + [C.c_float] * 6 + [_p]
         L.cdetr_relu_mask.restype = C.c_int
         L.cdetr_relu_mask.argtypes = [_p, _p, _p, C.c_int64, C.c_float, _p]
+        L.cdetr_relu_mask2.restype = C.c_int
+        L.cdetr_relu_mask2.argtypes = [_p, _p, _p, _p, C.c_int64, C.c_float, _p]
         L.cdetr_layernorm_fwd.restype = C.c_int
         L.cdetr_layernorm_fwd.argtypes = [_p] * 6 + [C.c_int32, C.c_int32, C.c_float, _p]
         L.cdetr_layernorm_fwd_add.restype = C.c_int

@@ -70,44 +70,54 @@ class Bottleneck(nn.Module):
         self.downsample = nn.Sequential(ConvW(inplanes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)) if has_down else None
         self.stride, self.dilation = stride, dilation
 
-    def forward_fused(self, x, save=None):
+    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False):
+        """twins: every activation a weight gradient of this block will read (a1, a2) and the block's output (the next block's x) also
+        leave their producing epilogue as a bf16 copy (ops.bf16_twins); x16 = the twin of x, from the previous block.
+        twin_out: only the output gets a twin (the last frozen block in front of the trainable ones)."""
+        twin_out = twin_out or twins
         s1, b1 = self.bn1.affine()
         s2, b2 = self.bn2.affine()
         s3, b3 = self.bn3.affine()
-        a1 = ops.conv_fwd(x, self.conv1.weight, s1, b1, relu=True)
-        a2 = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True)
+        a1 = ops.conv_fwd(x, self.conv1.weight, s1, b1, relu=True, twin=twins)
+        a1, a1_16 = a1 if twins else (a1, None)
+        a2 = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True, twin=twins)
+        a2, a2_16 = a2 if twins else (a2, None)
         if self.downsample is not None:
             sd, bd = self.downsample[1].affine()
             idn = ops.conv_fwd(x, self.downsample[0].weight, sd, bd, stride=self.stride)
         else:
             idn = x
-        out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn)
+        out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, twin=twin_out)
+        out, out16 = out if twin_out else (out, None)
         if save is not None:
-            save.append((x, a1, a2, out))
-        return out
+            save.append((x, a1, a2, out, x16, a1_16, a2_16, out16))
+        return (out, out16) if twin_out else out
 
-    def backward_fused(self, saved, dz, need_dx):
-        """dz = gradient w.r.t. the pre-ReLU output of this block (already masked by out > 0).
-        Returns the gradient w.r.t. the pre-ReLU output of the PREVIOUS block (masked by x > 0)."""
-        x, a1, a2, out = saved
+    def backward_fused(self, saved, dz, need_dx, dz16=None):
+        """dz = gradient w.r.t. the pre-ReLU output of this block (already masked by out > 0); dz16 its bf16 twin or None.
+        Returns the gradient w.r.t. the pre-ReLU output of the PREVIOUS block (masked by x > 0) -- with its twin when dz16 is given."""
+        x, a1, a2, out, x16, a1_16, a2_16, _ = saved
+        tw = dz16 is not None
         s1, _ = self.bn1.affine()
         s2, _ = self.bn2.affine()
         s3, _ = self.bn3.affine()
         w1, w2, w3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
         st, dl = self.stride, self.dilation
         if w3.requires_grad:
-            ops.conv_wgrad_(dz, a2, w3, s3)
-        dz2 = ops.conv_dgrad(dz, w3, s3, a2.shape[1:3], gate=a2)                 # masked by relu(a2)
+            ops.conv_wgrad_(dz, a2, w3, s3, dz16=dz16, x16=a2_16 if tw else None)
+        dz2 = ops.conv_dgrad(dz, w3, s3, a2.shape[1:3], gate=a2, twin=tw)                 # masked by relu(a2)
+        dz2, dz2_16 = dz2 if tw else (dz2, None)
         if w2.requires_grad:
-            ops.conv_wgrad_(dz2, a1, w2, s2, stride=st, pad=dl, dil=dl)
-        dz1 = ops.conv_dgrad(dz2, w2, s2, a1.shape[1:3], stride=st, pad=dl, dil=dl, gate=a1)
+            ops.conv_wgrad_(dz2, a1, w2, s2, stride=st, pad=dl, dil=dl, dz16=dz2_16, x16=a1_16 if tw else None)
+        dz1 = ops.conv_dgrad(dz2, w2, s2, a1.shape[1:3], stride=st, pad=dl, dil=dl, gate=a1, twin=tw)
+        dz1, dz1_16 = dz1 if tw else (dz1, None)
         if w1.requires_grad:
-            ops.conv_wgrad_(dz1, x, w1, s1)
+            ops.conv_wgrad_(dz1, x, w1, s1, dz16=dz1_16, x16=x16 if tw else None)
         if self.downsample is not None:
             wd = self.downsample[0].weight
             sd, _ = self.downsample[1].affine()
             if wd.requires_grad:
-                ops.conv_wgrad_(dz, x, wd, sd, stride=st)
+                ops.conv_wgrad_(dz, x, wd, sd, stride=st, dz16=dz16, x16=x16 if tw else None)
             if not need_dx:
                 return None
             d_idn = ops.conv_dgrad(dz, wd, sd, x.shape[1:3], stride=st)
@@ -116,7 +126,7 @@ class Bottleneck(nn.Module):
                 return None
             d_idn = dz
         # x = relu(previous pre-activation): the gate applies the previous block's ReLU mask in the same epilogue
-        return ops.conv_dgrad(dz1, w1, s1, x.shape[1:3], gate=x, resid=d_idn)
+        return ops.conv_dgrad(dz1, w1, s1, x.shape[1:3], gate=x, resid=d_idn, twin=tw)
 
 
 _BACKWARD_HOOK = None
@@ -151,8 +161,8 @@ class defer_trunk_backward:
 
 
 class TrunkBackward:
-    def __init__(self, blocks, saved, dz):
-        self.blocks, self.saved, self.dz = blocks, saved, dz
+    def __init__(self, blocks, saved, dz, dz16=None):
+        self.blocks, self.saved, self.dz, self.dz16 = blocks, saved, dz, dz16
         n2, n3 = RESNET50_LAYERS[1], RESNET50_LAYERS[2]
         n = len(blocks)
         self.ranges = {1: (n - 1, n2 + n3), 2: (n2 + n3 - 1, n2), 3: (n2 - 1, 0)}      # block indices, high -> low inclusive
@@ -160,7 +170,8 @@ class TrunkBackward:
     def run(self, seg):
         hi, lo = self.ranges[seg]
         for k in range(hi, lo - 1, -1):
-            self.dz = self.blocks[k].backward_fused(self.saved[k], self.dz, need_dx=(k > 0))
+            r = self.blocks[k].backward_fused(self.saved[k], self.dz, need_dx=(k > 0), dz16=self.dz16)
+            self.dz, self.dz16 = r if (self.dz16 is not None and r is not None) else (r, None)
             self.saved[k] = None
 
 
@@ -168,33 +179,41 @@ class _TrunkFn(torch.autograd.Function):
     """layer2..layer4 as one autograd node (explicit backward schedule instead of ~100 tiny autograd nodes)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, blocks):
+    def forward(ctx, x, anchor, blocks, x16):
         saved = []
+        twins = x16 is not None
         with torch.no_grad():
             for blk in blocks:
-                x = blk.forward_fused(x, saved)
-        ctx.blocks, ctx.saved_acts = blocks, saved
+                if twins:
+                    x, x16 = blk.forward_fused(x, saved, x16=x16, twins=True)
+                else:
+                    x = blk.forward_fused(x, saved)
+        ctx.blocks, ctx.saved_acts, ctx.twins = blocks, saved, twins
         return x
 
     @staticmethod
     def backward(ctx, d_out):
         blocks, saved = ctx.blocks, ctx.saved_acts
         out_last = saved[-1][3]
-        dz = ops.relu_mask(out_last, d_out)          # gradient through the last block's ReLU: one pass
+        dz16 = None
+        if ctx.twins:
+            dz, dz16 = ops.relu_mask(out_last, d_out, twin=True)
+        else:
+            dz = ops.relu_mask(out_last, d_out)      # gradient through the last block's ReLU: one pass
         if _DEFER is not None:                       # the trainer runs the segments itself (graph replay with bucketed exchange)
-            _DEFER.append(TrunkBackward(blocks, saved, dz))
+            _DEFER.append(TrunkBackward(blocks, saved, dz, dz16))
             ctx.saved_acts = None
-            return None, None, None
+            return None, None, None, None
         hook = _BACKWARD_HOOK
         if hook is not None:
             hook(0)          # autograd runs this node last: every gradient above the backbone is final
-        tb = TrunkBackward(blocks, saved, dz)
+        tb = TrunkBackward(blocks, saved, dz, dz16)
         for seg in (1, 2, 3):
             tb.run(seg)
             if hook is not None:
                 hook(seg)    # layer4 / layer3 / layer2 done
         ctx.saved_acts = None
-        return None, None, None
+        return None, None, None, None
 
 
 class ResNetBody(nn.Module):
@@ -262,6 +281,9 @@ class ResNetBody(nn.Module):
     def forward_nhwc(self, images):
         """images [B,3,H,W] (NCHW, as the reference API) -> layer4 features NHWC [B,H/16,W/16,2048]."""
         B, _, H, W = images.shape
+        blocks = list(self.layer2) + list(self.layer3) + list(self.layer4)
+        train = torch.is_grad_enabled() and any(p.requires_grad for blk in blocks for p in blk.parameters())
+        twins = train and ops.bf16_twins()            # layer1's output is layer2's first weight-gradient operand: it gets a twin too
         with torch.no_grad():
             if self.stem_packed:
                 x = self.stem_rows(images)
@@ -271,12 +293,15 @@ class ResNetBody(nn.Module):
                 s, b = self.bn1.affine()
                 x = ops.conv_fwd(x, self.stem_weight4(), s, b, stride=2, pad=3, relu=True)
             x = ops.maxpool3x3s2(x)
-            for blk in self.layer1:
-                x = blk.forward_fused(x)
-        blocks = list(self.layer2) + list(self.layer3) + list(self.layer4)
+            x16 = None
+            for i, blk in enumerate(self.layer1):
+                if twins and i == len(self.layer1) - 1:
+                    x, x16 = blk.forward_fused(x, twin_out=True)
+                else:
+                    x = blk.forward_fused(x)
         anchor = self.layer4[-1].conv3.weight
-        if torch.is_grad_enabled() and any(p.requires_grad for blk in blocks for p in blk.parameters()):
-            return _TrunkFn.apply(x, anchor, blocks)
+        if train:
+            return _TrunkFn.apply(x, anchor, blocks, x16)
         with torch.no_grad():
             for blk in blocks:
                 x = blk.forward_fused(x)

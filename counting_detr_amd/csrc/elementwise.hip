@@ -105,7 +105,7 @@ __global__ void adamw_finish_kernel(const float* __restrict__ sumsq, float* __re
 }
 
 __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict__ y, const float* __restrict__ dy,
-                                                        float* __restrict__ dz, long n, float scale) {
+                                                        float* __restrict__ dz, __bf16* __restrict__ dz16, long n, float scale) {
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float4 a = reinterpret_cast<const float4*>(y)[i];
@@ -115,9 +115,20 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
         b.z = a.z > 0.f ? b.z * scale : 0.f;
         b.w = a.w > 0.f ? b.w * scale : 0.f;
         reinterpret_cast<float4*>(dz)[i] = b;
+        if (dz16) {      // bf16 twin for the plain-bf16 weight gradient that consumes dz
+            const f32x2 lo = {b.x, b.y}, hi = {b.z, b.w};
+            uint2 t;
+            t.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            t.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            reinterpret_cast<uint2*>(dz16)[i] = t;
+        }
     }
     if (blockIdx.x == 0)
-        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) dz[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) {
+            const float v = y[i] > 0.f ? dy[i] * scale : 0.f;
+            dz[i] = v;
+            if (dz16) dz16[i] = (__bf16)v;
+        }
 }
 
 inline int grid_for(long n4) {
@@ -352,12 +363,22 @@ extern "C" int cdetr_adamw_step(float* p, const float* g, float* m, float* v, co
     return cdetr_launch_status("cdetr_adamw_step");
 }
 
+extern "C" int cdetr_relu_mask2(const float* y, const float* dy, float* dz, void* dz16, int64_t n, float scale, void* stream) {
+    CDETR_CHECK_ARG(y && dy && dz && n >= 0, "cdetr_relu_mask2: null pointer");
+    CDETR_CHECK_ARG(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(dz16) & 7) == 0, "cdetr_relu_mask2: buffers must be 16-byte (twin: 8-byte) aligned");
+    if (n == 0) return CDETR_OK;
+    hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, dy, dz,
+                       reinterpret_cast<__bf16*>(dz16), (long)n, scale);
+    return cdetr_launch_status("cdetr_relu_mask2");
+}
+
 extern "C" int cdetr_relu_mask(const float* y, const float* dy, float* dz, int64_t n, float scale, void* stream) {
     CDETR_CHECK_ARG(y && dy && dz && n >= 0, "cdetr_relu_mask: bad args");
     CDETR_CHECK_ARG(((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dz)) & 15) == 0,
                     "cdetr_relu_mask: buffers must be 16-byte aligned");
     hipLaunchKernelGGL(relu_mask_kernel, dim3(grid_for(n >> 2)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), y, dy, dz,
-                       (long)n, scale);
+                       (__bf16*)nullptr, (long)n, scale);
     return cdetr_launch_status("cdetr_relu_mask");
 }
 

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const cdetr_gemm_desc d, con
     const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
     const float* __restrict__ B = d.B + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
+    __bf16* __restrict__ C16 = d.C16 ? reinterpret_cast<__bf16*>(d.C16) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // bf16 twin of C
     const int K = d.K, taps = d.taps, Ktot = d.K * d.taps;
     const int nkt = (Ktot + BK - 1) / BK;
 
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const cdetr_gemm_desc d, con
                 float v = (acc[a][b][r] + bias) * d.out_scale + rv[r];
                 v = gv[r] > 0.f ? v : 0.f;
                 if (d.relu) v = fmaxf(v, 0.f);
-                if (nvalid && m < d.M) C[(long)m * d.ldc + n] = v;
+                if (nvalid && m < d.M) { C[(long)m * d.ldc + n] = v; if (C16) C16[(long)m * d.ldc + n] = (__bf16)v; }
             }
         }
     }
@@ -524,6 +525,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
     const float* __restrict__ B = (BRAW ? reinterpret_cast<const float*>(d.B_split) : d.B) + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
+    __bf16* __restrict__ C16 = d.C16 ? reinterpret_cast<__bf16*>(d.C16) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // bf16 twin of C
     const int K = d.K, taps = d.taps;
     const int nkt = (K / BKF) * taps;
 
@@ -823,7 +825,10 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
                 float v = (acc[a][b][r] + bias) * d.out_scale + rv[a][b][r];
                 v = gv[a][b][r] > 0.f ? v : 0.f;
                 if (d.relu) v = fmaxf(v, 0.f);
-                if (nvalid && m < d.M) C[(long)m * d.ldc + n] = v;
+                if (nvalid && m < d.M) {
+                    C[(long)m * d.ldc + n] = v;
+                    if (C16) C16[(long)m * d.ldc + n] = (__bf16)v;
+                }
             }
         }
     }
@@ -1292,6 +1297,180 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
     }
 }
 
+// The same kernel fed from bf16 TWINS of its operands (cdetr_wgrad_desc.dY16 / X16: the producers' epilogues write a bf16 copy of every
+// activation / activation gradient a plain-bf16 weight gradient consumes).  Half the L2 -> register bytes per k-tile (one 16-byte load =
+// 8 channels per thread and operand instead of two 4-channel loads), no conversion at staging (the 16 bytes go straight into the
+// [32-channel block][pixel][32] plane with one ds_write_b128), hi planes only.  Plain bf16 products (TERMS 1) by construction.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // a native vector: stays in registers through the select below
+__device__ __forceinline__ u32x4 ld16(const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); }
+
+template <int BI, int BJ>
+__device__ __forceinline__ void wgrad_tr16_body(const cdetr_wgrad_desc& d, const int tilesI, const int tilesJ, const int kt_per_slice,
+                                                const int bx, const int by, const int bz, const bool single) {
+    constexpr int BKF = 32;
+    constexpr int FM = BI / 64, FN = BJ / 64;
+    constexpr int A_BLK = BI / 32, B_BLK = BJ / 32;               // 32-channel blocks per operand tile
+    constexpr int A_SLOTS = BI / 64, B_SLOTS = BJ / 64;            // 256 threads = 32 pixels x 8 chunks of 8 channels (128 contiguous bytes per pixel row) per pass
+    constexpr int BLK = 32 * 32 + 32;                             // bf16 per [32 pixels][32 channels] block + 64 B: the two blocks a pixel row's
+                                                                  // 8 lanes write to land on different banks
+    constexpr int PLANE_A = A_BLK * BLK, PLANE_B = B_BLK * BLK;
+    constexpr int BUF = PLANE_A + PLANE_B;                        // per buffer: dY | X (hi planes only)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16* Zs = reinterpret_cast<__bf16*>(smem);                 // [2][BUF]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int i32 = lane & 31, g = lane >> 5;
+    const int ti = bx % tilesI;
+    const int tj = bx / tilesI;
+    const int tap = tj / tilesJ;
+    const int c0 = (tj - tap * tilesJ) * BJ;
+    const int i0 = ti * BI;
+    const int z = bz;
+    const __bf16* __restrict__ dY = reinterpret_cast<const __bf16*>(d.dY16) + batch_off(z, d.batch_inner, d.sY, d.sY2);
+    const __bf16* __restrict__ X = reinterpret_cast<const __bf16*>(d.X16) + batch_off(z, d.batch_inner, d.sX, d.sX2);
+    float* __restrict__ dW = d.dW + batch_off(z, d.batch_inner, d.sW, d.sW2);
+    const int nkt_all = (d.P + BKF - 1) / BKF;
+    const int kt_begin = by * kt_per_slice;
+    const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
+    if (kt_begin >= kt_end) return;
+
+    const int kr = tid >> 3, c8 = (tid & 7) * 8;
+    const bool dense = d.g.mode == CDETR_ROWS_DENSE;
+    const int ky = dense ? 0 : tap / d.g.kw, kx = dense ? 0 : tap - (tap / d.g.kw) * d.g.kw;
+    int p = kt_begin * BKF + kr;
+    int pn = 0, py = 0, px = 0;
+    if (!dense) {
+        const int hw = d.g.Hc * d.g.Wc;
+        pn = p / hw;
+        const int rem = p - pn * hw;
+        py = rem / d.g.Wc;
+        px = rem - py * d.g.Wc;
+    }
+    // two register sets = two pixel tiles in flight; unconditional clamped loads + validity bits
+    u32x4 ra[2][A_SLOTS], rb[2][B_SLOTS];
+    unsigned rf[2] = {0, 0};
+    int acol[A_SLOTS], bcol[B_SLOTS];
+    const int nk = kt_end - kt_begin;
+    int ft = 0;
+#pragma unroll
+    for (int s = 0; s < A_SLOTS; ++s) acol[s] = min(i0 + 64 * s + c8, d.Nout - 8);
+#pragma unroll
+    for (int s = 0; s < B_SLOTS; ++s) bcol[s] = min(c0 + 64 * s + c8, d.Cin - 8);
+    auto fetch = [&](u32x4 (&qa)[A_SLOTS], u32x4 (&qb)[B_SLOTS], unsigned& qf) __attribute__((always_inline)) {
+        const bool pv = p < d.P;
+        const __bf16* yp = dY + (long)(pv ? p : d.P - 1) * d.ldy;
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) qa[s] = ld16(yp + acol[s]);
+        long row = -1;
+        if (pv) {
+            if (dense) row = p;
+            else {
+                const int iy = py * d.g.stride - d.g.pad + ky * d.g.dil;
+                const int ix = px * d.g.stride - d.g.pad + kx * d.g.dil;
+                if (iy >= 0 && iy < d.g.Ha && ix >= 0 && ix < d.g.Wa) row = ((long)pn * d.g.Ha + iy) * d.g.Wa + ix;
+            }
+        }
+        qf = ((pv && ft < nk) ? 1u : 0u) | (row >= 0 ? 2u : 0u);
+        ++ft;
+        const __bf16* xp = X + (row >= 0 ? row : 0) * d.ldx;
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) qb[s] = ld16(xp + bcol[s]);
+        p += BKF;
+        if (!dense) {
+            px += BKF;
+            while (px >= d.g.Wc) { px -= d.g.Wc; ++py; }
+            while (py >= d.g.Hc) { py -= d.g.Hc; ++pn; }
+        }
+    };
+    __bf16* const wbase = Zs + (c8 >> 5) * BLK + kr * 32 + (c8 & 31);
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    auto stash = [&](const u32x4 (&qa)[A_SLOTS], const u32x4 (&qb)[B_SLOTS], unsigned qf, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < A_SLOTS; ++s) *reinterpret_cast<u32x4*>(wbase + buf * BUF + 2 * s * BLK) = (qf & 1u) ? qa[s] : z4;
+#pragma unroll
+        for (int s = 0; s < B_SLOTS; ++s) *reinterpret_cast<u32x4*>(wbase + buf * BUF + PLANE_A + 2 * s * BLK) = (qf & 2u) ? qb[s] : z4;
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int l16 = lane & 15;
+    const int roff = ((g * 8 + (l16 >> 2)) * 32) + ((lane >> 4) & 1) * 16 + (l16 & 3) * 4;
+    const __bf16* const abase = Zs + (wm * FM) * BLK + roff;
+    const __bf16* const bbase = Zs + PLANE_A + (wn * FN) * BLK + roff;
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const __bf16* as = abase + buf * BUF;
+        const __bf16* bs = bbase + buf * BUF;
+#pragma unroll
+        for (int hp = 0; hp < 2; ++hp) {
+            bf16x8 ah[FM], bh[FN];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) ah[a] = lds_tr8(as + a * BLK + hp * 512, as + a * BLK + hp * 512 + 128);
+#pragma unroll
+            for (int b = 0; b < FN; ++b) bh[b] = lds_tr8(bs + b * BLK + hp * 512, bs + b * BLK + hp * 512 + 128);
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int b = 0; b < FN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    fetch(ra[0], rb[0], rf[0]);
+    fetch(ra[1], rb[1], rf[1]);
+    stash(ra[0], rb[0], rf[0], 0);
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        fetch(ra[0], rb[0], rf[0]);            // tile kt+2
+        compute(0);
+        stash(ra[1], rb[1], rf[1], 1);
+        __syncthreads();
+        fetch(ra[1], rb[1], rf[1]);            // tile kt+3
+        compute(1);
+        stash(ra[0], rb[0], rf[0], 0);
+        __syncthreads();
+    }
+    if (kt < nk) compute(0);
+
+    mfma_drain(acc);
+#pragma unroll
+    for (int a = 0; a < FM; ++a) {
+#pragma unroll
+        for (int b = 0; b < FN; ++b) {
+            const int c = c0 + wn * (BJ / 2) + b * 32 + i32;
+            if (c >= d.Cin) continue;
+            float ws[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ws[r] = 1.f;
+            if (d.w_scale) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ws[r] = d.w_scale[min(i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g, d.Nout - 1)];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + wm * (BI / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+                if (i >= d.Nout) continue;
+                float v = acc[a][b][r] * ws[r];
+                float* dst = dW + (long)i * d.ldw + (long)tap * d.Cin + c;
+                if (single) *dst += v;
+                else atomicAdd(dst, v);
+            }
+        }
+    }
+}
+
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_tr16_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ, const int kt_per_slice) {
+    wgrad_tr16_body<BI, BJ>(d, tilesI, tilesJ, kt_per_slice, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
+}
+
 // XCD-aware slice placement (ny % 8 == 0, 1-D grid of nx * ny workgroups per batch item): workgroup b runs on XCD b % 8 (private
 // 4 MiB L2 each), and XCD x is given the pixel slices x, x + 8, ... -- every output tile of one slice back to back.  All tiles of a
 // slice read the SAME pixel rows of dY and X (a few hundred KB), so those rows come from HBM / MALL once per slice and are L2 hits for the
@@ -1339,6 +1518,18 @@ __global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const WgradGroupArg
     wgrad_tr_body<BI, BJ, TERMS>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, bx, by, z, false);
 }
 
+template <int BI, int BJ>
+__global__ __launch_bounds__(256) void wgrad_tr16_group_kernel(const WgradGroupArgs g) {
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
+    const WgradGroupItem& it = g.it[p];
+    const int lb = blockIdx.x - g.blk0[p];
+    const int per_z = it.nx * it.ny;
+    const int z = lb / per_z, l = lb - z * per_z;
+    if (z >= it.d.batch) return;
+    wgrad_tr16_body<BI, BJ>(it.d, it.tilesI, it.tilesJ, it.per, l % it.nx, l / it.nx, z, false);
+}
+
 // ------------------------------------------------------------------------------------------------ direct small GEMMs
 // Latency-optimised path for the ~450 small contractions per step (decoder M = B*Q = 600 rows, positional MLPs,
 // per-head dq/dk of RCDA): one wave = one 16x16 output tile on v_mfma_f32_16x16x4_f32, operands loaded straight from
@@ -1359,6 +1550,7 @@ __device__ __forceinline__ void igemm_direct_body(const cdetr_gemm_desc& d, cons
     const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
     const float* __restrict__ B = d.B + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
+    __bf16* __restrict__ C16 = d.C16 ? reinterpret_cast<__bf16*>(d.C16) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // bf16 twin of C
     const int K = d.K;
     const int kchunks = (K + 15) >> 4;
     const int cpw = (kchunks + 3) >> 2;                 // chunks per wave
@@ -1450,6 +1642,7 @@ __device__ __forceinline__ void igemm_direct_body(const cdetr_gemm_desc& d, cons
         v = gv[r] > 0.f ? v : 0.f;
         if (d.relu) v = fmaxf(v, 0.f);
         C[(long)mo * d.ldc + no] = v;
+        if (C16) C16[(long)mo * d.ldc + no] = (__bf16)v;
     }
 }
 
@@ -1857,6 +2050,12 @@ bool wgrad_is_direct(const cdetr_wgrad_desc& d) {
     static const int maxp = getenv("CDETR_WGRAD_DIRECT_MAXP") ? atoi(getenv("CDETR_WGRAD_DIRECT_MAXP")) : 256;
     return d.g.mode == CDETR_ROWS_DENSE && (d.P <= maxp || !((d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0)) && d.P <= 1024;
 }
+// bf16 twins usable (wgrad_tr16_kernel): plain-bf16 products requested, both twins given, 8-element granularity everywhere
+bool wgrad_has_twins(const cdetr_wgrad_desc& d) {
+    static const int on = getenv("CDETR_WGRAD_TWINS") ? atoi(getenv("CDETR_WGRAD_TWINS")) : 1;
+    return on && d.precision == 3 && d.dY16 && d.X16 && !d.dbias && (d.Nout & 7) == 0 && (d.Cin & 7) == 0 && (d.ldy & 7) == 0 && (d.ldx & 7) == 0 &&
+           (d.sY & 7) == 0 && (d.sX & 7) == 0 && (d.sY2 & 7) == 0 && (d.sX2 & 7) == 0 && aligned16(d.dY16) && aligned16(d.X16) && d.Nout >= 8 && d.Cin >= 8;
+}
 bool wgrad_is_fast(const cdetr_wgrad_desc& d) { return (d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0; }
 }  // namespace
 
@@ -1904,7 +2103,11 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
             if (xcd) grid = dim3((unsigned)(nx_xcd * slices), 1, d.batch);
             // split-bf16: the LDS transpose-read kernel (wgrad_tr_kernel); fp32 MFMA: wgrad_fast_kernel
-            if (d.precision >= 1) {
+            if (wgrad_has_twins(d) && !xcd) {
+                const int tbytes = 2 * ((BI + BJ) / 32) * (32 * 32 + 32) * 2;   // two buffers of hi planes (padded blocks)
+                if ((rcf = raise_lds(wgrad_tr16_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
+                hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per);
+            } else if (d.precision >= 1) {
                 const int tbytes = 2 * 2 * (BI + BJ) * 32 * 2;
                 if (d.precision == 2) {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ, 2>, tbytes, "cdetr_wgrad"))) return;
@@ -1988,7 +2191,7 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     static const int grouping = getenv("CDETR_WGRAD_GROUP") ? atoi(getenv("CDETR_WGRAD_GROUP")) : 1;
     const bool forced = getenv("CDETR_WGRAD_VARIANT") && atoi(getenv("CDETR_WGRAD_VARIANT")) != 0;
-    std::vector<int> direct, tr64;
+    std::vector<int> direct, tr64p, tr64t;                    // tr64t: the same class with bf16 twins (wgrad_tr16_group_kernel)
     for (int i = 0; i < n; ++i) {
         const cdetr_wgrad_desc& d = descs[i];
         if (int rcv = check_wgrad_desc(d)) return rcv;
@@ -1996,7 +2199,7 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
         if (grouping && wgrad_is_direct(d)) direct.push_back(i);
         else if (grouping && wgrad_is_fast(d) && d.precision >= 1 && !forced &&
                  !(d.taps > 1 && d.Nout >= 512 && d.Cin >= 512) && !(d.taps == 1 && (long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128))
-            tr64.push_back(i);                               // = the shapes cdetr_wgrad gives to wgrad_tr_kernel<64, 64>
+            (wgrad_has_twins(d) ? tr64t : tr64p).push_back(i);      // = the shapes cdetr_wgrad gives to wgrad_tr_kernel<64, 64>
         else if (int rc1 = cdetr_wgrad(&d, stream)) return rc1;
     }
     for (size_t c0 = 0; c0 < direct.size(); c0 += WG_MAX) {
@@ -2015,6 +2218,8 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
         hipLaunchKernelGGL(wgrad_direct_group_kernel, dim3(g.blk0[m]), dim3(256), 0, st, g);
         if (int rcl = cdetr_launch_status("cdetr_wgrad_group")) return rcl;
     }
+    for (int twins = 0; twins < 2; ++twins) {
+    const std::vector<int>& tr64 = twins ? tr64t : tr64p;
     for (size_t c0 = 0; c0 < tr64.size(); c0 += WG_MAX) {
         const int m = (int)std::min<size_t>(WG_MAX, tr64.size() - c0);
         if (m == 1) { if (int rc1 = cdetr_wgrad(&descs[tr64[c0]], stream)) return rc1; continue; }
@@ -2045,10 +2250,12 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
         }
         // one precision per grouped launch: the group's members come from one backward pass, the first member decides
         const int gprec = g.it[0].d.precision;
-        if (gprec == 2) hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64, 2>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
+        if (twins) hipLaunchKernelGGL((wgrad_tr16_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 4 * (32 * 32 + 32) * 2, st, g);
+        else if (gprec == 2) hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64, 2>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
         else if (gprec == 3) hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64, 1>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
         else hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
         if (int rcl = cdetr_launch_status("cdetr_wgrad_group")) return rcl;
+    }
     }
     return CDETR_OK;
 }

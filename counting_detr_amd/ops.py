@@ -60,8 +60,9 @@ def _geom(mode=_ffi.ROWS_DENSE, Ha=0, Wa=0, Hc=0, Wc=0, kh=1, kw=1, stride=1, pa
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
-             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None):
+             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None):
     d = GemmDesc()
+    d.C16 = ptr(C16)
     d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION if precision is None else precision
@@ -75,7 +76,7 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
     d.g = geom if geom is not None else _geom()
     if _GEMM_QUEUE is not None:       # inside gemm_queue(): submitted together by its exit (cdetr_gemm_group)
         _GEMM_QUEUE.append((d, 2.0 * M * N * K * taps * batch, 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
-                            (A, B, Cout, bias, w_scale, resid, gate, B_split)))
+                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16)))
         return
     # compulsory fp32 bytes: input rows once (a strided / dilated conv reads <= M*K of them), weights, output
     with _Timed("igemm", 2.0 * M * N * K * taps * batch, (M, N, K, taps, b_layout, batch), 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1)):
@@ -108,8 +109,10 @@ class gemm_queue:
 
 
 def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0,
-              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False):
+              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False, dY16=None, X16=None):
+    """dY16 / X16: optional bf16 twins of dY / X (same shape and strides in elements): the plain-bf16 kernel reads them instead."""
     d = WgradDesc()
+    d.dY16, d.X16 = ptr(dY16), ptr(X16)
     d.batch_inner, d.sY2, d.sX2, d.sW2 = batch_inner, sY2, sX2, sW2
     d.P, d.Nout, d.Cin, d.taps, d.batch = P, Nout, Cin, taps, batch
     d.precision = bwd_precision()
@@ -120,7 +123,7 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
     d.dbias = ptr(dbias)
     d.g = geom if geom is not None else _geom()
     if may_defer and _WG_QUEUE is not None:       # inside wgrad_queue(): submitted together by its exit (cdetr_wgrad_group)
-        _WG_QUEUE.append((d, 2.0 * P * Nout * Cin * taps * batch, (dY, X, dW, w_scale, dbias), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1)))
+        _WG_QUEUE.append((d, 2.0 * P * Nout * Cin * taps * batch, (dY, X, dW, w_scale, dbias, dY16, X16), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1)))
         return
     # compulsory bytes: dY and X once, dW read + written (accumulation into the gradient arena)
     with _Timed("wgrad", 2.0 * P * Nout * Cin * taps * batch, (P, Nout, Cin, taps, -1, batch), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1)):
@@ -167,12 +170,22 @@ def colsum_(X2d, out):
     check(lib().cdetr_colsum(ptr(X2d), X2d.stride(0), M, N, ptr(out), stream_ptr()), "cdetr_colsum")
 
 
-def relu_mask(y, dy, scale=1.0):
-    """dz = (y > 0) ? dy * scale : 0 in one pass."""
+def relu_mask(y, dy, scale=1.0, twin=False):
+    """dz = (y > 0) ? dy * scale : 0 in one pass; twin: -> (dz, bf16 copy of dz) from the same pass."""
     dy = dy.contiguous()
     dz = torch.empty_like(dy)
+    if twin:
+        dz16 = torch.empty(dy.shape, device=dy.device, dtype=torch.bfloat16)
+        check(lib().cdetr_relu_mask2(ptr(y), ptr(dy), ptr(dz), ptr(dz16), dy.numel(), scale, stream_ptr()), "cdetr_relu_mask2")
+        return dz, dz16
     check(lib().cdetr_relu_mask(ptr(y), ptr(dy), ptr(dz), dy.numel(), scale, stream_ptr()), "cdetr_relu_mask")
     return dz
+
+
+def bf16_twins():
+    """Whether the producers of the backbone's backward should write bf16 twins of their outputs: the plain-bf16 weight gradients read
+    them instead of the fp32 tensors (half the operand bytes, no conversion at staging; `wgrad_tr16_kernel`)."""
+    return TWINS and bwd_precision() == 3
 
 
 def grad_buffer(p):
@@ -577,39 +590,50 @@ def conv_geom_fwd(Hin, Win, kh, kw, stride, pad, dil):
     return g, Hout, Wout
 
 
-def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None):
+TWINS = os.environ.get("CDETR_TWINS", "1") != "0"
+
+
+def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False):
     """x [N,H,W,Cin] NHWC -> [N,Ho,Wo,Cout]; weight logical [Cout,Cin,kh,kw] in channels_last memory.
-    y = relu?( conv(x, W) * scale[c] + bias[c] + resid )   (A2/models/resnet.py:140-160 + backbone.py:50-60)."""
+    y = relu?( conv(x, W) * scale[c] + bias[c] + resid )   (A2/models/resnet.py:140-160 + backbone.py:50-60).
+    twin: -> (y, bf16 copy of y written by the same epilogue)."""
     Nb, H, W, Cin = x.shape
     Cout, Cin_w, kh, kw = weight.shape
     assert Cin_w == Cin and x.is_contiguous()
     g, Ho, Wo = conv_geom_fwd(H, W, kh, kw, stride, pad, dil)
     y = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    y16 = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if twin else None
     sp = MIRROR.lookup_fwd(weight, scale) if MIRROR is not None else None
     gemm_raw(x, Cin, weight, kh * kw * Cin, y, Cout, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, bias=bias,
-             relu=relu, resid=resid, ldr=Cout, geom=g, B_split=sp)
-    return y
+             relu=relu, resid=resid, ldr=Cout, geom=g, B_split=sp, C16=y16)
+    return (y, y16) if twin else y
 
 
-def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None):
-    """dx [N,Hin,Win,Cin] = conv_transpose(dz * scale, W) (+ resid), zeroed where gate <= 0."""
+def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False):
+    """dx [N,Hin,Win,Cin] = conv_transpose(dz * scale, W) (+ resid), zeroed where gate <= 0.  twin: -> (dx, bf16 copy of dx)."""
     Nb, Ho, Wo, Cout = dz.shape
     Cout_w, Cin, kh, kw = weight.shape
     Hin, Win = in_hw
     dense = kh == 1 and kw == 1 and stride == 1 and pad == 0
     g = _geom() if dense else _geom(_ffi.ROWS_CONV_DGRAD, Ho, Wo, Hin, Win, kh, kw, stride, pad, dil)
     dx = torch.empty((Nb, Hin, Win, Cin), device=dz.device, dtype=torch.float32)
+    dx16 = torch.empty((Nb, Hin, Win, Cin), device=dz.device, dtype=torch.bfloat16) if twin else None
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
-                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], precision=bwd_precision())
-        return dx
-    gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
-             gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, precision=bwd_precision())
-    return dx
+                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], precision=bwd_precision(), C16=dx16)
+    else:
+        gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
+                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, precision=bwd_precision(), C16=dx16)
+    return (dx, dx16) if twin else dx
 
 
-def conv_wgrad_(dz, x, weight, scale, stride=1, pad=0, dil=1):
+TWIN_EXPERIMENT = os.environ.get("CDETR_TWIN_EXP", "0") == "1"      # tools only: bf16 twins made by tensor casts, to time the twin-fed kernel alone
+
+
+def conv_wgrad_(dz, x, weight, scale, stride=1, pad=0, dil=1, dz16=None, x16=None):
+    if TWIN_EXPERIMENT and dz16 is None and bwd_precision() == 3:
+        dz16, x16 = dz.to(torch.bfloat16), x.to(torch.bfloat16)
     Nb, Ho, Wo, Cout = dz.shape
     _, H, W, Cin = x.shape
     kh, kw = weight.shape[2:]
@@ -617,7 +641,8 @@ def conv_wgrad_(dz, x, weight, scale, stride=1, pad=0, dil=1):
     assert (Ho2, Wo2) == (Ho, Wo)
     gw = grad_buffer(weight)
     assert gw.is_contiguous(memory_format=torch.channels_last) or (kh == 1 and kw == 1)
-    wgrad_raw(dz, Cout, x, Cin, gw, kh * kw * Cin, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, geom=g, may_defer=True)
+    wgrad_raw(dz, Cout, x, Cin, gw, kh * kw * Cin, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, geom=g, may_defer=True,
+              dY16=dz16, X16=x16)
 
 
 def maxpool3x3s2(x):

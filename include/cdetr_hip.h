@@ -72,6 +72,8 @@ typedef struct {
     int32_t batch_inner; /* 0: batch item z sits at z*s.  > 0: z = outer*batch_inner + inner sits at inner*s + outer*s2      */
     int32_t pad_;        /* (e.g. heads inside images: one launch for the per-head GEMMs of every image)                  */
     int64_t sA2, sB2, sC2;
+    void* C16;           /* optional (NULL = absent): a bf16 TWIN of C written by the same epilogue (same ldc / batch strides, in
+                          * elements) -- the operand format of the plain-bf16 weight gradients (cdetr_wgrad_desc.dY16 / X16).      */
 } cdetr_gemm_desc;
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 /* n INDEPENDENT GEMMs submitted together (same results as n cdetr_gemm calls; no problem may read another's output).  Few-row
@@ -97,6 +99,9 @@ typedef struct {
     int32_t batch_inner; /* two-level batch, as in cdetr_gemm_desc */
     int32_t pad_;
     int64_t sY2, sX2, sW2;
+    const void* dY16;  /* optional bf16 TWINS of dY / X (same shapes, leading dimensions and batch strides, in elements): with        */
+    const void* X16;   /* precision 3 (plain bf16) the kernel reads these instead -- half the operand bytes, no conversion at staging. */
+                       /* Needs both, Nout / Cin / ldy / ldx multiples of 8, 16-byte aligned bases, no dbias; otherwise dY / X are read. */
 } cdetr_wgrad_desc;
 int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
 /* n INDEPENDENT weight-gradient problems submitted together (same semantics as n cdetr_wgrad calls in any order; problems may
@@ -134,6 +139,8 @@ int cdetr_adamw_step2(float* p, const float* g, float* m, float* v, const float*
                       float grad_div, void* stream);
 /* dz[i] = y[i] > 0 ? dy[i] * scale : 0      (ReLU backward of the fused linear+ReLU layers) */
 int cdetr_relu_mask(const float* y, const float* dy, float* dz, int64_t n, float scale, void* stream);
+/* the same, also writing a bf16 twin of dz (dz16 may be NULL) */
+int cdetr_relu_mask2(const float* y, const float* dy, float* dz, void* dz16, int64_t n, float scale, void* stream);
 
 /* ---- transformer-layer glue (HBM-bound, fused so a layer touches its activations as few times as possible) --------
  * cdetr_layernorm_fwd/bwd: nn.LayerNorm over the last dim C (multiple of 256, <= 1024); fwd saves mean/rstd per row;

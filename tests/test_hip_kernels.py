@@ -797,10 +797,10 @@ def test_sumsq_value_and_bit_reproducibility(n):
     assert abs(float(out[0]) - ref) <= 2e-6 * ref + 1e-30
 
 
-@pytest.mark.parametrize("bwd,lim", [(2, 3e-3), (3, 5e-3)])
+@pytest.mark.parametrize("bwd,lim,twins", [(2, 3e-3, False), (3, 5e-3, False), (3, 5e-3, True)])
 @pytest.mark.parametrize("Cin,Cout,k,stride,pad,dil,H,W", [(256, 256, 3, 1, 1, 1, 50, 50), (512, 2048, 1, 1, 0, 1, 50, 50), (128, 128, 3, 2, 1, 1, 100, 100),
-                                                        (512, 512, 3, 1, 2, 2, 50, 50)])
-def test_reduced_term_backward_kernels(Cin, Cout, k, stride, pad, dil, H, W, bwd, lim):
+                                                        (512, 512, 3, 1, 2, 2, 50, 50), (72, 40, 3, 1, 1, 1, 21, 19)])
+def test_reduced_term_backward_kernels(Cin, Cout, k, stride, pad, dil, H, W, bwd, lim, twins):
     """ops.PRECISION_BWD 2 ("bf16x2": weights / activations rounded to bf16, the incoming gradient split) and 3 (plain bf16): data
     and weight gradients of a convolution through the weight mirror vs fp64.  A product then carries a 2^-9 rounding; over a
     K-term sum the error stays below ~1e-3 of the result's scale (bar 2.5e-3); the forward is untouched (bf16x3, 2e-4)."""
@@ -822,7 +822,10 @@ def test_reduced_term_backward_kernels(Cin, Cout, k, stride, pad, dil, H, W, bwd
         y = ops.conv_fwd(xd, wd.data, scd, bd, stride=stride, pad=pad, dil=dil)
         gy = torch.randn(y.shape, generator=g(14)).to(DEV)
         dx = ops.conv_dgrad(gy, wd.data, scd, (H, W), stride=stride, pad=pad, dil=dil)
-        ops.conv_wgrad_(gy, xd, wd, scd, stride=stride, pad=pad, dil=dil)
+        if twins:       # the kernel fed from bf16 twins of both operands (what the producers' epilogues write next to the fp32 tensors)
+            ops.conv_wgrad_(gy, xd, wd, scd, stride=stride, pad=pad, dil=dil, dz16=gy.to(torch.bfloat16), x16=xd.to(torch.bfloat16))
+        else:
+            ops.conv_wgrad_(gy, xd, wd, scd, stride=stride, pad=pad, dil=dil)
         x64 = x.double().requires_grad_(True)
         w64 = w.double().requires_grad_(True)
         y64 = F.conv2d(x64, w64 * sc.double().view(-1, 1, 1, 1), None, stride, pad, dil)
