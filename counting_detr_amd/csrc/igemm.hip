@@ -82,6 +82,8 @@ __device__ __forceinline__ long gather_row(const cdetr_conv_geom& g, const RowCo
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // a native vector (stays in registers through a select, unlike the uint4 struct)
+__device__ __forceinline__ u32x4 ld16(const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
@@ -482,9 +484,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 // PREC: 0 = fp32 MFMA (exact), 1 = split-bf16 x3 with the split per fragment (the n-contiguous operand form), 2 = split once at staging,
 // 3 = as 2 with B arriving pre-split from HBM.  (Measured dead ends of round 1, no longer built: a 4-deep register ring -- 0-25 % slower
 // at two images per GPU --, a staging-time transpose of the n-contiguous operand, 128-wide tiles on 4 waves, 32x64 / 128x64 tiles.)
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3>
+// A16: the A operand is read from its bf16 TWIN (cdetr_gemm_desc.A16; plain-bf16 products only): one 16-byte load = 8 k-values per thread,
+// stored into the hi plane as it is -- half the operand bytes and no conversion at staging (the data-gradient chain of the backbone).
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3, bool A16 = false>
 __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const int tilesM, const int bx, const int bz) {
     constexpr int PD = 2;                    // k-tiles in flight in registers
+    static_assert(!A16 || (TERMS == 1 && BL == 0), "the bf16 twin of A feeds the plain-bf16 products");
     static_assert(TERMS == 3 || ((PREC == 2 || PREC == 3) && BL == 0), "reduced-term products exist for the staging-split k-contiguous forms");
     static_assert(BL == 0 || PREC <= 1, "the n-contiguous operand has no staging-split form");
     constexpr int NT = 64 * WM * WN;
@@ -495,7 +500,10 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     // B rows per staging pass: normally every thread takes part (RPP rows); when the thread count does not divide BN (the 12-wave
     // 96x128 tile) only the first 64 * F4R threads stage B, 64 rows per pass -- the others re-read rows they do not keep
     constexpr int RPPB = (BN % RPP == 0) ? RPP : 64;
-    constexpr int A_SLOTS = BM / RPP, B_SLOTS = (BL == 0) ? BN / RPPB : BKF * BN / (4 * NT);
+    constexpr int CHA = A16 ? BKF / 8 : F4R;    // 16-byte chunks per A row
+    constexpr int RPPA = NT / CHA;              // A rows covered by one pass of the workgroup's threads
+    constexpr int A_SLOTS = (BM + RPPA - 1) / RPPA, B_SLOTS = (BL == 0) ? BN / RPPB : BKF * BN / (4 * NT);
+    static_assert(BM % RPPA == 0 || RPPA > BM, "A tile / thread mapping");
     constexpr int LDN = BN + 4;
     constexpr int A_TILE = BM * LDK;
     // PREC >= 2: the tile is split into bf16 hi / lo ONCE while it is staged; an LDS row holds [hi k0..BKF-1 | lo k0..BKF-1 | pad]
@@ -503,7 +511,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     constexpr bool SPL = (PREC == 2 || PREC == 3);     // operands live in LDS as bf16 hi / lo planes
     constexpr bool BRAW = (PREC == 3);                  // B arrives pre-split from HBM (cdetr_gemm_desc.B_split): staged by a plain copy
     constexpr int B_TILE = (BL == 0) ? BN * LDK : BKF * LDN;
-    static_assert(BM % RPP == 0 && (BL != 0 || BN % RPPB == 0) && (BL == 0 || (BKF * BN) % (4 * NT) == 0), "tile / thread mapping");
+    static_assert((A16 || BM % RPP == 0) && (BL != 0 || BN % RPPB == 0) && (BL == 0 || (BKF * BN) % (4 * NT) == 0), "tile / thread mapping");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
     float* Bs = smem + 2 * A_TILE;
@@ -522,7 +530,9 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     if (tm >= tilesM) return;
     const int m0 = tm * BM, n0 = tn * BN;
     const int z = bz;
-    const float* __restrict__ A = d.A + batch_off(z, d.batch_inner, d.sA, d.sA2);
+    using AElem = typename std::conditional<A16, __bf16, float>::type;
+    using AVec = typename std::conditional<A16, u32x4, float4>::type;
+    const AElem* __restrict__ A = (A16 ? reinterpret_cast<const AElem*>(d.A16) : reinterpret_cast<const AElem*>(d.A)) + batch_off(z, d.batch_inner, d.sA, d.sA2);
     const float* __restrict__ B = (BRAW ? reinterpret_cast<const float*>(d.B_split) : d.B) + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
     __bf16* __restrict__ C16 = d.C16 ? reinterpret_cast<__bf16*>(d.C16) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // bf16 twin of C
@@ -530,6 +540,8 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     const int nkt = (K / BKF) * taps;
 
     const int kq = tid % F4R, r8 = tid / F4R;
+    const int kqa = tid % CHA, r8a = tid / CHA;          // the A operand's own mapping (== kq, r8 unless A16)
+    const bool a_on = (RPPA <= BM) || r8a < BM;
     const int r8b = (RPPB == RPP) ? r8 : r8 % RPPB;
     const bool b_on = (RPPB == RPP) || r8 < RPPB;
     // Every global load of the pipeline is UNCONDITIONAL: a predicated load sits in its own basic block, the compiler then
@@ -537,16 +549,16 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     // in flight (measured: ~1.2 us per k-tile).  Rows that do not exist (conv padding, m >= M, n >= N) are redirected to
     // row 0 / the last row; padding rows are zeroed when they are staged (amask), the others are never stored.
     RowCoord arow[A_SLOTS];
-    const float* ap[A_SLOTS];
+    const AElem* ap[A_SLOTS];
     unsigned amask = 0;            // bit i: slot i of the tap being fetched is a real row
 #pragma unroll
-    for (int i = 0; i < A_SLOTS; ++i) arow[i] = decode_row(d.g, m0 + r8 + RPP * i, d.M);
+    for (int i = 0; i < A_SLOTS; ++i) arow[i] = decode_row(d.g, m0 + r8a + RPPA * i, d.M);
     auto set_tap = [&](int tap) {
         amask = 0;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const long row = gather_row(d.g, arow[i], tap);
-            ap[i] = A + (row >= 0 ? row : 0) * d.lda + kq * 4;
+            ap[i] = A + (row >= 0 ? row : 0) * d.lda + kqa * (A16 ? 8 : 4);
             amask |= (row >= 0 ? 1u : 0u) << i;
         }
     };
@@ -562,13 +574,16 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
     // register sets for the two k-tiles in flight.  Fetches are RAW loads (nothing in fetch() consumes a loaded value, so
     // no s_waitcnt lands between issuing a tile and computing on the previous one); scaling / splitting happens in stash().
-    float4 ra[PD][A_SLOTS];
+    AVec ra[PD][A_SLOTS];
     unsigned rm[PD];                           // amask of each register set
     float4 rb[PD][B_SLOTS];
-    auto fetch = [&](float4 (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], unsigned& qm, int tap, int kc) __attribute__((always_inline)) {
+    auto fetch = [&](AVec (&qa)[A_SLOTS], float4 (&qb)[B_SLOTS], unsigned& qm, int tap, int kc) __attribute__((always_inline)) {
         qm = amask;
 #pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) qa[i] = ld4(ap[i] + kc);
+        for (int i = 0; i < A_SLOTS; ++i) {
+            if constexpr (A16) qa[i] = ld16(ap[i] + kc);
+            else qa[i] = ld4(ap[i] + kc);
+        }
         if constexpr (BL == 0) {
             const int koff = tap * K + kc;
 #pragma unroll
@@ -590,17 +605,27 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
             }
         }
     };
-    auto stash = [&](const float4 (&qa0)[A_SLOTS], const float4 (&qb)[B_SLOTS], unsigned qm, int buf) __attribute__((always_inline)) {
+    auto stash = [&](const AVec (&qa0)[A_SLOTS], const float4 (&qb)[B_SLOTS], unsigned qm, int buf) __attribute__((always_inline)) {
         float* as = As + buf * A_TILE;
         float* bs = Bs + buf * B_TILE;
-        float4 qa[A_SLOTS];
+        AVec qa[A_SLOTS];
 #pragma unroll
-        for (int i = 0; i < A_SLOTS; ++i) qa[i] = ((qm >> i) & 1u) ? qa0[i] : zero4();
+        for (int i = 0; i < A_SLOTS; ++i) {
+            if constexpr (A16) { const u32x4 z4 = {0u, 0u, 0u, 0u}; qa[i] = ((qm >> i) & 1u) ? qa0[i] : z4; }
+            else qa[i] = ((qm >> i) & 1u) ? qa0[i] : zero4();
+        }
+        if constexpr (A16) {
+#pragma unroll
+            for (int i = 0; i < A_SLOTS; ++i)
+                if (a_on) *reinterpret_cast<u32x4*>(reinterpret_cast<__bf16*>(as + (r8a + RPPA * i) * LDK) + KPOS(kqa * 8)) = qa[i];
+        }
         if constexpr (SPL) {
+            if constexpr (!A16) {
 #pragma unroll
             for (int i = 0; i < A_SLOTS; ++i) {
                 if constexpr (TERMS == 1) stash_hi4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + KPOS(kq * 4), qa[i].x, qa[i].y, qa[i].z, qa[i].w);
                 else stash_split4(reinterpret_cast<__bf16*>(as + (r8 + RPP * i) * LDK) + KPOS(kq * 4), 32, qa[i].x, qa[i].y, qa[i].z, qa[i].w);
+            }
             }
             if constexpr (BRAW) {
 #pragma unroll
@@ -613,7 +638,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
                     if (b_on) stash_split4(reinterpret_cast<__bf16*>(bs + (r8b + RPPB * i) * LDK) + KPOS(kq * 4), 32, qb[i].x * s, qb[i].y * s, qb[i].z * s, qb[i].w * s);
                 }
             }
-        } else {
+        } else if constexpr (!A16) {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) *reinterpret_cast<float4*>(as + (r8 + RPP * i) * LDK + kq * 4) = qa[i];
         if constexpr (BL == 0) {
@@ -834,9 +859,9 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
 }
 
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3>
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3, bool A16 = false>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
-    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, TERMS>(d, tilesM, blockIdx.x, blockIdx.z);
+    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, TERMS, A16>(d, tilesM, blockIdx.x, blockIdx.z);
 }
 
 // Grouped launch of up to GG_MAX independent GEMMs of one kernel class (same idea as WgradGroupArgs below): the problems'
@@ -1301,8 +1326,7 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
 // activation / activation gradient a plain-bf16 weight gradient consumes).  Half the L2 -> register bytes per k-tile (one 16-byte load =
 // 8 channels per thread and operand instead of two 4-channel loads), no conversion at staging (the 16 bytes go straight into the
 // [32-channel block][pixel][32] plane with one ds_write_b128), hi planes only.  Plain bf16 products (TERMS 1) by construction.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // a native vector: stays in registers through the select below
-__device__ __forceinline__ u32x4 ld16(const __bf16* p) { return *reinterpret_cast<const u32x4*>(p); }
+
 
 template <int BI, int BJ>
 __device__ __forceinline__ void wgrad_tr16_body(const cdetr_wgrad_desc& d, const int tilesI, const int tilesJ, const int kt_per_slice,
@@ -1805,6 +1829,12 @@ int raise_lds(F func, int bytes, const char* what) {
     return CDETR_OK;
 }
 
+// bf16 twin of A usable: given, 8-element granularity of every row / batch stride (16-byte loads of 8 k-values)
+inline bool gemm_has_a_twin(const cdetr_gemm_desc& d) {
+    static const int on = getenv("CDETR_GEMM_A16") ? atoi(getenv("CDETR_GEMM_A16")) : 1;
+    return on && d.A16 && (d.lda & 7) == 0 && (d.sA & 7) == 0 && (d.sA2 & 7) == 0 && (reinterpret_cast<uintptr_t>(d.A16) & 15) == 0;
+}
+
 template <int WM, int WN, int FM, int FN, int BKF, int PREC>
 int launch_gemm_fast_pd(const cdetr_gemm_desc& d, hipStream_t st) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
@@ -1816,6 +1846,9 @@ int launch_gemm_fast_pd(const cdetr_gemm_desc& d, hipStream_t st) {
         if (d.precision == 2) {          // bf16x2: B rounded to bf16
             if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 2>, bytes, "cdetr_gemm"))) return rc;
             hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 2>), grid, block, bytes, st, d, tilesM);
+        } else if (d.precision == 3 && gemm_has_a_twin(d)) {   // plain bf16, A read from its bf16 twin
+            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1, true>, bytes, "cdetr_gemm"))) return rc;
+            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1, true>), grid, block, bytes, st, d, tilesM);
         } else if (d.precision == 3) {   // plain bf16
             if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1>, bytes, "cdetr_gemm"))) return rc;
             hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1>), grid, block, bytes, st, d, tilesM);

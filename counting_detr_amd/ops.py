@@ -60,9 +60,9 @@ def _geom(mode=_ffi.ROWS_DENSE, Ha=0, Wa=0, Hc=0, Wc=0, kh=1, kw=1, stride=1, pa
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
-             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None):
+             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None):
     d = GemmDesc()
-    d.C16 = ptr(C16)
+    d.C16, d.A16 = ptr(C16), ptr(A16)
     d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION if precision is None else precision
@@ -76,7 +76,7 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
     d.g = geom if geom is not None else _geom()
     if _GEMM_QUEUE is not None:       # inside gemm_queue(): submitted together by its exit (cdetr_gemm_group)
         _GEMM_QUEUE.append((d, 2.0 * M * N * K * taps * batch, 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
-                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16)))
+                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16)))
         return
     # compulsory fp32 bytes: input rows once (a strided / dilated conv reads <= M*K of them), weights, output
     with _Timed("igemm", 2.0 * M * N * K * taps * batch, (M, N, K, taps, b_layout, batch), 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1)):
@@ -609,8 +609,9 @@ def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=N
     return (y, y16) if twin else y
 
 
-def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False):
-    """dx [N,Hin,Win,Cin] = conv_transpose(dz * scale, W) (+ resid), zeroed where gate <= 0.  twin: -> (dx, bf16 copy of dx)."""
+def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False, dz16=None):
+    """dx [N,Hin,Win,Cin] = conv_transpose(dz * scale, W) (+ resid), zeroed where gate <= 0.  twin: -> (dx, bf16 copy of dx);
+    dz16: the bf16 twin of dz (read instead of dz by the plain-bf16 tile kernels)."""
     Nb, Ho, Wo, Cout = dz.shape
     Cout_w, Cin, kh, kw = weight.shape
     Hin, Win = in_hw
@@ -621,7 +622,7 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
-                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], precision=bwd_precision(), C16=dx16)
+                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], precision=bwd_precision(), C16=dx16, A16=dz16)
     else:
         gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
                  gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, precision=bwd_precision(), C16=dx16)

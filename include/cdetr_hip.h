@@ -72,6 +72,9 @@ typedef struct {
     int32_t batch_inner; /* 0: batch item z sits at z*s.  > 0: z = outer*batch_inner + inner sits at inner*s + outer*s2      */
     int32_t pad_;        /* (e.g. heads inside images: one launch for the per-head GEMMs of every image)                  */
     int64_t sA2, sB2, sC2;
+    const void* A16;     /* optional: a bf16 TWIN of A (same lda / batch strides, in elements): with precision 3 the tile kernels read it
+                          * instead of A -- half the operand bytes, no conversion at staging.  Needs lda and the strides to be multiples
+                          * of 8 and a 16-byte aligned base; other kernel classes read A.                                             */
     void* C16;           /* optional (NULL = absent): a bf16 TWIN of C written by the same epilogue (same ldc / batch strides, in
                           * elements) -- the operand format of the plain-bf16 weight gradients (cdetr_wgrad_desc.dY16 / X16).      */
 } cdetr_gemm_desc;

@@ -821,7 +821,7 @@ def test_reduced_term_backward_kernels(Cin, Cout, k, stride, pad, dil, H, W, bwd
         ops.MIRROR = mirror
         y = ops.conv_fwd(xd, wd.data, scd, bd, stride=stride, pad=pad, dil=dil)
         gy = torch.randn(y.shape, generator=g(14)).to(DEV)
-        dx = ops.conv_dgrad(gy, wd.data, scd, (H, W), stride=stride, pad=pad, dil=dil)
+        dx = ops.conv_dgrad(gy, wd.data, scd, (H, W), stride=stride, pad=pad, dil=dil, dz16=gy.to(torch.bfloat16) if twins else None)
         if twins:       # the kernel fed from bf16 twins of both operands (what the producers' epilogues write next to the fp32 tensors)
             ops.conv_wgrad_(gy, xd, wd, scd, stride=stride, pad=pad, dil=dil, dz16=gy.to(torch.bfloat16), x16=xd.to(torch.bfloat16))
         else:
