@@ -98,6 +98,13 @@ __device__ __forceinline__ f32x16 mfma_bf16x3(const bf16x8& ah, const bf16x8& al
     return acc;
 }
 
+// TERMS 3 = the split product above; 1 = plain bf16 (hi * hi only: the backward's arithmetic, ops.PRECISION_BWD 3)
+template <int TERMS>
+__device__ __forceinline__ f32x16 mfma_bf16_terms(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl, f32x16 acc) {
+    if constexpr (TERMS == 1) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    else return mfma_bf16x3(ah, al, bh, bl, acc);
+}
+
 // Wave-wide reductions on DPP lane permutes (quad_perm xor 1 / xor 2, row_half_mirror, row_mirror inside the rows of 16, row_bcast 15 /
 // 31 across them; lane 63 ends up with the total, v_readlane broadcasts it): ~6 VALU-latency steps instead of 6 ds_bpermute round
 // trips through the LDS pipe (a LayerNorm row does two reductions: they were most of its time).  The result is wave-uniform.

@@ -589,7 +589,8 @@ __host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW, bool w
     return s;
 }
 
-template <int NF, int NW, int PREC>
+// TERMS: bf16 MFMAs per product in the split-bf16 paths (3, or 1 = plain bf16: cdetr_rcda_bwd_desc.precision 3)
+template <int NF, int NW, int PREC, int TERMS = 3>
 __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
     constexpr int NT = 64 * NW, QB = QW * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -746,7 +747,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
                 for (int kp = 0; kp < 2; ++kp) {
                     const bf16x8 ah = *reinterpret_cast<const bf16x8*>(va + kp * 16);
                     const bf16x8 al = *reinterpret_cast<const bf16x8*>(va + 32 + kp * 16);
-                    gt = mfma_bf16x3(ah, al, dobh[kp], dobl[kp], gt);
+                    gt = mfma_bf16_terms<TERMS>(ah, al, dobh[kp], dobl[kp], gt);
                 }
             }
 #pragma unroll
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
                     bf16x8 ah, al, bh, bl;
                     split_bf16x8(a, ah, al);
                     split_bf16x8(b, bh, bl);
-                    acc = mfma_bf16x3(ah, al, bh, bl, acc);
+                    acc = mfma_bf16_terms<TERMS>(ah, al, bh, bl, acc);
                 }
                 mfma_drain(acc);
                 if (qvalid) {      // lane = query i32; register r = channel (r & 3) + 8 (r >> 2) + 4 g
@@ -909,7 +910,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
                             }
                             bf16x8 ah, al;
                             split_bf16x8(a, ah, al);
-                            acc = mfma_bf16x3(ah, al, bh[st], bl[st], acc);
+                            acc = mfma_bf16_terms<TERMS>(ah, al, bh[st], bl[st], acc);
                         }
                         mfma_drain(acc);
                         // accumulator: row = key 32 tl + (r & 3) + 8 (r >> 2) + 4 g, column = channel i32
@@ -1076,6 +1077,7 @@ __host__ __device__ inline Dv2Smem dv2_smem() {
     return s;
 }
 
+template <int TERMS = 3>
 __global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc d, const int q_per_slice) {
     constexpr int QT = 64, ARS = 136;                   // queries per tile; bf16 per A_row^T row
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1164,7 +1166,7 @@ __global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc
             for (int f = 0; f < 2; ++f) {
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(art + 32 * f * ARS + 16 * ks);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(art + 32 * f * ARS + 64 + 16 * ks);
-                acc[f] = mfma_bf16x3(ah, al, bh, bl, acc[f]);
+                acc[f] = mfma_bf16_terms<TERMS>(ah, al, bh, bl, acc[f]);
             }
         }
     };
@@ -1235,7 +1237,10 @@ int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st) {
     const int bytes = sm.total * 4;
     int rc;
     dim3 grid((d.L + QW * NW - 1) / (QW * NW), d.N * d.nh), block(64 * NW);
-    if (d.precision == 1) {
+    if (d.precision == 3) {          // plain-bf16 products (the backward's arithmetic)
+        if ((rc = set_smem(rcda_bwd_kernel<NF, NW, 1, 1>, bytes, "cdetr_rcda_bwd"))) return rc;
+        hipLaunchKernelGGL((rcda_bwd_kernel<NF, NW, 1, 1>), grid, block, bytes, st, d);
+    } else if (d.precision >= 1) {
         if ((rc = set_smem(rcda_bwd_kernel<NF, NW, 1>, bytes, "cdetr_rcda_bwd"))) return rc;
         hipLaunchKernelGGL((rcda_bwd_kernel<NF, NW, 1>), grid, block, bytes, st, d);
     } else {
@@ -1305,8 +1310,8 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     CDETR_CHECK_ARG((d.ds_row && d.ds_col) || (!d.ds_row && !d.ds_col && d.dk_row),
                     "cdetr_rcda_bwd: ds_row / ds_col may only be omitted (both) when the fused q / k gradients are requested");
     CDETR_CHECK_ARG(!d.dq_row || (d.dq_col && d.k_row && d.k_col), "cdetr_rcda_bwd: dq_row needs dq_col, k_row and k_col");
-    CDETR_CHECK_ARG(!d.dk_row || (d.dq_row && d.dk_col && d.q_row && d.q_col && d.precision == 1),
-                    "cdetr_rcda_bwd: dk_row needs dk_col, q_row, q_col, the dq_* outputs and precision 1");
+    CDETR_CHECK_ARG(!d.dk_row || (d.dq_row && d.dk_col && d.q_row && d.q_col && d.precision >= 1),
+                    "cdetr_rcda_bwd: dk_row needs dk_col, q_row, q_col, the dq_* outputs and a split-bf16 precision (1 or 3)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int NF = d.H <= 32 ? 1 : (d.H <= 64 ? 2 : 4);
     const int Wp = (d.W + 3) & ~3;
@@ -1323,7 +1328,7 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     else rc = nw == 4 ? launch_rcda_bwd<4, 4>(d, st) : launch_rcda_bwd<4, 2>(d, st);
     if (rc) return rc;
     static const int use_dv2 = getenv("CDETR_RCDA_DV2") ? atoi(getenv("CDETR_RCDA_DV2")) : 1;
-    if (use_dv2 && d.precision == 1 && d.W <= 64) {   // two-step dV (see rcda_dv2_kernel)
+    if (use_dv2 && d.precision >= 1 && d.W <= 64) {   // two-step dV (see rcda_dv2_kernel)
         const int bytes = dv2_smem().total * 4;
         const int hgroups = (d.H + 7) / 8;
         const long base = (long)hgroups * d.N * d.nh;
@@ -1335,8 +1340,13 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
         int per = (d.L + slices - 1) / slices;
         per = ((per + 63) / 64) * 64;
         slices = (d.L + per - 1) / per;
-        if ((rc = set_smem(rcda_dv2_kernel, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
-        hipLaunchKernelGGL(rcda_dv2_kernel, dim3(hgroups, d.N * d.nh, slices), dim3(512), bytes, st, d, per);
+        if (d.precision == 3) {
+            if ((rc = set_smem(rcda_dv2_kernel<1>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
+            hipLaunchKernelGGL(rcda_dv2_kernel<1>, dim3(hgroups, d.N * d.nh, slices), dim3(512), bytes, st, d, per);
+        } else {
+            if ((rc = set_smem(rcda_dv2_kernel<3>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
+            hipLaunchKernelGGL(rcda_dv2_kernel<3>, dim3(hgroups, d.N * d.nh, slices), dim3(512), bytes, st, d, per);
+        }
         return cdetr_launch_status("cdetr_rcda_bwd(dV)");
     }
     {   // dV kernel
@@ -1356,7 +1366,7 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
             hipLaunchKernelGGL(kern, grid, block, bytes, st, d, per);
         };
         rc = CDETR_OK;
-        if (d.precision == 1) {
+        if (d.precision >= 1) {
             if (NF == 1) dv(rcda_dv_kernel<1, 1>); else if (NF == 2) dv(rcda_dv_kernel<2, 1>); else dv(rcda_dv_kernel<4, 1>);
         } else {
             if (NF == 1) dv(rcda_dv_kernel<1, 0>); else if (NF == 2) dv(rcda_dv_kernel<2, 0>); else dv(rcda_dv_kernel<4, 0>);

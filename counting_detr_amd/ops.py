@@ -701,7 +701,7 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh, zbuf=No
     d_v = zbuf[:v.numel()].view(v.shape)
     d = RcdaBwdDesc()
     d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
-    d.precision = PRECISION
+    d.precision = (3 if bwd_precision() == 3 else 1) if PRECISION == 1 else PRECISION      # plain-bf16 products with the bf16 backward
     d.d_out, d.a_row, d.a_col, d.v = ptr(d_out), ptr(a_row), ptr(a_col), ptr(v)
     d.d_v = ptr(d_v)
     # logits -> projected query gradients: fused into the dS launch (the kernel still holds dS_row / dS_col in LDS)
