@@ -342,11 +342,12 @@ def main(argv=None):
     torch.cuda.synchronize()
     fam = {}
     shapes = {}
-    for family, flops, e0, e1, tag, nbytes in ops.PROFILE:
+    for family, flops, e0, e1, tag, nbytes, issued in ops.PROFILE:
         if tag is not None:
             sh = shapes.setdefault((family,) + tuple(tag), [0.0, 0.0, 0])
             sh[0] += flops; sh[1] += e0.elapsed_time(e1) * 1e-3; sh[2] += 1
-        f = fam.setdefault(family, [0.0, 0.0, 0, 0.0])
+        f = fam.setdefault(family, [0.0, 0.0, 0, 0.0, 0.0])
+        f[4] += issued
         f[0] += flops
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 1
@@ -370,22 +371,30 @@ def main(argv=None):
         if v[1] <= 0:
             continue
         tps = (tj or {}).get("families_bytes_per_step", {}).get(k)         # PMC bytes of the family per step (profiles/r2_traffic.json)
-        kern[k] = {"tflops": v[0] / v[1] / 1e12, "ms_per_step": v[1] / reps * 1e3, "launches_per_step": v[2] // reps,
+        kern[k] = {"tflops": v[0] / v[1] / 1e12, "mfma_issued_tflops": v[4] / v[1] / 1e12, "mfma_per_product": v[4] / max(v[0], 1.0),
+                   "frac_of_dense_mfma": v[4] / v[1] / 1e12 / (PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS),
+                   "ms_per_step": v[1] / reps * 1e3, "launches_per_step": v[2] // reps,
                    "gflop_per_step": v[0] / reps / 1e9, "algorithmic_bytes_per_launch": v[3] / max(v[2], 1),
                    "algorithmic_bytes_per_step": v[3] / reps, "traffic_bytes_per_step": tps,
                    "traffic_bytes_per_launch": (tps / max(v[2] // reps, 1)) if tps else None,     # per host-side launch (a grouped launch = one)
                    "traffic_over_algorithmic": (tps / (v[3] / reps)) if (tps and v[3]) else None}
-    ig = fam.get("igemm", [0.0, 1.0, 1, 0.0])
+    ig = fam.get("igemm", [0.0, 1.0, 1, 0.0, 1.0])
     achieved = ig[0] / ig[1] / 1e12
-    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / 3.0
+    # peak for ALGORITHMIC FLOPs of this family = dense bf16 MFMA peak / (bf16 MFMAs issued per algorithmic product, FLOP-weighted
+    # over the family's launches: 3 in the split-bf16 forward, 1 in the plain-bf16 backward) -- so frac = issued MFMA rate / 2500 TF
+    per_product = ig[4] / max(ig[0], 1.0)
+    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / per_product
     gflop_img = step_gflop_per_image(H, W, Q)
     roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": kern.get("igemm", {}).get("traffic_bytes_per_launch"), "traffic_unit": "bytes/launch",
                 "traffic_source": (tj or {}).get("source"),
                 "algorithmic_bytes_per_launch": ig[3] / max(ig[2], 1),
                 "peak_note": ("fp32 MFMA v_mfma_f32_32x32x2_f32" if a.precision == "fp32" else
-                              "2500 TF dense bf16 MFMA / 3 MFMAs per algorithmic product (hi*hi + hi*lo + lo*hi); "
-                              "frac_of_dense_bf16 prices the same FLOPs against the full 2500 TF"),
+                              f"2500 TF dense bf16 MFMA / {per_product:.3f} bf16 MFMAs issued per algorithmic product (FLOP-weighted over "
+                              "the family's launches: 3 = hi*hi + hi*lo + lo*hi in the split-bf16 forward, 1 in the plain-bf16 "
+                              "backward), i.e. frac = issued MFMA rate / 2500 TF; frac_of_dense_bf16 prices the ALGORITHMIC FLOPs "
+                              "against the full 2500 TF"),
+                "mfma_per_product": per_product,
                 "frac_of_dense_bf16": achieved / PEAK_BF16_MFMA_TFLOPS,
                 "kernel": "igemm_fast_kernel (conv fwd / dgrad / linear) -- algorithmic FLOPs 2*M*N*K*taps per launch",
                 "avg_launch_us": ig[1] / max(ig[2], 1) * 1e6, "families": kern,

@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 // split-plane LDS rows are groups of 32 k-values, [hi 32 | lo 32] each (= the byte layout of cdetr_gemm_desc.B_split): position
 // of k inside a row, in bf16 units; the lo plane of the same k sits 32 further.
 #define KPOS(k) ((((k) >> 5) << 6) + ((k) & 31))
+constexpr int SPLITK_COUNTERS = 4096;      // int32 arrival counters at the head of cdetr_gemm_desc.splitk_ws (one per output tile)
 // TERMS (split-bf16 staging modes only): bf16 MFMAs per algorithmic product -- 3 = hi*hi + hi*lo + lo*hi ("bf16x3", ~5e-6 relative),
 // 2 = hi*hi + lo*hi (the B operand rounded to bf16, A exact to 2^-17: "bf16x2"), 1 = hi*hi (both rounded: plain bf16).  Fewer terms
 // skip the MFMAs, the LDS reads of the unused lo planes and (TERMS 1) the lo half of the staging split of A.
@@ -486,13 +487,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 // at two images per GPU --, a staging-time transpose of the n-contiguous operand, 128-wide tiles on 4 waves, 32x64 / 128x64 tiles.)
 // A16: the A operand is read from its bf16 TWIN (cdetr_gemm_desc.A16; plain-bf16 products only): one 16-byte load = 8 k-values per thread,
 // stored into the hi plane as it is -- half the operand bytes and no conversion at staging (the data-gradient chain of the backbone).
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3, bool A16 = false>
-__device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const int tilesM, const int bx, const int bz) {
+// KG: wave groups per workgroup that share ONE output tile and split every staged k-tile between them (KG = 2: BKF = 64, group 0 multiplies
+// k 0..31 of the tile, group 1 k 32..63); the groups' accumulators meet in LDS before the epilogue.  Twice the waves per output tile and
+// half the barrier-separated k-steps: for the problems whose grid cannot fill the CUs (see gemm_ksplit) without any traffic through HBM.
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3, bool A16 = false, int KG = 1>
+__device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const int tilesM, const int bx, const int bz,
+                                                const int ksplit = 1, const int kslice = 0) {
     constexpr int PD = 2;                    // k-tiles in flight in registers
+    static_assert(KG == 1 || ((PREC == 2 || PREC == 3) && (BKF / 16) % KG == 0), "wave groups exist for the staging-split forms");
     static_assert(!A16 || (TERMS == 1 && BL == 0), "the bf16 twin of A feeds the plain-bf16 products");
     static_assert(TERMS == 3 || ((PREC == 2 || PREC == 3) && BL == 0), "reduced-term products exist for the staging-split k-contiguous forms");
     static_assert(BL == 0 || PREC <= 1, "the n-contiguous operand has no staging-split form");
-    constexpr int NT = 64 * WM * WN;
+    constexpr int NTQ = 64 * WM * WN;        // threads of one wave group
+    constexpr int NT = NTQ * KG;
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     constexpr int LDK = BKF + 4;             // 36 or 68 floats: (LDK/4) odd -> conflict-free ds_read_b128
     constexpr int F4R = BKF / 4;             // float4 per k-row (8 or 16)
@@ -517,7 +524,8 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     float* Bs = smem + 2 * A_TILE;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+    const int lane = tid & 63, wid = (tid >> 6) % (WM * WN), kg = (tid >> 6) / (WM * WN);
+    const int tidq = tid % NTQ;
     const int wm = wid / WN, wn = wid % WN;
     const int i32 = lane & 31, g = lane >> 5;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (private 4 MiB L2 each).  XCD x owns a contiguous band of
@@ -537,7 +545,10 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
     __bf16* __restrict__ C16 = d.C16 ? reinterpret_cast<__bf16*>(d.C16) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // bf16 twin of C
     const int K = d.K, taps = d.taps;
-    const int nkt = (K / BKF) * taps;
+    // split reduction (ksplit > 1): slice kslice of this output tile owns k-tiles [kt0, kt0 + nkt) of the (K / BKF) * taps
+    const int nkt_all = (K / BKF) * taps;
+    const int kt0 = (int)((long)nkt_all * kslice / ksplit);
+    const int nkt = (int)((long)nkt_all * (kslice + 1) / ksplit) - kt0;
 
     const int kq = tid % F4R, r8 = tid / F4R;
     const int kqa = tid % CHA, r8a = tid / CHA;          // the A operand's own mapping (== kq, r8 unless A16)
@@ -738,7 +749,8 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
                 const __bf16* a16 = reinterpret_cast<const __bf16*>(As + buf * A_TILE + (wm * (32 * FM) + i32) * LDK) + g * 8;
                 const __bf16* b16 = reinterpret_cast<const __bf16*>(Bs + buf * B_TILE + (wn * (32 * FN) + i32) * LDK) + g * 8;
     #pragma unroll
-                for (int hp = 0; hp < BKF / 16; ++hp) {
+                for (int hq = 0; hq < BKF / 16 / KG; ++hq) {
+                    const int hp = kg * (BKF / 16 / KG) + hq;        // this wave group's share of the staged k-tile
                     bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
     #pragma unroll
                     for (int a = 0; a < FM; ++a) {
@@ -772,7 +784,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     // The loop body is branch-free around the loads (every step fetches; past the end the last tile is fetched again and
     // never used): with conditional fetches the loaded registers become loop PHIs, the allocator copies them right after
     // the load is issued and the copy drags an s_waitcnt vmcnt(~0) in front of the MFMA block -- one tile in flight at best.
-    int f_tap = 0, f_kc = 0, f_idx = 0;       // coordinates of the most recently issued tile
+    int f_tap = kt0 / (K / BKF), f_kc = (kt0 % (K / BKF)) * BKF, f_idx = 0;       // coordinates of the most recently issued tile
     auto advance = [&]() {
         if (f_idx + 1 < nkt) {
             ++f_idx;
@@ -794,8 +806,8 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
         __syncthreads();
         compute(S & 1);
     };
-    set_tap(0);
-    fetch(ra[0], rb[0], rm[0], 0, 0);
+    set_tap(f_tap);
+    fetch(ra[0], rb[0], rm[0], f_tap, f_kc);
 #pragma unroll
     for (int j = 1; j < PD; ++j) {
         advance();
@@ -813,6 +825,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     // `if (m < M)` of the store loop sits in its own basic block and the compiler then waits for each of the 16 round trips in turn:
     // measured with cold operands, tools/cold_gemm.py, that doubled every GEMM with a residual -- 20000x512x128: 30 -> 64 us.)
     float rv[FM][FN][16], gv[FM][FN][16];
+    auto load_rg = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
 #pragma unroll
@@ -831,10 +844,95 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
             }
         }
     }
+    };
+    if (ksplit == 1 && kg == 0) load_rg();   // a split tile fetches them once it knows it is the one that finishes the tile
     const int rem = nkt - kt;                                      // 1 .. PD tiles left: tile kt is staged, the others sit in registers
     compute(0);
     if (rem > 1) drain_step(std::integral_constant<int, 1>{});
     mfma_drain(acc);
+
+    if constexpr (KG > 1) {
+        // the wave groups' partial tiles meet in LDS (the tile buffers are free once every wave is past its last read); group 0 carries on
+        __syncthreads();
+        float* red = smem;
+        if (kg > 0) {
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int b = 0; b < FN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[(((kg - 1) * FM * FN + a * FN + b) * 16 + r) * NTQ + tidq] = acc[a][b][r];
+        }
+        __syncthreads();
+        if (kg > 0) return;                  // (finished waves leave the workgroup's barrier count)
+#pragma unroll
+        for (int q = 0; q < KG - 1; ++q)
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int b = 0; b < FN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] += red[((q * FM * FN + a * FN + b) * 16 + r) * NTQ + tidq];
+    }
+
+    if (ksplit > 1) {
+        // ---- split reduction: every slice parks its partial tile in the scratch (fragment order: element e of thread t at [e][t], fully
+        // coalesced), then counts itself in; the slice that arrives last adds the partials IN SLICE ORDER (its own from registers) -- the
+        // same sum whichever slice that is -- and carries on into the fused epilogue.  No slice ever waits for another.
+        // Coherence across the 8 XCDs (one L2 each) WITHOUT fences: a device-scope fence writes back / invalidates the whole L2
+        // (measured: +80 us per launch).  The partials travel as relaxed device-scope atomic stores / loads (sc1: written through to,
+        // and read from, the level all XCDs share), s_waitcnt vmcnt(0) orders them before the arrival count, which is a device-scope RMW.
+        constexpr int FR = FM * FN * 16;
+        int* cnt = reinterpret_cast<int*>(d.splitk_ws);
+        float* wsp = reinterpret_cast<float*>(cnt + SPLITK_COUNTERS);
+        const int tile = tm * tilesN + tn;
+        float* mine = wsp + ((long)tile * ksplit + kslice) * FR * NTQ + tidq;
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(mine + ((a * FN + b) * 16 + r) * NTQ, acc[a][b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);       // the stores above have been acknowledged
+        __syncthreads();                     // ... by every wave; and every wave is past its last LDS read: the tile buffers are free
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tidq == 0) {
+            const int old = __hip_atomic_fetch_add(cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old == ksplit - 1) ? 1 : 0;
+            if (last) __hip_atomic_store(cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counters zero for the next launch
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        load_rg();
+        float sum[FR];
+#pragma unroll
+        for (int e = 0; e < FR; ++e) sum[e] = 0.f;
+        for (int q = 0; q < ksplit; ++q) {
+            if (q == kslice) {
+#pragma unroll
+                for (int a = 0; a < FM; ++a)
+#pragma unroll
+                    for (int b = 0; b < FN; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum[(a * FN + b) * 16 + r] += acc[a][b][r];
+            } else {
+                const float* other = wsp + ((long)tile * ksplit + q) * FR * NTQ + tidq;
+                float t[FR];
+#pragma unroll
+                for (int e = 0; e < FR; ++e) t[e] = __hip_atomic_load(other + e * NTQ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int e = 0; e < FR; ++e) sum[e] += t[e];
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = sum[(a * FN + b) * 16 + r];
+    }
 
 #pragma unroll
     for (int a = 0; a < FM; ++a) {
@@ -859,9 +957,9 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     }
 }
 
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3, bool A16 = false>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
-    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, TERMS, A16>(d, tilesM, blockIdx.x, blockIdx.z);
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3, bool A16 = false, int KG = 1>
+__global__ __launch_bounds__(64 * WM * WN * KG) void igemm_fast_kernel(const cdetr_gemm_desc d, const int tilesM) {
+    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, TERMS, A16, KG>(d, tilesM, blockIdx.x, blockIdx.z, gridDim.y, blockIdx.y);
 }
 
 // Grouped launch of up to GG_MAX independent GEMMs of one kernel class (same idea as WgradGroupArgs below): the problems'
@@ -1835,27 +1933,47 @@ inline bool gemm_has_a_twin(const cdetr_gemm_desc& d) {
     return on && d.A16 && (d.lda & 7) == 0 && (d.sA & 7) == 0 && (d.sA2 & 7) == 0 && (reinterpret_cast<uintptr_t>(d.A16) & 15) == 0;
 }
 
-template <int WM, int WN, int FM, int FN, int BKF, int PREC>
+// Slices per output tile (1 = no split).  The tile kernels hide their load latency with OTHER workgroups of the same CU; a problem of two
+// images has too few tiles for that (5000 x 256 outputs on 64x128 tiles: 158 workgroups on 256 CUs -- tools/m_scaling.py: twice the rows
+// cost 2-30 % more time), so its reduction is cut into slices until the grid reaches ~2 workgroups of 8 waves per CU.
+inline int gemm_ksplit(const cdetr_gemm_desc& d, int waves, long tiles, int nkt_all, long tile_bytes, int min_kt = 8) {
+    if (!d.splitk_ws || d.batch != 1 || tiles > SPLITK_COUNTERS) return 1;
+    const char* fs = getenv("CDETR_GEMM_SPLITK");           // A/B knob: 0 = never, n = n slices wherever legal
+    const int force = fs ? atoi(fs) : -1;
+    if (force == 0) return 1;
+    int S = force > 0 ? force : (int)((256L * 16 / waves) / tiles);
+    S = std::min(S, 4);
+    S = std::min(S, nkt_all / min_kt);                       // >= 8 k-tiles per slice: below that the exchange costs more than it hides (tools/splitk_sweep.py)
+    const long avail = d.splitk_ws_bytes - (long)SPLITK_COUNTERS * 4;
+    while (S > 1 && tiles * S * tile_bytes > avail) --S;
+    return std::max(S, 1);
+}
+
+template <int WM, int WN, int FM, int FN, int BKF, int PREC, int KG = 1>
 int launch_gemm_fast_pd(const cdetr_gemm_desc& d, hipStream_t st) {
     constexpr int BM = 32 * FM * WM, BN = 32 * FN * WN;
     const int tilesM = (d.M + BM - 1) / BM, tilesN = (d.N + BN - 1) / BN;
-    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN, 1, d.batch), block(64 * WM * WN);      // 8 XCD bands (see the kernel)
+    const int S = gemm_ksplit(d, WM * WN * KG, (long)tilesM * tilesN, (d.K / BKF) * d.taps, (long)BM * BN * 4, KG > 1 ? 4 : 8);
+    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN, S, d.batch), block(64 * WM * WN * KG);      // 8 XCD bands (see the kernel); grid.y = reduction slices
     int rc;
     if constexpr (PREC >= 2) {           // k-contiguous operands, split at staging (3: B pre-split); reduced-term forms by d.precision
         const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
         if (d.precision == 2) {          // bf16x2: B rounded to bf16
-            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 2>, bytes, "cdetr_gemm"))) return rc;
-            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 2>), grid, block, bytes, st, d, tilesM);
+            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 2, false, KG>, bytes, "cdetr_gemm"))) return rc;
+            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 2, false, KG>), grid, block, bytes, st, d, tilesM);
         } else if (d.precision == 3 && gemm_has_a_twin(d)) {   // plain bf16, A read from its bf16 twin
-            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1, true>, bytes, "cdetr_gemm"))) return rc;
-            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1, true>), grid, block, bytes, st, d, tilesM);
+            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1, true, KG>, bytes, "cdetr_gemm"))) return rc;
+            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1, true, KG>), grid, block, bytes, st, d, tilesM);
         } else if (d.precision == 3) {   // plain bf16
-            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1>, bytes, "cdetr_gemm"))) return rc;
-            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1>), grid, block, bytes, st, d, tilesM);
+            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1, false, KG>, bytes, "cdetr_gemm"))) return rc;
+            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 1, false, KG>), grid, block, bytes, st, d, tilesM);
         } else {
-            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC>, bytes, "cdetr_gemm"))) return rc;
-            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC>), grid, block, bytes, st, d, tilesM);
+            if ((rc = raise_lds(igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 3, false, KG>, bytes, "cdetr_gemm"))) return rc;
+            hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 0, BKF, PREC, 3, false, KG>), grid, block, bytes, st, d, tilesM);
         }
+    } else if constexpr (KG != 1) {
+        cdetr_set_error("cdetr_gemm: wave groups exist for the staging-split forms only");
+        return CDETR_ERR_UNSUPPORTED;
     } else if (d.b_layout == 0) {        // fp32 MFMA
         static_assert(PREC == 0 || PREC == 1, "");
         const int bytes = (2 * BM * (BKF + 4) + 2 * BN * (BKF + 4)) * 4;
@@ -1870,6 +1988,12 @@ int launch_gemm_fast_pd(const cdetr_gemm_desc& d, hipStream_t st) {
         hipLaunchKernelGGL((igemm_fast_kernel<WM, WN, FM, FN, 1, BKF, PREC>), grid, block, bytes, st, d, tilesM);
     }
     return cdetr_launch_status("cdetr_gemm");
+}
+
+// 64x64 tile, 64-deep k-tiles shared by TWO wave groups (8 waves): precision >= 1, k-contiguous weight
+int launch_gemm_fast_kg2(const cdetr_gemm_desc& d, hipStream_t st) {
+    if (d.B_split && d.batch == 1) return launch_gemm_fast_pd<2, 2, 1, 1, 64, 3, 2>(d, st);
+    return launch_gemm_fast_pd<2, 2, 1, 1, 64, 2, 2>(d, st);
 }
 
 template <int WM, int WN, int FM, int FN, int BKF>
@@ -1901,6 +2025,11 @@ int gemm_vec_b(const cdetr_gemm_desc& d) {
 // the kernel classes of the default dispatch (shared by cdetr_gemm and cdetr_gemm_group)
 bool gemm_is_direct(const cdetr_gemm_desc& d, int vecA, int vecB) {
     return d.g.mode == CDETR_ROWS_DENSE && (gemm_blocks(d, 64, 64) <= 48 || !(vecA && vecB && (d.K % 32) == 0)) && gemm_blocks(d, 64, 64) < 192;
+}
+bool gemm_is_fewrow_split(const cdetr_gemm_desc& d, int vecA, int vecB) {
+    const char* e = getenv("CDETR_GEMM_FEWROW_SPLIT");      // A/B knob (read per call: only few-row problems get here)
+    return !(e && atoi(e) == 0) && d.splitk_ws && d.batch == 1 && vecA && vecB && d.precision >= 1 && d.b_layout == 0 && (d.K % 64) == 0 && (long)d.K * d.taps >= 1024 &&
+           d.M >= 256;
 }
 // bf16x3 with a long reduction is bound by L2->CU operand delivery (~8 TB/s measured, tools/split_sweep.py): a
 // 128x128 tile shared by 16 waves of 32x32 halves that traffic at the same per-wave structure and occupancy.
@@ -1952,9 +2081,18 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     if (force == 13 && fast_ok && d.b_layout == 0) return launch_gemm_fast<3, 4, 1, 1, 32>(d, st);
     if (force == 3 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);
     if (force == 4 && fast_ok) return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);
+    if (force == 14 && fast_ok && (d.K % 64) == 0 && d.precision >= 1 && d.b_layout == 0) return launch_gemm_fast_kg2(d, st);
     if (force == 6) {
         if (d.N > 64 && d.M > 64) return launch_gemm<128, 128>(d, st, vecA, vecB);
         return launch_gemm<64, 64>(d, st, vecA, vecB);
+    }
+    // few rows, long reduction (decoder FFN 1024 -> 256 on 600 rows): a 64x64 tile on two wave groups with the reduction cut across
+    // 3-4 workgroups beats the one-wave-per-16x16-tile kernel (tools/splitk_sweep.py: 16.3 -> 10.6-12.6 us)
+    // (kept at bf16x3 in the backward too: the few-row kernel they replace computes exact fp32 products whatever d.precision says, and
+    // the decoder's gradient chain consists of nothing but few-row GEMMs -- tests/test_model_gpu.py trajectory test)
+    if (!force && gemm_is_direct(d, vecA, vecB) && gemm_is_fewrow_split(d, vecA, vecB)) {
+        if (d.precision >= 2) { d.precision = 1; d.A16 = nullptr; }
+        return launch_gemm_fast_kg2(d, st);
     }
     if ((force == 5 && d.g.mode == CDETR_ROWS_DENSE) || gemm_is_direct(d, vecA, vecB)) {   // latency-bound: one wave per 16x16 tile
         const int tilesM = (d.M + 15) / 16, tilesN = (d.N + 15) / 16;

@@ -37,8 +37,9 @@ def bwd_precision():
 
 
 class _Timed:
-    def __init__(self, family, flops, tag=None, nbytes=0.0):
+    def __init__(self, family, flops, tag=None, nbytes=0.0, issued=None):
         self.family, self.flops, self.tag, self.nbytes = family, flops, tag, nbytes     # nbytes: compulsory (algorithmic) HBM bytes of the launch
+        self.issued = flops if issued is None else issued     # matrix-core FLOPs actually issued (algorithmic x MFMAs per product)
 
     def __enter__(self):
         if PROFILE is not None:
@@ -50,12 +51,30 @@ class _Timed:
         if PROFILE is not None:
             t1 = torch.cuda.Event(enable_timing=True)
             t1.record()
-            PROFILE.append((self.family, self.flops, self.t0, t1, self.tag, self.nbytes))
+            PROFILE.append((self.family, self.flops, self.t0, t1, self.tag, self.nbytes, self.issued))
         return False
+
+
+_TERMS = {0: 1, 1: 3, 2: 2, 3: 1}      # bf16 MFMAs per algorithmic product of each arithmetic mode (0 = fp32 MFMA, priced on its own peak)
 
 
 def _geom(mode=_ffi.ROWS_DENSE, Ha=0, Wa=0, Hc=0, Wc=0, kh=1, kw=1, stride=1, pad=0, dil=1):
     return ConvGeom(mode, Ha, Wa, Hc, Wc, kh, kw, stride, pad, dil)
+
+
+# Scratch of the split-reduction GEMMs (cdetr_gemm_desc.splitk_ws): one per stream -- launches of one stream are ordered, launches of
+# two streams may overlap and must not share the arrival counters.  Zeroed once; every launch leaves the counters zero.
+SPLITK = int(_os.environ.get("CDETR_SPLITK", "1"))
+SPLITK_BYTES = 64 << 20
+_SPLITK_WS = {}
+
+
+def splitk_ws():
+    s = stream_ptr().value
+    t = _SPLITK_WS.get(s)
+    if t is None:
+        t = _SPLITK_WS[s] = torch.zeros(SPLITK_BYTES // 4, dtype=torch.int32, device="cuda")
+    return t
 
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
@@ -74,12 +93,16 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
     d.resid, d.ldr = ptr(resid), ldr
     d.gate, d.ldg = ptr(gate), ldg
     d.g = geom if geom is not None else _geom()
+    if SPLITK and batch == 1 and _GEMM_QUEUE is None and M * N <= (1 << 22) and K * taps >= 256:
+        ws = splitk_ws()
+        d.splitk_ws, d.splitk_ws_bytes = ptr(ws), SPLITK_BYTES
     if _GEMM_QUEUE is not None:       # inside gemm_queue(): submitted together by its exit (cdetr_gemm_group)
         _GEMM_QUEUE.append((d, 2.0 * M * N * K * taps * batch, 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
-                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16)))
+                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16), _TERMS[d.precision]))
         return
     # compulsory fp32 bytes: input rows once (a strided / dilated conv reads <= M*K of them), weights, output
-    with _Timed("igemm", 2.0 * M * N * K * taps * batch, (M, N, K, taps, b_layout, batch), 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1)):
+    fl = 2.0 * M * N * K * taps * batch
+    with _Timed("igemm", fl, (M, N, K, taps, b_layout, batch), 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1), fl * _TERMS[d.precision]):
         check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
 
 
@@ -103,7 +126,8 @@ class gemm_queue:
         q, _GEMM_QUEUE = _GEMM_QUEUE, None
         if et is None and q:
             arr = (GemmDesc * len(q))(*[e[0] for e in q])
-            with _Timed("igemm", sum(e[1] for e in q), ("group", sum(e[2] for e in q), len(q), 0, -1, 0), sum(e[2] for e in q)):
+            with _Timed("igemm", sum(e[1] for e in q), ("group", sum(e[2] for e in q), len(q), 0, -1, 0), sum(e[2] for e in q),
+                        sum(e[1] * e[4] for e in q)):
                 check(lib().cdetr_gemm_group(arr, len(q), stream_ptr()), "cdetr_gemm_group")
         return False
 
@@ -123,10 +147,12 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
     d.dbias = ptr(dbias)
     d.g = geom if geom is not None else _geom()
     if may_defer and _WG_QUEUE is not None:       # inside wgrad_queue(): submitted together by its exit (cdetr_wgrad_group)
-        _WG_QUEUE.append((d, 2.0 * P * Nout * Cin * taps * batch, (dY, X, dW, w_scale, dbias, dY16, X16), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1)))
+        _WG_QUEUE.append((d, 2.0 * P * Nout * Cin * taps * batch, (dY, X, dW, w_scale, dbias, dY16, X16), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1),
+                          _TERMS[d.precision]))
         return
     # compulsory bytes: dY and X once, dW read + written (accumulation into the gradient arena)
-    with _Timed("wgrad", 2.0 * P * Nout * Cin * taps * batch, (P, Nout, Cin, taps, -1, batch), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1)):
+    fl = 2.0 * P * Nout * Cin * taps * batch
+    with _Timed("wgrad", fl, (P, Nout, Cin, taps, -1, batch), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1), fl * _TERMS[d.precision]):
         check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
 
 
@@ -159,7 +185,7 @@ def wgrad_flush():
     q = _WG_QUEUE
     if q:
         arr = (WgradDesc * len(q))(*[e[0] for e in q])
-        with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0), sum(e[3] for e in q)):
+        with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0), sum(e[3] for e in q), sum(e[1] * e[4] for e in q)):
             check(lib().cdetr_wgrad_group(arr, len(q), stream_ptr()), "cdetr_wgrad_group")
         del q[:]
 
@@ -679,8 +705,9 @@ def rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
     d.mask_row, d.mask_col = ptr(mask_row), ptr(mask_col)
     d.out, d.a_row, d.a_col = ptr(out), ptr(a_row), ptr(a_col)
     # compulsory bytes: both query sets, both key sets, V, the output and the two saved attention maps
-    with _Timed("rcda_fwd", 2.0 * N * nh * L * (H * W * 32 + (H + W) * 32), None,
-                4.0 * N * (3 * L * E + (H + W) * E + H * W * E + nh * L * (Hp + Wp))):
+    fl = 2.0 * N * nh * L * (H * W * 32 + (H + W) * 32)
+    with _Timed("rcda_fwd", fl, None,
+                4.0 * N * (3 * L * E + (H + W) * E + H * W * E + nh * L * (Hp + Wp)), fl * _TERMS[d.precision]):
         check(lib().cdetr_rcda_fwd(C.byref(d), stream_ptr()), "cdetr_rcda_fwd")
     return out, a_row, a_col
 
@@ -720,8 +747,9 @@ def rcda_bwd_raw(d_out, q_row, q_col, k_row, k_col, v, a_row, a_col, nh, zbuf=No
         ds_row, ds_col = torch.empty_like(a_row), torch.empty_like(a_col)
         d.ds_row, d.ds_col = ptr(ds_row), ptr(ds_col)
     # compulsory bytes: d_out, attention maps, V, queries / keys in; dq (x2), dk (x2), dV out
-    with _Timed("rcda_bwd", 2.0 * N * nh * L * (2 * H * W * 32), None,
-                4.0 * N * (5 * L * E + 2 * (H + W) * E + 2 * H * W * E + nh * L * (Hp + Wp))):
+    fl = 2.0 * N * nh * L * (2 * H * W * 32)
+    with _Timed("rcda_bwd", fl, None,
+                4.0 * N * (5 * L * E + 2 * (H + W) * E + 2 * H * W * E + nh * L * (Hp + Wp)), fl * _TERMS[d.precision]):
         check(lib().cdetr_rcda_bwd(C.byref(d), stream_ptr()), "cdetr_rcda_bwd")
     # two-level batch (image x head): one launch per contraction for the whole batch of images
     if not fuse_dq:

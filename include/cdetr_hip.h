@@ -77,6 +77,13 @@ typedef struct {
                           * of 8 and a 16-byte aligned base; other kernel classes read A.                                             */
     void* C16;           /* optional (NULL = absent): a bf16 TWIN of C written by the same epilogue (same ldc / batch strides, in
                           * elements) -- the operand format of the plain-bf16 weight gradients (cdetr_wgrad_desc.dY16 / X16).      */
+    void* splitk_ws;     /* optional (NULL = never split): device scratch that lets the tile kernels split the reduction of a problem with
+                          * too few output tiles to fill 256 CUs (two images per GPU: 5000 rows x 256 channels = 158 workgroups) across
+                          * 2-4 workgroups per tile; the partial tiles meet here and the last workgroup to arrive adds them IN SLICE ORDER
+                          * (deterministic) and runs the fused epilogue.  Layout: [4096 int32 arrival counters | partial tiles]; the caller
+                          * zeroes the counters ONCE (every call leaves them zero) and must not share one scratch between streams that
+                          * may run cdetr_gemm concurrently.  16-byte aligned.                                                       */
+    int64_t splitk_ws_bytes; /* size of splitk_ws in bytes (>= 16 KiB + partial tiles; too small = fewer slices or none)            */
 } cdetr_gemm_desc;
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 /* n INDEPENDENT GEMMs submitted together (same results as n cdetr_gemm calls; no problem may read another's output).  Few-row

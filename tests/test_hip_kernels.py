@@ -537,7 +537,7 @@ def test_weight_mirror_and_dgrad(precision):
     close(b2, dy.double().cpu() @ wl[32:96].double().cpu(), **tol(precision))
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 9, 10, 13])
+@pytest.mark.parametrize("variant", [0, 3, 4, 9, 10, 13, 14])
 def test_gemm_variants_ragged_shapes(variant, monkeypatch):
     """Every tile variant of the implicit-GEMM kernel (CDETR_GEMM_VARIANT), bf16x3, on shapes whose M / N / K are NOT multiples
     of the tile (clamped-load tails), k-contiguous and n-contiguous weight operands, dense and 3x3 (strided / dilated) rows,
@@ -548,10 +548,11 @@ def test_gemm_variants_ragged_shapes(variant, monkeypatch):
     ops.PRECISION = 1
     try:
         rng = np.random.default_rng(100 + variant)
-        cases = [(1, 32, 32), (63, 36, 64), (65, 132, 96), (130, 260, 160), (257, 64, 32), (600, 256, 256), (1000, 516, 128), (3, 4, 64)]
+        cases = [(1, 32, 32), (63, 36, 64), (65, 132, 96), (130, 260, 160), (257, 64, 32), (600, 256, 256), (1000, 516, 128), (3, 4, 64),
+                 (1237, 132, 192)]
         for M, N, K in cases:
             for bl in (0, 1):
-                if variant == 3 and K % 64:
+                if variant in (3, 14) and K % 64:
                     continue
                 A = torch.randn(M, K, generator=g(M + N))
                 Bm = torch.randn(N, K, generator=g(M + K)) if bl == 0 else torch.randn(K, N, generator=g(M + K))
@@ -565,7 +566,7 @@ def test_gemm_variants_ragged_shapes(variant, monkeypatch):
                              w_scale=ws.to(DEV), resid=resid.to(DEV), ldr=N, gate=gate.to(DEV), ldg=N, relu=True, out_scale=0.5)
                 close(out, ref, msg=f"variant {variant} M{M} N{N} K{K} bl{bl}", **tol(1))
         # 3x3 conv rows: stride 2 and dilation 2, odd spatial sizes, channel counts off the tile
-        for (Cin, Cout, st, pd, dl, H, W) in [(32, 48, 1, 1, 1, 9, 11), (64, 80, 2, 1, 1, 13, 10), (32, 144, 1, 2, 2, 8, 15)]:      # dgrad with taps needs Cout % 16 == 0
+        for (Cin, Cout, st, pd, dl, H, W) in [(32, 48, 1, 1, 1, 9, 11), (64, 80, 2, 1, 1, 13, 10), (32, 144, 1, 2, 2, 8, 15), (128, 64, 1, 1, 1, 12, 7)]:      # dgrad with taps needs Cout % 16 == 0
             x = torch.randn(2, Cin, H, W, generator=g(Cin + H))
             w = torch.randn(Cout, Cin, 3, 3, generator=g(Cout)) / (Cin * 9) ** 0.5
             y64 = F.conv2d(x.double(), w.double(), stride=st, padding=pd, dilation=dl)
@@ -677,11 +678,13 @@ def test_groupnorm_nhwc(B, h, w, C, G):
     close(bp.grad, b64.grad, rtol=2e-4, msg="gn dbeta")
 
 
-def test_gemm_group_matches_individual_calls(precision):
+def test_gemm_group_matches_individual_calls(precision, monkeypatch):
     """cdetr_gemm_group (ops.gemm_queue): few-row problems of three k-lengths, the 64x128 class with a pre-split weight image,
     a data-gradient operand (n-contiguous weight), epilogues (bias, residual, ReLU, gate) and 14 problems of one class (two
-    grouped launches) == the same calls issued one by one (bit-identical) == fp64 within tolerance."""
+    grouped launches) == the same calls issued one by one (bit-identical) == fp64 within tolerance.  (Bit identity holds per kernel
+    class: the single-call route of few-row long reductions through the split 64x64 tile is switched off here.)"""
     from counting_detr_amd import ops
+    monkeypatch.setenv("CDETR_GEMM_FEWROW_SPLIT", "0")
     shapes = [(600, 256, 256), (100, 256, 256), (600, 256, 512), (600, 256, 1024), (37, 40, 36), (5000, 256, 256), (5000, 256, 256),
               (5000, 256, 256), (4000, 128, 64)] + [(50 + 13 * k, 256, 256) for k in range(14)]
     Ws = [torch.randn(N, K, generator=g(11 * i)) / K ** 0.5 for i, (M, N, K) in enumerate(shapes)]
@@ -945,3 +948,50 @@ def test_sine_embed_xy_matches_the_one_coordinate_form():
     ((fx * ge[0]).sum() + (fy * ge[1]).sum()).backward()
     assert torch.equal(ex, fx) and torch.equal(ey, fy)
     close(a.grad, b.grad, rtol=1e-6, msg="d points")
+
+
+@pytest.mark.parametrize("slices", [2, 3, 4])
+@pytest.mark.parametrize("prec,lim", [(0, 2e-5), (1, 5e-5), (3, 2e-2)])
+def test_gemm_split_reduction(slices, prec, lim, monkeypatch):
+    """cdetr_gemm_desc.splitk_ws: the reduction of a tile cut into 2-4 slices that meet in the scratch (the last workgroup to arrive
+    adds them in slice order and runs the epilogue).  Against fp64 and against the unsplit launch: dense rows and 3x3 taps (a slice
+    boundary inside a tap and on one), ragged M / N, bias + residual + gate + relu + bf16 twin, every tile class, called twice in a
+    row (the arrival counters must come back to zero) -- and bit-identical across repeats (ordered sum)."""
+    from counting_detr_amd import ops
+    cases = [(5000, 256, 1024, 0), (5000, 256, 256, 0), (1237, 132, 512, 0), (600, 512, 2048, 0), (130, 260, 160, 0), (2000, 1024, 256, 4),
+             (5000, 256, 1024, 14), (333, 70, 640, 14)]
+    for M, N, K, variant in cases:
+        monkeypatch.setenv("CDETR_GEMM_VARIANT", str(variant))
+        A = torch.randn(M, K, generator=g(M + N)).to(DEV)
+        Bm = (torch.randn(N, K, generator=g(M + K)) / K ** 0.5).to(DEV)
+        bias, resid, gate = torch.randn(N, generator=g(1)).to(DEV), torch.randn(M, N, generator=g(2)).to(DEV), torch.randn(M, N, generator=g(3)).to(DEV)
+        ref = torch.relu((A.double() @ Bm.double().t() + bias.double()) * 0.5 + resid.double()) * (gate > 0)
+        outs = []
+        for s in (1, slices, slices):
+            monkeypatch.setenv("CDETR_GEMM_SPLITK", "0" if s == 1 else str(s))
+            out, out16 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_raw(A, K, Bm, K, out, N, M, N, K, bias=bias, resid=resid, ldr=N, gate=gate, ldg=N, relu=True, out_scale=0.5,
+                         precision=prec, C16=out16)
+            outs.append(out)
+            close(out, ref, rtol=lim, atol_scale=lim, msg=f"M{M} N{N} K{K} slices {s}")
+            assert torch.equal(out16, out.to(torch.bfloat16))
+        close(outs[1], outs[0].double(), rtol=1e-5, atol_scale=1e-5, msg="split vs unsplit")
+        assert torch.equal(outs[1], outs[2]), "the ordered sum of the slices must not depend on arrival order"
+    monkeypatch.setenv("CDETR_GEMM_VARIANT", "0")
+    for (Cin, Cout, st, pd, dl, H, W) in [(256, 256, 1, 1, 1, 50, 50), (64, 80, 2, 1, 1, 13, 10), (512, 512, 1, 2, 2, 50, 50)]:
+        x = torch.randn(2, Cin, H, W, generator=g(Cin + H))
+        w = torch.randn(Cout, Cin, 3, 3, generator=g(Cout)) / (Cin * 9) ** 0.5
+        y64 = F.conv2d(x.double(), w.double(), stride=st, padding=pd, dilation=dl)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        wd = w.contiguous(memory_format=torch.channels_last).to(DEV)
+        old = ops.PRECISION
+        ops.PRECISION = prec if prec != 3 else 1
+        try:
+            monkeypatch.setenv("CDETR_GEMM_SPLITK", str(slices))
+            y = ops.conv_fwd(xd, wd, None, None, stride=st, pad=pd, dil=dl)
+            l2 = lim if prec != 3 else 5e-5
+            close(y.permute(0, 3, 1, 2), y64, rtol=l2, atol_scale=l2, msg=f"conv {Cin}->{Cout} slices {slices}")
+        finally:
+            ops.PRECISION = old
+    ws = ops.splitk_ws()
+    assert int(ws[:4096].abs().sum()) == 0, "arrival counters left non-zero"
