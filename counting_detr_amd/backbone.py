@@ -173,6 +173,8 @@ class TrunkBackward:
             r = self.blocks[k].backward_fused(self.saved[k], self.dz, need_dx=(k > 0), dz16=self.dz16)
             self.dz, self.dz16 = r if (self.dz16 is not None and r is not None) else (r, None)
             self.saved[k] = None
+            if ops.WGRAD_EVERY and (k - lo) % ops.WGRAD_EVERY == 0:
+                ops.wgrad_flush(overlap=True)    # these blocks' weight gradients run beside the next blocks' data-gradient chain
 
 
 class _TrunkFn(torch.autograd.Function):

@@ -43,7 +43,8 @@ class FlatGradExchange:
         self.launched = []
         self.probe = None       # a list: finish() appends (compute-side event, comm-side event) per step -> exposed_ms()
 
-    def segment_done(self, seg):
+    def segment_done(self, seg, also=None):
+        """also: a second stream whose work so far (parameter gradients running beside the backward) the bucket depends on."""
         lo, hi = self.seg_bounds[seg], self.seg_bounds[seg + 1]
         self.launched.append(seg)
         if hi <= lo or get_world_size() < 2:
@@ -53,6 +54,8 @@ class FlatGradExchange:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
+            if also is not None:
+                self.stream.wait_stream(also)
             with torch.cuda.stream(self.stream):
                 dist.all_reduce(buf)
         else:
@@ -209,7 +212,7 @@ class Trainer:
         """Called from the backbone's backward: `seg` (0 = everything above the backbone, 1..3 = layer4..layer2) is final."""
         from . import ops
         ops.wgrad_flush()           # queued parameter gradients of the finished segment must land before its bucket ships
-        self.exchange.segment_done(seg)
+        self.exchange.segment_done(seg, also=ops.wgrad_side_stream() if ops._WG_INFLIGHT else None)
 
     def _finish_allreduce(self):
         self.exchange.finish()      # the 1/world average is folded into cdetr_adamw_step (grad_div)
@@ -371,6 +374,7 @@ class Trainer:
         finally:
             if not defer_trunk:
                 ops.MIRROR = None
+        ops.wgrad_join()             # parameter gradients that ran beside the backward (ops.wgrad_flush(overlap=True))
         # detached: a returned loss that still references the autograd graph keeps its AccumulateGrad nodes (and their stream) alive
         # into the next step -- a later graph capture on another stream then records a cross-stream dependency and fails
         out = {k: v.detach() for k, v in loss_dict.items()}
@@ -384,6 +388,7 @@ class Trainer:
             if self._trunk_pending is not None:
                 with ops.wgrad_queue():
                     self._trunk_pending.run(seg)
+                ops.wgrad_join()
         finally:
             if last:
                 ops.MIRROR = None

@@ -180,14 +180,55 @@ class wgrad_queue:
         return False
 
 
-def wgrad_flush():
-    """Submit whatever the innermost wgrad_queue() holds (the gradient exchange calls this before it ships a bucket)."""
+# Parameter gradients OFF the critical path: the backward's data-gradient chain is a string of dependent launches that leave most CUs
+# idle at two images per GPU; the weight gradients of a finished layer depend on nothing downstream, so their grouped launch goes to a
+# side stream (fork after the layer, join before the optimizer / the bucket's all-reduce) and fills those CUs while the chain runs on.
+# The operand tensors of launches in flight are kept referenced until the join: the allocator must not hand their memory to the chain.
+WGRAD_ASYNC = int(_os.environ.get("CDETR_WGRAD_ASYNC", "1"))
+# Measured (one MI355X, B=2 800x800, same box, ms/step): everything at the end 10.95 | one overlapped submission per backbone segment
+# (layer4 / layer3 / layer2) 10.87 | every 3 blocks 10.95 | every block 11.02 (small groups lose the grouped launch) | encoder / decoder
+# layers overlapped as well 11.13-11.25 (their chains are latency-bound: a concurrent kernel slows every link).
+# Default: OFF.  The best setting buys 0.07 ms (0.7 %) and stretches every data-gradient kernel it runs beside (rocprofv3: the 64x64 dgrad
+# tiles 30.9 -> 43 us average), which muddies the per-kernel roofline accounting for less than the box-to-box spread of the step time.
+WGRAD_EVERY = int(_os.environ.get("CDETR_WGRAD_EVERY", "0"))       # backbone: blocks per overlapped submission (100: one per segment; 0 = at the end)
+WGRAD_STACKS = int(_os.environ.get("CDETR_WGRAD_STACKS", "0"))     # encoder / decoder: per-layer overlapped submissions
+_WG_SIDE = {}
+_WG_INFLIGHT = []
+
+
+def wgrad_side_stream():
+    dev = torch.cuda.current_device()
+    s = _WG_SIDE.get(dev)
+    if s is None:
+        s = _WG_SIDE[dev] = torch.cuda.Stream()
+    return s
+
+
+def wgrad_flush(overlap=False):
+    """Submit whatever the innermost wgrad_queue() holds (the gradient exchange calls this before it ships a bucket).
+    overlap: on the side stream, ordered after everything issued so far on the current one; wgrad_join() is the matching join."""
     q = _WG_QUEUE
     if q:
         arr = (WgradDesc * len(q))(*[e[0] for e in q])
-        with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0), sum(e[3] for e in q), sum(e[1] * e[4] for e in q)):
-            check(lib().cdetr_wgrad_group(arr, len(q), stream_ptr()), "cdetr_wgrad_group")
+        if overlap and WGRAD_ASYNC:
+            side = wgrad_side_stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0), sum(e[3] for e in q), sum(e[1] * e[4] for e in q)):
+                    check(lib().cdetr_wgrad_group(arr, len(q), stream_ptr()), "cdetr_wgrad_group")
+            _WG_INFLIGHT.append([e[2] for e in q])
+        else:
+            with _Timed("wgrad", sum(e[1] for e in q), (-len(q), 0, 0, 0, -1, 0), sum(e[3] for e in q), sum(e[1] * e[4] for e in q)):
+                check(lib().cdetr_wgrad_group(arr, len(q), stream_ptr()), "cdetr_wgrad_group")
         del q[:]
+
+
+def wgrad_join(stream=None):
+    """Make `stream` (default: the current one) wait for the parameter-gradient launches that were sent to the side stream."""
+    if _WG_INFLIGHT:
+        (stream or torch.cuda.current_stream()).wait_stream(wgrad_side_stream())
+        if stream is None:
+            del _WG_INFLIGHT[:]
 
 
 def colsum_(X2d, out):
@@ -1073,6 +1114,8 @@ class EncoderStackFn(torch.autograd.Function):
                 c = ctx.ctxs[li]
                 dX, accR, accC = EncoderLayerFn._backward(c, dX, accR, accC, zall[li * zn:(li + 1) * zn])[:3]
                 c.saved_tensors = None
+                if WGRAD_STACKS:
+                    wgrad_flush(overlap=True)   # this layer's parameter gradients run beside the next layer's chain
         ctx.ctxs = None
         return dX, accR, accC, None, None, None, None, None
 
@@ -1248,6 +1291,8 @@ class DecoderStackFn(torch.autograd.Function):
                 ga1 = linear_dgrad(dqk.view(M, 2 * E), Ws[0:2 * E])
                 t = linear_dgrad(dvs.view(M, E), Ws[2 * E:3 * E], resid=dY2)
             dx = grad_merge(t, ga1, None, acc_p, None)                         # d(x) = residual + v-path + q/k-path; d(qpos) += ga1
+            if li % 2 == 0 and WGRAD_STACKS:
+                wgrad_flush(overlap=True)       # two layers' parameter gradients (26 small problems) beside the next layers' chain
         if ctx.own_means:        # memory also fed the two key means: broadcast their gradients back in the same pass
             dMem = bcast_add2(dMem.view(N, H, W, E), dKrm, dKcm, 1.0 / H, 1.0 / W)
             return (dx.view(N, L, E), acc_p.view(N, L, E), acc_x.view(N, L, E), acc_y.view(N, L, E), dMem, None, None, None, None, None,

@@ -43,14 +43,25 @@ def main():
     write, nw = collect(sys.argv[2], {"WRITE_SIZE"})
     sq, nsq = collect(sys.argv[3], {"SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
                                     "SQ_ACTIVE_INST_LDS", "SQ_VALU_MFMA_BUSY_CYCLES"})
-    fams, pmc, detail = {}, {}, {}
+    fams, per_launch, pmc, detail = {}, {}, {}, {}
+    # the profiled process runs several step equivalents (warm-up + timed step + bench.py's roofline leg): one criterion launch each;
+    # the optimizer kernels run once per FULL step only (one adamw_finish each)
+    nstep = nfull = 0
+    with open(sys.argv[1]) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] == "FETCH_SIZE":
+                nstep += "criterion_fwd_kernel" in r["Kernel_Name"]
+                nfull += "adamw_finish" in r["Kernel_Name"]
+    nstep, nfull = max(nstep, 1), max(nfull, 1)
     for k in sorted(set(fetch) | set(write)):
         launches = max(nf[k]["FETCH_SIZE"], nw[k]["WRITE_SIZE"], 1)
         rd = 2.0 * fetch[k]["FETCH_SIZE"] * 1024.0
         wr = write[k]["WRITE_SIZE"] * 1024.0
-        fams[k] = (rd + wr) / launches
-        detail[k] = {"launches": launches, "read_bytes_per_launch": rd / launches, "write_bytes_per_launch": wr / launches,
-                     "bytes_per_step": rd + wr}
+        div = nfull if k == "optimizer" else nstep          # (the weight images are refreshed by every forward/backward, optimizer step or not)
+        fams[k] = (rd + wr) / div
+        per_launch[k] = (rd + wr) / launches
+        detail[k] = {"kernel_launches_per_step": launches / div, "read_bytes_per_kernel_launch": rd / launches,
+                     "write_bytes_per_kernel_launch": wr / launches}
     for k, c in sq.items():
         wc = c["SQ_WAVE_CYCLES"]
         if wc > 0:
@@ -58,8 +69,8 @@ def main():
                       "wait_inst_share": c["SQ_WAIT_INST_ANY"] / wc, "active_inst_share": c["SQ_ACTIVE_INST_ANY"] / wc,
                       "valu_share": c["SQ_ACTIVE_INST_VALU"] / wc, "lds_share": c["SQ_ACTIVE_INST_LDS"] / wc}
     out = {"workload": "B=2 800x800 Q=300 bf16x3 fwd / bf16 bwd, one eager step (bench.py --no-graph --steps 1 --warmup 1)",
-           "families": fams, "detail": detail, "pmc": pmc,
-           "total_bytes_per_step": sum(d["bytes_per_step"] for d in detail.values()),
+           "step_equivalents_in_the_profiled_process": nstep, "families_bytes_per_step": fams, "families_bytes_per_kernel_launch": per_launch,
+           "detail": detail, "pmc": pmc, "total_bytes_per_step": sum(fams.values()),
            "source": "profiles/r2_pmc_*.csv summaries: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* in separate passes with "
                      "--kernel-trace only; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section), KiB -> bytes; "
                      "tools/pmc_families.py"}

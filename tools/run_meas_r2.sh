@@ -16,7 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d /tmp/prof_w -- 
 find /tmp/prof_w -name "*counter_collection.csv" -exec cp {} /tmp/write.csv \;
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d /tmp/prof_s -- $B > $O/pmc_sq.log 2>&1
 find /tmp/prof_s -name "*counter_collection.csv" -exec cp {} /tmp/sq.csv \;
-python tools/pmc_families.py /tmp/fetch.csv /tmp/write.csv /tmp/sq.csv $O/traffic.json > $O/traffic.txt 2>&1
+cp /tmp/fetch.csv /tmp/write.csv /tmp/sq.csv $O/ 2>/dev/null; python tools/pmc_families.py /tmp/fetch.csv /tmp/write.csv /tmp/sq.csv $O/traffic.json > $O/traffic.txt 2>&1
 python tools/pmc_traffic.py /tmp/fetch.csv /tmp/write.csv > $O/pmc_traffic.txt 2>&1
 python tools/pmc_summary.py /tmp/sq.csv igemm_fast > $O/pmc_sq_igemm_fast.txt 2>&1
 python tools/pmc_summary.py /tmp/sq.csv wgrad_tr > $O/pmc_sq_wgrad_tr.txt 2>&1

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_hip_kernels.py -x -q -m gpu 2>&1 | tail -3
-for s in "CDETR_SPLITK=0" "CDETR_SPLITK=1 CDETR_GEMM_FEWROW_SPLIT=0" "CDETR_SPLITK=1" "CDETR_SPLITK=0" "CDETR_SPLITK=1"; do
-  env $s python bench.py --mode graph --steps 30 --warmup 5 --no-cpu-baseline --no-alt --no-extra 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.readlines()[-1]); print('$s', round(d['ms_per_step'],3), d['step_ms']['median'], d['config']['final_loss'])"
-done
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -- python bench.py --mode graph --steps 8 --warmup 3 --no-cpu-baseline --no-alt --no-extra > /tmp/b.log 2>&1
+tail -1 /tmp/b.log | cut -c1-200
+f=$(find /tmp/prof_t -name "*kernel_trace.csv")
+python tools/step_gap.py $f | tail -10
