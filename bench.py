@@ -396,7 +396,9 @@ def main(argv=None):
                               "against the full 2500 TF"),
                 "mfma_per_product": per_product,
                 "frac_of_dense_bf16": achieved / PEAK_BF16_MFMA_TFLOPS,
-                "kernel": "igemm_fast_kernel (conv fwd / dgrad / linear) -- algorithmic FLOPs 2*M*N*K*taps per launch",
+                "kernel": "igemm_fast_kernel (the tile kernels: conv fwd / dgrad / linears of > 48 output tiles) -- algorithmic FLOPs 2*M*N*K*taps "
+                          "per launch; the few-row GEMMs (decoder, positional MLPs, heads: launch-latency class, igemm_direct_kernel) are the "
+                          "separate family igemm_fewrow",
                 "avg_launch_us": ig[1] / max(ig[2], 1) * 1e6, "families": kern,
                 "whole_step_tflops": gflop_img * a.batch / ms_per_step, "step_gflop_per_image": gflop_img,
                 "pmc": (tj or {}).get("pmc")}

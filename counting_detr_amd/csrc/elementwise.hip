@@ -388,6 +388,7 @@ extern "C" int cdetr_relu_mask(const float* y, const float* dy, float* dz, int64
 namespace {
 
 constexpr int LN_MAXV = 4;   // float4 per lane: C <= 64 * 4 * 4 = 1024
+constexpr int LN_RB = 4;     // rows a wave of the backward kernel keeps in flight (C == 256)
 
 // y = (x - mean) * rstd * gamma + beta ; saves mean / rstd per row (A2/models/transformer.py norm1 / norm2 / ffn.norm2)
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -459,6 +460,42 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         ab[i] = ag[i];
         if (i < nv) g4[i] = reinterpret_cast<const float4*>(gamma)[lane + 64 * i];
     }
+    // C == 256 (every LayerNorm of this model): a wave takes its rows FOUR at a time -- the 12 loads of a batch (x, dy, residual gradient) are
+    // all in flight before the first reduction, so a wave pays one memory round trip per four rows instead of one per row (the kernel is a
+    // chain of round trips: 157 workgroups x 8 rows per wave at the encoder shape).  Rows past the end are clamped and masked.
+    if (nv == 1) {
+        const float4 gg = g4[0];
+        const int stride = gridDim.x * 4;
+        for (int row0 = blockIdx.x * 4 + wid; row0 < rows; row0 += stride * LN_RB) {
+            float4 xv[LN_RB], dv[LN_RB], av[LN_RB];
+            float mu[LN_RB], rs[LN_RB];
+#pragma unroll
+            for (int b = 0; b < LN_RB; ++b) {
+                const long r = min(row0 + b * stride, rows - 1);
+                xv[b] = reinterpret_cast<const float4*>(x + r * C)[lane];
+                dv[b] = reinterpret_cast<const float4*>(dy + r * C)[lane];
+                av[b] = add ? reinterpret_cast<const float4*>(add + r * C)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                mu[b] = mean[r];
+                rs[b] = rstd[r];
+            }
+#pragma unroll
+            for (int b = 0; b < LN_RB; ++b) {
+                const int row = row0 + b * stride;
+                if (row >= rows) break;               // wave-uniform
+                const float4 xh = make_float4((xv[b].x - mu[b]) * rs[b], (xv[b].y - mu[b]) * rs[b], (xv[b].z - mu[b]) * rs[b], (xv[b].w - mu[b]) * rs[b]);
+                const float4 dg = make_float4(dv[b].x * gg.x, dv[b].y * gg.y, dv[b].z * gg.z, dv[b].w * gg.w);
+                const float s1 = (dg.x + dg.y) + (dg.z + dg.w);
+                const float s2 = (dg.x * xh.x + dg.y * xh.y) + (dg.z * xh.z + dg.w * xh.w);
+                ag[0].x += dv[b].x * xh.x; ag[0].y += dv[b].y * xh.y; ag[0].z += dv[b].z * xh.z; ag[0].w += dv[b].w * xh.w;
+                ab[0].x += dv[b].x; ab[0].y += dv[b].y; ab[0].z += dv[b].z; ab[0].w += dv[b].w;
+                const float m1 = wave_sum(s1) / C, m2 = wave_sum(s2) / C;
+                float4 o;
+                o.x = rs[b] * (dg.x - m1 - xh.x * m2) + av[b].x; o.y = rs[b] * (dg.y - m1 - xh.y * m2) + av[b].y;
+                o.z = rs[b] * (dg.z - m1 - xh.z * m2) + av[b].z; o.w = rs[b] * (dg.w - m1 - xh.w * m2) + av[b].w;
+                reinterpret_cast<float4*>(dx + (long)row * C)[lane] = o;
+            }
+        }
+    } else
     for (int row = blockIdx.x * 4 + wid; row < rows; row += gridDim.x * 4) {
         const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
         const float4* dr = reinterpret_cast<const float4*>(dy + (long)row * C);

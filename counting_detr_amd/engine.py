@@ -434,14 +434,17 @@ class Trainer:
         st["num_boxes"] = nb0.clone() if torch.is_tensor(nb0) else nb0
         hook = _bb._BACKWARD_HOOK
         _bb.set_backward_hook(None)                # no collectives inside the capture
+        # CDETR_SEGMENTED_GRAPH=1: the five-graph form on ONE rank (no collectives): what the segmentation itself costs (tools / DESIGN section 7)
+        import os
+        segmented = world > 1 or os.environ.get("CDETR_SEGMENTED_GRAPH", "0") == "1"
         try:
-            g_a, segs, g_b, out = self._capture_graphs(st, world, warmup)
+            g_a, segs, g_b, out = self._capture_graphs(st, world, warmup, segmented)
         finally:                                   # a failed capture must leave the stream-ordered step intact
             _bb.set_backward_hook(hook)
         self._graph, self._seg_graphs, self._graph_b, self._static, self._static_out = g_a, segs, g_b, st, out
         return out
 
-    def _capture_graphs(self, st, world, warmup):
+    def _capture_graphs(self, st, world, warmup, segmented):
         self._dry_run(st)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -462,7 +465,7 @@ class Trainer:
             time.sleep(0.5)
         g_a = torch.cuda.CUDAGraph()
         segs = None
-        if world == 1:
+        if not segmented:
             with torch.cuda.graph(g_a):
                 out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
                 out["grad_norm"] = self._optimizer_step()

@@ -73,7 +73,8 @@ def splitk_ws():
     s = stream_ptr().value
     t = _SPLITK_WS.get(s)
     if t is None:
-        t = _SPLITK_WS[s] = torch.zeros(SPLITK_BYTES // 4, dtype=torch.int32, device="cuda")
+        t = _SPLITK_WS[s] = torch.empty(SPLITK_BYTES // 4, dtype=torch.int32, device="cuda")
+        t[:4096].zero_()        # only the arrival counters need a defined start (a scratch first met inside a graph capture re-runs this fill on replay)
     return t
 
 
@@ -102,11 +103,20 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
         return
     # compulsory fp32 bytes: input rows once (a strided / dilated conv reads <= M*K of them), weights, output
     fl = 2.0 * M * N * K * taps * batch
-    with _Timed("igemm", fl, (M, N, K, taps, b_layout, batch), 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1), fl * _TERMS[d.precision]):
+    with _Timed(_gemm_family(M, N, batch, geom), fl, (M, N, K, taps, b_layout, batch), 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
+                fl * _TERMS[d.precision]):
         check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
 
 
 _GEMM_QUEUE = None
+
+
+def _gemm_family(M, N, batch, geom):
+    """Profile family of a GEMM launch: the tile kernels (`igemm`: igemm_fast_kernel and its generic sibling) or the few-row class
+    (`igemm_fewrow`: dense problems of <= 48 tiles of 64x64 -- the decoder's 600-row GEMMs, positional MLPs, heads; csrc/igemm.hip
+    gemm_is_direct) whose time is launch latency, not matrix work."""
+    dense = geom is None or geom.mode == _ffi.ROWS_DENSE
+    return "igemm_fewrow" if dense and ((M + 63) // 64) * ((N + 63) // 64) * max(batch, 1) <= 48 else "igemm"
 
 
 class gemm_queue:
@@ -126,8 +136,9 @@ class gemm_queue:
         q, _GEMM_QUEUE = _GEMM_QUEUE, None
         if et is None and q:
             arr = (GemmDesc * len(q))(*[e[0] for e in q])
-            with _Timed("igemm", sum(e[1] for e in q), ("group", sum(e[2] for e in q), len(q), 0, -1, 0), sum(e[2] for e in q),
-                        sum(e[1] * e[4] for e in q)):
+            d0 = q[0][0]
+            with _Timed(_gemm_family(d0.M, d0.N, d0.batch, d0.g), sum(e[1] for e in q), ("group", sum(e[2] for e in q), len(q), 0, -1, 0),
+                        sum(e[2] for e in q), sum(e[1] * e[4] for e in q)):
                 check(lib().cdetr_gemm_group(arr, len(q), stream_ptr()), "cdetr_gemm_group")
         return False
 

@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 bash tools/run_meas_r2.sh > /dev/null 2>&1
 O=gpurun_out/r2m
 rm -f $O/fetch.csv $O/write.csv $O/sq.csv
@@ -11,5 +12,4 @@ f=$(find /tmp/prof_u -name "*kernel_trace.csv")
 python tools/step_phases.py $f $O/step_phases_384x576.txt > /dev/null
 CDETR_BENCH_SHAPES=$O/shapes.csv python bench.py --no-cpu-baseline --no-alt --no-extra > /dev/null 2>&1
 python tools/bwd_precision.py > $O/bwd_precision.txt 2>&1
-timeout 600 python -m pytest tests/test_model_gpu.py tests/test_dp_shared_gpu.py -x -q -m gpu 2>&1 | tail -2
 tail -1 $O/bench_full.log | cut -c1-300

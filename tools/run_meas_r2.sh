@@ -1,4 +1,4 @@
-# Round-2 measurement set: the default bench line, rocprofv3 kernel stats of the same command, PMC traffic / SQ passes (own runs,
+# Round-2 measurement set (called by tools/run_final_r2.sh, which adds the phase traces, the per-shape table and the backward-precision table): the default bench line, rocprofv3 kernel stats of the same command, PMC traffic / SQ passes (own runs,
 # --kernel-trace only).  Outputs under gpurun_out/r2m/; the summaries are copied to profiles/ by hand.
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
