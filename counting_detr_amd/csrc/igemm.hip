@@ -2082,6 +2082,7 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     if (force == 3 && fast_ok && (d.K % 64) == 0) return launch_gemm_fast<2, 2, 1, 1, 64>(d, st);
     if (force == 4 && fast_ok) return launch_gemm_fast<2, 2, 1, 1, 32>(d, st);
     if (force == 14 && fast_ok && (d.K % 64) == 0 && d.precision >= 1 && d.b_layout == 0) return launch_gemm_fast_kg2(d, st);
+    if (force == 16 && fast_ok && d.precision >= 1 && d.b_layout == 0) return launch_gemm_fast<2, 4, 2, 1, 32>(d, st);     // 128x128, 8 waves of 64x32
     if (force == 6) {
         if (d.N > 64 && d.M > 64) return launch_gemm<128, 128>(d, st, vecA, vecB);
         return launch_gemm<64, 64>(d, st, vecA, vecB);
@@ -2119,6 +2120,11 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
             // 128x128 tiles that leave > 1/8 of the CUs idle in a single round: 96x128 tiles (12 waves) when those still fit one round --
             // 5000 x 512 outputs are 160 workgroups of 128 rows but 212 of 96 (each 3/4 of the work)
             static const int t96 = getenv("CDETR_GEMM_T96") ? atoi(getenv("CDETR_GEMM_T96")) : 1;
+            // ... except the longest reductions (3x3 512 -> 512 at 50x50: 144 k-tiles): 128x128 on 8 waves of 64x32 with the reduction cut
+            // three ways (480 workgroups) -- 112 -> 101 us bf16x3, 70 -> 65 us bf16 (tools/splitk_sweep.py SWEEP_BIG=1; larger per-wave tiles
+            // lose on every other shape of the step, 64x64 per wave on all of them)
+            static const int t128s = getenv("CDETR_GEMM_T128S") ? atoi(getenv("CDETR_GEMM_T128S")) : 1;
+            if (t128s && d.splitk_ws && d.batch == 1 && blocks(128, 128) < 224 && (long)d.K * d.taps >= 4096) return launch_gemm_fast<2, 4, 2, 1, 32>(d, st);
             if (t96 && blocks(128, 128) < 224 && blocks(96, 128) <= 256) return launch_gemm_fast<3, 4, 1, 1, 32>(d, st);
             return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
         }

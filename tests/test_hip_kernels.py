@@ -537,7 +537,7 @@ def test_weight_mirror_and_dgrad(precision):
     close(b2, dy.double().cpu() @ wl[32:96].double().cpu(), **tol(precision))
 
 
-@pytest.mark.parametrize("variant", [0, 3, 4, 9, 10, 13, 14])
+@pytest.mark.parametrize("variant", [0, 3, 4, 9, 10, 13, 14, 16])
 def test_gemm_variants_ragged_shapes(variant, monkeypatch):
     """Every tile variant of the implicit-GEMM kernel (CDETR_GEMM_VARIANT), bf16x3, on shapes whose M / N / K are NOT multiples
     of the tile (clamped-load tails), k-contiguous and n-contiguous weight operands, dense and 3x3 (strided / dilated) rows,
@@ -959,7 +959,7 @@ def test_gemm_split_reduction(slices, prec, lim, monkeypatch):
     row (the arrival counters must come back to zero) -- and bit-identical across repeats (ordered sum)."""
     from counting_detr_amd import ops
     cases = [(5000, 256, 1024, 0), (5000, 256, 256, 0), (1237, 132, 512, 0), (600, 512, 2048, 0), (130, 260, 160, 0), (2000, 1024, 256, 4),
-             (5000, 256, 1024, 14), (333, 70, 640, 14)]
+             (5000, 256, 1024, 14), (333, 70, 640, 14), (1237, 260, 1024, 16)]
     for M, N, K, variant in cases:
         monkeypatch.setenv("CDETR_GEMM_VARIANT", str(variant))
         A = torch.randn(M, K, generator=g(M + N)).to(DEV)

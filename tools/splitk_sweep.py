@@ -41,11 +41,14 @@ if __name__ == "__main__":
               "per 64x64 tile: unsplit / 2 / 3 slices")
         for M, N, K, taps, geo in shapes:
             row = f"  M={M:6d} N={N:5d} K={K:5d} taps={taps}: "
-            for v, s in (("0", "0"), ("0", None), ("0", "2"), ("0", "3"), ("0", "4"), ("14", "0"), ("14", "2"), ("14", "3")):
+            combos = (("0", "0"), ("0", None), ("0", "2"), ("0", "3"), ("0", "4"), ("14", "0"), ("14", "2"), ("14", "3"))
+            if os.environ.get("SWEEP_BIG"):      # larger per-wave tiles: 15 = 128x128 / 4 waves of 64x64, 16 = 128x128 / 8 waves of 64x32, 17 = 64x128 / 4 waves
+                combos = (("0", None), ("15", "0"), ("15", None), ("15", "2"), ("16", "0"), ("16", None), ("17", "0"), ("17", None))
+            for v, s in combos:
                 os.environ["CDETR_GEMM_VARIANT"] = v
                 if s is None:
                     os.environ.pop("CDETR_GEMM_SPLITK", None)
                 else:
                     os.environ["CDETR_GEMM_SPLITK"] = s
-                row += ("   |" if (v, s) == ("14", "0") else "") + f"{run(M, N, K, taps, geo, prec, twin):8.1f}"
+                row += ("   |" if s == "0" and v != "0" else "") + f"{run(M, N, K, taps, geo, prec, twin):8.1f}"
             print(row, flush=True)
