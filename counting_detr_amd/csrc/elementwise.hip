@@ -699,9 +699,11 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict_
 }
 
 // out[n,y,x,:] = T[n,y,x,:] + sr * Br[n,x,:] + sc * Bc[n,y,:]   (backward of the two key means: broadcast back)
+// (T2 / T3: optional further addends of T's shape -- sibling data gradients that ran as one grouped launch instead of a residual chain)
 __global__ __launch_bounds__(256) void bcast_add2_kernel(const float* __restrict__ T, const float* __restrict__ Br,
                                                          const float* __restrict__ Bc, float* __restrict__ out, int N, int H,
-                                                         int W, int C4, float sr, float sc) {
+                                                         int W, int C4, float sr, float sc, const float* __restrict__ T2 = nullptr,
+                                                         const float* __restrict__ T3 = nullptr) {
     const long total = (long)N * H * W * C4;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c = (int)(idx % C4);
@@ -709,9 +711,11 @@ __global__ __launch_bounds__(256) void bcast_add2_kernel(const float* __restrict
         const int xw = (int)(t % W); t /= W;
         const int yh = (int)(t % H);
         const int n = (int)(t / H);
-        const float4 v = reinterpret_cast<const float4*>(T)[idx];
+        float4 v = reinterpret_cast<const float4*>(T)[idx];
         const float4 br = reinterpret_cast<const float4*>(Br)[((long)n * W + xw) * C4 + c];
         const float4 bc = reinterpret_cast<const float4*>(Bc)[((long)n * H + yh) * C4 + c];
+        if (T2) { const float4 u = reinterpret_cast<const float4*>(T2)[idx]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
+        if (T3) { const float4 u = reinterpret_cast<const float4*>(T3)[idx]; v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w; }
         reinterpret_cast<float4*>(out)[idx] = make_float4(v.x + sr * br.x + sc * bc.x, v.y + sr * br.y + sc * bc.y,
                                                           v.z + sr * br.z + sc * bc.z, v.w + sr * br.w + sc * bc.w);
     }
@@ -801,6 +805,15 @@ extern "C" int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc
     hipLaunchKernelGGL(bcast_add2_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, Br, Bc, out, N,
                        H, W, C / 4, sr, sc);
     return cdetr_launch_status("cdetr_bcast_add2");
+}
+
+extern "C" int cdetr_bcast_add2_sum(const float* T, const float* T2, const float* T3, const float* Br, const float* Bc, float* out, int32_t N,
+                                    int32_t H, int32_t W, int32_t C, float sr, float sc, void* stream) {
+    CDETR_CHECK_ARG(T && Br && Bc && out && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (T2 || !T3), "cdetr_bcast_add2_sum: bad args");
+    const long n4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(bcast_add2_kernel, dim3(grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), T, Br, Bc, out, N,
+                       H, W, C / 4, sr, sc, T2, T3);
+    return cdetr_launch_status("cdetr_bcast_add2_sum");
 }
 
 extern "C" int cdetr_weight_mirror(const cdetr_mirror_item* items_dev, int32_t n_items, int32_t total_tiles, void* stream) {

@@ -969,13 +969,13 @@ struct GemmGroupItem { cdetr_gemm_desc d; int tilesM, tilesN, vecA, vecB, nx, pa
 struct GemmGroupArgs { int n; int blk0[GG_MAX + 1]; GemmGroupItem it[GG_MAX]; };
 static_assert(sizeof(GemmGroupArgs) <= 4000, "grouped launch arguments must fit the kernel-argument segment");
 
-template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC>
+template <int WM, int WN, int FM, int FN, int BL, int BKF, int PREC, int TERMS = 3>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_fast_group_kernel(const GemmGroupArgs g) {
     int p = 0;
     while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
     const GemmGroupItem& it = g.it[p];
     const int lb = blockIdx.x - g.blk0[p];             // nx is a multiple of 8: the XCD banding of the body is preserved
-    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC>(it.d, it.tilesM, lb % it.nx, lb / it.nx);
+    igemm_fast_body<WM, WN, FM, FN, BL, BKF, PREC, TERMS>(it.d, it.tilesM, lb % it.nx, lb / it.nx);
 }
 
 // ------------------------------------------------------------------------------------------------ fast wgrad
@@ -2147,7 +2147,7 @@ extern "C" int cdetr_gemm_group(const cdetr_gemm_desc* descs, int32_t n, void* s
     CDETR_CHECK_ARG(n >= 0 && (descs != nullptr || n == 0), "cdetr_gemm_group: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     static const bool grouping = !(getenv("CDETR_GEMM_GROUP") && atoi(getenv("CDETR_GEMM_GROUP")) == 0) && !getenv("CDETR_GEMM_VARIANT");
-    std::vector<int> cls[4];          // direct UB 4 / 8 / 16 (k-contiguous weight), fast 64x128 with a pre-split weight
+    std::vector<int> cls[5];          // direct UB 4 / 8 / 16 (k-contiguous weight), fast 64x128 with a pre-split weight (bf16x3 | plain bf16)
     for (int i = 0; i < n; ++i) {
         const cdetr_gemm_desc& d = descs[i];
         if (int rcv = check_gemm_desc(d)) return rcv;
@@ -2160,12 +2160,12 @@ extern "C" int cdetr_gemm_group(const cdetr_gemm_desc* descs, int32_t n, void* s
                 c = cpw <= 4 ? 0 : (cpw <= 8 ? 1 : 2);
             }
         } else if (grouping && vecA && vecB && (d.K % 32) == 0 && !gemm_is_f44(d) && gemm_is_f24(d) && d.B_split && d.batch == 1) {
-            c = 3;
+            c = d.precision == 3 ? 4 : 3;
         }
         if (c >= 0) cls[c].push_back(i);
         else if (int rc1 = cdetr_gemm(&d, stream)) return rc1;
     }
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < 5; ++c) {
         for (size_t c0 = 0; c0 < cls[c].size(); c0 += GG_MAX) {
             const int m = (int)std::min<size_t>(GG_MAX, cls[c].size() - c0);
             if (m == 1) { if (int rc1 = cdetr_gemm(&descs[cls[c][c0]], stream)) return rc1; continue; }
@@ -2187,10 +2187,14 @@ extern "C" int cdetr_gemm_group(const cdetr_gemm_desc* descs, int32_t n, void* s
             if (c == 0) hipLaunchKernelGGL((igemm_direct_group_kernel<0, 4>), dim3(g.blk0[m]), dim3(256), 0, st, g);
             else if (c == 1) hipLaunchKernelGGL((igemm_direct_group_kernel<0, 8>), dim3(g.blk0[m]), dim3(256), 0, st, g);
             else if (c == 2) hipLaunchKernelGGL((igemm_direct_group_kernel<0, 16>), dim3(g.blk0[m]), dim3(256), 0, st, g);
-            else {
+            else if (c == 3) {
                 const int bytes = (2 * 64 * 36 + 2 * 128 * 36) * 4;
                 if (int rcl = raise_lds(igemm_fast_group_kernel<2, 4, 1, 1, 0, 32, 3>, bytes, "cdetr_gemm_group")) return rcl;
                 hipLaunchKernelGGL((igemm_fast_group_kernel<2, 4, 1, 1, 0, 32, 3>), dim3(g.blk0[m]), dim3(512), bytes, st, g);
+            } else {                   // the backward's plain-bf16 products (data gradients of sibling projections)
+                const int bytes = (2 * 64 * 36 + 2 * 128 * 36) * 4;
+                if (int rcl = raise_lds(igemm_fast_group_kernel<2, 4, 1, 1, 0, 32, 3, 1>, bytes, "cdetr_gemm_group")) return rcl;
+                hipLaunchKernelGGL((igemm_fast_group_kernel<2, 4, 1, 1, 0, 32, 3, 1>), dim3(g.blk0[m]), dim3(512), bytes, st, g);
             }
             if (int rcl = cdetr_launch_status("cdetr_gemm_group")) return rcl;
         }

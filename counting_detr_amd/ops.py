@@ -987,6 +987,14 @@ def hw_reduce(Xr, Xc, Ar, Ac, scale_r, scale_c):
     return Or, Oc
 
 
+def bcast_add2_sum(T, T2, T3, Br, Bc, sr, sc):
+    """T + T2 + T3 + sr * Br[n,x,:] + sc * Bc[n,y,:] in one pass (T2 / T3 optional)."""
+    N, H, W, Cc = T.shape
+    out = torch.empty_like(T)
+    check(lib().cdetr_bcast_add2_sum(ptr(T), ptr(T2), ptr(T3), ptr(Br), ptr(Bc), ptr(out), N, H, W, Cc, sr, sc, stream_ptr()), "cdetr_bcast_add2_sum")
+    return out
+
+
 def bcast_add2(T, Br, Bc, sr, sc):
     N, H, W, Cc = T.shape
     out = torch.empty_like(T)
@@ -1075,17 +1083,19 @@ class EncoderLayerFn(torch.autograd.Function):
         _wg(dk_col2, Kc.view(N * H, Cc), Wip, bip, 3 * E, 4 * E)
         _wg(dv2, X.view(R, Cc), Wip, bip, 4 * E, 5 * E)
         # ---- d(src): residual + three projection inputs chained through the dgrad epilogues, then the two key means
-        t = linear_dgrad(dq_row2, Wi[0:E], resid=dY1)
-        t = linear_dgrad(dq_col2, Wi[E:2 * E], resid=t)
-        t = linear_dgrad(dv2, Wi[4 * E:5 * E], resid=t)
+        # (the three [R, C] products ride in ONE grouped launch -- 474 workgroups instead of three dependent launches of 158 -- and are
+        # summed by the broadcast pass below; tools/step_listing.py: 33 -> ~15 us per layer)
         with gemm_queue():
+            t = linear_dgrad(dq_row2, Wi[0:E], resid=dY1)
+            t2 = linear_dgrad(dq_col2, Wi[E:2 * E])
+            t3 = linear_dgrad(dv2, Wi[4 * E:5 * E])
             dKr = linear_dgrad(dk_row2, Wi[2 * E:3 * E])                           # [N*W, C]
             dKc = linear_dgrad(dk_col2, Wi[3 * E:4 * E])                           # [N*H, C]
             # the same two (tiny) products once more with the accumulated d(posemb) of the layers above in the epilogue: they ride in
             # the same grouped launch, and the accumulation costs no launch of its own
             dKrA = linear_dgrad(dk_row2, Wi[2 * E:3 * E], resid=accR.reshape(N * W, Cc)) if accR is not None else dKr
             dKcA = linear_dgrad(dk_col2, Wi[3 * E:4 * E], resid=accC.reshape(N * H, Cc)) if accC is not None else dKc
-        dX = bcast_add2(t.view(N, H, W, Cc), dKr, dKc, 1.0 / H, 1.0 / W)
+        dX = bcast_add2_sum(t.view(N, H, W, Cc), t2.view(N, H, W, Cc), t3.view(N, H, W, Cc), dKr, dKc, 1.0 / H, 1.0 / W)
         # ---- d(posemb): sum over the broadcast axis BEFORE projecting back (linearity) + the key-mean terms
         sr, sc = hw_reduce(dq_row.view(N, H, W, E), dq_col.view(N, H, W, E), None, None, 1.0, 1.0)
         with gemm_queue():

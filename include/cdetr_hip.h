@@ -181,6 +181,11 @@ int cdetr_hw_reduce(const float* Xr, const float* Xc, const float* Ar, const flo
                     int32_t H, int32_t W, int32_t C, float scale_r, float scale_c, void* stream);
 int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
                      float sr, float sc, void* stream);
+/* the same with up to two further addends of T's shape (T2, T3; NULL = absent): out = T + T2 + T3 + sr*Br + sc*Bc -- sibling data gradients
+ * of one input (the three projections of A2/models/row_column_decoupled_attention.py:165-208 that read src) run as ONE grouped launch into
+ * separate buffers and are summed here instead of being chained through residual epilogues.                                           */
+int cdetr_bcast_add2_sum(const float* T, const float* T2, const float* T3, const float* Br, const float* Bc, float* out, int32_t N, int32_t H,
+                         int32_t W, int32_t C, float sr, float sc, void* stream);
 /* decoder-layer glue (A2/models/transformer.py:366-403): cdetr_add2: O1 = T + A, O2 = T + B (B and O2 NULL together);
  * cdetr_grad_merge (backward of those sites): out = base + g1 (+ g2), acc1 += g1, acc2 += g2 (g2 / acc1 / acc2 may be NULL);
  * n = element count, a multiple of 4, all pointers 16-byte aligned.                                                    */
