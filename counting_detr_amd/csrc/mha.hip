@@ -422,10 +422,13 @@ __global__ __launch_bounds__(NTF) void fwd_kernel(const float* __restrict__ qk, 
     }
 }
 
-__global__ __launch_bounds__(NTF) void bwd_q_kernel(const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ o,
-                                                    const float* __restrict__ dO, const float* __restrict__ lse, float* __restrict__ dqk,
-                                                    float* __restrict__ Dbuf, int N, int L, int nh, float scale) {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 3 * TILE];          // [buf][K | V | K^T]
+// The backward is ONE launch: workgroups with blockIdx.z == 0 own queries (dq), those with blockIdx.z == 1 own keys (dk, dv).  The two
+// halves are independent -- the key half forms D = rowsum(dO * O) of each query tile itself while it stages the tile (it used to read the
+// query half's result, which serialised two 17 us launches of 80 workgroups each) -- so they share the chip instead of following each other.
+__device__ __forceinline__ void bwd_q_body(__bf16* lds, const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ o,
+                                           const float* __restrict__ dO, const float* __restrict__ lse, float* __restrict__ dqk,
+                                           int N, int L, int nh, float scale) {
+    // lds: [buf][K | V | K^T]
     const int E = nh * D;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i32 = lane & 31, g = lane >> 5;
     const int n = blockIdx.y / nh, head = blockIdx.y % nh;
@@ -492,15 +495,13 @@ __global__ __launch_bounds__(NTF) void bwd_q_kernel(const float* __restrict__ qk
     }
     if (q < L) {
         store_own(dqk + ((long)n * L + q) * 2 * E + head * D, g, dQT, scale);
-        if (g == 0) Dbuf[((long)n * nh + head) * L + q] = Di;
     }
 }
 
-__global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ dO,
-                                                     const float* __restrict__ lse, const float* __restrict__ Dbuf, float* __restrict__ dqk,
-                                                     float* __restrict__ dv, int N, int L, int nh, float scale) {
-    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 4 * TILE];          // [buf][Q | dO | Q^T | dO^T]
-    __shared__ __attribute__((aligned(16))) float stat[2][2][32];              // [buf][lse | D][query of the tile]
+__device__ __forceinline__ void bwd_kv_body(__bf16* lds, float (*stat)[2][32], const float* __restrict__ qk, const float* __restrict__ v,
+                                            const float* __restrict__ o, const float* __restrict__ dO, const float* __restrict__ lse,
+                                            float* __restrict__ dqk, float* __restrict__ dv, int N, int L, int nh, float scale) {
+    // lds: [buf][Q | dO | Q^T | dO^T]; stat: [buf][lse | D][query of the tile]
     const int E = nh * D;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, i32 = lane & 31, g = lane >> 5;
     const int n = blockIdx.y / nh, head = blockIdx.y % nh;
@@ -508,8 +509,8 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
     const int jc = min(j, L - 1);
     const float* qkn = qk + (long)n * L * 2 * E;
     const float* don = dO + (long)n * L * E;
+    const float* on = o + (long)n * L * E;
     const float* lsn = lse + ((long)n * nh + head) * L;
-    const float* dbn = Dbuf + ((long)n * nh + head) * L;
     bf16x8 kh[2], kl[2], vh[2], vl[2];
     own_frag(qkn + (long)jc * 2 * E + E + head * D, g, scale, kh, kl);
     own_frag(v + ((long)n * L + jc) * E + head * D, g, 1.f, vh, vl);
@@ -517,31 +518,41 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
     constexpr int PD = 3;
     const float* trsrc = (wid == 0) ? qkn : don;                               // wave 0 stages Q^T, wave 1 dO^T
     const long trld = (wid == 0) ? 2 * E : E;
-    const float* stsrc = (tid & 32) ? dbn : lsn;
-    struct Ring { NatRegs q, d; TrRegs t; float s; } r0, r1, r2;
+    struct Ring { NatRegs q, d, o; TrRegs t; float s; } r0, r1, r2;
     const int ntile = (L + 31) / 32;
-    auto fetch = [&](NatRegs& a, NatRegs& b, TrRegs& c, float& sv, int t) __attribute__((always_inline)) {
+    auto fetch = [&](Ring& r, int t) __attribute__((always_inline)) {
         const int r0 = min(t, ntile - 1) * 32;
-        nat_fetch(a, qkn, 2 * E, head * D, r0, L, tid);
-        nat_fetch(b, don, E, head * D, r0, L, tid);
-        tr_fetch(c, trsrc, trld, head * D, r0, L, lane);
-        const int qq = t * 32 + (tid & 31);                                // lse (lanes 0-31 of wave 0) / D (lanes 32-63) of the tile
-        const float x = stsrc[min(qq, L - 1)];                             // (true, unclamped index: surplus tiles must be inert)
-        sv = (qq < L) ? x : ((tid & 32) ? 0.f : INFINITY);                 // p = exp(s - inf) = 0 beyond L
+        nat_fetch(r.q, qkn, 2 * E, head * D, r0, L, tid);
+        nat_fetch(r.d, don, E, head * D, r0, L, tid);
+        nat_fetch(r.o, on, E, head * D, r0, L, tid);                        // the forward's output rows of the tile: D = rowsum(dO * O)
+        tr_fetch(r.t, trsrc, trld, head * D, r0, L, lane);
+        const int qq = t * 32 + (tid & 31);                                // lse of the tile (lanes 0-31 of wave 0)
+        const float x = lsn[min(qq, L - 1)];                               // (true, unclamped index: surplus tiles must be inert)
+        r.s = (qq < L) ? x : INFINITY;                                     // p = exp(s - inf) = 0 beyond L
     };
-    auto stash = [&](const NatRegs& a, const NatRegs& b, const TrRegs& c, float sv, int buf) __attribute__((always_inline)) {
+    auto stash = [&](const Ring& r, int buf) __attribute__((always_inline)) {
         __bf16* nb = lds + buf * 4 * TILE;
-        nat_stash(a, nb, tid);
-        nat_stash(b, nb + TILE, tid);
-        tr_stash(c, nb + (wid == 0 ? 2 : 3) * TILE, lane);
-        if (tid < 64) stat[buf][tid >> 5][tid & 31] = sv;
+        nat_stash(r.q, nb, tid);
+        nat_stash(r.d, nb + TILE, tid);
+        tr_stash(r.t, nb + (wid == 0 ? 2 : 3) * TILE, lane);
+        if (tid < 32) stat[buf][0][tid] = r.s;
+        // D of the tile's 32 queries: thread (row = idx >> 3, 4 columns) holds a quarter-row product of dO and O; the 8 threads of a row
+        // are consecutive lanes (rows past L are clamped copies: their p is 0, any finite D will do)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float pd = (r.d.v[s2].x * r.o.v[s2].x + r.d.v[s2].y * r.o.v[s2].y) + (r.d.v[s2].z * r.o.v[s2].z + r.d.v[s2].w * r.o.v[s2].w);
+            pd += __shfl_xor(pd, 1, 64);
+            pd += __shfl_xor(pd, 2, 64);
+            pd += __shfl_xor(pd, 4, 64);
+            if ((tid & 7) == 0) stat[buf][1][(tid + NTF * s2) >> 3] = pd;
+        }
     };
-    fetch(r0.q, r0.d, r0.t, r0.s, 0); fetch(r1.q, r1.d, r1.t, r1.s, 1); fetch(r2.q, r2.d, r2.t, r2.s, 2);
-    stash(r0.q, r0.d, r0.t, r0.s, 0);
+    fetch(r0, 0); fetch(r1, 1); fetch(r2, 2);
+    stash(r0, 0);
     __syncthreads();
     auto step = [&](Ring& cur, const Ring& nxt, int t) __attribute__((always_inline)) {
         const int buf = t & 1;
-        fetch(cur.q, cur.d, cur.t, cur.s, t + PD);
+        fetch(cur, t + PD);
         const __bf16* base = lds + buf * 4 * TILE;
         if (t < ntile) {           // workgroup-uniform: surplus steps of the last ring turn only stage and synchronise
         f32x16 S = mma_tile(zero16(), base, i32, g, kh, kl);                   // S^T[q, key]
@@ -565,7 +576,7 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
         reg_frag(S, sh, sl);
         dKT = mma_tile(dKT, base + 2 * TILE, i32, g, sh, sl);                  // dK^T[c, key] += Q^T[c, q] dS[q, key]
         }
-        stash(nxt.q, nxt.d, nxt.t, nxt.s, buf ^ 1);
+        stash(nxt, buf ^ 1);
         __syncthreads();
     };
     for (int t0 = 0; t0 < ntile; t0 += PD) {
@@ -577,6 +588,15 @@ __global__ __launch_bounds__(NTF) void bwd_kv_kernel(const float* __restrict__ q
         store_own(dqk + ((long)n * L + j) * 2 * E + E + head * D, g, dKT, scale);
         store_own(dv + ((long)n * L + j) * E + head * D, g, dVT, 1.f);
     }
+}
+
+__global__ __launch_bounds__(NTF) void bwd_kernel(const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ o,
+                                                  const float* __restrict__ dO, const float* __restrict__ lse, float* __restrict__ dqk,
+                                                  float* __restrict__ dv, int N, int L, int nh, float scale) {
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 4 * TILE];
+    __shared__ __attribute__((aligned(16))) float stat[2][2][32];
+    if (blockIdx.z == 0) bwd_q_body(lds, qk, v, o, dO, lse, dqk, N, L, nh, scale);
+    else bwd_kv_body(lds, stat, qk, v, o, dO, lse, dqk, dv, N, L, nh, scale);
 }
 }  // namespace flash
 
@@ -599,8 +619,7 @@ extern "C" int cdetr_mha_bwd(const float* qk, const float* v, const float* o, co
     dim3 grid((L + 63) / 64, N * nh);
     static const int use_mfma = getenv("CDETR_MHA_MFMA") ? atoi(getenv("CDETR_MHA_MFMA")) : 1;
     if (use_mfma && precision == 1) {
-        hipLaunchKernelGGL(flash::bwd_q_kernel, grid, dim3(flash::NTF), 0, st, qk, v, o, d_o, lse, d_qk, work, N, L, nh, scale);
-        hipLaunchKernelGGL(flash::bwd_kv_kernel, grid, dim3(flash::NTF), 0, st, qk, v, d_o, lse, work, d_qk, d_v, N, L, nh, scale);
+        hipLaunchKernelGGL(flash::bwd_kernel, dim3(grid.x, grid.y, 2), dim3(flash::NTF), 0, st, qk, v, o, d_o, lse, d_qk, d_v, N, L, nh, scale);
         return cdetr_launch_status("cdetr_mha_bwd");
     }
     hipLaunchKernelGGL(mha_bwd_q_kernel, grid, dim3(256), 0, st, qk, v, o, d_o, lse, d_qk, work, N, L, nh, scale);

@@ -17,6 +17,7 @@
 // Head dim is fixed at 32 (E = 256, 8 heads in every shipped config).
 #include "../../include/cdetr_hip.h"
 #include "common.h"
+#include <algorithm>
 #include <type_traits>
 #include <stdlib.h>
 
@@ -591,7 +592,7 @@ __host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW, bool w
 
 // TERMS: bf16 MFMAs per product in the split-bf16 paths (3, or 1 = plain bf16: cdetr_rcda_bwd_desc.precision 3)
 template <int NF, int NW, int PREC, int TERMS = 3>
-__global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
+__device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, const int bx, const int by) {
     constexpr int NT = 64 * NW, QB = QW * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int VS = 36;                 // V tile row stride (floats): 36/4 odd -> conflict-free ds_read_b128
@@ -601,8 +602,8 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
     const BwdSmem sm = bwd_smem(H, W, NF, NW, d.dq_row != nullptr);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, g = lane >> 5;
-    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
-    const int qbase = blockIdx.x * QB + wid * QW;
+    const int n = by / d.nh, head = by % d.nh;
+    const int qbase = bx * QB + wid * QW;
     const int q = qbase + i32;
     const bool qvalid = q < L;
     const int nq = min(QW, L - qbase);
@@ -954,6 +955,11 @@ __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_
     }
 }
 
+template <int NF, int NW, int PREC, int TERMS = 3>
+__global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
+    rcda_bwd_body<NF, NW, PREC, TERMS>(d, blockIdx.x, blockIdx.y);
+}
+
 // ------------------------------------------------------------------------------------------------ backward (dV)
 // dV[h,w,c] += sum_q A_col[q,h] A_row[q,w] dOut[q,c].  Workgroup = (4 consecutive w (one per wave), (n,head), q-slice).
 template <int NF, int PREC>
@@ -1078,7 +1084,7 @@ __host__ __device__ inline Dv2Smem dv2_smem() {
 }
 
 template <int TERMS = 3>
-__global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc d, const int q_per_slice) {
+__device__ __forceinline__ void rcda_dv2_body(const cdetr_rcda_bwd_desc& d, const int q_per_slice, const int bx, const int by, const int bz) {
     constexpr int QT = 64, ARS = 136;                   // queries per tile; bf16 per A_row^T row
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Dv2Smem sm = dv2_smem();
@@ -1086,9 +1092,9 @@ __global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, g = lane >> 5;
-    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
-    const int h0 = blockIdx.x * 8, h = h0 + wid;
-    const int qs = blockIdx.z * q_per_slice;
+    const int n = by / d.nh, head = by % d.nh;
+    const int h0 = bx * 8, h = h0 + wid;
+    const int qs = bz * q_per_slice;
     const int qe = min(L, qs + q_per_slice);
     const int ntile = (qe - qs + QT - 1) / QT;
     if (ntile <= 0) return;
@@ -1200,6 +1206,26 @@ __global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc
         }
 }
 
+template <int TERMS = 3>
+__global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc d, const int q_per_slice) {
+    rcda_dv2_body<TERMS>(d, q_per_slice, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// dS / dq / dk (rcda_bwd_body) and dV (rcda_dv2_body) of one attention in ONE launch: the two read the same saved attention maps and d_out
+// and write disjoint outputs, so their workgroups share the chip instead of following each other (encoder: 61 + 33 us as two launches).
+// blockIdx.x < nqb: a query block of the dS kernel (its 64 * NW threads; the surplus waves of the 512-thread block leave at once);
+// the rest: (key-row group, query slice) of the dV kernel.
+template <int NF, int NW, int TERMS>
+__global__ __launch_bounds__(512) void rcda_bwd_all_kernel(const cdetr_rcda_bwd_desc d, const int nqb, const int hgroups, const int q_per_slice) {
+    if ((int)blockIdx.x < nqb) {
+        if ((int)threadIdx.x >= 64 * NW) return;
+        rcda_bwd_body<NF, NW, 1, TERMS>(d, blockIdx.x, blockIdx.y);
+    } else {
+        const int t = (int)blockIdx.x - nqb;
+        rcda_dv2_body<TERMS>(d, q_per_slice, t % hgroups, blockIdx.y, t / hgroups);
+    }
+}
+
 template <typename F>
 int set_smem(F func, int bytes, const char* what) {
     if (bytes > 160 * 1024) {
@@ -1231,12 +1257,26 @@ int launch_rcda_fwd(const cdetr_rcda_fwd_desc& d, hipStream_t st) {
     }
     return cdetr_launch_status("cdetr_rcda_fwd");
 }
+// hgroups > 0: the two-step dV of the same attention (hgroups x slices workgroups, `per` queries per slice) rides in the same launch
 template <int NF, int NW>
-int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st) {
+int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st, int hgroups = 0, int slices = 0, int per = 0) {
     const BwdSmem sm = bwd_smem(d.H, d.W, NF, NW, d.dq_row != nullptr);
-    const int bytes = sm.total * 4;
+    int bytes = sm.total * 4;
     int rc;
     dim3 grid((d.L + QW * NW - 1) / (QW * NW), d.N * d.nh), block(64 * NW);
+    if (hgroups > 0) {
+        bytes = std::max(bytes, dv2_smem().total * 4);
+        const int nqb = grid.x;
+        dim3 g2(nqb + hgroups * slices, d.N * d.nh);
+        if (d.precision == 3) {
+            if ((rc = set_smem(rcda_bwd_all_kernel<NF, NW, 1>, bytes, "cdetr_rcda_bwd"))) return rc;
+            hipLaunchKernelGGL((rcda_bwd_all_kernel<NF, NW, 1>), g2, dim3(512), bytes, st, d, nqb, hgroups, per);
+        } else {
+            if ((rc = set_smem(rcda_bwd_all_kernel<NF, NW, 3>, bytes, "cdetr_rcda_bwd"))) return rc;
+            hipLaunchKernelGGL((rcda_bwd_all_kernel<NF, NW, 3>), g2, dim3(512), bytes, st, d, nqb, hgroups, per);
+        }
+        return cdetr_launch_status("cdetr_rcda_bwd(dS+dV)");
+    }
     if (d.precision == 3) {          // plain-bf16 products (the backward's arithmetic)
         if ((rc = set_smem(rcda_bwd_kernel<NF, NW, 1, 1>, bytes, "cdetr_rcda_bwd"))) return rc;
         hipLaunchKernelGGL((rcda_bwd_kernel<NF, NW, 1, 1>), grid, block, bytes, st, d);
@@ -1317,29 +1357,41 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     const int Wp = (d.W + 3) & ~3;
     const int nw = pick_nw(d.L, d.N * d.nh);
     int rc;
-    if (NF == 1) rc = nw == 4 ? launch_rcda_bwd<1, 4>(d, st) : launch_rcda_bwd<1, 2>(d, st);
+    // the two-step dV (rcda_dv2_kernel) rides in the dS launch (rcda_bwd_all_kernel) unless CDETR_RCDA_MERGE=0
+    static const int use_dv2 = getenv("CDETR_RCDA_DV2") ? atoi(getenv("CDETR_RCDA_DV2")) : 1;
+    static const int merge = getenv("CDETR_RCDA_MERGE") ? atoi(getenv("CDETR_RCDA_MERGE")) : 1;
+    const bool dv2 = use_dv2 && d.precision >= 1 && d.W <= 64;
+    int hgroups = 0, slices = 0, per = 0;
+    if (dv2) {
+        hgroups = (d.H + 7) / 8;
+        const long base = (long)hgroups * d.N * d.nh;
+        static const int dv2_target = getenv("CDETR_RCDA_DV2_TARGET") ? atoi(getenv("CDETR_RCDA_DV2_TARGET")) : 448;
+        slices = (int)((dv2_target + base - 1) / base);              // < 2 workgroups of 8 waves per CU (measured: 448 -> 46 us, 512 -> 54 us at the encoder shape)
+        const int max_slices = (d.L + 255) / 256;                    // >= 4 q-tiles per slice
+        if (slices > max_slices) slices = max_slices;
+        if (slices < 1) slices = 1;
+        per = (d.L + slices - 1) / slices;
+        per = ((per + 63) / 64) * 64;
+        slices = (d.L + per - 1) / per;
+    }
+    // ... when the dS grid leaves most CUs free (decoder: 48 workgroups; 51 + 14 us as two launches -> 52 us as one).  At the encoder shape the
+    // dS kernel already puts one 5-wave workgroup on every CU and the dV workgroups cannot move in beside them (8 waves at the merged kernel's
+    // 200 registers fill a CU): 61 + 33 us became 117 us -- measured, so the rule looks at the grid.  (The H > 64 kernels need more than the
+    // 256 registers a 512-thread block leaves a wave: never merged.)
+    const long ds_wgs = (long)((d.L + QW * nw - 1) / (QW * nw)) * d.N * d.nh;
+    const int mh = (dv2 && NF < 4 && (merge == 2 || (merge == 1 && ds_wgs <= 128))) ? hgroups : 0;
+    if (NF == 1) rc = nw == 4 ? launch_rcda_bwd<1, 4>(d, st, mh, slices, per) : launch_rcda_bwd<1, 2>(d, st, mh, slices, per);
     else if (NF == 2) {
         // 5-wave workgroups when they put the grid on <= one workgroup per CU and 4-wave ones do not (see cdetr_rcda_fwd)
         static const int nw5 = getenv("CDETR_RCDA_NW5") ? atoi(getenv("CDETR_RCDA_NW5")) : 1;
         const long wg4 = (long)((d.L + QW * 4 - 1) / (QW * 4)) * d.N * d.nh, wg5 = (long)((d.L + QW * 5 - 1) / (QW * 5)) * d.N * d.nh;
-        if (nw5 && nw == 4 && wg4 > 256 && wg4 <= 512 && wg5 <= 256) rc = launch_rcda_bwd<2, 5>(d, st);
-        else rc = nw == 4 ? launch_rcda_bwd<2, 4>(d, st) : launch_rcda_bwd<2, 2>(d, st);
+        if (nw5 && nw == 4 && wg4 > 256 && wg4 <= 512 && wg5 <= 256) rc = launch_rcda_bwd<2, 5>(d, st, mh, slices, per);
+        else rc = nw == 4 ? launch_rcda_bwd<2, 4>(d, st, mh, slices, per) : launch_rcda_bwd<2, 2>(d, st, mh, slices, per);
     }
-    else rc = nw == 4 ? launch_rcda_bwd<4, 4>(d, st) : launch_rcda_bwd<4, 2>(d, st);
-    if (rc) return rc;
-    static const int use_dv2 = getenv("CDETR_RCDA_DV2") ? atoi(getenv("CDETR_RCDA_DV2")) : 1;
-    if (use_dv2 && d.precision >= 1 && d.W <= 64) {   // two-step dV (see rcda_dv2_kernel)
+    else rc = nw == 4 ? launch_rcda_bwd<4, 4>(d, st, mh, slices, per) : launch_rcda_bwd<4, 2>(d, st, mh, slices, per);
+    if (rc || mh) return rc;
+    if (dv2) {   // two-step dV as its own launch
         const int bytes = dv2_smem().total * 4;
-        const int hgroups = (d.H + 7) / 8;
-        const long base = (long)hgroups * d.N * d.nh;
-        static const int dv2_target = getenv("CDETR_RCDA_DV2_TARGET") ? atoi(getenv("CDETR_RCDA_DV2_TARGET")) : 448;
-        int slices = (int)((dv2_target + base - 1) / base);          // < 2 workgroups of 8 waves per CU (measured: 448 -> 46 us, 512 -> 54 us at the encoder shape)
-        const int max_slices = (d.L + 255) / 256;                    // >= 4 q-tiles per slice
-        if (slices > max_slices) slices = max_slices;
-        if (slices < 1) slices = 1;
-        int per = (d.L + slices - 1) / slices;
-        per = ((per + 63) / 64) * 64;
-        slices = (d.L + per - 1) / per;
         if (d.precision == 3) {
             if ((rc = set_smem(rcda_dv2_kernel<1>, bytes, "cdetr_rcda_bwd(dV)"))) return rc;
             hipLaunchKernelGGL(rcda_dv2_kernel<1>, dim3(hgroups, d.N * d.nh, slices), dim3(512), bytes, st, d, per);
