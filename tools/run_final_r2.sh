@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 bash tools/run_meas_r2.sh > /dev/null 2>&1
 O=gpurun_out/r2m
 rm -f $O/fetch.csv $O/write.csv $O/sq.csv
