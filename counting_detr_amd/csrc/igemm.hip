@@ -1783,6 +1783,24 @@ __global__ __launch_bounds__(256) void igemm_direct_group_kernel(const GemmGroup
     igemm_direct_body<BL, UB>(it.d, it.tilesM, it.tilesN, it.vecA, it.vecB, lb % it.nx, lb / it.nx);
 }
 
+// Few-row problems (K <= 256: one round trip per wave) AND 64x128-tile problems of one gemm_queue in ONE launch: the two classes are independent
+// by contract, and a few-row group next to a tile group used to cost its own 6-10 us link in the launch chain (the encoder's key projections
+// beside its query / value projections, the decoder's per-layer query gradients beside the memory gradient).  `pad_` of an item = its class;
+// a few-row item uses the first 4 waves of the 512-thread block.
+template <int TERMS>
+__global__ __launch_bounds__(512) void igemm_mixed_group_kernel(const GemmGroupArgs g) {
+    int p = 0;
+    while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
+    const GemmGroupItem& it = g.it[p];
+    const int lb = blockIdx.x - g.blk0[p];
+    if (it.pad_ == 0) {
+        if (threadIdx.x >= 256) return;
+        igemm_direct_body<0, 4>(it.d, it.tilesM, it.tilesN, it.vecA, it.vecB, lb % it.nx, lb / it.nx);
+    } else {
+        igemm_fast_body<2, 4, 1, 1, 0, 32, 3, TERMS>(it.d, it.tilesM, lb % it.nx, lb / it.nx);
+    }
+}
+
 // dW[i][c] += scale[i] * sum_p dY[p][i] X[p][c] (+ dbias[i] += sum_p dY[p][i]) for short reductions (P <= 1024):
 // one wave = one 16x16 output tile x one slice of the pixel range (grid.y slices); results are added atomically.
 __device__ __forceinline__ void wgrad_direct_body(const cdetr_wgrad_desc& d, const int tilesI, const int tilesJ, const int p_per_slice,
@@ -2164,6 +2182,42 @@ extern "C" int cdetr_gemm_group(const cdetr_gemm_desc* descs, int32_t n, void* s
         }
         if (c >= 0) cls[c].push_back(i);
         else if (int rc1 = cdetr_gemm(&d, stream)) return rc1;
+    }
+    // one launch for a few-row (K <= 256) class next to ONE tile class, when everything fits a single argument table
+    static const int mixed = getenv("CDETR_GEMM_MIXED") ? atoi(getenv("CDETR_GEMM_MIXED")) : 1;
+    const int tc = !cls[3].empty() ? 3 : 4;
+    if (mixed && !cls[0].empty() && (cls[3].empty() != cls[4].empty()) && cls[0].size() + cls[tc].size() <= (size_t)GG_MAX) {
+        GemmGroupArgs g;
+        int m = 0;
+        g.blk0[0] = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int idx : (pass == 0 ? cls[tc] : cls[0])) {
+                GemmGroupItem& it = g.it[m];
+                it.d = descs[idx];
+                it.vecA = gemm_vec_a(it.d); it.vecB = gemm_vec_b(it.d); it.pad_ = pass == 0 ? 1 : 0;
+                if (pass == 1) {
+                    it.tilesM = (it.d.M + 15) / 16; it.tilesN = (it.d.N + 15) / 16;
+                    it.nx = it.tilesM * it.tilesN;
+                } else {
+                    it.tilesM = (it.d.M + 63) / 64; it.tilesN = (it.d.N + 127) / 128;
+                    it.nx = 8 * ((it.tilesM + 7) / 8) * it.tilesN;
+                }
+                g.blk0[m + 1] = g.blk0[m] + it.nx * it.d.batch;
+                ++m;
+            }
+        }
+        g.n = m;
+        const int bytes = (2 * 64 * 36 + 2 * 128 * 36) * 4;
+        if (tc == 3) {
+            if (int rcl = raise_lds(igemm_mixed_group_kernel<3>, bytes, "cdetr_gemm_group")) return rcl;
+            hipLaunchKernelGGL(igemm_mixed_group_kernel<3>, dim3(g.blk0[m]), dim3(512), bytes, st, g);
+        } else {
+            if (int rcl = raise_lds(igemm_mixed_group_kernel<1>, bytes, "cdetr_gemm_group")) return rcl;
+            hipLaunchKernelGGL(igemm_mixed_group_kernel<1>, dim3(g.blk0[m]), dim3(512), bytes, st, g);
+        }
+        if (int rcl = cdetr_launch_status("cdetr_gemm_group")) return rcl;
+        cls[0].clear();
+        cls[tc].clear();
     }
     for (int c = 0; c < 5; ++c) {
         for (size_t c0 = 0; c0 < cls[c].size(); c0 += GG_MAX) {
