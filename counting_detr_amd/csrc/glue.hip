@@ -143,17 +143,22 @@ __global__ __launch_bounds__(256) void aggr_weight_fwd_kernel(const float* __res
 }
 
 // From dWeff [B][d][C]:  gW[o][c] += sum_b dWeff;  gW[o][C + c] += sum_b dWeff * pf[b][c];  dpf[b][c] += sum_o dWeff[b][o][c] * W[o][C + c].
-// grid (C / 256 rounded up, d / 32): thread = one column c over a slice of 32 output rows, all images (B <= 16) in registers.
-constexpr int AGG_MAX_B = 16;
+// grid (C / 256 rounded up, d / AGG_ROWS): thread = one column c over a slice of AGG_ROWS output rows, all images (B <= 16) in registers.
+// (8 rows, unrolled: the loads of a slice are in flight together and the grid is 256 workgroups at d = 256, C = 2048 -- with 32-row slices
+// the kernel was a chain of 32 dependent round trips on 64 workgroups: 56 us.)
+constexpr int AGG_MAX_B = 16, AGG_ROWS = 8;
 __global__ __launch_bounds__(256) void aggr_weight_bwd_kernel(const float* __restrict__ dWeff, const float* __restrict__ pf,
                                                               const float* __restrict__ W, float* __restrict__ gW, float* __restrict__ dpf,
                                                               int B, int d, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const int o0 = blockIdx.y * 32, o1 = min(o0 + 32, d);
+    const int o0 = blockIdx.y * AGG_ROWS, o1 = min(o0 + AGG_ROWS, d);
     float pfb[AGG_MAX_B], acc[AGG_MAX_B];
     for (int b = 0; b < B; ++b) { pfb[b] = pf[(long)b * C + c]; acc[b] = 0.f; }
-    for (int o = o0; o < o1; ++o) {
+#pragma unroll
+    for (int oo = 0; oo < AGG_ROWS; ++oo) {
+        const int o = o0 + oo;
+        if (o >= o1) break;
         const float w2 = W[(long)o * 2 * C + C + c];
         float s1 = 0.f, s2 = 0.f;
         for (int b = 0; b < B; ++b) {
@@ -270,7 +275,7 @@ extern "C" int cdetr_aggr_weight_fwd(const float* W, const float* pf, float* Wef
 extern "C" int cdetr_aggr_weight_bwd(const float* dWeff, const float* pf, const float* W, float* gW, float* dpf, int32_t B, int32_t d,
                                      int32_t C, void* stream) {
     CDETR_CHECK_ARG(dWeff && pf && W && dpf && B > 0 && B <= AGG_MAX_B && d > 0 && C > 0, "cdetr_aggr_weight_bwd: bad args (B <= %d)", AGG_MAX_B);
-    hipLaunchKernelGGL(aggr_weight_bwd_kernel, dim3((C + 255) / 256, (d + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dWeff,
+    hipLaunchKernelGGL(aggr_weight_bwd_kernel, dim3((C + 255) / 256, (d + AGG_ROWS - 1) / AGG_ROWS), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dWeff,
                        pf, W, gW, dpf, B, d, C);
     return cdetr_launch_status("cdetr_aggr_weight_bwd");
 }

@@ -449,6 +449,9 @@ class Trainer:
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
+            from . import ops
+            if ops.SPLITK:
+                ops.splitk_ws()        # the capture below runs on this stream: its split-reduction scratch exists (and is zeroed) before, not inside, the graph
             for _ in range(warmup):
                 self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
                 if world > 1:
@@ -466,21 +469,21 @@ class Trainer:
         g_a = torch.cuda.CUDAGraph()
         segs = None
         if not segmented:
-            with torch.cuda.graph(g_a):
+            with torch.cuda.graph(g_a, stream=s):
                 out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
                 out["grad_norm"] = self._optimizer_step()
             g_b = None
         else:                                      # (capturing records work, it does not run it)
-            with torch.cuda.graph(g_a):
+            with torch.cuda.graph(g_a, stream=s):
                 out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"], defer_trunk=True)
             segs = []
             for seg in (1, 2, 3):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=g_a.pool()):
+                with torch.cuda.graph(g, pool=g_a.pool(), stream=s):
                     self._trunk_segment(seg, last=(seg == 3))
                 segs.append(g)
             g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_b, pool=g_a.pool()):
+            with torch.cuda.graph(g_b, pool=g_a.pool(), stream=s):
                 out["grad_norm"] = self._optimizer_step()
         return g_a, segs, g_b, out
 
