@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 FAMILIES = (("igemm_fewrow", ("igemm_direct", "false, 2>(", "true, 2>(")),      # few-row class: the one-wave-per-tile kernel and the two-wave-group tile
-            ("igemm", ("igemm_fast", "igemm_kernel")), ("wgrad", ("wgrad_tr", "wgrad_fast", "wgrad_direct", "wgrad_kernel")),
+            ("igemm", ("igemm_fast", "igemm_kernel", "igemm_mixed")), ("wgrad", ("wgrad_tr", "wgrad_fast", "wgrad_direct", "wgrad_kernel")),
             ("rcda_fwd", ("rcda_fwd",)), ("rcda_bwd", ("rcda_bwd", "rcda_dv")), ("mha", ("flash::",)), ("lsap", ("lsap_",)),
             ("layernorm", ("ln_fwd", "ln_bwd")), ("optimizer", ("adamw", "sumsq")), ("weight_mirror", ("weight_mirror",)))
 
