@@ -4,7 +4,9 @@
 For every image of the val / test split: forward, losses (logged), the counting rule `sigmoid(logit[..., 0]) >= 0.5`,
 predictions written in the reference's wire format (COCO-style json: bbox = [cx, cy, w, h] ints in original pixels, `point` =
 the query's reference point, one `images` entry per image) to <output_dir>/predictions_<split>.json, then MAE / RMSE / NAE /
-SRE of the predicted counts against the ground-truth instance counts.  AP is out of scope (detectron2 / pycocotools).
+SRE of the predicted counts against the ground-truth instance counts, and -- when the split's `instances_<split>.json` is there -- the box AP /
+AP50 / AP75 / APs / APm / APl of A2/eval_all.py:285-331 from a dependency-free restatement of pycocotools' COCOeval
+(counting_detr_amd/coco_ap.py; parity unpinned: there is no pycocotools in this image to check it against).
 
   python infer.py -dp /data/FSC147 --split val --resume out/detr_retrain.pth -o out
 """
@@ -94,6 +96,10 @@ def main(args):
     dl = DataLoader(ds, batch_size=1, shuffle=False, collate_fn=data.collate, num_workers=args.num_workers)
     os.makedirs(args.output_dir, exist_ok=True)
     metrics, _ = infer(model, criterion, dl, device, args.output_dir, split=args.split)
+    gt_json = os.path.join(args.data_path, "instances_" + args.split + ".json")
+    if os.path.isfile(gt_json):
+        from counting_detr_amd.coco_ap import ap_from_json
+        metrics.update(ap_from_json(os.path.join(args.output_dir, "predictions_" + args.split + ".json"), gt_json))
     print(json.dumps(metrics))
     with open(os.path.join(args.output_dir, "results_" + args.split + ".txt"), "w") as f:
         f.write(json.dumps(metrics) + "\n")

@@ -181,6 +181,16 @@ def test_dataset_train_epoch_and_infer(tmp_path):
     m2 = infer_mod.counting_metrics_from_json(str(tmp_path / "predictions_val.json"), os.path.join(args.data_path, "instances_val.json"))
     for k in ("MAE", "RMSE", "NAE", "SRE"):
         np.testing.assert_allclose(m2[k], metrics[k], rtol=1e-12)
+    # box AP of the same json pair (counting_detr_amd/coco_ap.py): defined, within [0, 100]; and 100 when the ground truth is fed back as predictions
+    from counting_detr_amd import coco_ap
+    ap = coco_ap.ap_from_json(str(tmp_path / "predictions_val.json"), os.path.join(args.data_path, "instances_val.json"))
+    assert set(ap) == {"AP", "AP50", "AP75", "APs", "APm", "APl"} and 0.0 <= ap["AP"] <= ap["AP50"] <= 100.0
+    gtj = json.load(open(os.path.join(args.data_path, "instances_val.json")))
+    g_by, d_by = {}, {}
+    for k_, a_ in enumerate(gtj["annotations"]):
+        g_by.setdefault(a_["image_id"], []).append({"bbox": a_["bbox"], "area": a_["area"]})
+        d_by.setdefault(a_["image_id"], []).append({"bbox": a_["bbox"], "score": 0.9 - 1e-3 * k_, "area": a_["area"]})
+    assert coco_ap.summarize(g_by, d_by)["AP"] == pytest.approx(100.0)        # the ground truth fed back as detections
     model.eval()
     with torch.no_grad():
         b = next(iter(vl))
