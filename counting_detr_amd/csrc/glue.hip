@@ -36,20 +36,25 @@ __global__ __launch_bounds__(256) void mask_prep_kernel(const uint8_t* __restric
         const int yy = min((int)floorf(y * sy), H - 1), xx = min((int)floorf(x * sx), W - 1);
         return src[(long)yy * W + xx] != 0;
     };
-    for (int x = tid; x < w; x += 256) mask_row[(long)b * w + x] = cell(0, x) ? 1 : 0;     // mask[:, 0, :]
-    for (int y = tid; y < h; y += 256) mask_col[(long)b * h + y] = cell(y, 0) ? 1 : 0;     // mask[:, :, 0]
+    // (the cells of the first row / column are fetched by all threads at once and parked in LDS: the two scans below used to be chains of
+    // ~50 dependent global loads each -- 20 us for a handful of bytes)
+    __shared__ float free_row[1024], free_col[1024];
+    for (int x = tid; x < w; x += 256) { const bool c = cell(0, x); mask_row[(long)b * w + x] = c ? 1 : 0; if (x < 1024) free_row[x] = c ? 0.f : 1.f; }     // mask[:, 0, :]
+    for (int y = tid; y < h; y += 256) { const bool c = cell(y, 0); mask_col[(long)b * h + y] = c ? 1 : 0; if (y < 1024) free_col[y] = c ? 0.f : 1.f; }     // mask[:, :, 0]
+    __syncthreads();
+    const bool lds_ok = h <= 1024 && w <= 1024;
     if (tid == 64) {     // mask2pos: (cumsum(~mask) - 0.5) / total along each axis; tens of elements -- a serial scan is the cheapest form
         float ty = 0.f;
-        for (int y = 0; y < h; ++y) ty += cell(y, 0) ? 0.f : 1.f;
+        for (int y = 0; y < h; ++y) ty += lds_ok ? free_col[y] : (cell(y, 0) ? 0.f : 1.f);
         float run = 0.f;
-        for (int y = 0; y < h; ++y) { run += cell(y, 0) ? 0.f : 1.f; pos_col[(long)b * h + y] = (run - 0.5f) / ty; }
+        for (int y = 0; y < h; ++y) { run += lds_ok ? free_col[y] : (cell(y, 0) ? 0.f : 1.f); pos_col[(long)b * h + y] = (run - 0.5f) / ty; }
         extent[2 * b] = ty;          // un-padded rows of this image, in feature cells
     }
     if (tid == 128) {
         float tx = 0.f;
-        for (int x = 0; x < w; ++x) tx += cell(0, x) ? 0.f : 1.f;
+        for (int x = 0; x < w; ++x) tx += lds_ok ? free_row[x] : (cell(0, x) ? 0.f : 1.f);
         float run = 0.f;
-        for (int x = 0; x < w; ++x) { run += cell(0, x) ? 0.f : 1.f; pos_row[(long)b * w + x] = (run - 0.5f) / tx; }
+        for (int x = 0; x < w; ++x) { run += lds_ok ? free_row[x] : (cell(0, x) ? 0.f : 1.f); pos_row[(long)b * w + x] = (run - 0.5f) / tx; }
         extent[2 * b + 1] = tx;      // un-padded columns
     }
 }

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 export TMPDIR=/tmp
 bash tools/run_meas_r2.sh > /dev/null 2>&1
 O=gpurun_out/r2m
