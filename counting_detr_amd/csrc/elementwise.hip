@@ -449,7 +449,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ add,
                                                      float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int rows, int C) {
+                                                     int rows, int C, const float* __restrict__ g1 = nullptr,
+                                                     const float* __restrict__ g2 = nullptr, float* __restrict__ acc1 = nullptr,
+                                                     float* __restrict__ acc2 = nullptr) {
+    // g1 / g2 (C == 256 only): further addends of the incoming gradient, dy_eff = dy + g1 + g2, with acc1 += g1, acc2 += g2 in place -- the
+    // cdetr_grad_merge pass that used to precede this kernel in the decoder's backward (its output had no other reader)
     __shared__ float red[2][4][1024];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nv = C >> 8;
@@ -477,6 +481,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 av[b] = add ? reinterpret_cast<const float4*>(add + r * C)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
                 mu[b] = mean[r];
                 rs[b] = rstd[r];
+            }
+            if (g1) {            // merged addends (wave-uniform): their loads join the batch; the accumulators are updated for real rows only
+                float4 u1[LN_RB], u2[LN_RB], c1[LN_RB], c2[LN_RB];
+#pragma unroll
+                for (int b = 0; b < LN_RB; ++b) {
+                    const long r = min(row0 + b * stride, rows - 1);
+                    u1[b] = reinterpret_cast<const float4*>(g1 + r * C)[lane];
+                    u2[b] = g2 ? reinterpret_cast<const float4*>(g2 + r * C)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    c1[b] = acc1 ? reinterpret_cast<const float4*>(acc1 + r * C)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    c2[b] = acc2 ? reinterpret_cast<const float4*>(acc2 + r * C)[lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int b = 0; b < LN_RB; ++b) {
+                    const int row = row0 + b * stride;
+                    if (row >= rows) break;
+                    dv[b].x += u1[b].x + u2[b].x; dv[b].y += u1[b].y + u2[b].y; dv[b].z += u1[b].z + u2[b].z; dv[b].w += u1[b].w + u2[b].w;
+                    if (acc1) reinterpret_cast<float4*>(acc1 + (long)row * C)[lane] = make_float4(c1[b].x + u1[b].x, c1[b].y + u1[b].y, c1[b].z + u1[b].z, c1[b].w + u1[b].w);
+                    if (acc2) reinterpret_cast<float4*>(acc2 + (long)row * C)[lane] = make_float4(c2[b].x + u2[b].x, c2[b].y + u2[b].y, c2[b].z + u2[b].z, c2[b].w + u2[b].w);
+                }
             }
 #pragma unroll
             for (int b = 0; b < LN_RB; ++b) {
@@ -779,6 +802,20 @@ extern "C" int cdetr_layernorm_bwd(const float* dy, const float* x, const float*
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma,
                        add, dx, dgamma, dbeta, rows, C);
     return cdetr_launch_status("cdetr_layernorm_bwd");
+}
+
+extern "C" int cdetr_layernorm_bwd_merge(const float* dy, const float* g1, const float* g2, float* acc1, float* acc2, const float* x,
+                                         const float* mean, const float* rstd, const float* gamma, const float* add, float* dx, float* dgamma,
+                                         float* dbeta, int32_t rows, int32_t C, void* stream) {
+    CDETR_CHECK_ARG(dy && g1 && x && mean && rstd && gamma && dx && dgamma && dbeta && rows >= 0 && (g2 || !acc2), "cdetr_layernorm_bwd_merge: bad args");
+    CDETR_CHECK_ARG(C == 256, "cdetr_layernorm_bwd_merge: C must be 256 (got %d)", C);
+    if (rows == 0) return CDETR_OK;
+    static const int rpb = getenv("CDETR_LN_BWD_ROWS") ? atoi(getenv("CDETR_LN_BWD_ROWS")) : 32;
+    int blocks = rows <= 2048 ? (rows + 3) / 4 : (rows + rpb - 1) / rpb;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma,
+                       add, dx, dgamma, dbeta, rows, C, g1, g2, acc1, acc2);
+    return cdetr_launch_status("cdetr_layernorm_bwd_merge");
 }
 
 extern "C" int cdetr_posadd2(const float* X, const float* Prow, const float* Pcol, float* Qr, float* Qc, int32_t N, int32_t H,

@@ -938,10 +938,18 @@ def ln_fwd_add_raw(x2d, weight, bias, eps, a1, a2=None):
     return y, mean, rstd, o1, o2
 
 
-def ln_bwd_raw(dy2d, x2d, mean, rstd, weight, gw, gb, add=None):
-    """dx (+ add); dgamma / dbeta accumulate into gw / gb."""
+def ln_bwd_raw(dy2d, x2d, mean, rstd, weight, gw, gb, add=None, merge=None):
+    """dx (+ add); dgamma / dbeta accumulate into gw / gb.  merge = (g1, g2 | None, acc1 | None, acc2 | None): the incoming gradient is
+    dy2d + g1 + g2 and acc1 += g1, acc2 += g2 in place (cdetr_grad_merge folded in; C = 256)."""
     rows, Cc = x2d.shape
     dx = torch.empty_like(x2d)
+    if merge is not None and Cc == 256:
+        g1, g2, acc1, acc2 = merge
+        check(lib().cdetr_layernorm_bwd_merge(ptr(dy2d), ptr(g1), ptr(g2), ptr(acc1), ptr(acc2), ptr(x2d), ptr(mean), ptr(rstd), ptr(weight),
+                                              ptr(add), ptr(dx), ptr(gw), ptr(gb), rows, Cc, stream_ptr()), "cdetr_layernorm_bwd_merge")
+        return dx
+    if merge is not None:
+        dy2d = grad_merge(dy2d, *merge)
     check(lib().cdetr_layernorm_bwd(ptr(dy2d), ptr(x2d), ptr(mean), ptr(rstd), ptr(weight), ptr(add), ptr(dx), ptr(gw), ptr(gb),
                                     rows, Cc, stream_ptr()), "cdetr_layernorm_bwd")
     return dx
@@ -1258,7 +1266,7 @@ class DecoderStackFn(torch.autograd.Function):
         acc = zall[:3 * M * E].view(3, M, E)                                    # d(query_pos), d(query_pos_x), d(query_pos_y)
         acc_p, acc_x, acc_y = acc[0], acc[1], acc[2]
         dMem = dKrm = dKcm = None
-        dx = None                                                               # gradient flowing into the layer output
+        pend_t = pend_g = None                                                  # the layer above's d(x) = pend_t + pend_g, summed by its consumer
         for li in range(len(layers) - 1, -1, -1):
             layer = layers[li]
             sa, ca, f = layer.self_attn, layer.cross_attn, layer.ffn
@@ -1266,15 +1274,17 @@ class DecoderStackFn(torch.autograd.Function):
              Y1, mu1, rs1, T2, Hd, Y3, mu3, rs3) = saved[li]
             saved[li] = None
             g_out = d_outs[li].reshape(M, E).contiguous() if d_outs[li] is not None else None
-            if dx is None:
-                dOut = g_out
-            else:
-                dOut = dx if g_out is None else grad_merge(dx, g_out)
-            if dOut is None:            # this layer's output feeds nothing (cannot happen for the last layer)
-                continue
             Ws, Wc = sa.in_proj_weight.detach(), ca.in_proj_weight.detach()
-            # ---- FFN: out = LN3(T2 + relu(T2 W1^T + b1) W2^T + b2)
-            dY3 = ln_bwd_raw(dOut, Y3, mu3, rs3, f.norm2.weight.detach(), grad_buffer(f.norm2.weight), grad_buffer(f.norm2.bias))
+            # ---- FFN: out = LN3(T2 + relu(T2 W1^T + b1) W2^T + b2).  The gradient of this layer's output = the layer above's d(x)
+            # (residual + v-path `pend_t`, plus the q/k-path `pend_g` whose value also accumulates into d(qpos)) + this layer's own output
+            # gradient (aux losses / the last layer): summed inside the LayerNorm backward that consumes it
+            ln3 = (Y3, mu3, rs3, f.norm2.weight.detach(), grad_buffer(f.norm2.weight), grad_buffer(f.norm2.bias))
+            if pend_t is None:
+                if g_out is None:       # this layer's output feeds nothing (cannot happen for the last layer)
+                    continue
+                dY3 = ln_bwd_raw(g_out, *ln3)
+            else:
+                dY3 = ln_bwd_raw(pend_t, *ln3, merge=(pend_g, g_out, acc_p, None))
             _wg(dY3, Hd, f.linear2.weight, f.linear2.bias, 0, E)
             dHd = linear_dgrad(dY3, f.linear2.weight.detach(), gate=Hd)
             _wg(dHd, T2, f.linear1.weight, f.linear1.bias, 0, Hd.shape[1])
@@ -1299,9 +1309,10 @@ class DecoderStackFn(torch.autograd.Function):
                 dKrm = linear_dgrad(dk_row2, Wc[2 * E:3 * E], resid=dKrm)      # shared inputs: chained across layers
                 dKcm = linear_dgrad(dk_col2, Wc[3 * E:4 * E], resid=dKcm)
                 dMem = linear_dgrad(dv2, Wc[4 * E:5 * E], resid=dMem)
-            dT1 = grad_merge(dY1, gx, gy, acc_x, acc_y)                        # + both query projections; d(qx) += gx, d(qy) += gy
+            # d(T1) = dY1 + both query projections, d(qx) += gx, d(qy) += gy: formed inside the LayerNorm backward that consumes it
             # ---- self attention: T1 = LN2(x + mha((x + qpos) Wqk, x Wv) Wo^T + bo)
-            dY2 = ln_bwd_raw(dT1, Y2, mu2, rs2, layer.norm2.weight.detach(), grad_buffer(layer.norm2.weight), grad_buffer(layer.norm2.bias))
+            dY2 = ln_bwd_raw(dY1, Y2, mu2, rs2, layer.norm2.weight.detach(), grad_buffer(layer.norm2.weight), grad_buffer(layer.norm2.bias),
+                             merge=(gx, gy, acc_x, acc_y))
             _wg(dY2, o1.view(M, E), sa.out_proj.weight, sa.out_proj.bias, 0, E)
             dO1 = linear_dgrad(dY2, sa.out_proj.weight.detach()).view(N, L, E)
             dqk, dvs = mha_bwd_raw(qk.view(N, L, 2 * E), vs.view(N, L, E), o1, dO1, lse, sa.num_heads)
@@ -1311,9 +1322,10 @@ class DecoderStackFn(torch.autograd.Function):
             with gemm_queue():
                 ga1 = linear_dgrad(dqk.view(M, 2 * E), Ws[0:2 * E])
                 t = linear_dgrad(dvs.view(M, E), Ws[2 * E:3 * E], resid=dY2)
-            dx = grad_merge(t, ga1, None, acc_p, None)                         # d(x) = residual + v-path + q/k-path; d(qpos) += ga1
+            pend_t, pend_g = t, ga1                                            # d(x) = t + ga1 and d(qpos) += ga1: formed by the consumer
             if li % 2 == 0 and WGRAD_STACKS:
                 wgrad_flush(overlap=True)       # two layers' parameter gradients (26 small problems) beside the next layers' chain
+        dx = grad_merge(pend_t, pend_g, None, acc_p, None)                     # the first layer's input gradient leaves the node: merged for real
         if ctx.own_means:        # memory also fed the two key means: broadcast their gradients back in the same pass
             dMem = bcast_add2(dMem.view(N, H, W, E), dKrm, dKcm, 1.0 / H, 1.0 / W)
             return (dx.view(N, L, E), acc_p.view(N, L, E), acc_x.view(N, L, E), acc_y.view(N, L, E), dMem, None, None, None, None, None,
