@@ -451,7 +451,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      int rows, int C, const float* __restrict__ g1 = nullptr,
                                                      const float* __restrict__ g2 = nullptr, float* __restrict__ acc1 = nullptr,
-                                                     float* __restrict__ acc2 = nullptr) {
+                                                     float* __restrict__ acc2 = nullptr, const float* __restrict__ Br = nullptr,
+                                                     const float* __restrict__ Bc = nullptr, float sr = 0.f, float sc = 0.f, int bH = 1, int bW = 1) {
+    // Br / Bc (with g1; rows = N * bH * bW): two broadcast addends, dy_eff += sr * Br[n, x] + sc * Bc[n, y] (row = (n, y, x)) -- the encoder's
+    // cdetr_bcast_add2_sum pass folded in the same way
     // g1 / g2 (C == 256 only): further addends of the incoming gradient, dy_eff = dy + g1 + g2, with acc1 += g1, acc2 += g2 in place -- the
     // cdetr_grad_merge pass that used to precede this kernel in the decoder's backward (its output had no other reader)
     __shared__ float red[2][4][1024];
@@ -497,6 +500,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                     const int row = row0 + b * stride;
                     if (row >= rows) break;
                     dv[b].x += u1[b].x + u2[b].x; dv[b].y += u1[b].y + u2[b].y; dv[b].z += u1[b].z + u2[b].z; dv[b].w += u1[b].w + u2[b].w;
+                    if (Br) {
+                        const int xw = row % bW, t2 = row / bW, yh = t2 % bH, nn = t2 / bH;
+                        const float4 br = reinterpret_cast<const float4*>(Br + ((long)nn * bW + xw) * C)[lane];
+                        const float4 bc = reinterpret_cast<const float4*>(Bc + ((long)nn * bH + yh) * C)[lane];
+                        dv[b].x += sr * br.x + sc * bc.x; dv[b].y += sr * br.y + sc * bc.y; dv[b].z += sr * br.z + sc * bc.z; dv[b].w += sr * br.w + sc * bc.w;
+                    }
                     if (acc1) reinterpret_cast<float4*>(acc1 + (long)row * C)[lane] = make_float4(c1[b].x + u1[b].x, c1[b].y + u1[b].y, c1[b].z + u1[b].z, c1[b].w + u1[b].w);
                     if (acc2) reinterpret_cast<float4*>(acc2 + (long)row * C)[lane] = make_float4(c2[b].x + u2[b].x, c2[b].y + u2[b].y, c2[b].z + u2[b].z, c2[b].w + u2[b].w);
                 }
@@ -804,17 +813,19 @@ extern "C" int cdetr_layernorm_bwd(const float* dy, const float* x, const float*
     return cdetr_launch_status("cdetr_layernorm_bwd");
 }
 
-extern "C" int cdetr_layernorm_bwd_merge(const float* dy, const float* g1, const float* g2, float* acc1, float* acc2, const float* x,
+extern "C" int cdetr_layernorm_bwd_merge(const float* dy, const float* g1, const float* g2, float* acc1, float* acc2, const float* Br,
+                                         const float* Bc, float sr, float sc, int32_t H, int32_t W, const float* x,
                                          const float* mean, const float* rstd, const float* gamma, const float* add, float* dx, float* dgamma,
                                          float* dbeta, int32_t rows, int32_t C, void* stream) {
     CDETR_CHECK_ARG(dy && g1 && x && mean && rstd && gamma && dx && dgamma && dbeta && rows >= 0 && (g2 || !acc2), "cdetr_layernorm_bwd_merge: bad args");
+    CDETR_CHECK_ARG(!Br == !Bc && (!Br || (H > 0 && W > 0 && rows % (H * W) == 0)), "cdetr_layernorm_bwd_merge: Br / Bc come as a pair, rows = N * H * W");
     CDETR_CHECK_ARG(C == 256, "cdetr_layernorm_bwd_merge: C must be 256 (got %d)", C);
     if (rows == 0) return CDETR_OK;
     static const int rpb = getenv("CDETR_LN_BWD_ROWS") ? atoi(getenv("CDETR_LN_BWD_ROWS")) : 32;
     int blocks = rows <= 2048 ? (rows + 3) / 4 : (rows + rpb - 1) / rpb;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma,
-                       add, dx, dgamma, dbeta, rows, C, g1, g2, acc1, acc2);
+                       add, dx, dgamma, dbeta, rows, C, g1, g2, acc1, acc2, Br, Bc, sr, sc, Br ? H : 1, Br ? W : 1);
     return cdetr_launch_status("cdetr_layernorm_bwd_merge");
 }
 

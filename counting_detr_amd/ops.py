@@ -195,6 +195,7 @@ class wgrad_queue:
 # idle at two images per GPU; the weight gradients of a finished layer depend on nothing downstream, so their grouped launch goes to a
 # side stream (fork after the layer, join before the optimizer / the bucket's all-reduce) and fills those CUs while the chain runs on.
 # The operand tensors of launches in flight are kept referenced until the join: the allocator must not hand their memory to the chain.
+ENC_DEFER = int(_os.environ.get("CDETR_ENC_DEFER", "1"))      # encoder backward: a layer's d(src) parts are summed by the LayerNorm backward below it
 WGRAD_ASYNC = int(_os.environ.get("CDETR_WGRAD_ASYNC", "1"))
 # Measured (one MI355X, B=2 800x800, same box, ms/step): everything at the end 10.95 | one overlapped submission per backbone segment
 # (layer4 / layer3 / layer2) 10.87 | every 3 blocks 10.95 | every block 11.02 (small groups lose the grouped launch) | encoder / decoder
@@ -938,17 +939,21 @@ def ln_fwd_add_raw(x2d, weight, bias, eps, a1, a2=None):
     return y, mean, rstd, o1, o2
 
 
-def ln_bwd_raw(dy2d, x2d, mean, rstd, weight, gw, gb, add=None, merge=None):
+def ln_bwd_raw(dy2d, x2d, mean, rstd, weight, gw, gb, add=None, merge=None, bcast=None):
     """dx (+ add); dgamma / dbeta accumulate into gw / gb.  merge = (g1, g2 | None, acc1 | None, acc2 | None): the incoming gradient is
-    dy2d + g1 + g2 and acc1 += g1, acc2 += g2 in place (cdetr_grad_merge folded in; C = 256)."""
+    dy2d + g1 + g2 and acc1 += g1, acc2 += g2 in place (cdetr_grad_merge folded in; C = 256).  bcast = (Br, Bc, sr, sc, H, W), with merge:
+    + sr * Br[n,x] + sc * Bc[n,y] as well (cdetr_bcast_add2_sum folded in)."""
     rows, Cc = x2d.shape
     dx = torch.empty_like(x2d)
     if merge is not None and Cc == 256:
         g1, g2, acc1, acc2 = merge
-        check(lib().cdetr_layernorm_bwd_merge(ptr(dy2d), ptr(g1), ptr(g2), ptr(acc1), ptr(acc2), ptr(x2d), ptr(mean), ptr(rstd), ptr(weight),
-                                              ptr(add), ptr(dx), ptr(gw), ptr(gb), rows, Cc, stream_ptr()), "cdetr_layernorm_bwd_merge")
+        Br, Bc, sr, sc, bh, bw = bcast if bcast is not None else (None, None, 0.0, 0.0, 1, 1)
+        check(lib().cdetr_layernorm_bwd_merge(ptr(dy2d), ptr(g1), ptr(g2), ptr(acc1), ptr(acc2), ptr(Br), ptr(Bc), sr, sc, bh, bw, ptr(x2d),
+                                              ptr(mean), ptr(rstd), ptr(weight), ptr(add), ptr(dx), ptr(gw), ptr(gb), rows, Cc, stream_ptr()),
+              "cdetr_layernorm_bwd_merge")
         return dx
     if merge is not None:
+        assert bcast is None
         dy2d = grad_merge(dy2d, *merge)
     check(lib().cdetr_layernorm_bwd(ptr(dy2d), ptr(x2d), ptr(mean), ptr(rstd), ptr(weight), ptr(add), ptr(dx), ptr(gw), ptr(gb),
                                     rows, Cc, stream_ptr()), "cdetr_layernorm_bwd")
@@ -1060,9 +1065,11 @@ class EncoderLayerFn(torch.autograd.Function):
             return EncoderLayerFn._backward(ctx, dX2)
 
     @staticmethod
-    def _backward(ctx, dX2, accR=None, accC=None, zbuf=None):
+    def _backward(ctx, dX2, accR=None, accC=None, zbuf=None, defer_out=False):
         """accR / accC: d(posemb_row) / d(posemb_col) accumulated by the layers ABOVE (EncoderStackFn): added inside the data-gradient
-        epilogues, the returned d(posemb) then already contain them."""
+        epilogues, the returned d(posemb) then already contain them.
+        dX2 may be the PARTS of the output gradient, a tuple (t, t2, t3, dKr, dKc) as a layer above returns them under defer_out=True
+        (d(src) = t + t2 + t3 + broadcast(dKr) / H + broadcast(dKc) / W): they are summed inside this layer's first LayerNorm backward."""
         (X, Qr, Qc, Kr, Kc, q_row, q_col, k_row, k_col, v, a_row, a_col, o, Y1, mu1, rs1, X1, Hd, Y2, mu2, rs2) = ctx.saved_tensors
         layer = ctx.layer
         N, H, W, Cc, E, nh = ctx.dims
@@ -1070,9 +1077,13 @@ class EncoderLayerFn(torch.autograd.Function):
         att, f = layer.self_attn, layer.ffn
         Wi = att.in_proj_weight.detach()
         Wip, bip = att.in_proj_weight, att.in_proj_bias
-        dX2 = dX2.reshape(R, Cc).contiguous()
+        ln2 = (Y2, mu2, rs2, f.norm2.weight.detach(), grad_buffer(f.norm2.weight), grad_buffer(f.norm2.bias))
         # ---- FFN (post-norm): X2 = LN2(X1 + relu(X1 W1^T + b1) W2^T + b2)
-        dY2 = ln_bwd_raw(dX2, Y2, mu2, rs2, f.norm2.weight.detach(), grad_buffer(f.norm2.weight), grad_buffer(f.norm2.bias))
+        if isinstance(dX2, tuple):
+            pt, pt2, pt3, pKr, pKc = dX2
+            dY2 = ln_bwd_raw(pt, *ln2, merge=(pt2, pt3, None, None), bcast=(pKr, pKc, 1.0 / H, 1.0 / W, H, W))
+        else:
+            dY2 = ln_bwd_raw(dX2.reshape(R, Cc).contiguous(), *ln2)
         _wg(dY2, Hd, f.linear2.weight, f.linear2.bias, 0, Cc)
         dHd = linear_dgrad(dY2, f.linear2.weight.detach(), gate=Hd)               # ReLU mask fused in the epilogue
         _wg(dHd, X1, f.linear1.weight, f.linear1.bias, 0, Hd.shape[1])
@@ -1103,7 +1114,9 @@ class EncoderLayerFn(torch.autograd.Function):
             # the same grouped launch, and the accumulation costs no launch of its own
             dKrA = linear_dgrad(dk_row2, Wi[2 * E:3 * E], resid=accR.reshape(N * W, Cc)) if accR is not None else dKr
             dKcA = linear_dgrad(dk_col2, Wi[3 * E:4 * E], resid=accC.reshape(N * H, Cc)) if accC is not None else dKc
-        dX = bcast_add2_sum(t.view(N, H, W, Cc), t2.view(N, H, W, Cc), t3.view(N, H, W, Cc), dKr, dKc, 1.0 / H, 1.0 / W)
+        # (defer_out: the sum is left to the LayerNorm backward of the layer below)
+        dX = (t, t2, t3, dKr, dKc) if defer_out else bcast_add2_sum(t.view(N, H, W, Cc), t2.view(N, H, W, Cc), t3.view(N, H, W, Cc), dKr, dKc,
+                                                                    1.0 / H, 1.0 / W)
         # ---- d(posemb): sum over the broadcast axis BEFORE projecting back (linearity) + the key-mean terms
         sr, sc = hw_reduce(dq_row.view(N, H, W, E), dq_col.view(N, H, W, E), None, None, 1.0, 1.0)
         with gemm_queue():
@@ -1141,7 +1154,7 @@ class EncoderStackFn(torch.autograd.Function):
         with wgrad_queue():
             for li in range(len(ctx.ctxs) - 1, -1, -1):
                 c = ctx.ctxs[li]
-                dX, accR, accC = EncoderLayerFn._backward(c, dX, accR, accC, zall[li * zn:(li + 1) * zn])[:3]
+                dX, accR, accC = EncoderLayerFn._backward(c, dX, accR, accC, zall[li * zn:(li + 1) * zn], defer_out=(li > 0 and ENC_DEFER))[:3]
                 c.saved_tensors = None
                 if WGRAD_STACKS:
                     wgrad_flush(overlap=True)   # this layer's parameter gradients run beside the next layer's chain
