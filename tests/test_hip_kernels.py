@@ -995,3 +995,54 @@ def test_gemm_split_reduction(slices, prec, lim, monkeypatch):
             ops.PRECISION = old
     ws = ops.splitk_ws()
     assert int(ws[:4096].abs().sum()) == 0, "arrival counters left non-zero"
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 50, 50), (1, 7, 5), (3, 16, 20)])
+def test_layernorm_backward_with_merged_addends(N, H, W):
+    """cdetr_layernorm_bwd_merge == cdetr_grad_merge / cdetr_bcast_add2_sum followed by cdetr_layernorm_bwd: the incoming gradient as a sum of
+    up to three tensors (+ the accumulator side effects) and, optionally, two addends broadcast over the map; rows not a multiple of the
+    kernel's row batch; against the composition of the separate launches (bit-identical sums are not required: the order of additions differs)."""
+    from counting_detr_amd import ops
+    C = 256
+    R = N * H * W
+    gen = g(R)
+    x = torch.randn(R, C, generator=gen).to(DEV)
+    gamma, beta = (1 + 0.1 * torch.randn(C, generator=gen)).to(DEV), torch.randn(C, generator=gen).to(DEV)
+    y, mu, rs = ops.ln_fwd_raw(x, gamma, beta, 1e-5) if hasattr(ops, "ln_fwd_raw") else (None, None, None)
+    if y is None:
+        mu = x.mean(1)
+        rs = 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)
+    dy, g1, g2 = [torch.randn(R, C, generator=gen).to(DEV) for _ in range(3)]
+    Br, Bc = torch.randn(N * W, C, generator=gen).to(DEV), torch.randn(N * H, C, generator=gen).to(DEV)
+    add = torch.randn(R, C, generator=gen).to(DEV)
+
+    def run(merged, bcast, with_acc):
+        gw, gb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        a1 = torch.ones(R, C, device=DEV) if with_acc else None
+        a2 = torch.full((R, C), 2.0, device=DEV) if with_acc else None
+        if merged:
+            dx = ops.ln_bwd_raw(dy, x, mu, rs, gamma, gw, gb, add=add, merge=(g1, g2, a1, a2),
+                                bcast=(Br, Bc, 1.0 / H, 1.0 / W, H, W) if bcast else None)
+        else:
+            if bcast:
+                t = ops.bcast_add2_sum(dy.view(N, H, W, C), g1.view(N, H, W, C), g2.view(N, H, W, C), Br, Bc, 1.0 / H, 1.0 / W).view(R, C)
+                if with_acc:
+                    a1 += g1; a2 += g2
+            else:
+                t = ops.grad_merge(dy, g1, g2, a1, a2)
+            dx = ops.ln_bwd_raw(t, x, mu, rs, gamma, gw, gb, add=add)
+        return dx, gw, gb, a1, a2
+
+    for bcast in (False, True):
+        for with_acc in (False, True):
+            ref, out = run(False, bcast, with_acc), run(True, bcast, with_acc)
+            for a, b, name in zip(out, ref, ("dx", "dgamma", "dbeta", "acc1", "acc2")):
+                if a is not None:
+                    close(a, b, rtol=2e-5, atol_scale=2e-5, msg=f"{name} bcast={bcast} acc={with_acc}")
+    # fp64 check of the merged form itself
+    xe = x.double().cpu().requires_grad_(True)
+    ye = F.layer_norm(xe, (C,), gamma.double().cpu(), beta.double().cpu(), 1e-5)
+    tot = (dy + g1 + g2).double().cpu() + (Br.double().cpu().view(N, 1, W, C) / H + Bc.double().cpu().view(N, H, 1, C) / W).expand(N, H, W, C).reshape(R, C)
+    ye.backward(tot)
+    dx = run(True, True, False)[0]
+    close(dx, xe.grad + add.double().cpu(), rtol=5e-5, atol_scale=5e-5, msg="merged vs fp64")
