@@ -66,8 +66,17 @@ def get_args_parser():
                    help="torchvision-layout ResNet-50 state dict (the reference hard-codes pretrained_models/resnet50-0676ba61.pth)")
     p.add_argument("--resume_skip_mismatch", action="store_true",
                    help="--resume: drop checkpoint keys whose shape differs (e.g. an Anchor-DETR COCO class head) instead of raising")
-    p.add_argument("--no_resume_optimizer", dest="resume_optimizer", action="store_false",
-                   help="--resume: model weights only, like the reference (default: also restore AdamW moments / epoch when present)")
+    p.add_argument("--resume_optimizer", action="store_true",
+                   help="--resume: ALSO restore AdamW moments, StepLR state and the epoch counter from the checkpoint (continue an "
+                        "interrupted run).  Default: model weights only and training starts at --start_epoch, exactly like the "
+                        "reference (A2/main.py:195-209), which fine-tunes from a full detector checkpoint this way")
+    p.add_argument("--no_resume_optimizer", dest="resume_optimizer", action="store_false", help="(default; kept for scripts of round 2)")
+    p.add_argument("--no_graph_cache", dest="graph_cache", action="store_false",
+                   help="train with the stream-ordered step instead of cached HIP graphs (one per padded image size / target-capacity class)")
+    p.add_argument("--graph_cache_size", default=32, type=int, help="captured steps kept alive (least recently used is dropped)")
+    p.add_argument("--bwd_precision", default=None, choices=["bf16", "bf16x2", "bf16x3"],
+                   help="arithmetic of the backward contractions (default bf16 = 1 MFMA per product, gradient error 4.7e-3 of its norm; "
+                        "bf16x3 = the forward's split arithmetic, 1.6e-3; DESIGN section 3).  Same as CDETR_PRECISION_BWD=3/2/1")
     p.add_argument("--exemplar_mode", default="per_image", choices=["per_image", "reference"],
                    help="per_image: image b is conditioned on its own exemplars; reference: rects[0] for the whole batch "
                         "(A2/models/backbone.py:122 -- exact only at batch 1)")

@@ -15,6 +15,19 @@ import torch
 BODY_PREFIX = "backbone.body."
 
 
+def invalidate_caches(model):
+    """Drop every device table derived from parameter VALUES: the FrozenBN folds (`_cache`) and the packed stem images
+    (`_stem_w4` / `_stem_wr`).  Call after anything that overwrites weights outside the optimizer step (checkpoint loads,
+    replica broadcast) -- a forward that ran before would otherwise keep using images of the old values."""
+    for m in model.modules():
+        if hasattr(m, "_cache"):
+            m._cache = None
+        if hasattr(m, "_stem_w4"):
+            m._stem_w4 = None
+        if hasattr(m, "_stem_wr"):
+            m._stem_wr = None
+
+
 def _read(path_or_dict):
     if isinstance(path_or_dict, dict):
         return path_or_dict
@@ -43,10 +56,7 @@ def load_backbone_pretrained(model, path_or_state_dict):
             if tuple(t.shape) != tuple(src[k].shape):
                 raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(src[k].shape)} vs model {tuple(t.shape)}")
             t.copy_(src[k].to(t.device, t.dtype))        # copy_ honours the destination's (channels_last) strides
-    for m in body.modules():                              # cached FrozenBN folds / padded stem images are stale now
-        if hasattr(m, "_cache"):
-            m._cache = None
-    body._stem_w4 = body._stem_wr = None
+    invalidate_caches(model)                              # cached FrozenBN folds / padded stem images are stale now
     return len(own)
 
 
@@ -72,7 +82,5 @@ def resume_model(model, path_or_ckpt, skip_mismatch=False, log=print):
         log("Unexpected Keys: {}".format(unexpected))
     if skipped:
         log("Skipped (shape mismatch): {}".format(skipped))
-    for m in model.modules():
-        if hasattr(m, "_cache"):
-            m._cache = None
+    invalidate_caches(model)
     return ckpt, list(missing), skipped

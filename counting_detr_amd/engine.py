@@ -167,9 +167,8 @@ class Trainer:
             for t in uniq:
                 t.copy_(flat[off:off + t.numel()].view(t.shape))
                 off += t.numel()
-        for m in self.model.modules():          # cached FrozenBN folds / stem images depend on what was just overwritten
-            if hasattr(m, "_cache"):
-                m._cache = None
+        from .checkpoint import invalidate_caches
+        invalidate_caches(self.model)           # cached FrozenBN folds / stem images depend on what was just overwritten
 
     def _build_mirror(self, named):
         """Weight images (ops.WeightMirror), rewritten once per step: k-contiguous transposes of every trainable matrix that
@@ -283,7 +282,9 @@ class Trainer:
             groups, _ = self._torch_param_order()
             order = [n for g in groups for n in g]
             ids = [i for g in sd["param_groups"] for i in g["params"]]
-            assert len(ids) == len(order), "optimizer state does not match this model's parameter list"
+            if len(ids) != len(order):
+                raise RuntimeError(f"optimizer state holds {len(ids)} parameters, this model's optimizer has {len(order)}: the "
+                                   "checkpoint comes from another model (pass weights only: drop --resume_optimizer)")
             params = dict(self.model.named_parameters())
             step = 0.0
             self.exp_avg.zero_()
@@ -298,7 +299,8 @@ class Trainer:
                 step = max(step, float(st["step"]))
             self.opt_state[0] = step
         else:                                   # round-1 format: flat moments + names
-            assert sd["names"] == self.names, "optimizer state does not match this model's parameter layout"
+            if sd["names"] != self.names:
+                raise RuntimeError("optimizer state does not match this model's parameter layout")
             self.exp_avg.copy_(sd["exp_avg"])
             self.exp_avg_sq.copy_(sd["exp_avg_sq"])
             self.opt_state.copy_(sd["state"])

@@ -67,9 +67,15 @@ def main(args):
         checkpoint, _, _ = ckpt_io.resume_model(model, args.resume, skip_mismatch=args.resume_skip_mismatch)
 
     trainer = Trainer(model, criterion, args, device=device)           # 3 lr groups + flat AdamW (A2/main.py:157-189); syncs replicas
-    if checkpoint is not None and args.resume_optimizer and checkpoint.get("optimizer"):
+    if checkpoint is not None and (args.resume_optimizer or args.auto_resume) and checkpoint.get("optimizer"):
+        # opt-in (the reference loads weights only and starts at --start_epoch, A2/main.py:195-209): continue an interrupted run
         trainer.load_state_dict(checkpoint["optimizer"], checkpoint.get("lr_scheduler"))
-        args.start_epoch = max(args.start_epoch, int(checkpoint.get("epoch", -1)) + 1)
+        resumed = int(checkpoint.get("epoch", -1)) + 1
+        if resumed > args.start_epoch:
+            print(f"resume: optimizer state restored, continuing at epoch {resumed} (checkpoint epoch {resumed - 1})")
+            args.start_epoch = resumed
+    if args.start_epoch >= args.epochs:
+        print(f"nothing to train: start epoch {args.start_epoch} >= --epochs {args.epochs}")
     torch.manual_seed(args.seed + 1 + utils.get_rank())                 # data-side RNG (synthetic batches, augmentation)
     sampler = None
     if args.synthetic:
@@ -93,14 +99,24 @@ def main(args):
         paths = [output_dir / "detr_retrain.pth"]
         if (epoch + 1) % args.lr_drop == 0 or (epoch + 1) % 10 == 0:
             paths.append(output_dir / f"detr_retrain_{epoch:04}.pth")
-        for p in paths:
-            utils.save_on_master({"model": model.state_dict(), "optimizer": trainer.state_dict(),
-                                  "lr_scheduler": trainer.lr_scheduler_state_dict(),
-                                  "epoch": epoch, "args": args}, p)
+        if utils.is_main_process():            # only rank 0 pays for the host copy of the moments
+            ckpt = {"model": model.state_dict(), "optimizer": trainer.state_dict(), "lr_scheduler": trainer.lr_scheduler_state_dict(),
+                    "epoch": epoch, "args": args}
+            for p in paths:
+                torch.save(ckpt, p)
         if utils.is_main_process():
             with (output_dir / "detr_retrain.txt").open("a") as f:
                 f.write(json.dumps({**{f"train_{k}": v for k, v in stats.items()}, "epoch": epoch}) + "\n")
     print("time: ", time.time() - start)
+    if args.eval and not args.synthetic:                                # counting evaluation on the validation split (A2/infer.py)
+        if utils.is_main_process():
+            import infer as _infer
+            from torch.utils.data import DataLoader
+            from counting_detr_amd import data
+            dl = DataLoader(data.build_test_dataset(args, image_set=args.split), batch_size=1, shuffle=False, collate_fn=data.collate,
+                            num_workers=args.num_workers)
+            metrics, _ = _infer.infer(model, criterion, dl, device, args.output_dir, split=args.split)
+            print("counting metrics ({}): {}".format(args.split, json.dumps(metrics)))
     if args.eval and args.synthetic:                                    # counting rule + MAE on the synthetic shard
         pred, gt = [], []
         for ret in SyntheticLoader(args, device, 2):

@@ -377,7 +377,7 @@ def test_main_resume_and_pretrained_backbone_end_to_end(tmp_path):
     assert set(ck["optimizer"]) == {"state", "param_groups"} and len(ck["optimizer"]["param_groups"]) == 3
     assert torch.equal(ck["model"]["backbone.body.conv1.weight"], tv["conv1.weight"])          # frozen stem: the pretrained values
     assert not torch.equal(ck["model"]["backbone.body.layer4.2.conv3.weight"], tv["layer4.2.conv3.weight"])   # trained
-    a2 = get_args_parser().parse_args(base + ["--epochs", "2", "-o", str(tmp_path / "run2"), "--resume",
+    a2 = get_args_parser().parse_args(base + ["--epochs", "2", "-o", str(tmp_path / "run2"), "--resume_optimizer", "--resume",
                                               str(tmp_path / "run1" / "detr_retrain.pth")])
     main_mod.main(a2)
     ck2 = torch.load(tmp_path / "run2" / "detr_retrain.pth", map_location="cpu", weights_only=False)
@@ -388,6 +388,12 @@ def test_main_resume_and_pretrained_backbone_end_to_end(tmp_path):
     assert float(st2[k]["step"]) == float(st1[k]["step"]) + 2                                   # moments / step count were restored
     lines = open(tmp_path / "run2" / "detr_retrain.txt").read().strip().splitlines()
     assert len(lines) == 1 and '"epoch": 1' in lines[0]
+    # the reference's own --resume (A2/main.py:195-209) is weights only and starts at --start_epoch: the default
+    a3 = get_args_parser().parse_args(base + ["--epochs", "1", "-o", str(tmp_path / "run3"), "--resume",
+                                              str(tmp_path / "run1" / "detr_retrain.pth")])
+    main_mod.main(a3)
+    ck3 = torch.load(tmp_path / "run3" / "detr_retrain.pth", map_location="cpu", weights_only=False)
+    assert ck3["epoch"] == 0 and float(ck3["optimizer"]["state"][k]["step"]) == 2.0            # fresh optimizer, epoch 0 trained
 
 
 def test_bench_self_launches_two_ranks_rehearsal():
