@@ -142,11 +142,17 @@ class SetCriterion(nn.Module):
         out = {k: v for k, v in outputs.items() if k not in ("aux_outputs", "enc_outputs")}
         logits = out["pred_logits"]
         B, Q = logits.shape[:2]
-        sizes = tuple(len(t["boxes"]) for t in targets)
-        plan = self._plan(sizes, Q, logits.device)
-        tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
-        tgt_labels_all = torch.cat([t["labels"] for t in targets])
         aux = outputs.get("aux_outputs")
+        if isinstance(targets, ops.PackedTargets):     # fixed-address buffers + capacity plan (the graph-cached step): counts live on the device
+            if aux:
+                raise NotImplementedError("PackedTargets with aux_outputs: the stacked matching needs tightly packed targets")
+            plan, tgt_boxes_all, tgt_labels_all = targets.plan, targets.boxes, targets.labels
+            sizes = tuple(plan.sizes)
+        else:
+            sizes = tuple(len(t["boxes"]) for t in targets)
+            plan = self._plan(sizes, Q, logits.device)
+            tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
+            tgt_labels_all = torch.cat([t["labels"] for t in targets])
         if aux:
             layers = list(aux) + [out]
             L = len(layers)

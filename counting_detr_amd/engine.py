@@ -138,8 +138,12 @@ class Trainer:
         self.sumsq = torch.zeros(1, device=self.device)
         self.sumsq_ws = torch.zeros(2048, device=self.device)       # CDETR_SUMSQ_WS_FLOATS: per-block partial sums
         self.epoch = 0
-        self._graph = self._graph_b = self._static = self._static_out = None
-        self._seg_graphs = None
+        self._entry = None                      # capture() / replay(): the explicitly captured step
+        self._cap_stream = None
+        self._cache = {}                        # step(): captured steps by (image shape, target capacity, arithmetic), LRU order
+        self._cache_on = bool(getattr(args, "graph_cache", True))
+        self._cache_size = int(getattr(args, "graph_cache_size", 32))
+        self.cache_stats = {"captures": 0, "steps": 0}
         self.mirror = self._build_mirror(named)
         self.exchange = FlatGradExchange(self.flat_g, self.seg_bounds)
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
@@ -419,8 +423,43 @@ class Trainer:
             outputs, _ = self.model(NestedTensor(st["images"], st["mask"]), rects=st["rects"])
             self.criterion(outputs, st["targets"], num_boxes=1.0)
 
+    def _queries(self):
+        t = self.model.transformer
+        return int(t.num_position) * int(t.num_pattern)
+
+    def target_capacity(self, tmax):
+        """Capacity class of a batch whose fullest image holds `tmax` targets: the smallest of {128, Q, 512, 1024, 2048, 3800}
+        that fits.  128 is the largest count whose cost matrix still sits in the assignment kernel's LDS next to Q = 300 columns
+        (csrc/matcher.hip), Q is where the matrix flips to its transposed layout, 3800 the LDS-resident solver's limit."""
+        Q = self._queries()
+        for c in sorted({min(128, Q), Q, 512, 1024, 2048, 3800}):
+            if tmax <= c:
+                return c
+        raise ValueError(f"{tmax} targets in one image exceed the assignment solver's capacity (3800)")
+
+    def _make_static(self, images, mask, rects, targets):
+        """Fixed-address inputs of one captured step: image / mask / exemplar buffers and the packed targets with a capacity plan
+        (any target counts up to the capacity class of this batch)."""
+        from . import ops
+        B = images.shape[0]
+        cap = self.target_capacity(max([len(t["boxes"]) for t in targets], default=0))
+        packed = ops.PackedTargets.with_capacity(B, self._queries(), cap, self.device)
+        packed.load(targets)
+        st = {"images": images.clone(), "mask": mask.clone(), "rects": rects.clone(), "targets": packed,
+              "num_boxes": torch.ones(1, device=self.device, dtype=torch.float32)}
+        self._load_num_boxes(st, targets)
+        return st
+
+    def _load_num_boxes(self, st, targets):
+        nb = self._num_boxes(targets)
+        if torch.is_tensor(nb):
+            st["num_boxes"].copy_(nb.reshape(1))
+        else:
+            st["num_boxes"].fill_(float(nb))
+
     def capture(self, samples, rects, targets, warmup=0):
-        """Capture (record, not run) the step for fixed shapes / target counts; `replay()` executes it.
+        """Capture (record, not run) the step for these image shapes; `replay()` executes it -- on the captured batch, or on any new
+        batch of the same padded image size whose target counts fit the captured capacity class (`target_capacity`).
         world_size == 1: ONE graph = zero-grad + forward + device matcher + losses + backward + clip + AdamW.
         world_size  > 1: FIVE graphs -- [everything down to the gradient w.r.t. layer4's output] [layer4 backward] [layer3
         backward] [layer2 backward] [clip + AdamW].  A collective cannot sit inside a captured graph, so the gradient exchange
@@ -429,11 +468,15 @@ class Trainer:
         order, same overlap as the stream-ordered step."""
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
         images, mask = nt.decompose()
-        st = {"images": images.clone(), "mask": mask.clone(), "rects": rects.clone(),
-              "targets": [{k: v.clone() for k, v in t.items()} for t in targets]}
+        self._entry = self._capture_entry(images, mask, rects, targets, warmup)
+        return self._entry["out"]
+
+    def _capture_entry(self, images, mask, rects, targets, warmup=0):
+        if getattr(self.model, "aux_loss", False):
+            raise NotImplementedError("graph capture with aux_loss=True: the stacked per-layer matching needs tightly packed targets; "
+                                      "use the stream-ordered step (train_step)")
+        st = self._make_static(images, mask, rects, targets)
         world = get_world_size()
-        nb0 = self._num_boxes(targets)
-        st["num_boxes"] = nb0.clone() if torch.is_tensor(nb0) else nb0
         hook = _bb._BACKWARD_HOOK
         _bb.set_backward_hook(None)                # no collectives inside the capture
         # CDETR_SEGMENTED_GRAPH=1: the five-graph form on ONE rank (no collectives): what the segmentation itself costs (tools / DESIGN section 7)
@@ -443,12 +486,13 @@ class Trainer:
             g_a, segs, g_b, out = self._capture_graphs(st, world, warmup, segmented)
         finally:                                   # a failed capture must leave the stream-ordered step intact
             _bb.set_backward_hook(hook)
-        self._graph, self._seg_graphs, self._graph_b, self._static, self._static_out = g_a, segs, g_b, st, out
-        return out
+        return {"g_a": g_a, "segs": segs, "g_b": g_b, "st": st, "out": out, "replays": 0}
 
     def _capture_graphs(self, st, world, warmup, segmented):
         self._dry_run(st)
-        s = torch.cuda.Stream()
+        if self._cap_stream is None:               # ONE capture stream per trainer: per-stream scratch (ops.splitk_ws) exists once
+            self._cap_stream = torch.cuda.Stream(device=self.device)
+        s = self._cap_stream
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             from . import ops
@@ -460,59 +504,90 @@ class Trainer:
                     dist.all_reduce(self.flat_g)
                 self._optimizer_step()
         torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        if world > 1:
-            # every collective issued so far has completed AND been retired by the process group's watchdog thread before the capture
-            # starts: the watchdog polls its pending work with event queries, which a capturing process must not see
-            import time
-            dist.barrier()
-            torch.cuda.synchronize()
-            time.sleep(0.5)
+        torch.cuda.synchronize()                   # everything this rank issued (collectives included) has completed
+        # The process group's watchdog thread polls its work with event queries; in the default ("global") capture mode such a call from
+        # ANOTHER thread invalidates a capture in progress.  "thread_local" confines the check to the capturing thread, so a rank can
+        # capture at any time -- ranks meet different image sizes at different steps, a rendezvous here would deadlock.
+        mode = {"capture_error_mode": "thread_local"} if world > 1 else {}
         g_a = torch.cuda.CUDAGraph()
         segs = None
         if not segmented:
-            with torch.cuda.graph(g_a, stream=s):
+            with torch.cuda.graph(g_a, stream=s, **mode):
                 out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
                 out["grad_norm"] = self._optimizer_step()
             g_b = None
         else:                                      # (capturing records work, it does not run it)
-            with torch.cuda.graph(g_a, stream=s):
+            with torch.cuda.graph(g_a, stream=s, **mode):
                 out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"], defer_trunk=True)
             segs = []
             for seg in (1, 2, 3):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=g_a.pool(), stream=s):
+                with torch.cuda.graph(g, pool=g_a.pool(), stream=s, **mode):
                     self._trunk_segment(seg, last=(seg == 3))
                 segs.append(g)
             g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_b, pool=g_a.pool(), stream=s):
+            with torch.cuda.graph(g_b, pool=g_a.pool(), stream=s, **mode):
                 out["grad_norm"] = self._optimizer_step()
         return g_a, segs, g_b, out
 
-    def replay(self, samples=None, rects=None, targets=None):
-        """Run the captured step; with arguments, on a NEW batch of the captured shapes / target counts (copied into the
-        graph's static inputs first)."""
-        st = self._static
-        if samples is not None:
-            nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
-            images, mask = nt.decompose()
-            st["images"].copy_(images)
-            st["mask"].copy_(mask)
-            st["rects"].copy_(rects)
-            for s_t, t in zip(st["targets"], targets):
-                for k in s_t:
-                    s_t[k].copy_(t[k])
-            if torch.is_tensor(st["num_boxes"]):
-                st["num_boxes"].copy_(self._num_boxes(targets))
-        self._graph.replay()
-        if self._graph_b is not None:
+    def _load_entry(self, e, images, mask, rects, targets):
+        st = e["st"]
+        st["images"].copy_(images)
+        st["mask"].copy_(mask)
+        st["rects"].copy_(rects)
+        st["targets"].load(targets)
+        self._load_num_boxes(st, targets)
+
+    def _replay_entry(self, e):
+        e["replays"] += 1
+        e["g_a"].replay()
+        if e["g_b"] is not None:
             self.exchange.segment_done(0)          # everything above the backbone is final: first bucket leaves now
-            for seg, g in zip((1, 2, 3), self._seg_graphs):
+            for seg, g in zip((1, 2, 3), e["segs"]):
                 g.replay()
                 self.exchange.segment_done(seg)
             self.exchange.finish()
-            self._graph_b.replay()
-        return self._static_out
+            e["g_b"].replay()
+        return e["out"]
+
+    def replay(self, samples=None, rects=None, targets=None):
+        """Run the captured step; with arguments, on a NEW batch of the captured image size whose target counts fit the captured
+        capacity class (copied into the graph's static inputs first)."""
+        e = self._entry
+        if samples is not None:
+            nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
+            images, mask = nt.decompose()
+            self._load_entry(e, images, mask, rects, targets)
+        return self._replay_entry(e)
+
+    # ------------------------------------------------------------------ graph cache: the step the data loader drives
+    def step(self, samples, rects, targets):
+        """One training step on an arbitrary batch at graph-replay speed: captured steps are cached by (padded image size, batch,
+        target-capacity class, arithmetic mode); a batch whose key is new is captured first (one dry forward + the capture, ~0.1 s),
+        every later batch of that key is three small copies + one graph launch.  FSC-147 images are 384 high and a multiple of 32
+        wide after the reference's resize rule (A2/data/fsc147.py:75-77), so an epoch meets a few dozen keys; the least recently
+        used entry is dropped beyond `args.graph_cache_size`.  Falls back to the stream-ordered `train_step` where a capture cannot
+        represent the step (aux_loss=True) or `args.graph_cache` is off.  Returns the step's loss dict (device scalars; valid
+        until the same entry is replayed again)."""
+        from . import ops
+        if not self._cache_on or not self.flat_g.is_cuda or getattr(self.model, "aux_loss", False):
+            return self.train_step(samples, rects, targets)
+        nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
+        images, mask = nt.decompose()
+        cap = self.target_capacity(max([len(t["boxes"]) for t in targets], default=0))
+        key = (tuple(images.shape), cap, ops.PRECISION, ops.PRECISION_BWD)
+        e = self._cache.pop(key, None)
+        if e is None:
+            while len(self._cache) >= max(self._cache_size, 1):
+                torch.cuda.synchronize()           # nothing of the entry being dropped is still running
+                self._cache.pop(next(iter(self._cache)))
+            e = self._capture_entry(images, mask, rects, targets)
+            self.cache_stats["captures"] += 1
+        else:
+            self._load_entry(e, images, mask, rects, targets)
+        self._cache[key] = e                       # most recently used last
+        self.cache_stats["steps"] += 1
+        return self._replay_entry(e)
 
 
 def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
@@ -521,9 +596,12 @@ def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
     flag (cdetr_adamw_step), the loss statistics accumulate on the device every step, and the host looks at both every
     `print_freq` iterations (and at the end of the epoch) -- so no polluted update is ever applied, and the abort happens at
     most `print_freq` no-op steps later."""
+    import time
     trainer.model.train()
     trainer.criterion.train()
     keys, acc, n = None, None, 0
+    cs0 = dict(getattr(trainer, "cache_stats", {}))
+    t_start = time.perf_counter()
 
     def check(it, vals=None):
         bad = trainer.nonfinite_steps()
@@ -536,7 +614,7 @@ def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
     it = -1
     for it, ret in enumerate(data_loader):
         samples = NestedTensor(ret["image"], ret["mask"]) if "mask" in ret else ret["image"]     # data.collate pads + masks
-        out = trainer.train_step(samples, ret["ex_rects"], ret["targets"])
+        out = trainer.step(samples, ret["ex_rects"], ret["targets"])       # cached HIP graph per padded size / target-capacity class
         if keys is None:
             keys = sorted(k for k, v in out.items() if torch.is_tensor(v))
             acc = torch.zeros(len(keys), device=trainer.device, dtype=torch.float32)
@@ -551,7 +629,13 @@ def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
         return {}
     check(it)
     red = reduce_dict({k: acc[i] / n for i, k in enumerate(keys)})
-    return {k: float(v) for k, v in red.items()}
+    stats = {k: float(v) for k, v in red.items()}           # (the float() above is the epoch's device synchronisation)
+    stats["ms_per_step"] = (time.perf_counter() - t_start) / n * 1e3
+    cs1 = getattr(trainer, "cache_stats", None)
+    if cs1:                                                 # graph cache: steps replayed from a captured HIP graph / new captures this epoch
+        stats["graph_steps"] = cs1["steps"] - cs0.get("steps", 0)
+        stats["graph_captures"] = cs1["captures"] - cs0.get("captures", 0)
+    return stats
 
 
 @torch.no_grad()

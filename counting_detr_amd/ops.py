@@ -1349,27 +1349,83 @@ class DecoderStackFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------------------------------- matcher
 class MatchPlan:
-    """Host-side (static) description of one batch of targets: sizes and device offset tables."""
+    """Description of one batch of targets for the matcher / criterion kernels: per-image target counts as a DEVICE offset table
+    (`tgt_off`, read by every kernel), plus the static sizes the launches are dimensioned by (`Mmax`, `nc_max`, `cost_off`).
 
-    def __init__(self, sizes, Q, device):
-        self.sizes = [int(s) for s in sizes]
+    `MatchPlan(sizes, Q, device)`: exact plan of one tuple of counts (tables built once per tuple).
+    `MatchPlan.capacity(B, Q, Tcap, device)`: ONE plan for every batch of B images with at most `Tcap` targets each -- launch
+    dimensions, cost-matrix slots (`b * Q * Tcap`) and index strides come from the capacity, the actual counts live only in
+    `tgt_off` and are rewritten by `set_counts()` before each step: a captured HIP graph serves any target counts."""
+
+    def __init__(self, sizes, Q, device, _capacity=None):
         self.Q = Q
+        self.device = device
+        self.Tcap = _capacity
+        if _capacity is None:
+            self._set_host(sizes)
+            coff = [0]
+            for s in self.sizes:
+                coff.append(coff[-1] + Q * s)
+            self.tgt_off = torch.tensor(self.tgt_off_host, dtype=torch.int32, device=device)
+            self.sizes_f = torch.tensor([float(s) for s in self.sizes], dtype=torch.float32, device=device)
+            self.Mmax = max(max(self.M), 1)
+            self.nc_max = max([Q] + self.sizes)
+        else:
+            B = int(sizes)
+            self.B = B
+            coff = [b * Q * _capacity for b in range(B + 1)]
+            self.tgt_off = torch.zeros(B + 1, dtype=torch.int32, device=device)
+            self.sizes_f = torch.zeros(B, dtype=torch.float32, device=device)
+            self.Mmax = max(min(Q, _capacity), 1)
+            self.nc_max = max(Q, _capacity)
+            self._set_host([0] * B)
+        self.cost_off = torch.tensor(coff[:-1], dtype=torch.int64, device=device)
+        self.cost_numel = max(coff[-1], 1)
+        self.cost_off_host = coff
+
+    @classmethod
+    def capacity(cls, B, Q, Tcap, device):
+        return cls(B, Q, device, _capacity=int(Tcap))
+
+    def _set_host(self, sizes):
+        self.sizes = [int(s) for s in sizes]
         self.B = len(self.sizes)
         off = [0]
         for s in self.sizes:
             off.append(off[-1] + s)
-        coff = [0]
-        for s in self.sizes:
-            coff.append(coff[-1] + Q * s)
-        self.tgt_off = torch.tensor(off, dtype=torch.int32, device=device)
-        self.cost_off = torch.tensor(coff[:-1], dtype=torch.int64, device=device)
-        self.cost_numel = max(coff[-1], 1)
-        self.cost_off_host = coff
         self.tgt_off_host = off
-        self.M = [min(Q, s) for s in self.sizes]
-        self.Mmax = max(max(self.M), 1)
-        self.nc_max = max([Q] + self.sizes)
-        self.sizes_f = torch.tensor([float(s) for s in self.sizes], dtype=torch.float32, device=device)
+        self.M = [min(self.Q, s) for s in self.sizes]
+
+    def set_counts(self, sizes):
+        """Capacity plan: the counts of the batch about to run (stream-ordered copies into the device tables)."""
+        assert self.Tcap is not None and len(sizes) == self.B and max(sizes, default=0) <= self.Tcap
+        self._set_host(sizes)
+        self.tgt_off.copy_(torch.tensor(self.tgt_off_host, dtype=torch.int32))
+        self.sizes_f.copy_(torch.tensor([float(s) for s in self.sizes], dtype=torch.float32))
+
+
+class PackedTargets:
+    """The targets of one batch in the form the device matcher / criterion consume: boxes [ΣT (or B*Tcap), 4] fp32 and labels
+    int64 concatenated in image order, and the MatchPlan holding the per-image offsets.  `SetCriterion.forward` accepts it in
+    place of the reference's list of dicts; the graph-cached train step keeps one per captured graph (fixed addresses)."""
+
+    def __init__(self, boxes, labels, plan):
+        self.boxes, self.labels, self.plan = boxes, labels, plan
+
+    @classmethod
+    def with_capacity(cls, B, Q, Tcap, device):
+        return cls(torch.zeros((B * Tcap, 4), dtype=torch.float32, device=device), torch.zeros(B * Tcap, dtype=torch.int64, device=device),
+                   MatchPlan.capacity(B, Q, Tcap, device))
+
+    def load(self, targets):
+        """Copy a list of {"boxes", "labels"} dicts (the reference's target format) into the fixed buffers."""
+        sizes = [int(t["boxes"].shape[0]) for t in targets]
+        n = sum(sizes)
+        if n:
+            self.boxes[:n].copy_(torch.cat([t["boxes"].reshape(-1, 4) for t in targets]))
+            self.labels[:n].copy_(torch.cat([t["labels"].reshape(-1) for t in targets]))
+        self.plan.set_counts(sizes)
+        return n
 
 
 def match_cost(logits, boxes, tgt_boxes, plan, w_class=2.0, w_bbox=5.0, w_giou=2.0):

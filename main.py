@@ -56,6 +56,9 @@ def main(args):
     # every rank builds the SAME initial weights (the init draws from the global RNG); only the data order is rank-specific.
     # Trainer additionally broadcasts rank 0's parameters and buffers (what DistributedDataParallel does at construction).
     torch.manual_seed(args.seed)
+    if getattr(args, "bwd_precision", None):                            # arithmetic of the backward contractions
+        from counting_detr_amd import ops
+        ops.PRECISION_BWD = {"bf16": 3, "bf16x2": 2, "bf16x3": 1}[args.bwd_precision]
     model, criterion, _ = counting_detr_amd.build_model(args)
     model.to(device)
     if args.pretrained_backbone:                                        # A2/models/backbone.py:153-155 -> resnet.py:292-297

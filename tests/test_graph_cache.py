@@ -1,0 +1,212 @@
+"""The graph-cached train step (engine.Trainer.step): one captured HIP graph per padded image size and
+target-capacity class serves batches of ANY target counts -- every count-dependent quantity of the matcher / criterion is a
+device table (ops.MatchPlan.capacity + ops.PackedTargets).  Reference loop: A2/engine.py:14-67 fed by A2/data/fsc147.py:69-102
+(variable image widths, 7...3731 targets per image).
+
+CPU part: the capacity plan's tables.  GPU part (-m gpu): capacity plan == exact plan through the device matcher + criterion
+(indices bit-exact), cached-graph steps == stream-ordered steps on fresh batches of different sizes / counts, LRU eviction,
+and main.py on a generated FSC-147-format dataset with several image sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from counting_detr_amd import ops
+
+HAS_GPU = torch.cuda.is_available()
+DEV = "cuda:0"
+
+
+def test_capacity_plan_tables_cpu():
+    p = ops.MatchPlan.capacity(3, 300, 128, "cpu")
+    assert (p.Mmax, p.nc_max, p.cost_numel) == (128, 300, 3 * 300 * 128)
+    assert p.cost_off.tolist() == [0, 300 * 128, 2 * 300 * 128]
+    p.set_counts([5, 0, 128])
+    assert p.tgt_off.tolist() == [0, 5, 5, 133] and p.sizes_f.tolist() == [5.0, 0.0, 128.0] and p.M == [5, 0, 128]
+    with pytest.raises(AssertionError):
+        p.set_counts([129, 0, 0])
+    q = ops.MatchPlan.capacity(2, 300, 512, "cpu")              # more targets than queries: the matrix is [Q][T], Q rows get matched
+    assert (q.Mmax, q.nc_max) == (300, 512)
+    e = ops.MatchPlan([5, 0, 128], 300, "cpu")                  # the exact plan of the same counts packs the cost matrices tightly
+    assert e.tgt_off.tolist() == p.tgt_off.tolist() and e.Mmax == 128 and e.cost_off.tolist() == [0, 1500, 1500]
+
+
+def test_packed_targets_load_cpu():
+    pk = ops.PackedTargets.with_capacity(2, 300, 128, "cpu")
+    tg = [{"boxes": torch.rand(3, 4), "labels": torch.zeros(3, dtype=torch.int64)},
+          {"boxes": torch.rand(0, 4), "labels": torch.zeros(0, dtype=torch.int64)}]
+    assert pk.load(tg) == 3
+    assert torch.equal(pk.boxes[:3], tg[0]["boxes"]) and pk.plan.tgt_off.tolist() == [0, 3, 3]
+    tg2 = [{"boxes": torch.rand(1, 4), "labels": torch.ones(1, dtype=torch.int64)},
+           {"boxes": torch.rand(2, 4), "labels": torch.zeros(2, dtype=torch.int64)}]
+    ptr = pk.boxes.data_ptr()
+    pk.load(tg2)
+    assert pk.boxes.data_ptr() == ptr and pk.plan.tgt_off.tolist() == [0, 1, 3] and int(pk.labels[0]) == 1
+    assert torch.equal(pk.boxes[1:3], tg2[1]["boxes"])
+
+
+def test_trainer_capacity_classes_cpu():
+    from counting_detr_amd.engine import Trainer
+
+    class _T:
+        _queries = lambda self: 300          # noqa: E731
+    t = _T()
+    f = lambda n: Trainer.target_capacity(t, n)      # noqa: E731
+    assert [f(n) for n in (0, 7, 128, 129, 300, 301, 512, 513, 3731)] == [128, 128, 128, 300, 300, 512, 512, 1024, 3800]
+    with pytest.raises(ValueError):
+        f(3801)
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+gpu = pytest.mark.gpu
+
+
+def _build(Q=100):
+    import counting_detr_amd
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.init import seeded_init_
+    args = default_args(device=DEV, num_query_position=Q)
+    model, crit, _ = counting_detr_amd.build_model(args)
+    seeded_init_(model)
+    model.to(DEV).train()
+    crit.train()
+    return model, crit, args
+
+
+def _batch(B, H, W, Ts, seed):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    rects = torch.tensor([[.10, .10, .20, .20], [.40, .40, .50, .55], [.70, .20, .80, .30]])[None].repeat(B, 1, 1).to(DEV)
+    tg = []
+    for b in range(B):
+        T = Ts[b]
+        box = torch.cat([torch.rand(T, 2, generator=g) * 0.8 + 0.1, torch.rand(T, 2, generator=g) * 0.10 + 0.02], 1)
+        tg.append({"boxes": box.to(DEV), "labels": torch.zeros(T, dtype=torch.int64, device=DEV)})
+    return images, rects, tg
+
+
+@gpu
+@pytest.mark.parametrize("Ts,cap", [((7, 13), 128), ((0, 31), 128), ((100, 3), 100), ((130, 40), 512), ((250, 0), 512)])
+def test_capacity_plan_equals_exact_plan_on_device(Ts, cap):
+    """Device matcher + fused criterion on PackedTargets with a capacity plan == on the reference's list of dicts with the exact
+    plan: Hungarian indices bit-exact (rows beyond min(Q, T) are not part of the contract), every loss equal."""
+    from counting_detr_amd.matcher import OriginalHungarianMatcher
+    Q, B = 100, 2
+    g = torch.Generator().manual_seed(11)
+    out = {"pred_logits": torch.randn(B, Q, 2, generator=g).to(DEV), "pred_boxes": (torch.rand(B, Q, 4, generator=g) * 0.5 + 0.2).to(DEV),
+           "pred_vars": (torch.rand(B, Q, 2, generator=g) + 0.5).to(DEV)}
+    _, _, tg = _batch(B, 32, 32, Ts, seed=3)
+    m = OriginalHungarianMatcher(2, 5, 2)
+    ii, jj, st, plan = m.match_device(out, tg)
+    pk = ops.PackedTargets.with_capacity(B, Q, cap, DEV)
+    pk.load(tg)
+    ii2, jj2, st2, _ = m.match_device(out, None, pk.plan, tgt_boxes=pk.boxes)
+    assert int(st.abs().sum()) == 0 and int(st2.abs().sum()) == 0
+    for b in range(B):
+        Mb = min(Q, Ts[b])
+        assert torch.equal(ii[b, :Mb], ii2[b, :Mb]) and torch.equal(jj[b, :Mb], jj2[b, :Mb])
+    _, crit, _ = _build(Q)
+    l1 = crit(out, tg)
+    l2 = crit(out, pk)
+    for k in l1:
+        np.testing.assert_allclose(float(l2[k]), float(l1[k]), rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+@gpu
+def test_cached_graph_steps_equal_eager_steps_on_varied_batches():
+    """Trainer.step (graph cache) vs Trainer.train_step (stream-ordered) from the SAME weights / moments on six fresh batches of
+    three image sizes whose target counts change inside a capacity class and across classes (incl. an image with no target
+    and one with more targets than queries): losses to 1e-5, updated parameters to the atomic-order noise of one AdamW step;
+    the third size re-uses its captured graph with other counts; captures happen once per (size, class)."""
+    from counting_detr_amd.engine import Trainer
+    model, crit, args = _build(Q=100)
+    tr = Trainer(model, crit, args, device=DEV)
+    seq = [((2, 128, 160), (7, 13)), ((2, 96, 128), (30, 5)), ((2, 128, 160), (64, 0)), ((2, 64, 96), (3, 3)),
+           ((2, 128, 160), (101, 9)), ((2, 96, 128), (2, 41)), ((2, 128, 160), (1, 100))]
+    state = lambda: [t.detach().clone() for t in (tr.flat_p, tr.exp_avg, tr.exp_avg_sq, tr.opt_state)]      # noqa: E731
+    for i, ((B, H, W), Ts) in enumerate(seq):
+        images, rects, tg = _batch(B, H, W, Ts, seed=100 + i)
+        saved = state()
+        eo = {k: float(v) for k, v in tr.train_step(images, rects, tg).items()}
+        p_eager = tr.flat_p.detach().clone()
+        for dst, src in zip((tr.flat_p, tr.exp_avg, tr.exp_avg_sq, tr.opt_state), saved):
+            dst.copy_(src)
+        go = {k: float(v) for k, v in tr.step(images, rects, tg).items()}
+        torch.cuda.synchronize()
+        for k in eo:
+            np.testing.assert_allclose(go[k], eo[k], rtol=1e-4 if k == "grad_norm" else 1e-5, atol=1e-6, err_msg=f"step {i} {k}")
+        diff = (tr.flat_p - p_eager).abs()
+        assert float(diff.max()) <= 2.1e-4 and float((diff > 2e-6).float().mean()) < 2e-3, f"step {i}"
+    # keys: (128x160, cap 100) x3 [7,13 / 64,0 / 1,100], (96x128, 100) x2, (64x96, 100), (128x160, cap 512) -> 4 captures for 7 steps
+    assert tr.cache_stats == {"captures": 4, "steps": 7}
+    assert sorted(e["replays"] for e in tr._cache.values()) == [1, 1, 2, 3]
+
+
+@gpu
+def test_graph_cache_evicts_least_recently_used():
+    from counting_detr_amd.engine import Trainer
+    model, crit, args = _build(Q=100)
+    args.graph_cache_size = 2
+    tr = Trainer(model, crit, args, device=DEV)
+    shapes = [(64, 96), (96, 96), (64, 96), (64, 64), (96, 96)]
+    for i, (H, W) in enumerate(shapes):
+        out = tr.step(*_batch(1, H, W, (5,), seed=i))
+        assert np.isfinite(float(out["loss"]))
+    # (64,96) (96,96) cached; (64,96) hit; (64,64) evicts (96,96); (96,96) captured again, evicting (64,96)
+    assert tr.cache_stats["captures"] == 4 and len(tr._cache) == 2
+    assert [k[0][2:] for k in tr._cache] == [(64, 64), (96, 96)]
+
+
+def _write_fsc147(root, sizes, counts, seed=0):
+    """An FSC-147-format training set (A2/data/fsc147.py:12-67): images_384_VarV2/*.png, annotation_FSC147_384.json with three
+    exemplar boxes per image, annotations/pseudo_bbox_train.json with [cx, cy, w, h] pixel boxes."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "images_384_VarV2"))
+    os.makedirs(os.path.join(root, "annotations"))
+    anno, images, anns = {}, [], []
+    aid = 1
+    for i, ((h, w), n) in enumerate(zip(sizes, counts)):
+        name = f"{i + 1}.png"
+        Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(os.path.join(root, "images_384_VarV2", name))
+        ex = []
+        for _ in range(3):
+            x1, y1 = rng.uniform(0.1, 0.6) * w, rng.uniform(0.1, 0.6) * h
+            x2, y2 = x1 + 0.1 * w, y1 + 0.15 * h
+            ex.append([[x1, y1], [x1, y2], [x2, y2], [x2, y1]])
+        anno[name] = {"box_examples_coordinates": ex}
+        images.append({"id": i + 1, "file_name": name, "width": w, "height": h})
+        for _ in range(n):
+            anns.append({"id": aid, "image_id": i + 1, "category_id": 1, "iscrowd": 0,
+                         "bbox": [float(rng.uniform(0.1, 0.9) * w), float(rng.uniform(0.1, 0.9) * h), float(rng.uniform(4, 12)), float(rng.uniform(4, 12))]})
+            aid += 1
+    json.dump(anno, open(os.path.join(root, "annotation_FSC147_384.json"), "w"))
+    json.dump({"images": images, "annotations": anns, "categories": [{"id": 1, "name": "fg"}]},
+              open(os.path.join(root, "annotations", "pseudo_bbox_train.json"), "w"))
+
+
+@gpu
+def test_main_trains_a_multi_size_dataset_through_the_graph_cache(tmp_path, capsys):
+    """main.py (reader -> collate -> prefetch -> Trainer.step) on a generated FSC-147-format set with three image sizes and target
+    counts from 0 to more than the number of queries: two epochs, every step after the first epoch is a cache hit, the result
+    equals the run with --no_graph_cache (stream-ordered step) to the noise of the steps' atomics."""
+    import main as main_mod
+    from counting_detr_amd.args import get_args_parser
+    root = str(tmp_path / "data")
+    sizes = [(64, 100), (64, 100), (96, 130), (96, 130), (64, 70), (64, 70), (96, 130), (96, 130)]
+    counts = [5, 9, 17, 0, 3, 3, 120, 2]
+    _write_fsc147(root, sizes, counts)
+    base = ["-dp", root, "--no_aux_loss", "--num_query_pattern", "1", "--num_query_position", "100", "--images_per_gpu", "2", "--device", DEV,
+            "--epochs", "2", "--num_workers", "0", "--seed", "7"]
+    losses = {}
+    for tag, extra in (("graph", []), ("eager", ["--no_graph_cache"])):
+        out = str(tmp_path / tag)
+        main_mod.main(get_args_parser().parse_args(base + ["-o", out] + extra))
+        lines = [json.loads(l) for l in open(os.path.join(out, "detr_retrain.txt")).read().strip().splitlines()]
+        assert [l["epoch"] for l in lines] == [0, 1]
+        losses[tag] = [l["train_loss"] for l in lines]
+        if tag == "graph":
+            assert lines[0]["train_graph_captures"] >= 1 and lines[1]["train_graph_steps"] == 4
+    np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-2)
