@@ -30,7 +30,9 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense bf16 MFMA; the split-bf16 mode spends 3 bf16 MFMAs per algorithmic product
 PRECISIONS = {"bf16x3": 1, "fp32": 0}
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_traffic.json")
+if not os.path.exists(TRAFFIC_JSON):
+    TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_traffic.json")
 
 
 def step_gflop_per_image(H, W, Q):
@@ -220,6 +222,87 @@ def extra_shape(dev, H, W, queries, prior, Ts, batch, precision, steps=10):
             "steps": steps, "whole_step_tflops": step_gflop_per_image(H, W, Q) * batch / (dt / steps * 1e3), "final_loss": float(q)}
 
 
+def inference_leg(dev, shapes, batch, precision, steps=20):
+    """Forward + counting rule (A2/infer.py:57-81) through engine.InferenceEngine: pre-split weight images built once, one captured
+    HIP graph per shape, replayed `steps` times after 3 warm-ups.  images/s per shape, plus the eager (stream-ordered) rate."""
+    import counting_detr_amd
+    from counting_detr_amd import ops
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.engine import InferenceEngine
+    from counting_detr_amd.init import seeded_init_
+    ops.PRECISION = PRECISIONS[precision]
+    args = default_args(device=str(dev))
+    model, _, _ = counting_detr_amd.build_model(args)
+    seeded_init_(model)
+    model.to(dev).eval()
+    out = []
+    for (H, W) in shapes:
+        images, rects, _ = synthetic_batch(batch, H, W, (1,), seed=7, device=dev)
+        row = {"image": [H, W], "images_per_gpu": batch, "queries": 300}
+        for tag, graphs in (("graph", True), ("eager", False)):
+            eng = InferenceEngine(model, graphs=graphs)
+            for _ in range(3):
+                counts = eng(images, rects)[0]
+            torch.cuda.synchronize()
+            dt, per, _ = timed_steps(lambda: eng(images, rects), steps, torch.cuda.synchronize)
+            row[tag] = {"value": batch * steps / dt, "unit": "images/s", "ms_per_batch": dt / steps * 1e3, "step_ms": percentiles(per)}
+        row["counts"] = [int(c) for c in counts]
+        out.append(row)
+    return {"what": "forward + counting rule (sigmoid(logit[...,0]) >= 0.5), inputs resident in HBM, graph replay vs stream-ordered launches",
+            "dtype": "forward bf16x3, fp32 accumulate / storage", "steps": steps, "shapes": out}
+
+
+def real_data_leg(dev, precision, batch=2, reps=4):
+    """The loop main.py runs (engine.train_one_epoch -> Trainer.step: cached HIP graphs keyed by padded image size and target-capacity
+    class) on batches shaped like FSC-147 after the reference's resize rule (384 high, widths multiples of 32, A2/data/fsc147.py:75-77)
+    with target counts that change every step; ms/step of the steady state per image size next to the fixed-shape replay of the same
+    size (Trainer.capture / replay, what `value` times).  In-memory batches: the reader / PIL decode is not part of the step."""
+    from counting_detr_amd import ops
+    ops.PRECISION = PRECISIONS[precision]
+    tr = build_trainer(dev, 300, "learned", precision)
+    sizes = [(384, 576), (384, 512), (384, 640)]
+    counts = [(37, 120), (7, 64), (101, 3), (56, 0), (12, 128), (90, 77)]
+    batches = []
+    for r in range(reps * len(counts)):
+        H, W = sizes[r % len(sizes)]
+        Ts = counts[r % len(counts)] if r % 7 else (180, 20)                      # every 7th batch falls into the next capacity class (128 < T <= Q)
+        images, rects, targets = synthetic_batch(batch, H, W, Ts, seed=300 + r, device=dev)
+        batches.append(((H, W), Ts, images, rects, targets))
+    for b in batches:                                                            # first meeting of every key: captures
+        tr.step(b[2], b[3], b[4])
+    torch.cuda.synchronize()
+    cap0 = dict(tr.cache_stats)
+    per_size = {}
+    evs = []
+    for b in batches:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = tr.step(b[2], b[3], b[4])
+        e1.record()
+        evs.append((b[0], e0, e1))
+    t0 = time.perf_counter()
+    for b in batches:
+        out = tr.step(b[2], b[3], b[4])
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / len(batches) * 1e3
+    for sz, e0, e1 in evs:
+        per_size.setdefault(sz, []).append(e0.elapsed_time(e1))
+    rows = []
+    for (H, W) in sizes:
+        images, rects, targets = synthetic_batch(batch, H, W, (37, 120), seed=1, device=dev)
+        tr.capture(images, rects, targets, warmup=0)
+        for _ in range(3):
+            tr.replay()
+        dt, per, _ = timed_steps(tr.replay, 10, torch.cuda.synchronize)
+        fixed = dt / 10 * 1e3
+        cached = sorted(per_size[(H, W)])[len(per_size[(H, W)]) // 2]
+        rows.append({"image": [H, W], "cached_step_ms_median": cached, "fixed_replay_ms": fixed, "ratio": cached / fixed,
+                     "steps": len(per_size[(H, W)])})
+    return {"what": "Trainer.step over batches of 3 image sizes x 7 target-count tuples (2 capacity classes), steady state after the captures",
+            "wall_ms_per_step_all_sizes": wall, "new_captures_in_timed_part": tr.cache_stats["captures"] - cap0["captures"],
+            "graphs_cached": len(tr._cache), "per_size": rows, "final_loss": float(out["loss"])}
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -239,6 +322,8 @@ def main(argv=None):
                     help="matrix-core arithmetic of the GEMM kernels: split-bf16 x3 (default, ~5e-6 rel) or fp32 MFMA (exact products)")
     ap.add_argument("--no-alt", action="store_true", help="skip the short run in the other precision mode")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra shapes (grid-576 queries, 384x576 image)")
+    ap.add_argument("--no-inference", action="store_true", help="skip the inference leg (forward + counting rule, graph replay)")
+    ap.add_argument("--no-real-data", action="store_true", help="skip the graph-cache leg (variable image sizes / target counts)")
     a = ap.parse_args(argv)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -372,7 +457,9 @@ def main(argv=None):
             continue
         tps = (tj or {}).get("families_bytes_per_step", {}).get(k)         # PMC bytes of the family per step (profiles/r2_traffic.json)
         kern[k] = {"tflops": v[0] / v[1] / 1e12, "mfma_issued_tflops": v[4] / v[1] / 1e12, "mfma_per_product": v[4] / max(v[0], 1.0),
-                   "frac_of_dense_mfma": v[4] / v[1] / 1e12 / (PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS),
+                   "frac": v[0] / v[1] / 1e12 / (PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS),
+                   "mfma_issue_frac": v[4] / v[1] / 1e12 / (PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS),
+                   "traffic_GBps": (tps / (v[1] / reps) / 1e9) if tps else None,
                    "ms_per_step": v[1] / reps * 1e3, "launches_per_step": v[2] // reps,
                    "gflop_per_step": v[0] / reps / 1e9, "algorithmic_bytes_per_launch": v[3] / max(v[2], 1),
                    "algorithmic_bytes_per_step": v[3] / reps, "traffic_bytes_per_step": tps,
@@ -383,24 +470,29 @@ def main(argv=None):
     # peak for ALGORITHMIC FLOPs of this family = dense bf16 MFMA peak / (bf16 MFMAs issued per algorithmic product, FLOP-weighted
     # over the family's launches: 3 in the split-bf16 forward, 1 in the plain-bf16 backward) -- so frac = issued MFMA rate / 2500 TF
     per_product = ig[4] / max(ig[0], 1.0)
-    peak = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS / per_product
     gflop_img = step_gflop_per_image(H, W, Q)
-    roofline = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": kern.get("igemm", {}).get("traffic_bytes_per_launch"), "traffic_unit": "bytes/launch",
+    dense = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+    total_traffic = (tj or {}).get("total_bytes_per_step")
+    roofline = {"bound": "mfma", "achieved": achieved, "peak": dense, "unit": "TFLOP/s",
+                "frac": achieved / dense,
+                "frac_note": "ALGORITHMIC FLOPs (2*M*N*K*taps per launch) of the dominant kernel family / HIP-event time of its launches / the "
+                             "dense MFMA peak of the arithmetic's input type (2500 TF bf16; 157.3 TF for --precision fp32).  The split-bf16 forward "
+                             "issues 3 bf16 MFMAs per algorithmic product, the plain-bf16 backward 1: mfma_issue_frac is the issued-MFMA rate "
+                             "over the same peak (round 2 reported THAT number as frac)",
+                "mfma_per_product": per_product, "mfma_issue_frac": achieved * per_product / dense,
+                "traffic": kern.get("igemm", {}).get("traffic_bytes_per_launch"), "traffic_unit": "bytes/launch",
                 "traffic_source": (tj or {}).get("source"),
                 "algorithmic_bytes_per_launch": ig[3] / max(ig[2], 1),
-                "peak_note": ("fp32 MFMA v_mfma_f32_32x32x2_f32" if a.precision == "fp32" else
-                              f"2500 TF dense bf16 MFMA / {per_product:.3f} bf16 MFMAs issued per algorithmic product (FLOP-weighted over "
-                              "the family's launches: 3 = hi*hi + hi*lo + lo*hi in the split-bf16 forward, 1 in the plain-bf16 "
-                              "backward), i.e. frac = issued MFMA rate / 2500 TF; frac_of_dense_bf16 prices the ALGORITHMIC FLOPs "
-                              "against the full 2500 TF"),
-                "mfma_per_product": per_product,
-                "frac_of_dense_bf16": achieved / PEAK_BF16_MFMA_TFLOPS,
-                "kernel": "igemm_fast_kernel (the tile kernels: conv fwd / dgrad / linears of > 48 output tiles) -- algorithmic FLOPs 2*M*N*K*taps "
-                          "per launch; the few-row GEMMs (decoder, positional MLPs, heads: launch-latency class, igemm_direct_kernel) are the "
-                          "separate family igemm_fewrow",
+                "hbm": ({"bytes_per_step": total_traffic, "achieved_TBps": total_traffic / (ms_per_step * 1e-3) / 1e12,
+                         "frac_of_8TBps": total_traffic / (ms_per_step * 1e-3) / 8e12,
+                         "note": "all kernels of one captured step, FETCH_SIZE (x2, gfx950) + WRITE_SIZE from separate --pmc passes"}
+                        if total_traffic else None),
+                "kernel": "the tile GEMM kernels (igemm_fast_kernel / igemm_dl_kernel: conv fwd / dgrad / linears of > 48 output tiles) -- algorithmic "
+                          "FLOPs 2*M*N*K*taps per launch; the few-row GEMMs (decoder, positional MLPs, heads: launch-latency class, igemm_direct_kernel) "
+                          "are the separate family igemm_fewrow",
                 "avg_launch_us": ig[1] / max(ig[2], 1) * 1e6, "families": kern,
-                "whole_step_tflops": gflop_img * a.batch / ms_per_step, "step_gflop_per_image": gflop_img,
+                "whole_step_tflops": gflop_img * a.batch / ms_per_step, "whole_step_frac": gflop_img * a.batch / ms_per_step / dense,
+                "step_gflop_per_image": gflop_img,
                 "pmc": (tj or {}).get("pmc")}
 
     res = {"metric": "images/sec FSCD-147 2nd-stage train step", "value": value, "unit": "images/s", "n_gpus": world,
@@ -451,6 +543,10 @@ def main(argv=None):
             extra_shape(dev, 800, 800, 600, "grid", Ts, a.batch, a.precision),
             # a typical FSC-147 image after the resize rule (A2/data/fsc147.py:75-77)
             extra_shape(dev, 384, 576, 300, "learned", Ts, a.batch, a.precision)]
+    if world == 1 and not a.no_inference:
+        res["inference"] = inference_leg(dev, [(800, 800), (384, 576)], a.batch, a.precision)
+    if world == 1 and not a.no_real_data:
+        res["real_data_loop"] = real_data_leg(dev, a.precision, a.batch)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.batch, H, W, Ts)
     if rank == 0:

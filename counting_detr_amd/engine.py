@@ -84,6 +84,39 @@ class FlatGradExchange:
         return [max(0.0, ea.elapsed_time(eb)) for ea, eb in self.probe]
 
 
+def build_weight_mirror(model, named, dgrad=True):
+    """Weight images (ops.WeightMirror), rewritten once per step (training) or once after the weights are loaded (inference):
+    k-contiguous transposes of every trainable matrix that is a data-gradient operand (backbone convs with the FrozenBN scale
+    folded in, 1x1 projections, linears with both dims >= 32; `dgrad=False` leaves them out) and pre-split forward operands of
+    every conv / linear weight with K % 32 == 0 (frozen layers included).  `named`: [(name, parameter)] of the matrices outside
+    the backbone's bottlenecks that take part."""
+    from . import ops
+    entries, fwd, seen = [], [], set()
+    for m in model.modules():
+        if isinstance(m, _bb.Bottleneck):
+            pairs = [(m.conv1, m.bn1), (m.conv2, m.bn2), (m.conv3, m.bn3)]
+            if m.downsample is not None:
+                pairs.append((m.downsample[0], m.downsample[1]))
+            for conv, bn in pairs:
+                w = conv.weight.data
+                seen.add(w.data_ptr())
+                if not w.is_cuda:
+                    continue
+                if conv.weight.requires_grad and dgrad:
+                    entries.append((w, bn.affine()[0]))
+                if w.shape[1] % 32 == 0:
+                    fwd.append((w, bn.affine()[0]))
+    for _, p in named:
+        if p.data_ptr() in seen or not p.is_cuda or min(p.shape[:2] if p.dim() >= 2 else (0,)) < 32:
+            continue
+        if p.dim() == 2 or (p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1):
+            if dgrad:
+                entries.append((p.data, None))
+            if p.shape[1] % 32 == 0:
+                fwd.append((p.data, None))
+    return ops.WeightMirror(entries, fwd) if (entries or fwd) else None
+
+
 class Trainer:
     def __init__(self, model, criterion, args, device=None):
         self.model, self.criterion, self.args = model, criterion, args
@@ -175,33 +208,7 @@ class Trainer:
         invalidate_caches(self.model)           # cached FrozenBN folds / stem images depend on what was just overwritten
 
     def _build_mirror(self, named):
-        """Weight images (ops.WeightMirror), rewritten once per step: k-contiguous transposes of every trainable matrix that
-        is a data-gradient operand (backbone convs with the FrozenBN scale folded in, 1x1 projections, linears with both dims
-        >= 32) and pre-split forward operands of every conv / linear weight with K % 32 == 0 (frozen layers included)."""
-        from . import ops
-        entries, fwd, seen = [], [], set()
-        for m in self.model.modules():
-            if isinstance(m, _bb.Bottleneck):
-                pairs = [(m.conv1, m.bn1), (m.conv2, m.bn2), (m.conv3, m.bn3)]
-                if m.downsample is not None:
-                    pairs.append((m.downsample[0], m.downsample[1]))
-                for conv, bn in pairs:
-                    w = conv.weight.data
-                    seen.add(w.data_ptr())
-                    if not w.is_cuda:
-                        continue
-                    if conv.weight.requires_grad:
-                        entries.append((w, bn.affine()[0]))
-                    if w.shape[1] % 32 == 0:
-                        fwd.append((w, bn.affine()[0]))
-        for _, p in named:
-            if p.data_ptr() in seen or not p.is_cuda or min(p.shape[:2] if p.dim() >= 2 else (0,)) < 32:
-                continue
-            if p.dim() == 2 or (p.dim() == 4 and p.shape[2] == 1 and p.shape[3] == 1):
-                entries.append((p.data, None))
-                if p.shape[1] % 32 == 0:
-                    fwd.append((p.data, None))
-        return ops.WeightMirror(entries, fwd) if (entries or fwd) else None
+        return build_weight_mirror(self.model, named)
 
     @staticmethod
     def _view_like(chunk, p):
@@ -645,6 +652,78 @@ def count_from_logits(pred_logits, threshold=0.5):
     prob = pred_logits.sigmoid()[..., 0]
     keep = prob >= threshold
     return keep.sum(-1), keep, prob
+
+
+class InferenceEngine:
+    """Forward + counting rule (A2/infer.py:57-81) at graph-replay speed: pre-split forward weight images built ONCE (the
+    weights do not change), one captured HIP graph per padded image shape (val / test images are resized to multiples of
+    `scale_factor`, A2/data/fsc147.py:150-152 -- a few dozen shapes), replayed with three small input copies.
+    `engine(samples, rects)` -> (counts [B] int64, keep [B,Q] bool, outputs dict, reference points, prob [B,Q]); the tensors are the graph's
+    static outputs: valid until the same shape runs again (clone to keep)."""
+
+    def __init__(self, model, threshold=0.5, graphs=True, max_graphs=48, device=None):
+        self.model, self.threshold, self.graphs, self.max_graphs = model, threshold, graphs, max_graphs
+        p0 = next(model.parameters(), None)
+        self.device = torch.device(device) if device is not None else (p0.device if p0 is not None else torch.device("cpu"))
+        self.model.eval()
+        named = [(n, p) for n, p in model.named_parameters() if not n.startswith(UNUSED_PREFIXES)]
+        self.mirror = build_weight_mirror(model, named, dgrad=False) if (self.device.type == "cuda" and p0 is not None) else None
+        self._cache = {}
+        self._stream = None
+        self.stats = {"captures": 0, "calls": 0}
+        self.refresh_weights()
+
+    def refresh_weights(self):
+        """Call after loading / changing the model's weights: rebuilds the forward weight images (and drops the graphs' cached folds)."""
+        from .checkpoint import invalidate_caches
+        invalidate_caches(self.model)
+        if self.mirror is not None:
+            self.mirror.refresh("fwd")
+        self._cache.clear()
+
+    @torch.no_grad()
+    def _run(self, images, mask, rects):
+        from . import ops
+        prev = ops.MIRROR
+        ops.MIRROR = self.mirror
+        try:
+            outputs, ref = self.model(NestedTensor(images, mask), rects=rects)
+        finally:
+            ops.MIRROR = prev
+        counts, keep, prob = count_from_logits(outputs["pred_logits"], self.threshold)
+        return counts, keep, outputs, ref, prob
+
+    @torch.no_grad()
+    def __call__(self, samples, rects):
+        nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
+        images, mask = nt.decompose()
+        self.stats["calls"] += 1
+        if not self.graphs or not images.is_cuda:
+            return self._run(images, mask, rects)
+        key = (tuple(images.shape), tuple(rects.shape))
+        e = self._cache.pop(key, None)
+        if e is None:
+            while len(self._cache) >= max(self.max_graphs, 1):
+                torch.cuda.synchronize()
+                self._cache.pop(next(iter(self._cache)))
+            st = (images.clone(), mask.clone(), rects.clone())
+            self._run(*st)                             # lazily cached tables of this shape exist before the capture
+            if self._stream is None:
+                self._stream = torch.cuda.Stream(device=self.device)
+            self._stream.wait_stream(torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self._stream):
+                out = self._run(*st)
+            e = (g, st, out)
+            self.stats["captures"] += 1
+        else:
+            e[1][0].copy_(images)
+            e[1][1].copy_(mask)
+            e[1][2].copy_(rects)
+        self._cache[key] = e
+        e[0].replay()
+        return e[2]
 
 
 @torch.no_grad()

@@ -23,13 +23,16 @@ from counting_detr_amd.misc import NestedTensor
 
 
 @torch.no_grad()
-def infer(model, criterion, data_loader, device, output_dir, split="test", threshold=0.5):
-    """-> (metrics dict, predictions dict); writes predictions_<split>.json like A2/infer.py:28-121."""
+def infer(model, criterion, data_loader, device, output_dir, split="test", threshold=0.5, graphs=True):
+    """-> (metrics dict, predictions dict); writes predictions_<split>.json like A2/infer.py:28-121.  The forward + counting rule
+    runs through engine.InferenceEngine (pre-split weight images, one captured HIP graph per image shape; `graphs=False`: eager)."""
     output_path = os.path.join(output_dir, "predictions_" + split + ".json")
     if os.path.isfile(output_path):
         os.remove(output_path)
     model.eval()
     criterion.eval()
+    from counting_detr_amd.engine import InferenceEngine
+    engine = InferenceEngine(model, threshold, graphs=graphs and torch.device(device).type == "cuda", device=device)
     predictions = {"categories": [{"name": "fg", "id": 1}], "images": [], "annotations": []}
     anno_id = 1
     pred_counts, gt_counts, loss_sum, n_img = [], [], {}, 0
@@ -37,11 +40,10 @@ def infer(model, criterion, data_loader, device, output_dir, split="test", thres
         image, mask = ret["image"].to(device), ret["mask"].to(device)
         rects = ret["ex_rects"].to(device)
         targets = [{k: v.to(device) for k, v in t.items()} for t in ret["targets"]]
-        outputs, ref_points = model(NestedTensor(image, mask), rects=rects)
+        _, keep, outputs, ref_points, prob = engine(NestedTensor(image, mask), rects)            # forward + :75-81
         loss_dict = criterion(outputs, targets)
         for k, v in loss_dict.items():
             loss_sum[k] = loss_sum.get(k, 0.0) + float(v) * len(targets)
-        _, keep, prob = count_from_logits(outputs["pred_logits"], threshold)  # :75-81
         for b in range(image.shape[0]):
             ori_h, ori_w = [int(x) for x in ret["orig_size"][b]]
             image_id = int(ret["image_id"][b]) if "image_id" in ret else n_img

@@ -210,3 +210,21 @@ def test_main_trains_a_multi_size_dataset_through_the_graph_cache(tmp_path, caps
         if tag == "graph":
             assert lines[0]["train_graph_captures"] >= 1 and lines[1]["train_graph_steps"] == 4
     np.testing.assert_allclose(losses["graph"], losses["eager"], rtol=1e-2)
+
+
+@gpu
+def test_inference_engine_graph_equals_eager_forward():
+    """engine.InferenceEngine (pre-split weight images + one captured graph per image shape) == the model's plain forward + counting
+    rule on two shapes, the first shape seen twice (second time: a cache hit on other pixels / exemplars)."""
+    from counting_detr_amd.engine import InferenceEngine, count_objects
+    model, _, _ = _build(Q=100)
+    eng = InferenceEngine(model)
+    for i, (H, W) in enumerate([(96, 128), (64, 96), (96, 128)]):
+        images, rects, _ = _batch(2, H, W, (1, 1), seed=40 + i)
+        counts, keep, out, ref, prob = eng(images, rects)
+        c0, k0, o0, r0 = count_objects(model, images, rects)
+        assert torch.equal(counts, c0) and torch.equal(keep, k0)
+        for k in ("pred_logits", "pred_boxes", "pred_vars"):
+            np.testing.assert_allclose(out[k].cpu().numpy(), o0[k].cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(ref.cpu().numpy(), r0.cpu().numpy(), rtol=1e-6)
+    assert eng.stats == {"captures": 2, "calls": 3}
