@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("w_scale", _p), ("bias", _p), ("resid", _p), ("ldr", C.c_int64), ("gate", _p), ("ldg", C.c_int64),
                 ("g", ConvGeom), ("B_split", _p), ("batch_inner", C.c_int32), ("pad_", C.c_int32),
                 ("sA2", C.c_int64), ("sB2", C.c_int64), ("sC2", C.c_int64), ("A16", _p), ("C16", _p),
-                ("splitk_ws", _p), ("splitk_ws_bytes", C.c_int64)]
+                ("splitk_ws", _p), ("splitk_ws_bytes", C.c_int64), ("A16lo", _p), ("B16", _p), ("C16lo", _p)]
 
 
 class WgradDesc(C.Structure):
@@ -63,11 +63,11 @@ class CriterionDesc(C.Structure):
 
 class MirrorItem(C.Structure):
     _fields_ = [("src", _p), ("dst", _p), ("dst_split", _p), ("scale", _p), ("R", C.c_int32), ("C", C.c_int32), ("taps", C.c_int32),
-                ("tile0", C.c_int32), ("transpose", C.c_int32), ("pad_", C.c_int32)]
+                ("tile0", C.c_int32), ("transpose", C.c_int32), ("pad_", C.c_int32), ("dst_hi", _p)]
 
 
-EXPORTS = ["cdetr_gemm", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_layernorm_bwd_merge", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
-           "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_bcast_add2_sum", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
+EXPORTS = ["cdetr_gemm", "cdetr_gemm_dl", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_layernorm_bwd_merge", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
+           "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_bcast_add2_sum", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_maxpool3x3s2_split", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_mask_prep", "cdetr_stem_pack", "cdetr_exemplar_fwd", "cdetr_exemplar_bwd", "cdetr_aggr_weight_fwd", "cdetr_aggr_weight_bwd",
            "cdetr_box_head_fwd", "cdetr_box_head_bwd", "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
 
@@ -84,6 +84,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cdetr_last_error.restype = C.c_char_p
         L.cdetr_abi_version.restype = C.c_int
+        L.cdetr_gemm_dl.restype = C.c_int
+        L.cdetr_gemm_dl.argtypes = [_p, C.c_int32, C.c_int32, _p]
         for name in ("cdetr_gemm", "cdetr_wgrad", "cdetr_rcda_fwd", "cdetr_rcda_bwd"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [_p, _p]
@@ -139,6 +141,8 @@ def lib():
         L.cdetr_bcast_add2_sum.argtypes = [_p] * 6 + [C.c_int32] * 4 + [C.c_float, C.c_float, _p]
         L.cdetr_maxpool3x3s2.restype = C.c_int
         L.cdetr_maxpool3x3s2.argtypes = [_p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
+        L.cdetr_maxpool3x3s2_split.restype = C.c_int
+        L.cdetr_maxpool3x3s2_split.argtypes = [_p, _p, _p, _p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _p]
         L.cdetr_mha_fwd.restype = C.c_int
         L.cdetr_mha_fwd.argtypes = [_p] * 4 + [C.c_int32] * 3 + [C.c_float, C.c_int32, _p]
         L.cdetr_mha_bwd.restype = C.c_int
@@ -158,7 +162,7 @@ def lib():
                            ("cdetr_box_head_bwd", [_p] * 5 + [C.c_int32] * 2 + [_p])):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = args
-        if L.cdetr_abi_version() != 1:
+        if L.cdetr_abi_version() != 2:
             raise RuntimeError("libcdetr_hip.so ABI version mismatch")
         _lib = L
     return _lib

@@ -70,14 +70,33 @@ class Bottleneck(nn.Module):
         self.downsample = nn.Sequential(ConvW(inplanes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)) if has_down else None
         self.stride, self.dilation = stride, dilation
 
-    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False):
+    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False, xlo=None, split=False, last=False):
         """twins: every activation a weight gradient of this block will read (a1, a2) and the block's output (the next block's x) also
         leave their producing epilogue as a bf16 copy (ops.bf16_twins); x16 = the twin of x, from the previous block.
-        twin_out: only the output gets a twin (the last frozen block in front of the trainable ones)."""
+        twin_out: only the output gets a twin (the last frozen block in front of the trainable ones).
+        split: every activation leaves its epilogue as split-bf16 planes hi | lo (ops.split_forward: the operand format of the
+        direct-to-LDS tile kernel); x16 / xlo = the planes of x; the hi planes double as the backward's twins.  -> (out, hi, lo)."""
         twin_out = twin_out or twins
         s1, b1 = self.bn1.affine()
         s2, b2 = self.bn2.affine()
         s3, b3 = self.bn3.affine()
+        if split:
+            xs = (x16, xlo) if (x16 is not None and xlo is not None) else None
+            a1, a1h, a1l = ops.conv_fwd(x, self.conv1.weight, s1, b1, relu=True, split=True, xs=xs)
+            a2, a2h, a2l = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True,
+                                        split=True, xs=(a1h, a1l))
+            if self.downsample is not None:
+                sd, bd = self.downsample[1].affine()
+                idn = ops.conv_fwd(x, self.downsample[0].weight, sd, bd, stride=self.stride, xs=xs)
+            else:
+                idn = x
+            if last:        # the trunk's output feeds the projection as fp32 only: no planes
+                out, outh, outl = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, xs=(a2h, a2l)), None, None
+            else:
+                out, outh, outl = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, split=True, xs=(a2h, a2l))
+            if save is not None:
+                save.append((x, a1, a2, out, x16, a1h, a2h, outh))
+            return out, outh, outl
         a1 = ops.conv_fwd(x, self.conv1.weight, s1, b1, relu=True, twin=twins)
         a1, a1_16 = a1 if twins else (a1, None)
         a2 = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True, twin=twins)
@@ -181,16 +200,20 @@ class _TrunkFn(torch.autograd.Function):
     """layer2..layer4 as one autograd node (explicit backward schedule instead of ~100 tiny autograd nodes)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, blocks, x16):
+    def forward(ctx, x, anchor, blocks, x16, xlo=None):
         saved = []
         twins = x16 is not None
+        split_mode = xlo is not None
         with torch.no_grad():
             for blk in blocks:
-                if twins:
+                if split_mode:      # split-bf16 planes travel with the activation (their hi planes are the backward's twins)
+                    x, x16, xlo = blk.forward_fused(x, saved, x16=x16, xlo=xlo, split=True, last=blk is blocks[-1])
+                elif twins:
                     x, x16 = blk.forward_fused(x, saved, x16=x16, twins=True)
                 else:
                     x = blk.forward_fused(x, saved)
-        ctx.blocks, ctx.saved_acts, ctx.twins = blocks, saved, twins
+        ctx.blocks, ctx.saved_acts = blocks, saved
+        ctx.twins = twins and ops.bf16_twins()
         return x
 
     @staticmethod
@@ -205,7 +228,7 @@ class _TrunkFn(torch.autograd.Function):
         if _DEFER is not None:                       # the trainer runs the segments itself (graph replay with bucketed exchange)
             _DEFER.append(TrunkBackward(blocks, saved, dz, dz16))
             ctx.saved_acts = None
-            return None, None, None, None
+            return None, None, None, None, None
         hook = _BACKWARD_HOOK
         if hook is not None:
             hook(0)          # autograd runs this node last: every gradient above the backbone is final
@@ -215,7 +238,7 @@ class _TrunkFn(torch.autograd.Function):
             if hook is not None:
                 hook(seg)    # layer4 / layer3 / layer2 done
         ctx.saved_acts = None
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class ResNetBody(nn.Module):
@@ -294,19 +317,28 @@ class ResNetBody(nn.Module):
                 x[..., :3] = images.permute(0, 2, 3, 1)
                 s, b = self.bn1.affine()
                 x = ops.conv_fwd(x, self.stem_weight4(), s, b, stride=2, pad=3, relu=True)
-            x = ops.maxpool3x3s2(x)
-            x16 = None
-            for i, blk in enumerate(self.layer1):
-                if twins and i == len(self.layer1) - 1:
-                    x, x16 = blk.forward_fused(x, twin_out=True)
-                else:
-                    x = blk.forward_fused(x)
+            split = ops.split_forward() and images.is_cuda
+            x16 = xlo = None
+            if split:
+                x, x16, xlo = ops.maxpool3x3s2(x, split=True)
+                for blk in self.layer1:
+                    x, x16, xlo = blk.forward_fused(x, x16=x16, xlo=xlo, split=True)
+            else:
+                x = ops.maxpool3x3s2(x)
+                for i, blk in enumerate(self.layer1):
+                    if twins and i == len(self.layer1) - 1:
+                        x, x16 = blk.forward_fused(x, twin_out=True)
+                    else:
+                        x = blk.forward_fused(x)
         anchor = self.layer4[-1].conv3.weight
         if train:
-            return _TrunkFn.apply(x, anchor, blocks, x16)
+            return _TrunkFn.apply(x, anchor, blocks, x16, xlo)
         with torch.no_grad():
             for blk in blocks:
-                x = blk.forward_fused(x)
+                if split:
+                    x, x16, xlo = blk.forward_fused(x, x16=x16, xlo=xlo, split=True, last=blk is blocks[-1])
+                else:
+                    x = blk.forward_fused(x)
         return x
 
 

@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256) void weight_mirror_kernel(const cdetr_mirror_i
         if (r < it.R && c < it.C) {
             const float v = tile[tx][ty + 8 * p];
             if (it.dst) it.dst[((long)c * it.taps + tap) * it.R + r] = v;
+            if (it.dst_hi) reinterpret_cast<__bf16*>(it.dst_hi)[((long)c * it.taps + tap) * it.R + r] = (__bf16)v;
             if (sp) {                                            // transposed image: row c, k = tap*R + r (R % 32 == 0)
                 const __bf16 h = (__bf16)v;
                 __bf16* g = sp + (long)c * it.taps * it.R * 2 + (long)((tap * it.R + r0) >> 5) * 64;

@@ -12,6 +12,7 @@
 // ds_read_b128 feeds four MFMAs; A and B use the same permutation, so the sum is unchanged up to fp32 reassociation.
 #include "../../include/cdetr_hip.h"
 #include "common.h"
+#include "rows.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <vector>
@@ -19,67 +20,8 @@
 
 namespace {
 
-// two-level batch index: z = outer * batch_inner + inner -> inner * s + outer * s2 (batch_inner == 0: one level, z * s)
-__host__ __device__ __forceinline__ long batch_off(int z, int inner, long s, long s2) {
-    if (inner <= 0) return (long)z * s;
-    const int zo = z / inner;
-    return (long)(z - zo * inner) * s + (long)zo * s2;
-}
-
 constexpr int BK = 16;
 constexpr int LDS_K = BK + 4;  // padded k-contiguous row
-
-struct RowCoord {
-    int ybase, xbase, nbase, m;
-    bool valid;
-};
-
-__device__ __forceinline__ RowCoord decode_row(const cdetr_conv_geom& g, int m, int M) {
-    RowCoord r;
-    r.m = m;
-    r.valid = m < M;
-    r.ybase = r.xbase = r.nbase = 0;
-    if (g.mode != CDETR_ROWS_DENSE && r.valid) {
-        const int hw = g.Hc * g.Wc;
-        const int n = m / hw;
-        const int rem = m - n * hw;
-        const int y = rem / g.Wc;
-        const int x = rem - y * g.Wc;
-        r.nbase = n * g.Ha * g.Wa;
-        if (g.mode == CDETR_ROWS_CONV_FWD) {
-            r.ybase = y * g.stride - g.pad;
-            r.xbase = x * g.stride - g.pad;
-        } else {
-            r.ybase = y + g.pad;
-            r.xbase = x + g.pad;
-        }
-    }
-    return r;
-}
-
-// row index into the gathered tensor for (row coord, tap); -1 when the tap falls outside (zero contribution)
-__device__ __forceinline__ long gather_row(const cdetr_conv_geom& g, const RowCoord& r, int tap) {
-    if (!r.valid) return -1;
-    if (g.mode == CDETR_ROWS_DENSE) return r.m;
-    const int ky = tap / g.kw;
-    const int kx = tap - ky * g.kw;
-    if (g.mode == CDETR_ROWS_CONV_FWD) {
-        const int iy = r.ybase + ky * g.dil;
-        const int ix = r.xbase + kx * g.dil;
-        if (iy < 0 || iy >= g.Ha || ix < 0 || ix >= g.Wa) return -1;
-        return (long)r.nbase + (long)iy * g.Wa + ix;
-    }
-    int ty = r.ybase - ky * g.dil;
-    int tx = r.xbase - kx * g.dil;
-    if (ty < 0 || tx < 0) return -1;
-    if (g.stride > 1) {
-        if ((ty % g.stride) != 0 || (tx % g.stride) != 0) return -1;
-        ty /= g.stride;
-        tx /= g.stride;
-    }
-    if (ty >= g.Ha || tx >= g.Wa) return -1;
-    return (long)r.nbase + (long)ty * g.Wa + tx;
-}
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));      // a native vector (stays in registers through a select, unlike the uint4 struct)
@@ -109,6 +51,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const cdetr_gemm_desc d, con
     const float* __restrict__ B = d.B + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
     __bf16* __restrict__ C16 = d.C16 ? reinterpret_cast<__bf16*>(d.C16) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // bf16 twin of C
+    __bf16* __restrict__ C16lo = (d.C16 && d.C16lo) ? reinterpret_cast<__bf16*>(d.C16lo) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // its lo plane
     const int K = d.K, taps = d.taps, Ktot = d.K * d.taps;
     const int nkt = (Ktot + BK - 1) / BK;
 
@@ -544,6 +487,7 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
     const float* __restrict__ B = (BRAW ? reinterpret_cast<const float*>(d.B_split) : d.B) + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
     __bf16* __restrict__ C16 = d.C16 ? reinterpret_cast<__bf16*>(d.C16) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // bf16 twin of C
+    __bf16* __restrict__ C16lo = (d.C16 && d.C16lo) ? reinterpret_cast<__bf16*>(d.C16lo) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // its lo plane
     const int K = d.K, taps = d.taps;
     // split reduction (ksplit > 1): slice kslice of this output tile owns k-tiles [kt0, kt0 + nkt) of the (K / BKF) * taps
     const int nkt_all = (K / BKF) * taps;
@@ -950,7 +894,11 @@ __device__ __forceinline__ void igemm_fast_body(const cdetr_gemm_desc& d, const 
                 if (d.relu) v = fmaxf(v, 0.f);
                 if (nvalid && m < d.M) {
                     C[(long)m * d.ldc + n] = v;
-                    if (C16) C16[(long)m * d.ldc + n] = (__bf16)v;
+                    if (C16) {
+                        const __bf16 h = (__bf16)v;
+                        C16[(long)m * d.ldc + n] = h;
+                        if (C16lo) C16lo[(long)m * d.ldc + n] = (__bf16)(v - (float)h);
+                    }
                 }
             }
         }
@@ -1673,6 +1621,7 @@ __device__ __forceinline__ void igemm_direct_body(const cdetr_gemm_desc& d, cons
     const float* __restrict__ B = d.B + batch_off(z, d.batch_inner, d.sB, d.sB2);
     float* __restrict__ C = d.C + batch_off(z, d.batch_inner, d.sC, d.sC2);
     __bf16* __restrict__ C16 = d.C16 ? reinterpret_cast<__bf16*>(d.C16) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // bf16 twin of C
+    __bf16* __restrict__ C16lo = (d.C16 && d.C16lo) ? reinterpret_cast<__bf16*>(d.C16lo) + batch_off(z, d.batch_inner, d.sC, d.sC2) : nullptr;   // its lo plane
     const int K = d.K;
     const int kchunks = (K + 15) >> 4;
     const int cpw = (kchunks + 3) >> 2;                 // chunks per wave
@@ -1894,8 +1843,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     atomicAdd(out + n, s);
 }
 
-__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ X, float* __restrict__ Y, int Nimg, int H,
-                                                      int W, int C, int Ho, int Wo) {
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ X, float* __restrict__ Y, __bf16* __restrict__ Y16,
+                                                      __bf16* __restrict__ Y16lo, int Nimg, int H, int W, int C, int Ho, int Wo) {
     const long total = (long)Nimg * Ho * Wo * (C / 4);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int c4 = (int)(idx % (C / 4));
@@ -1916,7 +1865,15 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        *reinterpret_cast<float4*>(Y + (((long)n * Ho + oy) * Wo + ox) * C + c4 * 4) = m;
+        const long o = (((long)n * Ho + oy) * Wo + ox) * C + c4 * 4;
+        *reinterpret_cast<float4*>(Y + o) = m;
+        if (Y16) {                            // split-bf16 planes of the pooled map: the A16 / A16lo operand of layer1's first convolutions
+            uint2 h, l;
+            split_bf16_pk(m.x, m.y, h.x, l.x);
+            split_bf16_pk(m.z, m.w, h.y, l.y);
+            *reinterpret_cast<uint2*>(Y16 + o) = h;
+            if (Y16lo) *reinterpret_cast<uint2*>(Y16lo + o) = l;
+        }
     }
 }
 
@@ -2079,6 +2036,52 @@ int check_gemm_desc(const cdetr_gemm_desc& d) {
 }
 }  // namespace
 
+// igemm_dl.hip: the direct-to-LDS tile kernel (operands pre-split in HBM)
+bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d);
+int cdetr_gemm_dl_launch(const cdetr_gemm_desc& d, int tile, int stages, hipStream_t st);
+
+namespace {
+// Tile of the direct-to-LDS kernel for a problem: 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64 (rows x channels), or -1 = leave the
+// problem to the register-staged kernels.  Measured on the backbone's shapes at two 800x800 images, cold operands (tools/dl_sweep.py,
+// profiles/r3_dl_sweep.txt):
+//   * plain bf16 (the data gradients: A = the bf16 twin of dY, B = the plain-bf16 weight image): the direct-to-LDS kernel wins on
+//     every shape, 1.1-1.7x (sum 494 -> 386 us over the sweep); 64x64 tiles / 3-deep ring is the best or within 5 % of it everywhere
+//     (3 workgroups per CU de-synchronise the store bursts of the epilogues), 128-row tiles only from K * taps >= 2048 on;
+//   * split-bf16 x3 (the forward): the register-staged kernel reads fp32 rows = full 128-byte lines per k-tile, the planes
+//     (64 B of hi + 64 B of lo per row and k-tile) are half lines -- the direct-to-LDS kernel wins where the epilogue dominates
+//     (K <= 256: 1.1-1.2x) and loses on the long reductions (3x3, K >= 1024: 0.8-0.95x), -7 % over the sweep AFTER charging every
+//     producer for the lo plane: not the default (the producers only write lo planes under ops.SPLIT_FWD).
+// CDETR_GEMM_DL (read once): 0 = never, 1 = this rule (default), 100 + 10 * tile + stages = force one configuration wherever legal.
+int gemm_dl_choice(const cdetr_gemm_desc& d, int& stages) {
+    static const int mode = getenv("CDETR_GEMM_DL") ? atoi(getenv("CDETR_GEMM_DL")) : 1;
+    if (mode == 0 || !cdetr_gemm_dl_eligible(d)) return -1;
+    if (mode >= 100) {
+        stages = mode % 10;
+        return (mode / 10) % 10;
+    }
+    auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
+    stages = 3;
+    if (!d.C) return blocks(64, 64) >= 512 && (long)d.K * d.taps >= 2048 && d.N % 128 == 0 ? 0 : 3;   // no fp32 output: only this kernel can run it
+    if (blocks(64, 64) < 192) return -1;                                      // few tiles: the split-reduction forms of the register-staged kernels
+    if (d.precision == 3) return ((long)d.K * d.taps >= 2048 && d.N % 128 == 0 && blocks(128, 128) >= 128) ? 0 : 3;
+    // split-bf16 x3 with planes given (ops.SPLIT_FWD): where the sweep has it ahead
+    if ((long)d.K * d.taps <= 512 && d.N >= 2 * d.K) return 3;
+    return -1;
+}
+}  // namespace
+
+extern "C" int cdetr_gemm_dl(const cdetr_gemm_desc* dp, int32_t tile, int32_t stages, void* stream) {
+    CDETR_CHECK_ARG(dp != nullptr, "cdetr_gemm_dl: null descriptor");
+    if (int rcv = check_gemm_desc(*dp)) return rcv;
+    if (dp->M == 0) return CDETR_OK;
+    if (!cdetr_gemm_dl_eligible(*dp)) {
+        cdetr_set_error("cdetr_gemm_dl: needs b_layout 0, batch 1, A16 (+ A16lo for precision 1), B_split, K %% %d == 0, 16-byte aligned operands",
+                        dp->precision == 1 ? 32 : 64);
+        return CDETR_ERR_UNSUPPORTED;
+    }
+    return cdetr_gemm_dl_launch(*dp, tile, stages, reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     CDETR_CHECK_ARG(dp != nullptr, "cdetr_gemm: null descriptor");
     cdetr_gemm_desc d = *dp;
@@ -2104,6 +2107,11 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     if (force == 6) {
         if (d.N > 64 && d.M > 64) return launch_gemm<128, 128>(d, st, vecA, vecB);
         return launch_gemm<64, 64>(d, st, vecA, vecB);
+    }
+    if (!force) {
+        int stages = 3;
+        const int tile = gemm_dl_choice(d, stages);
+        if (tile >= 0) return cdetr_gemm_dl_launch(d, tile, stages, st);
     }
     // few rows, long reduction (decoder FFN 1024 -> 256 on 600 rows): a 64x64 tile on two wave groups with the reduction cut across
     // 3-4 workgroups beats the one-wave-per-16x16-tile kernel (tools/splitk_sweep.py: 16.3 -> 10.6-12.6 us)
@@ -2506,12 +2514,17 @@ extern "C" int cdetr_colsum(const float* X, int64_t ldx, int32_t M, int32_t N, f
 }
 
 extern "C" int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream) {
-    CDETR_CHECK_ARG(X && Y && Nimg > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "cdetr_maxpool: bad args");
+    return cdetr_maxpool3x3s2_split(X, Y, nullptr, nullptr, Nimg, H, W, C, stream);
+}
+
+extern "C" int cdetr_maxpool3x3s2_split(const float* X, float* Y, void* Y16, void* Y16lo, int32_t Nimg, int32_t H, int32_t W, int32_t C,
+                                        void* stream) {
+    CDETR_CHECK_ARG(X && Y && Nimg > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0 && (Y16 || !Y16lo), "cdetr_maxpool: bad args");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long total = (long)Nimg * Ho * Wo * (C / 4);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, Y, Nimg, H, W,
-                       C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, Y,
+                       reinterpret_cast<__bf16*>(Y16), reinterpret_cast<__bf16*>(Y16lo), Nimg, H, W, C, Ho, Wo);
     return cdetr_launch_status("cdetr_maxpool3x3s2");
 }

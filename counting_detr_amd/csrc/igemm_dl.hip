@@ -1,0 +1,380 @@
+// igemm_dl.hip -- the tile GEMM of the backbone with DIRECT-TO-LDS operand loads (gfx950 `global_load_lds_dwordx4`).
+//
+// Same contraction and fused epilogue as igemm_fast_kernel (igemm.hip; math: A2/models/resnet.py:140-160 conv + FrozenBN + ReLU
+// + residual, and their data gradients), for operands that ALREADY sit in HBM in the matrix pipe's input format:
+//   A  = bf16 planes of the activation / activation gradient, written by the producing epilogue (cdetr_gemm_desc.A16 = hi,
+//        A16lo = lo = bf16(x - hi); plain-bf16 products read the hi plane only),
+//   B  = the pre-split weight image of cdetr_weight_mirror (cdetr_gemm_desc.B_split: groups of 32 k, [hi 32 | lo 32]).
+// A k-tile is then a pure byte copy HBM -> LDS: every lane issues `global_load_lds_dwordx4` (16 bytes = 8 bf16 of one row, DMA'd
+// into LDS without touching a VGPR), no conversion, no staging VALU, no ds_write; STAGES tiles ring in LDS, the loads of tile
+// t + STAGES - 1 are issued right after the barrier that frees its slot and stay in flight across the next barriers (counted
+// `s_waitcnt vmcnt(N)`, raw `s_barrier`): one barrier per k-tile, and between two barriers a wave issues 8-24 MFMAs.
+//
+// LDS image of one operand tile: [row][8 slots of 16 B] = 128 bytes of k per row (32 k x {hi, lo} for the split product, 64 k of hi
+// for plain bf16).  The DMA writes lane l of a wave at base + 16 l, so a wave fills 8 complete rows; WHICH 16-byte chunk of the row a
+// lane fetches is free (the global address is per lane), so the bank swizzle lives on the source side: slot s of row r holds logical
+// chunk c = s ^ ((r >> 1) & 7).  A fragment read (32 rows x one chunk, ds_read_b128) then touches 16 distinct 16-byte slots in every
+// 16-lane service group of MI355X_MICROARCH.md's LDS table: conflict-free.
+//
+// MFMA operand order: the WEIGHT fragment is the A operand and the activation fragment the B operand of v_mfma_f32_32x32x16_bf16,
+// so an accumulator lane holds ONE output row m and, per register quad, four CONSECUTIVE output channels n: the epilogue reads
+// residual / gate and writes C (fp32), C16 and C16lo with 16- / 8-byte accesses per lane instead of 48 scalar ones per fragment.
+#include "../../include/cdetr_hip.h"
+#include "common.h"
+#include "rows.h"
+#include <stdlib.h>
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned int dl_zero_page[64];      // 256 zero bytes: the source of padding / out-of-range rows
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* gbl_vp;
+
+template <int FM, int FN, int TERMS, int STAGES>
+struct DlCfg {
+    static constexpr int BM = 64 * FM, BN = 64 * FN;          // 2 x 2 waves, FM x FN fragments of 32 x 32 each
+    static constexpr int NA = BM / 32, NB = BN / 32;          // 16-byte pieces per thread per k-tile (A, B)
+    static constexpr int KT = (TERMS == 3) ? 32 : 64;         // k-values per tile: 128 bytes per row either way
+    static constexpr int A_STAGE = BM * 128, B_STAGE = BN * 128;
+    static constexpr int RING = STAGES * (A_STAGE + B_STAGE);
+    static constexpr int STAGING = 4 * 32 * FM * (32 * FN + 4) * 4;       // the epilogue's transposition tiles (one per wave) reuse the ring
+    static constexpr int LDS = RING > STAGING ? RING : STAGING;
+};
+
+__device__ __forceinline__ void wait_vm(int n) {              // counted wait: at most n of this wave's loads still in flight
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+// PROBE: wave 0 of every workgroup stamps s_memtime at its phase boundaries into cdetr_gemm_desc.splitk_ws (8 x uint64 per workgroup:
+// start, prologue issued, first tile landed, k-loop done, epilogue operands loaded, stores issued) -- tools/dl_probe.py.
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false>
+__global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN) {
+    using Cf = DlCfg<FM, FN, TERMS, STAGES>;
+    unsigned long long* probe = PROBE ? reinterpret_cast<unsigned long long*>(d.splitk_ws) + (long)blockIdx.x * 8 : nullptr;
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (PROBE) {
+            if (threadIdx.x == 0) probe[slot] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    stamp(0);
+    constexpr int BM = Cf::BM, BN = Cf::BN, NA = Cf::NA, NB = Cf::NB, KT = Cf::KT;
+    constexpr int A_STAGE = Cf::A_STAGE, B_STAGE = Cf::B_STAGE;
+    constexpr int NI = NA + NB;                                // loads per wave per k-tile
+    static_assert(TERMS == 3 || TERMS == 1, "split-bf16 x3 or plain bf16");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // the ONLY LDS object (a second one makes hipcc drain vmcnt before every ds_read)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = w >> 1, wn = w & 1;
+    const int i32 = lane & 31, g = lane >> 5;
+    // XCD-aware tile order (as igemm_fast_kernel): workgroup b runs on XCD b % 8; XCD x owns a band of row-tiles and sweeps the
+    // column-tiles of a row-tile back to back, so an activation row-panel is fetched once per XCD and the weights stay L2-resident
+    const int bx = blockIdx.x;
+    const int band = (tilesM + 7) >> 3;
+    const int xcd = bx & 7, jloc = bx >> 3;
+    const int tm = xcd * band + jloc / tilesN, tn = jloc % tilesN;
+    if (tm >= tilesM) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int K = d.K, taps = d.taps;
+    const int nkt_tap = K / KT, nkt = nkt_tap * taps;
+
+    // ---------------------------------------------------------------- loader state: which 16 bytes this lane fetches
+    const int prow = tid >> 3;                                  // row inside a 32-row pass (one pass = one load per thread)
+    const int chunk = (tid & 7) ^ ((tid >> 4) & 7);             // logical chunk behind LDS slot (tid & 7) of row prow (+ 32 j)
+    const unsigned char* zero = reinterpret_cast<const unsigned char*>(dl_zero_page) + (tid & 7) * 16;
+    const __bf16* Apl = reinterpret_cast<const __bf16*>((TERMS == 3 && (chunk >> 2)) ? d.A16lo : d.A16);
+    const int a_kk = (TERMS == 3) ? (chunk & 3) * 8 : chunk * 8;
+    RowCoord arow[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) arow[j] = decode_row(d.g, m0 + j * 32 + prow, d.M);
+    const unsigned char* ap[NA];
+    unsigned amask = 0;
+    auto set_tap = [&](int tap) {
+        amask = 0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const long row = gather_row(d.g, arow[j], tap);
+            ap[j] = row >= 0 ? reinterpret_cast<const unsigned char*>(Apl + row * d.lda + a_kk) : zero;
+            amask |= (row >= 0 ? 1u : 0u) << j;
+        }
+    };
+    const unsigned char* bp[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int n = min(n0 + j * 32 + prow, d.N - 1);
+        if (TERMS == 1 && d.B16)    // plain bf16 image: 64 k = one full 128-byte line per row and k-tile
+            bp[j] = reinterpret_cast<const unsigned char*>(d.B16) + (long)n * d.ldb * 2 + chunk * 16;
+        else                        // pre-split groups [hi 32 | lo 32]: both halves (x3) or the hi halves of two groups (plain bf16)
+            bp[j] = reinterpret_cast<const unsigned char*>(d.B_split) + (long)n * d.ldb * 4 +
+                    ((TERMS == 3) ? chunk * 16 : (chunk >> 2) * 128 + (chunk & 3) * 16);
+    }
+    const int bshift = (TERMS == 1 && d.B16) ? 1 : 2;           // log2(bytes per k of the weight image)
+    auto issue = [&](int stage, int tap, int kc) __attribute__((always_inline)) {
+        const int koa = kc * 2;                                 // bytes along k of the A planes
+        const long kob = ((long)tap * K + kc) << bshift;        // bytes along (tap, k) of the weight image
+        unsigned char* la = smem + stage * A_STAGE + w * 1024;
+        unsigned char* lb = smem + STAGES * A_STAGE + stage * B_STAGE + w * 1024;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_vp)(ap[j] + (((amask >> j) & 1u) ? koa : 0)), (lds_vp)(la + j * 4096), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            __builtin_amdgcn_global_load_lds((gbl_vp)(bp[j] + kob), (lds_vp)(lb + j * 4096), 16, 0, 0);
+    };
+
+    // ---------------------------------------------------------------- fragment addresses
+    const int fx = (i32 >> 1) & 7;
+    int xo[4], wo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int s16 = ((2 * j + g) ^ fx) << 4;
+        xo[j] = (wm * 32 * FM + i32) * 128 + s16;
+        wo[j] = STAGES * A_STAGE + (wn * 32 * FN + i32) * 128 + s16;
+    }
+    f32x16 acc[FN][FM];
+#pragma unroll
+    for (int b = 0; b < FN; ++b)
+#pragma unroll
+        for (int a = 0; a < FM; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[b][a][r] = 0.f;
+
+    auto compute = [&](int stage) __attribute__((always_inline)) {
+        const unsigned char* xs = smem + stage * A_STAGE;
+        const unsigned char* ws = smem + stage * B_STAGE;
+#pragma unroll
+        for (int hp = 0; hp < KT / 16; ++hp) {
+            bf16x8 xh[FM], xl[FM], wh[FN], wl[FN];
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+                xh[a] = *reinterpret_cast<const bf16x8*>(xs + xo[hp] + a * 4096);
+                if constexpr (TERMS == 3) xl[a] = *reinterpret_cast<const bf16x8*>(xs + xo[2 + hp] + a * 4096);
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b) {
+                wh[b] = *reinterpret_cast<const bf16x8*>(ws + wo[hp] + b * 4096);
+                if constexpr (TERMS == 3) wl[b] = *reinterpret_cast<const bf16x8*>(ws + wo[2 + hp] + b * 4096);
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+#pragma unroll
+                for (int a = 0; a < FM; ++a) acc[b][a] = mfma_bf16_terms<TERMS>(wh[b], wl[b], xh[a], xl[a], acc[b][a]);
+        }
+    };
+
+    // ---------------------------------------------------------------- the pipeline
+    int f_tap = 0, f_kc = 0, f_idx = 0;                         // coordinates of the next tile to issue
+    auto issue_next = [&](int stage) __attribute__((always_inline)) {
+        issue(stage, f_tap, f_kc);
+        ++f_idx;
+        f_kc += KT;
+        if (f_kc == K) {
+            f_kc = 0;
+            ++f_tap;
+            if (f_tap < taps) set_tap(f_tap);
+        }
+    };
+    set_tap(0);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nkt) issue_next(s);
+    stamp(1);
+    int st = 0, sn = STAGES - 1;                                 // stage of the tile being computed / of the tile being issued
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tiles kt .. min(kt + STAGES - 2, nkt - 1) are in flight; tile kt must have landed (this wave's pieces), the others may fly on
+        const int fly = min(STAGES - 2, nkt - 1 - kt);
+        if (fly >= 2) wait_vm(2 * NI);
+        else if (fly == 1) wait_vm(NI);
+        else wait_vm(0);
+        __builtin_amdgcn_s_barrier();                           // every wave's pieces of tile kt are in LDS; everyone is done reading slot sn
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PROBE) { if (kt == 0) stamp(2); }
+        if (f_idx < nkt) issue_next(sn);
+        compute(st);
+        __builtin_amdgcn_sched_barrier(0);
+        st = (st + 1 == STAGES) ? 0 : st + 1;
+        sn = (sn + 1 == STAGES) ? 0 : sn + 1;
+    }
+    mfma_drain(acc);
+    stamp(3);
+
+    // ---------------------------------------------------------------- epilogue
+    // The accumulators (lane = output row m, register quad = 4 consecutive channels) are transposed through LDS -- the ring is free
+    // once every wave is past its last fragment read -- so that 4 FN lanes hold 8 consecutive channels each of ONE row: residual /
+    // gate loads and the C / C16 / C16lo stores are full 128- / 256-byte row segments (8 rows per instruction) instead of 16 bytes
+    // in each of 32 rows.  Staging rows are padded by 16 bytes: the float4 writes of 8 consecutive lanes (8 rows, same column) and
+    // the row-major float4 reads both spread over the banks.
+    constexpr int LDW = 32 * FN + 4;                            // floats per staged row
+    constexpr int LR = 4 * FN;                                  // lanes per output row (8 channels each)
+    constexpr int RPP = 64 / LR;                                // rows per pass of the wave
+    constexpr int NPASS = 32 * FM / RPP;
+    static_assert(32 * FM * LDW * 4 * 4 <= Cf::LDS, "the staging tiles fit the ring");
+    __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring
+    float* stg = reinterpret_cast<float*>(smem) + w * (32 * FM * LDW);
+#pragma unroll
+    for (int a = 0; a < FM; ++a)
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4*>(stg + (a * 32 + i32) * LDW + b * 32 + 8 * q + 4 * g) =
+                    make_float4(acc[b][a][4 * q], acc[b][a][4 * q + 1], acc[b][a][4 * q + 2], acc[b][a][4 * q + 3]);
+    float* __restrict__ C = d.C;
+    __bf16* __restrict__ C16 = reinterpret_cast<__bf16*>(d.C16);
+    __bf16* __restrict__ C16lo = reinterpret_cast<__bf16*>(d.C16lo);
+    const int rr = lane / LR, cc = (lane % LR) * 8;
+    const int n = n0 + wn * 32 * FN + cc;
+    const bool v0 = n < d.N, v1 = n + 4 < d.N;                  // the two 4-channel halves of this lane's 8 channels (N % 4 == 0)
+    const int nl0 = min(n, d.N - 4), nl1 = min(n + 4, d.N - 4);
+    float bias8[8];
+    {
+        const float4 b0 = d.bias ? *reinterpret_cast<const float4*>(d.bias + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b1 = d.bias ? *reinterpret_cast<const float4*>(d.bias + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
+    }
+    const int mw = m0 + wm * 32 * FM;
+    // residual / gate rows of every pass: ONE batch of unconditional loads (clamped row / channel, masked use) ahead of the math
+    float4 res[NPASS][2], gat[NPASS][2];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const long mrow = min(mw + p * RPP + rr, d.M - 1);
+        res[p][0] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        res[p][1] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
+        gat[p][0] = d.gate ? *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl0) : make_float4(1.f, 1.f, 1.f, 1.f);
+        gat[p][1] = d.gate ? *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl1) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    if constexpr (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4); }
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+        const int row = p * RPP + rr;
+        const int m = mw + row;
+        const float4 s0 = *reinterpret_cast<const float4*>(stg + row * LDW + cc);
+        const float4 s1 = *reinterpret_cast<const float4*>(stg + row * LDW + cc + 4);
+        const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float re[8] = {res[p][0].x, res[p][0].y, res[p][0].z, res[p][0].w, res[p][1].x, res[p][1].y, res[p][1].z, res[p][1].w};
+        const float ga[8] = {gat[p][0].x, gat[p][0].y, gat[p][0].z, gat[p][0].w, gat[p][1].x, gat[p][1].y, gat[p][1].z, gat[p][1].w};
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = (sv[e] + bias8[e]) * d.out_scale + re[e];
+            t = ga[e] > 0.f ? t : 0.f;
+            if (d.relu) t = fmaxf(t, 0.f);
+            v[e] = t;
+        }
+        if (m < d.M && v0) {
+            const long o = (long)m * d.ldc + n;
+            unsigned hh[4], ll[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split_bf16_pk(v[2 * e], v[2 * e + 1], hh[e], ll[e]);
+            const u32x4 h = {hh[0], hh[1], hh[2], hh[3]}, l = {ll[0], ll[1], ll[2], ll[3]};
+            if (C) {
+                *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (v1) *reinterpret_cast<float4*>(C + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (C16) {
+                if (v1 && ((o & 7) == 0)) {
+                    *reinterpret_cast<u32x4*>(C16 + o) = h;
+                    if (C16lo) *reinterpret_cast<u32x4*>(C16lo + o) = l;
+                } else {
+                    *reinterpret_cast<uint2*>(C16 + o) = make_uint2(h[0], h[1]);
+                    if (C16lo) *reinterpret_cast<uint2*>(C16lo + o) = make_uint2(l[0], l[1]);
+                    if (v1) {
+                        *reinterpret_cast<uint2*>(C16 + o + 4) = make_uint2(h[2], h[3]);
+                        if (C16lo) *reinterpret_cast<uint2*>(C16lo + o + 4) = make_uint2(l[2], l[3]);
+                    }
+                }
+            }
+        }
+    }
+    stamp(5);
+    if constexpr (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6); }
+}
+
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false>
+int launch_dl(const cdetr_gemm_desc& d, hipStream_t st) {
+    using Cf = DlCfg<FM, FN, TERMS, STAGES>;
+    const int tilesM = (d.M + Cf::BM - 1) / Cf::BM, tilesN = (d.N + Cf::BN - 1) / Cf::BN;
+    auto kern = igemm_dl_kernel<FM, FN, TERMS, STAGES, PROBE>;
+    if (Cf::LDS > 64 * 1024) {
+        static bool raised = false;                             // per instantiation
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+            if (e != hipSuccess) {
+                cdetr_set_error("cdetr_gemm (direct-to-LDS): hipFuncSetAttribute(%d): %s", Cf::LDS, hipGetErrorString(e));
+                return CDETR_ERR_LAUNCH;
+            }
+            raised = true;
+        }
+    }
+    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN), block(256);
+    hipLaunchKernelGGL(kern, grid, block, Cf::LDS, st, d, tilesM, tilesN);
+    return cdetr_launch_status("cdetr_gemm");
+}
+
+}  // namespace
+
+// Whether the direct-to-LDS tile kernel can run this problem (operand formats / alignment); the dispatcher in igemm.hip decides
+// whether it SHOULD (problem size) and which tile.
+bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d) {
+    if (d.b_layout != 0 || d.batch != 1 || !d.A16) return false;
+    if (!d.B_split && !(d.precision == 3 && d.B16)) return false;
+    if (d.B16 && ((reinterpret_cast<uintptr_t>(d.B16) & 15) || (d.ldb & 7))) return false;
+    if (d.precision != 1 && d.precision != 3) return false;
+    if (d.precision == 1 && !d.A16lo) return false;
+    const int KT = d.precision == 1 ? 32 : 64;
+    if (d.K % KT != 0 || (d.lda & 7) != 0 || (d.ldb & 31) != 0 || (d.N & 3) != 0 || (d.ldc & 3) != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(d.A16) & 15) || (reinterpret_cast<uintptr_t>(d.A16lo) & 15) || (reinterpret_cast<uintptr_t>(d.B_split) & 15)) return false;
+    if ((reinterpret_cast<uintptr_t>(d.C) & 15) || (reinterpret_cast<uintptr_t>(d.C16) & 7) || (reinterpret_cast<uintptr_t>(d.C16lo) & 7)) return false;
+    if (d.resid && ((reinterpret_cast<uintptr_t>(d.resid) & 15) || (d.ldr & 3))) return false;
+    if (d.gate && ((reinterpret_cast<uintptr_t>(d.gate) & 15) || (d.ldg & 3))) return false;
+    if (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15)) return false;
+    if (!d.C && !d.C16) return false;
+    if (d.C16lo && !d.C16) return false;
+    return true;
+}
+
+// tile: 0 = 128x128, 1 = 128x64 (rows x channels), 2 = 64x128, 3 = 64x64; stages 2..4
+int cdetr_gemm_dl_launch(const cdetr_gemm_desc& d, int tile, int stages, hipStream_t st) {
+    const bool x3 = d.precision == 1;
+    if (stages >= 100) {                                        // phase probe (tools/dl_probe.py): splitk_ws receives the time stamps
+        if (!d.splitk_ws) { cdetr_set_error("cdetr_gemm_dl: the phase probe writes into splitk_ws"); return CDETR_ERR_ARG; }
+        if (tile == 0 && stages == 103) return x3 ? launch_dl<2, 2, 3, 3, true>(d, st) : launch_dl<2, 2, 1, 3, true>(d, st);
+        if (tile == 3 && stages == 103) return x3 ? launch_dl<1, 1, 3, 3, true>(d, st) : launch_dl<1, 1, 1, 3, true>(d, st);
+        if (tile == 1 && stages == 103) return x3 ? launch_dl<2, 1, 3, 3, true>(d, st) : launch_dl<2, 1, 1, 3, true>(d, st);
+    }
+#define DL_GO(FM, FN, S) return x3 ? launch_dl<FM, FN, 3, S>(d, st) : launch_dl<FM, FN, 1, S>(d, st)
+    switch (tile * 8 + stages) {
+        case 0 * 8 + 2: DL_GO(2, 2, 2);
+        case 0 * 8 + 3: DL_GO(2, 2, 3);
+        case 1 * 8 + 2: DL_GO(2, 1, 2);
+        case 1 * 8 + 3: DL_GO(2, 1, 3);
+        case 1 * 8 + 4: DL_GO(2, 1, 4);
+        case 2 * 8 + 2: DL_GO(1, 2, 2);
+        case 2 * 8 + 3: DL_GO(1, 2, 3);
+        case 2 * 8 + 4: DL_GO(1, 2, 4);
+        case 3 * 8 + 2: DL_GO(1, 1, 2);
+        case 3 * 8 + 3: DL_GO(1, 1, 3);
+        case 3 * 8 + 4: DL_GO(1, 1, 4);
+        default: break;
+    }
+#undef DL_GO
+    cdetr_set_error("cdetr_gemm (direct-to-LDS): no kernel for tile %d with %d stages", tile, stages);
+    return CDETR_ERR_UNSUPPORTED;
+}

@@ -80,9 +80,10 @@ def splitk_ws():
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
-             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None):
+             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None, A16lo=None, C16lo=None, dl=None, probe_ws=None, B16=None):
+    """dl = (tile, stages): run the direct-to-LDS tile kernel with that configuration (cdetr_gemm_dl; tests / sweeps)."""
     d = GemmDesc()
-    d.C16, d.A16 = ptr(C16), ptr(A16)
+    d.C16, d.A16, d.A16lo, d.C16lo, d.B16 = ptr(C16), ptr(A16), ptr(A16lo), ptr(C16lo), ptr(B16)
     d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION if precision is None else precision
@@ -94,18 +95,23 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
     d.resid, d.ldr = ptr(resid), ldr
     d.gate, d.ldg = ptr(gate), ldg
     d.g = geom if geom is not None else _geom()
-    if SPLITK and batch == 1 and _GEMM_QUEUE is None and M * N <= (1 << 22) and K * taps >= 256:
+    if probe_ws is not None:
+        d.splitk_ws, d.splitk_ws_bytes = ptr(probe_ws), probe_ws.numel() * probe_ws.element_size()
+    elif SPLITK and batch == 1 and _GEMM_QUEUE is None and M * N <= (1 << 22) and K * taps >= 256:
         ws = splitk_ws()
         d.splitk_ws, d.splitk_ws_bytes = ptr(ws), SPLITK_BYTES
     if _GEMM_QUEUE is not None:       # inside gemm_queue(): submitted together by its exit (cdetr_gemm_group)
         _GEMM_QUEUE.append((d, 2.0 * M * N * K * taps * batch, 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
-                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16), _TERMS[d.precision]))
+                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16, A16lo, C16lo, B16), _TERMS[d.precision]))
         return
     # compulsory fp32 bytes: input rows once (a strided / dilated conv reads <= M*K of them), weights, output
     fl = 2.0 * M * N * K * taps * batch
     with _Timed(_gemm_family(M, N, batch, geom), fl, (M, N, K, taps, b_layout, batch), 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
                 fl * _TERMS[d.precision]):
-        check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
+        if dl is not None:
+            check(lib().cdetr_gemm_dl(C.byref(d), int(dl[0]), int(dl[1]), stream_ptr()), "cdetr_gemm_dl")
+        else:
+            check(lib().cdetr_gemm(C.byref(d), stream_ptr()), "cdetr_gemm")
 
 
 _GEMM_QUEUE = None
@@ -261,6 +267,13 @@ def relu_mask(y, dy, scale=1.0, twin=False):
     return dz
 
 
+def split_planes(x):
+    """fp32 tensor -> (hi, lo) bf16 planes of the split-bf16 form: hi = bf16(x), lo = bf16(x - hi) -- what the producing epilogues
+    write as C16 / C16lo (tests and tools; the product path never converts with tensor ops)."""
+    hi = x.to(torch.bfloat16)
+    return hi, (x - hi.float()).to(torch.bfloat16)
+
+
 def bf16_twins():
     """Whether the producers of the backbone's backward should write bf16 twins of their outputs: the plain-bf16 weight gradients read
     them instead of the fp32 tensors (half the operand bytes, no conversion at staging; `wgrad_tr16_kernel`)."""
@@ -292,6 +305,7 @@ class WeightMirror:
         tot_f = sum(w.numel() for w, _ in fwd_entries)
         self.flat = torch.zeros(max(tot_t, 1), device=dev, dtype=torch.float32)          # fp32 transposes
         self.flat_ts = torch.zeros(max(tot_t, 1), device=dev, dtype=torch.float32)       # their bf16 hi/lo images (same byte size)
+        self.flat_t16 = torch.zeros(max(tot_t, 1), device=dev, dtype=torch.bfloat16)     # their plain-bf16 images (cdetr_gemm_desc.B16)
         self.flat_fs = torch.zeros(max(tot_f, 1), device=dev, dtype=torch.float32)       # forward bf16 hi/lo images
         self._keep = []
         items = (MirrorItem * (len(entries) + len(fwd_entries)))()
@@ -315,6 +329,7 @@ class WeightMirror:
             it.src, it.dst = w.data_ptr(), self.flat.data_ptr() + 4 * off
             has_split = R % 32 == 0
             it.dst_split = (self.flat_ts.data_ptr() + 4 * off) if has_split else None
+            it.dst_hi = self.flat_t16.data_ptr() + 2 * off
             it.scale = sc.data_ptr() if sc is not None else None
             it.R, it.C, it.taps, it.tile0, it.transpose = R, Cc, taps, tile0, 1
             self.t_entries.append((w.data_ptr(), w.numel() * 4, off, R, Cc, taps, sc.data_ptr() if sc is not None else 0, has_split))
@@ -369,7 +384,7 @@ class WeightMirror:
         return e, row0
 
     def lookup(self, w, scale=None):
-        """data-gradient operand of `w` (or of a row slice of it) -> (fp32 mirror view, ldb, pre-split view or None) or None"""
+        """data-gradient operand of `w` (or of a row slice of it) -> (fp32 mirror view, ldb, pre-split view or None, bf16 view or None) or None"""
         key = (w.data_ptr(), scale.data_ptr() if scale is not None else 0)
         hit = self._memo_t.get(key, False)
         if hit is not False:
@@ -380,7 +395,7 @@ class WeightMirror:
         else:
             (base, nbytes, off, R, Cc, taps, sptr, has_split), row0 = r
             sp = self.flat_ts[off + row0:] if (has_split and row0 % 32 == 0) else None
-            out = (self.flat[off + row0:], taps * R, sp)
+            out = (self.flat[off + row0:], taps * R, sp, self.flat_t16[off + row0:] if row0 % 8 == 0 else None)
         self._memo_t[key] = out        # the images never move: the answer for a given operand address is fixed
         return out
 
@@ -423,7 +438,7 @@ def linear_dgrad(dy2d, weight, gate=None, resid=None):
     if m is not None:
         gemm_raw(dy2d, dy2d.stride(0), m[0], m[1], dx, K, M, K, N, b_layout=0,
                  gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
-                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0), B_split=m[2], precision=bwd_precision())
+                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0), B_split=m[2], B16=m[3], precision=bwd_precision())
         return dx
     gemm_raw(dy2d, dy2d.stride(0), weight, weight.stride(0), dx, K, M, K, N, b_layout=1,
              gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
@@ -672,19 +687,36 @@ def conv_geom_fwd(Hin, Win, kh, kw, stride, pad, dil):
 TWINS = os.environ.get("CDETR_TWINS", "1") != "0"
 
 
-def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False):
+# Forward activations of the backbone also leave their producing epilogue as split-bf16 planes (hi | lo) -- the operand format of the
+# direct-to-LDS tile kernel (csrc/igemm_dl.hip): the next convolution copies its tiles HBM -> LDS without touching a register.
+# Measured (tools/dl_sweep.py): ahead only on the epilogue-dominated 1x1 convolutions, behind on the long reductions, and every producer
+# pays 2 more bytes per element for the lo plane: OFF by default (the plain-bf16 data gradients DO use the direct-to-LDS kernel, fed by
+# the bf16 twins that exist anyway).
+SPLIT_FWD = os.environ.get("CDETR_SPLIT_FWD", "0") != "0"
+
+
+def split_forward():
+    return SPLIT_FWD and PRECISION == 1
+
+
+def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False, xs=None, split=False):
     """x [N,H,W,Cin] NHWC -> [N,Ho,Wo,Cout]; weight logical [Cout,Cin,kh,kw] in channels_last memory.
     y = relu?( conv(x, W) * scale[c] + bias[c] + resid )   (A2/models/resnet.py:140-160 + backbone.py:50-60).
-    twin: -> (y, bf16 copy of y written by the same epilogue)."""
+    twin: -> (y, bf16 copy of y written by the same epilogue).  split: -> (y, hi, lo) = y with its split-bf16 planes.
+    xs = (hi, lo) planes of x (from the producer's epilogue): the tile kernels read them instead of x."""
     Nb, H, W, Cin = x.shape
     Cout, Cin_w, kh, kw = weight.shape
     assert Cin_w == Cin and x.is_contiguous()
     g, Ho, Wo = conv_geom_fwd(H, W, kh, kw, stride, pad, dil)
     y = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    y16 = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if twin else None
+    y16 = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if (twin or split) else None
+    ylo = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if split else None
     sp = MIRROR.lookup_fwd(weight, scale) if MIRROR is not None else None
+    xh, xl = xs if xs is not None else (None, None)
     gemm_raw(x, Cin, weight, kh * kw * Cin, y, Cout, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, bias=bias,
-             relu=relu, resid=resid, ldr=Cout, geom=g, B_split=sp, C16=y16)
+             relu=relu, resid=resid, ldr=Cout, geom=g, B_split=sp, C16=y16, C16lo=ylo, A16=xh if xl is not None else None, A16lo=xl)
+    if split:
+        return y, y16, ylo
     return (y, y16) if twin else y
 
 
@@ -701,7 +733,7 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
-                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], precision=bwd_precision(), C16=dx16, A16=dz16)
+                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], B16=m[3], precision=bwd_precision(), C16=dx16, A16=dz16)
     else:
         gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
                  gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, precision=bwd_precision(), C16=dx16)
@@ -725,10 +757,16 @@ def conv_wgrad_(dz, x, weight, scale, stride=1, pad=0, dil=1, dz16=None, x16=Non
               dY16=dz16, X16=x16)
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, split=False):
+    """split: -> (y, hi, lo) with the split-bf16 planes of y written by the same pass."""
     Nb, H, W, Cc = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty((Nb, Ho, Wo, Cc), device=x.device, dtype=torch.float32)
+    if split:
+        yh = torch.empty((Nb, Ho, Wo, Cc), device=x.device, dtype=torch.bfloat16)
+        yl = torch.empty((Nb, Ho, Wo, Cc), device=x.device, dtype=torch.bfloat16)
+        check(lib().cdetr_maxpool3x3s2_split(ptr(x), ptr(y), ptr(yh), ptr(yl), Nb, H, W, Cc, stream_ptr()), "cdetr_maxpool3x3s2_split")
+        return y, yh, yl
     check(lib().cdetr_maxpool3x3s2(ptr(x), ptr(y), Nb, H, W, Cc, stream_ptr()), "cdetr_maxpool3x3s2")
     return y
 

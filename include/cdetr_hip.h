@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CDETR_ABI_VERSION 1
+#define CDETR_ABI_VERSION 2
 
 /* row-gather modes of cdetr_conv_geom */
 #define CDETR_ROWS_DENSE 0      /* row(m) = m (linear layers, 1x1 stride-1 convs) */
@@ -84,8 +84,21 @@ typedef struct {
                           * zeroes the counters ONCE (every call leaves them zero) and must not share one scratch between streams that
                           * may run cdetr_gemm concurrently.  16-byte aligned.                                                       */
     int64_t splitk_ws_bytes; /* size of splitk_ws in bytes (>= 16 KiB + partial tiles; too small = fewer slices or none)            */
+    const void* A16lo;   /* optional: the LO plane of A's split-bf16 form, lo = bf16(A - float(A16)) (same shape / strides as A16).  With
+                          * A16 + A16lo + B_split the split-bf16 x3 product (precision 1) needs no conversion at all: the direct-to-LDS
+                          * tile kernel (igemm_dl_kernel) copies operand tiles HBM -> LDS with global_load_lds and feeds the matrix
+                          * pipe from there.  Same arithmetic as splitting the fp32 operand at staging (bit-identical products).       */
+    const void* B16;     /* optional, b_layout 0: bf16(B * w_scale), same [N][taps*K] shape and ldb (in elements): what the plain-bf16
+                          * (precision 3) direct-to-LDS kernel streams instead of the hi halves of B_split's interleaved groups.   */
+    void* C16lo;         /* optional: the LO plane of C written by the same epilogue, C16lo = bf16(C - float(C16)) (needs C16): the
+                          * next layer's A16lo.  C itself may then be NULL when no consumer reads the fp32 tensor.                     */
 } cdetr_gemm_desc;
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
+/* The direct-to-LDS tile kernel (csrc/igemm_dl.hip) with an explicit configuration -- what cdetr_gemm picks by itself for problems
+ * whose operands are given pre-split (A16 [+ A16lo] and B_split); for tests and tile sweeps.  tile: 0 = 128x128, 1 = 128x64,
+ * 2 = 64x128, 3 = 64x64 (rows x channels per workgroup); stages: LDS ring depth 2..4 (3 for tile 0).  CDETR_ERR_UNSUPPORTED when the
+ * operand formats / alignment do not allow it (cdetr_last_error says why).                                                        */
+int cdetr_gemm_dl(const cdetr_gemm_desc* d, int32_t tile, int32_t stages, void* stream);
 /* n INDEPENDENT GEMMs submitted together (same results as n cdetr_gemm calls; no problem may read another's output).  Few-row
  * problems and the 64x128-tile class with a pre-split weight run as grouped launches (one kernel for up to 12 problems).
  * Replaces: sibling F.linear calls on independent inputs, e.g. the five in-projections of
@@ -222,11 +235,15 @@ typedef struct {
                           /* transpose = 0: of W itself (needs C % 32 == 0); layout as cdetr_gemm_desc.B_split  */
     const float* scale;   /* [R] or NULL                                                                        */
     int32_t R, C, taps, tile0, transpose, pad_;
+    void* dst_hi;         /* optional, transpose = 1: bf16(Wt) [C][taps][R], the plain-bf16 data-gradient operand        */
+                          /* (cdetr_gemm_desc.B16: full cache lines of hi values, no interleaved lo halves)             */
 } cdetr_mirror_item;
 int cdetr_weight_mirror(const cdetr_mirror_item* items_dev, int32_t n_items, int32_t total_tiles, void* stream);
 
 /* 3x3 stride-2 pad-1 max pooling, NHWC (A2/models/resnet.py:206,265) */
 int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream);
+/* the same, also writing the split-bf16 planes of Y (Y16 = bf16(Y), Y16lo = bf16(Y - float(Y16)); either may be NULL) */
+int cdetr_maxpool3x3s2_split(const float* X, float* Y, void* Y16, void* Y16lo, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream);
 
 /* ---- Row-Column Decoupled Attention core (A2/models/row_column_decoupled_attention.py:215-309) -------------
  * Inputs are the PROJECTED tensors: q_row,q_col [N][L][E]; k_row [N][W][E] (already averaged over H);

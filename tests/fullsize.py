@@ -30,6 +30,18 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
+def elementwise_rel_err(a, b, floor=1e-2):
+    """north_star's "within 1e-3 rel" read ELEMENT-WISE: max over elements of |a - b| / |b|, for the elements whose reference magnitude
+    is at least `floor` x the tensor's scale (below that a relative error is a statement about rounding noise around zero; those
+    elements are held to floor x 1e-3 x scale absolutely by rel_err).  -> (worst relative error, share of elements it covers)."""
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    big = np.abs(b) >= floor * max(np.abs(b).max(), 1e-30)
+    if not big.any():
+        return 0.0, 0.0
+    return float((np.abs(a - b)[big] / np.abs(b)[big]).max()), float(big.mean())
+
+
 def check_tap(z, key, t, tol, what=""):
     """t: tensor in the REFERENCE's layout (NCHW feature maps, [B,Q,C] decoder states)."""
     t = t.detach().to(torch.float64).reshape(-1).cpu()

@@ -29,7 +29,7 @@ def test_exports_every_declared_symbol(libpath):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/cdetr_hip.h but not exported"
     L.cdetr_abi_version.restype = ctypes.c_int
-    assert L.cdetr_abi_version() == 1
+    assert L.cdetr_abi_version() == 2
 
 
 def test_ffi_export_list_matches_header(libpath):

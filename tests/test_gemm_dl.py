@@ -1,0 +1,157 @@
+"""Parity of the direct-to-LDS tile kernel (csrc/igemm_dl.hip, entry cdetr_gemm_dl / picked by cdetr_gemm for pre-split operands)
+against fp64 math on the SAME split operands -- conv + FrozenBN fold + bias + residual + ReLU (A2/models/resnet.py:140-160,
+backbone.py:50-60) and the data-gradient form with its ReLU gate.  Every tile (128x128, 128x64, 64x128, 64x64) x ring depth x
+arithmetic (split-bf16 x3 from hi|lo planes, plain bf16 from the hi plane), ragged M / N, 1x1 / 3x3 / strided / dilated rows,
+padding rows from the zero page.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+CONFIGS = [(0, 2), (0, 3), (1, 2), (1, 3), (1, 4), (2, 2), (2, 3), (2, 4), (3, 2), (3, 3), (3, 4)]
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _mirror(w, scale):
+    from counting_detr_amd import ops
+    mir = ops.WeightMirror([], [(w, scale)])
+    mir.refresh("fwd")
+    return mir, mir.lookup_fwd(w, scale)
+
+
+def _split_ref(x):
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    return hi, lo
+
+
+def _check_planes(y, y16, y16lo):
+    assert torch.equal(y16, y.bfloat16()), "hi plane != bf16(C)"
+    assert torch.equal(y16lo, (y - y16.float()).bfloat16()), "lo plane != bf16(C - hi)"
+
+
+@pytest.mark.parametrize("tile,stages", CONFIGS)
+@pytest.mark.parametrize("precision", [1, 3], ids=["bf16x3", "bf16"])
+def test_dl_dense_rows(tile, stages, precision):
+    """Dense rows (1x1 conv / linear): ragged M and N (tails clamp to valid rows / the zero page), K = 1..5 k-tiles."""
+    from counting_detr_amd import ops
+    for (M, N, K, epi) in [(300, 132, 128, True), (1000, 256, 256, False), (129, 64, 64, True), (5000, 512, 320, True), (64, 4, 64, False)]:
+        if precision == 3 and K % 64:
+            continue
+        x = torch.randn(M, K, generator=g(M + K)).to(DEV)
+        w = (torch.randn(N, K, generator=g(N + K)) / K ** 0.5).to(DEV)
+        sc = (1 + 0.2 * torch.randn(N, generator=g(7))).to(DEV)
+        bias = torch.randn(N, generator=g(8)).to(DEV) if epi else None
+        resid = torch.randn(M, N, generator=g(9)).to(DEV) if epi else None
+        gate = torch.randn(M, N, generator=g(10)).to(DEV) if epi else None
+        mir, sp = _mirror(w, sc)
+        xh, xl = ops.split_planes(x)
+        y = torch.empty(M, N, device=DEV)
+        y16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        y16lo = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_raw(x, K, w, K, y, N, M, N, K, w_scale=sc, bias=bias, relu=epi, resid=resid, ldr=N, gate=gate, ldg=N, B_split=sp,
+                     precision=precision, A16=xh, A16lo=xl, C16=y16, C16lo=y16lo, dl=(tile, stages), out_scale=0.5 if epi else 1.0)
+        ws = (w * sc[:, None])
+        wh, wl = _split_ref(ws)
+        if precision == 1:
+            ref = (xh.double() + xl.double()) @ (wh.double() + wl.double()).t() - xl.double() @ wl.double().t()     # the lo*lo term is dropped
+        else:
+            ref = xh.double() @ wh.double().t()
+        if epi:
+            ref = (ref + bias.double()) * 0.5 + resid.double()
+            ref = torch.where(gate.double() > 0, ref, torch.zeros_like(ref)).clamp(min=0)
+        err = (y.double() - ref).abs().max().item()
+        assert err <= 3e-5 * (ref.abs().max().item() + 1.0), f"M={M} N={N} K={K}: {err:.3e}"
+        _check_planes(y, y16, y16lo)
+
+
+@pytest.mark.parametrize("tile,stages", [(0, 3), (1, 3), (2, 2), (3, 4)])
+@pytest.mark.parametrize("precision", [1, 3], ids=["bf16x3", "bf16"])
+@pytest.mark.parametrize("geom", [(3, 1, 1, 1), (3, 2, 1, 1), (3, 1, 2, 2), (1, 2, 0, 1)], ids=["3x3", "3x3s2", "3x3d2", "1x1s2"])
+def test_dl_conv_forward(tile, stages, precision, geom):
+    """Convolution rows: k-tiles never straddle a tap, padding taps read the zero page, strided / dilated gathers."""
+    from counting_detr_amd import ops
+    kh, stride, pad, dil = geom
+    Nb, H, W, Cin, Cout = 2, 19, 23, 64, 132
+    x = torch.randn(Nb, H, W, Cin, generator=g(1)).to(DEV)
+    w = (torch.randn(Cout, Cin, kh, kh, generator=g(2)) / (Cin * kh * kh) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    sc = (1 + 0.2 * torch.randn(Cout, generator=g(3))).to(DEV)
+    bias = torch.randn(Cout, generator=g(4)).to(DEV)
+    geo, Ho, Wo = ops.conv_geom_fwd(H, W, kh, kh, stride, pad, dil)
+    resid = torch.randn(Nb, Ho, Wo, Cout, generator=g(5)).to(DEV)
+    mir, sp = _mirror(w, sc)
+    xh, xl = ops.split_planes(x)
+    y = torch.empty(Nb, Ho, Wo, Cout, device=DEV)
+    y16 = torch.empty(Nb, Ho, Wo, Cout, device=DEV, dtype=torch.bfloat16)
+    y16lo = torch.empty_like(y16)
+    ops.gemm_raw(x, Cin, w, kh * kh * Cin, y, Cout, Nb * Ho * Wo, Cout, Cin, taps=kh * kh, w_scale=sc, bias=bias, relu=True, resid=resid,
+                 ldr=Cout, geom=geo, B_split=sp, precision=precision, A16=xh, A16lo=xl, C16=y16, C16lo=y16lo, dl=(tile, stages))
+    ws = w * sc.view(-1, 1, 1, 1)
+    wh, wl = _split_ref(ws)
+    conv = lambda a, b: F.conv2d(a.double().permute(0, 3, 1, 2).cpu(), b.double().cpu(), stride=stride, padding=pad, dilation=dil).permute(0, 2, 3, 1)   # noqa: E731
+    if precision == 1:
+        ref = conv(xh.double() + xl.double(), wh.double() + wl.double()) - conv(xl, wl)
+    else:
+        ref = conv(xh, wh)
+    ref = (ref + bias.double().cpu() + resid.double().cpu()).clamp(min=0)
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 3e-5 * (ref.abs().max().item() + 1.0), f"{err:.3e}"
+    _check_planes(y, y16, y16lo)
+
+
+@pytest.mark.parametrize("precision", [1, 3], ids=["bf16x3", "bf16"])
+def test_dl_conv_dgrad_rows(precision):
+    """The data-gradient row mode (transposed gather, stride 2) through the same kernel, with the ReLU gate of the layer below."""
+    from counting_detr_amd import ops, _ffi
+    Nb, Hin, Win, Cin, Cout, kh, stride, pad, dil = 2, 20, 22, 64, 128, 3, 2, 1, 1
+    Ho, Wo = (Hin + 2 * pad - dil * (kh - 1) - 1) // stride + 1, (Win + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    dz = torch.randn(Nb, Ho, Wo, Cout, generator=g(1)).to(DEV)
+    w = (torch.randn(Cout, Cin, kh, kh, generator=g(2)) / (Cout * 9) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    sc = (1 + 0.2 * torch.randn(Cout, generator=g(3))).to(DEV)
+    gate = torch.randn(Nb, Hin, Win, Cin, generator=g(4)).to(DEV)
+    mir = ops.WeightMirror([(w, sc)], [])
+    mir.refresh("bwd")
+    m = mir.lookup(w, sc)
+    ws_ = (w * sc.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(Cin, kh * kh * Cout)          # Wt [c][tap][o]
+    assert torch.equal(m[3][:ws_.numel()].view(Cin, -1), ws_.bfloat16())                        # the plain-bf16 image of cdetr_weight_mirror
+    geo = ops._geom(_ffi.ROWS_CONV_DGRAD, Ho, Wo, Hin, Win, kh, kh, stride, pad, dil)
+    dh, dl_ = ops.split_planes(dz)
+    for tile, stages in [(1, 3), (3, 3), (0, 3)]:
+        dx = torch.empty(Nb, Hin, Win, Cin, device=DEV)
+        dx16 = torch.empty(Nb, Hin, Win, Cin, device=DEV, dtype=torch.bfloat16)
+        ops.gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kh, gate=gate, ldg=Cin, geom=geo, B_split=m[2],
+                     B16=m[3] if tile != 3 else None,           # plain bf16: the hi-only weight image, or (tile 3) the hi halves of the split image
+                     precision=precision, A16=dh, A16lo=dl_, C16=dx16, dl=(tile, stages))
+        ws = (w * sc.view(-1, 1, 1, 1))
+        wh, wl = _split_ref(ws)
+        ct = lambda a, b: F.conv_transpose2d(a.double().permute(0, 3, 1, 2).cpu(), b.double().cpu(), stride=stride, padding=pad, dilation=dil,   # noqa: E731
+                                             output_padding=(Hin - ((Ho - 1) * stride - 2 * pad + dil * (kh - 1) + 1),
+                                                             Win - ((Wo - 1) * stride - 2 * pad + dil * (kh - 1) + 1))).permute(0, 2, 3, 1)
+        ref = (ct(dh.double() + dl_.double(), wh.double() + wl.double()) - ct(dl_, wl)) if precision == 1 else ct(dh, wh)
+        ref = torch.where(gate.double().cpu() > 0, ref, torch.zeros_like(ref))
+        err = (dx.double().cpu() - ref).abs().max().item()
+        assert err <= 3e-5 * (ref.abs().max().item() + 1.0), f"tile {tile}: {err:.3e}"
+        assert torch.equal(dx16, dx.bfloat16())
+
+
+def test_dl_is_what_cdetr_gemm_picks_for_presplit_operands():
+    """cdetr_gemm itself routes a large-enough problem with A16 + A16lo + B_split to the direct-to-LDS kernel: same result as the
+    forced configuration, and within the split-product error of the register-staged kernel fed the fp32 operand."""
+    from counting_detr_amd import ops
+    M, N, K = 20000, 512, 128
+    x = torch.randn(M, K, generator=g(1)).to(DEV)
+    w = (torch.randn(N, K, generator=g(2)) / K ** 0.5).to(DEV)
+    mir, sp = _mirror(w, None)
+    xh, xl = ops.split_planes(x)
+    y_auto, y_forced, y_old = (torch.empty(M, N, device=DEV) for _ in range(3))
+    ops.gemm_raw(x, K, w, K, y_auto, N, M, N, K, B_split=sp, precision=1, A16=xh, A16lo=xl)
+    ops.gemm_raw(x, K, w, K, y_forced, N, M, N, K, B_split=sp, precision=1, A16=xh, A16lo=xl, dl=(0, 3))
+    ops.gemm_raw(x, K, w, K, y_old, N, M, N, K, B_split=sp, precision=1)
+    assert torch.equal(y_auto, y_forced)
+    np.testing.assert_allclose(y_auto.cpu().numpy(), y_old.cpu().numpy(), rtol=0, atol=2e-5 * float(y_old.abs().max()))

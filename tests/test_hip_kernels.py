@@ -19,16 +19,38 @@ def precision(request):
     ops.PRECISION = old
 
 
+# Kernel tests that contain a backward contraction also run in the library's DEFAULT backward arithmetic (ops.PRECISION_BWD = 3: plain
+# bf16 products fed by bf16 twins, 1 MFMA per product) with its own bar: a bf16 rounding of both operands is 2^-9 relative per
+# product, random in sign -- a contraction's error is ~3e-3 of its typical magnitude, 1.5e-2 of the tensor's scale is the bar (the
+# forward's split-bf16 / fp32 results inside those tests are held to their strict bars by the bf16x3-backward run of the same test).
+BWD_DEFAULT_TESTS = {"test_linear_forward_backward", "test_conv_forward_dgrad_wgrad", "test_rcda_core", "test_multihead_rcda_module_vs_oracle",
+                     "test_encoder_layer_fused_equals_unfused", "test_decoder_stack_fused_equals_unfused", "test_mha_core",
+                     "test_weight_mirror_and_dgrad", "test_exemplar_feature_and_concat_free_projection", "test_wgrad_group_matches_individual_calls",
+                     "test_two_level_batch_image_by_head"}
+BF16_BWD_BAR = 1.5e-2
+_BWD_MODE = 1
+
+
+def pytest_generate_tests(metafunc):
+    if "bwd_mode" in metafunc.fixturenames:
+        modes = [1, 3] if metafunc.function.__name__ in BWD_DEFAULT_TESTS else [1]
+        metafunc.parametrize("bwd_mode", modes, ids=["bwd-as-fwd" if m == 1 else "bwd-bf16" for m in modes])
+
+
 @pytest.fixture(autouse=True)
-def _bf16x3_backward():
-    """The kernel-level tests pin the backward contractions to the forward's arithmetic (bf16x3 / fp32): their 2e-4 bars are the
-    bars of those kernels.  The reduced-term backward forms (ops.PRECISION_BWD 2 / 3, the library default) have their own test
-    below, and the end-to-end tests run with the default."""
+def _backward_arithmetic(request, bwd_mode):
+    """bwd-as-fwd: the backward contractions pinned to the forward's arithmetic (bf16x3 / fp32): the strict 2e-4 bars are the bars of
+    those kernels.  bwd-bf16: the shipped default (plain bf16, twins), bar BF16_BWD_BAR; only with the bf16x3 forward (the fp32-MFMA
+    mode ignores PRECISION_BWD)."""
+    global _BWD_MODE
     from counting_detr_amd import ops
+    if bwd_mode == 3 and "precision" in request.fixturenames and request.getfixturevalue("precision") != 1:
+        pytest.skip("PRECISION_BWD only applies to the split-bf16 mode")
     old = ops.PRECISION_BWD
-    ops.PRECISION_BWD = 1
+    ops.PRECISION_BWD = _BWD_MODE = bwd_mode
     yield
     ops.PRECISION_BWD = old
+    _BWD_MODE = 1
 
 
 def tol(precision):
@@ -46,6 +68,8 @@ def close(actual, ref, rtol=2e-4, atol_scale=2e-5, msg=""):
     assert a.shape == r.shape, (a.shape, r.shape)
     scale = r.abs().max().item() + 1e-30
     err = (a - r).abs().max().item()
+    if _BWD_MODE == 3:
+        rtol = max(rtol, BF16_BWD_BAR)
     assert torch.isfinite(a).all(), msg + " non-finite output"
     assert err <= rtol * scale + atol_scale * scale, f"{msg} max err {err:.3e} vs scale {scale:.3e}"
 
@@ -482,7 +506,8 @@ def test_weight_mirror_and_dgrad(precision):
     w1 = torch.randn(48, 64, 1, 1, device=dev).contiguous(memory_format=torch.channels_last)
     mir = ops.WeightMirror([(w3, s3), (wl, None), (w1, None)], [(w3, s3), (wl, None)])
     mir.refresh()
-    m3, ld3, sp3 = mir.lookup(w3, s3)
+    m3, ld3, sp3, h3 = mir.lookup(w3, s3)
+    assert torch.equal(h3[:32 * 9 * 64].view(32, 9 * 64), (w3 * s3.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(32, 9 * 64).bfloat16())     # plain-bf16 image
     ref3 = (w3 * s3.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(32, 9 * 64)        # [c][tap][o]
     assert ld3 == 9 * 64 and torch.equal(m3[:32 * 9 * 64].view(32, 9 * 64), ref3)
 
@@ -491,7 +516,7 @@ def test_weight_mirror_and_dgrad(precision):
         return v[:, :, 0].reshape(rows, klen), v[:, :, 1].reshape(rows, klen)
     hi, lo = unsplit(sp3, 32, 9 * 64)
     assert torch.equal(hi, ref3.bfloat16().float()) and torch.equal(lo, (ref3 - ref3.bfloat16().float()).bfloat16().float())
-    ml, ldl, spl = mir.lookup(wl[32:96])
+    ml, ldl, spl, _ = mir.lookup(wl[32:96])
     assert ldl == 160 and float(ml[0]) == float(wl[32, 0]) and float(ml[160]) == float(wl[32, 1]) and spl is not None
     full = mir.lookup(wl)[0][:96 * 160].view(96, 160)
     assert torch.equal(full, wl.t())
