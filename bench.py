@@ -408,6 +408,12 @@ def main(argv=None):
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    per_rank_ms = [float(t.item()) / a.steps * 1e3]
+    if world > 1:
+        mine = torch.tensor([dt / a.steps * 1e3], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(x[0]) for x in allr]
     dt = float(t.item())
     loss = float(out["loss"])
     ms_per_step = dt / a.steps * 1e3
@@ -506,6 +512,10 @@ def main(argv=None):
                       "precision_backward": ({1: "bf16x3", 2: "bf16x2", 3: "bf16"}[ops.PRECISION_BWD] if a.precision != "fp32" else "fp32"),
                       "final_loss": loss},
            "step_ms": percentiles(per_step),
+           "per_rank_ms_per_step": per_rank_ms,
+           "scaling_note": ("measured on %d ranks" % world) if world > 1 else
+                           "single-GPU line; no N > 1 scaling curve has been measured for this repo yet (one-GPU leases only: the driver's "
+                           "SCALE run is the first RCCL execution of the N > 1 path)",
            "roofline": roofline}
     if world > 1:
         ex = torch.tensor([sum(exposed) / max(len(exposed), 1) if exposed else 0.0], dtype=torch.float64, device=dev)

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcdetr_hip.so")
-SOURCES = ["api.hip", "igemm.hip", "igemm_dl.hip", "rcda.hip", "mha.hip", "matcher.hip", "criterion.hip", "elementwise.hip", "glue.hip"]
+SOURCES = ["api.hip", "igemm.hip", "igemm_dl.hip", "wgrad_dl.hip", "rcda.hip", "mha.hip", "matcher.hip", "criterion.hip", "elementwise.hip", "glue.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,7 +24,7 @@ def _hipcc():
 def _deps():
     inc = os.path.join(os.path.dirname(HERE), "include", "cdetr_hip.h")
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))] + \
-        [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rows.h"), inc]
+        [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "rows.h"), os.path.join(CSRC, "dl_common.h"), inc]
 
 
 def needs_build():

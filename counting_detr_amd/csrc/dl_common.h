@@ -1,0 +1,31 @@
+// Shared pieces of the direct-to-LDS kernels (igemm_dl.hip, wgrad_dl.hip): the zero page that stands in for padding / out-of-range
+// rows, address-space typedefs of __builtin_amdgcn_global_load_lds, the counted vmcnt wait.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace {
+
+__device__ __attribute__((aligned(256))) unsigned int dl_zero_page[64];      // 256 zero bytes: the source of padding / out-of-range rows
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* gbl_vp;
+
+__device__ __forceinline__ void wait_vm(int n) {              // counted wait: at most n of this wave's loads still in flight
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+
+}  // namespace

@@ -22,15 +22,10 @@
 #include "../../include/cdetr_hip.h"
 #include "common.h"
 #include "rows.h"
+#include "dl_common.h"
 #include <stdlib.h>
 
 namespace {
-
-__device__ __attribute__((aligned(256))) unsigned int dl_zero_page[64];      // 256 zero bytes: the source of padding / out-of-range rows
-
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_vp;
-typedef const __attribute__((address_space(1))) void* gbl_vp;
 
 template <int FM, int FN, int TERMS, int STAGES>
 struct DlCfg {
@@ -42,23 +37,6 @@ struct DlCfg {
     static constexpr int STAGING = 4 * 32 * FM * (32 * FN + 4) * 4;       // the epilogue's transposition tiles (one per wave) reuse the ring
     static constexpr int LDS = RING > STAGING ? RING : STAGING;
 };
-
-__device__ __forceinline__ void wait_vm(int n) {              // counted wait: at most n of this wave's loads still in flight
-    switch (n) {
-        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-        case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
-        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
 
 // PROBE: wave 0 of every workgroup stamps s_memtime at its phase boundaries into cdetr_gemm_desc.splitk_ws (8 x uint64 per workgroup:
 // start, prologue issued, first tile landed, k-loop done, epilogue operands loaded, stores issued) -- tools/dl_probe.py.

@@ -23,6 +23,21 @@
 
 namespace {
 
+// XCD-aware placement of a 2-D grid (x = tile of one (image, head), y = (image, head)): workgroup b of the launch runs on XCD b % 8, each
+// with a private 4 MiB L2.  In dispatch order the x-tiles of ONE (image, head) land on all 8 XCDs, so every XCD fetches every head's V / K /
+// attention rows from the fabric (PMC round 2: 4.5x the algorithmic bytes in the RCDA backward, 2x in the forward).  Remapped, XCD c owns
+// the contiguous range [c * total / 8, (c + 1) * total / 8) of the row-major (y, x) index space -- whole (image, head) slabs, whose operands
+// then come from the fabric once.  Identity when the grid is not a multiple of 8 workgroups.  Placement only affects speed.
+__device__ __forceinline__ void xcd_slab(int& bx, int& by) {
+    const int gx = gridDim.x, total = gx * gridDim.y;
+    if (total & 7) return;
+    const int lin = by * gx + bx;
+    const int l2 = (lin & 7) * (total >> 3) + (lin >> 3);
+    by = l2 / gx;
+    bx = l2 - by * gx;
+}
+
+
 constexpr int D = 32;          // head dim
 constexpr int QW = 32;         // queries per wave
 
@@ -196,8 +211,10 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
     const FwdSmem sm = fwd_smem(H, W, NW);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, g = lane >> 5;
-    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
-    const int qbase = blockIdx.x * QB + wid * QW;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    xcd_slab(bx_, by_);
+    const int n = by_ / d.nh, head = by_ % d.nh;
+    const int qbase = bx_ * QB + wid * QW;
     const int q = qbase + i32;
     const bool qvalid = q < L;
 
@@ -455,8 +472,10 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
     const FwdSmem sm = fwd_smem(H, W, NW);
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, g = lane >> 5;
-    const int n = blockIdx.y / d.nh, head = blockIdx.y % d.nh;
-    const int qbase = blockIdx.x * QB + wid * QW;
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    xcd_slab(bx_, by_);
+    const int n = by_ / d.nh, head = by_ % d.nh;
+    const int qbase = bx_ * QB + wid * QW;
     const int q = qbase + i32;
     const bool qvalid = q < L;
     float* Srow = smem + sm.off_srow + wid * QW * sm.sw;
@@ -957,7 +976,9 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
 
 template <int NF, int NW, int PREC, int TERMS = 3>
 __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
-    rcda_bwd_body<NF, NW, PREC, TERMS>(d, blockIdx.x, blockIdx.y);
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    xcd_slab(bx_, by_);
+    rcda_bwd_body<NF, NW, PREC, TERMS>(d, bx_, by_);
 }
 
 // ------------------------------------------------------------------------------------------------ backward (dV)
@@ -1208,7 +1229,9 @@ __device__ __forceinline__ void rcda_dv2_body(const cdetr_rcda_bwd_desc& d, cons
 
 template <int TERMS = 3>
 __global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc d, const int q_per_slice) {
-    rcda_dv2_body<TERMS>(d, q_per_slice, blockIdx.x, blockIdx.y, blockIdx.z);
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    xcd_slab(bx_, by_);                  // (every z-plane of the grid is a multiple of 8 workgroups or the map is the identity)
+    rcda_dv2_body<TERMS>(d, q_per_slice, bx_, by_, blockIdx.z);
 }
 
 // dS / dq / dk (rcda_bwd_body) and dV (rcda_dv2_body) of one attention in ONE launch: the two read the same saved attention maps and d_out
@@ -1217,12 +1240,14 @@ __global__ __launch_bounds__(512) void rcda_dv2_kernel(const cdetr_rcda_bwd_desc
 // the rest: (key-row group, query slice) of the dV kernel.
 template <int NF, int NW, int TERMS>
 __global__ __launch_bounds__(512) void rcda_bwd_all_kernel(const cdetr_rcda_bwd_desc d, const int nqb, const int hgroups, const int q_per_slice) {
-    if ((int)blockIdx.x < nqb) {
+    int bx_ = blockIdx.x, by_ = blockIdx.y;
+    xcd_slab(bx_, by_);
+    if (bx_ < nqb) {
         if ((int)threadIdx.x >= 64 * NW) return;
-        rcda_bwd_body<NF, NW, 1, TERMS>(d, blockIdx.x, blockIdx.y);
+        rcda_bwd_body<NF, NW, 1, TERMS>(d, bx_, by_);
     } else {
-        const int t = (int)blockIdx.x - nqb;
-        rcda_dv2_body<TERMS>(d, q_per_slice, t % hgroups, blockIdx.y, t / hgroups);
+        const int t = bx_ - nqb;
+        rcda_dv2_body<TERMS>(d, q_per_slice, t % hgroups, by_, t / hgroups);
     }
 }
 

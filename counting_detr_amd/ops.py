@@ -150,13 +150,13 @@ class gemm_queue:
 
 
 def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0,
-              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False, dY16=None, X16=None):
+              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False, dY16=None, X16=None, dl=None, precision=None):
     """dY16 / X16: optional bf16 twins of dY / X (same shape and strides in elements): the plain-bf16 kernel reads them instead."""
     d = WgradDesc()
     d.dY16, d.X16 = ptr(dY16), ptr(X16)
     d.batch_inner, d.sY2, d.sX2, d.sW2 = batch_inner, sY2, sX2, sW2
     d.P, d.Nout, d.Cin, d.taps, d.batch = P, Nout, Cin, taps, batch
-    d.precision = bwd_precision()
+    d.precision = bwd_precision() if precision is None else precision
     d.dY, d.ldy, d.sY = ptr(dY), ldy, sY
     d.X, d.ldx, d.sX = ptr(X), ldx, sX
     d.dW, d.ldw, d.sW = ptr(dW), ldw, sW
@@ -170,7 +170,10 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
     # compulsory bytes: dY and X once, dW read + written (accumulation into the gradient arena)
     fl = 2.0 * P * Nout * Cin * taps * batch
     with _Timed("wgrad", fl, (P, Nout, Cin, taps, -1, batch), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1), fl * _TERMS[d.precision]):
-        check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
+        if dl is not None:          # (configuration, workgroup target): the direct-to-LDS kernel, forced (tests / sweeps)
+            check(lib().cdetr_wgrad_dl(C.byref(d), int(dl[0]), int(dl[1]), stream_ptr()), "cdetr_wgrad_dl")
+        else:
+            check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
 
 
 _WG_QUEUE = None

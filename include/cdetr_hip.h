@@ -127,6 +127,10 @@ typedef struct {
                        /* Needs both, Nout / Cin / ldy / ldx multiples of 8, 16-byte aligned bases, no dbias; otherwise dY / X are read. */
 } cdetr_wgrad_desc;
 int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
+/* The direct-to-LDS weight-gradient kernel (csrc/wgrad_dl.hip) with an explicit configuration -- what cdetr_wgrad / cdetr_wgrad_group
+ * pick themselves for precision 3 with twins; for tests and sweeps.  cfg = tile * 100 + (pixels per LDS tile / 32) * 10 + ring depth,
+ * tile 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64 (output x input channels); target = workgroups to aim at (0 = default).      */
+int cdetr_wgrad_dl(const cdetr_wgrad_desc* d, int32_t cfg, int64_t target, void* stream);
 /* n INDEPENDENT weight-gradient problems submitted together (same semantics as n cdetr_wgrad calls in any order; problems may
  * accumulate into the same dW / dbias).  Problems of the few-pixel and of the 64x64 transpose-read kernel class run as grouped
  * launches (one kernel for up to 16 problems), the rest one by one.  Replaces: the per-parameter autograd weight-gradient nodes of
