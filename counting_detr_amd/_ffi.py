@@ -29,7 +29,7 @@ class GemmDesc(C.Structure):
                 ("w_scale", _p), ("bias", _p), ("resid", _p), ("ldr", C.c_int64), ("gate", _p), ("ldg", C.c_int64),
                 ("g", ConvGeom), ("B_split", _p), ("batch_inner", C.c_int32), ("pad_", C.c_int32),
                 ("sA2", C.c_int64), ("sB2", C.c_int64), ("sC2", C.c_int64), ("A16", _p), ("C16", _p),
-                ("splitk_ws", _p), ("splitk_ws_bytes", C.c_int64), ("A16lo", _p), ("B16", _p), ("C16lo", _p)]
+                ("splitk_ws", _p), ("splitk_ws_bytes", C.c_int64), ("A16lo", _p), ("B16", _p), ("gate16", _p), ("C16lo", _p)]
 
 
 class WgradDesc(C.Structure):
@@ -66,7 +66,7 @@ class MirrorItem(C.Structure):
                 ("tile0", C.c_int32), ("transpose", C.c_int32), ("pad_", C.c_int32), ("dst_hi", _p)]
 
 
-EXPORTS = ["cdetr_gemm", "cdetr_gemm_dl", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_dl", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_layernorm_bwd_merge", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
+EXPORTS = ["cdetr_gemm", "cdetr_gemm_dl", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_layernorm_bwd_merge", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
            "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_bcast_add2_sum", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_maxpool3x3s2_split", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_mask_prep", "cdetr_stem_pack", "cdetr_exemplar_fwd", "cdetr_exemplar_bwd", "cdetr_aggr_weight_fwd", "cdetr_aggr_weight_bwd",
            "cdetr_box_head_fwd", "cdetr_box_head_bwd", "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
@@ -84,8 +84,6 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.cdetr_last_error.restype = C.c_char_p
         L.cdetr_abi_version.restype = C.c_int
-        L.cdetr_wgrad_dl.restype = C.c_int
-        L.cdetr_wgrad_dl.argtypes = [_p, C.c_int32, C.c_int64, _p]
         L.cdetr_gemm_dl.restype = C.c_int
         L.cdetr_gemm_dl.argtypes = [_p, C.c_int32, C.c_int32, _p]
         for name in ("cdetr_gemm", "cdetr_wgrad", "cdetr_rcda_fwd", "cdetr_rcda_bwd"):

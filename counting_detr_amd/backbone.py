@@ -124,11 +124,11 @@ class Bottleneck(nn.Module):
         st, dl = self.stride, self.dilation
         if w3.requires_grad:
             ops.conv_wgrad_(dz, a2, w3, s3, dz16=dz16, x16=a2_16 if tw else None)
-        dz2 = ops.conv_dgrad(dz, w3, s3, a2.shape[1:3], gate=a2, twin=tw, dz16=dz16)      # masked by relu(a2)
+        dz2 = ops.conv_dgrad(dz, w3, s3, a2.shape[1:3], gate=a2, twin=tw, dz16=dz16, gate16=a2_16 if tw else None)      # masked by relu(a2)
         dz2, dz2_16 = dz2 if tw else (dz2, None)
         if w2.requires_grad:
             ops.conv_wgrad_(dz2, a1, w2, s2, stride=st, pad=dl, dil=dl, dz16=dz2_16, x16=a1_16 if tw else None)
-        dz1 = ops.conv_dgrad(dz2, w2, s2, a1.shape[1:3], stride=st, pad=dl, dil=dl, gate=a1, twin=tw, dz16=dz2_16)
+        dz1 = ops.conv_dgrad(dz2, w2, s2, a1.shape[1:3], stride=st, pad=dl, dil=dl, gate=a1, twin=tw, dz16=dz2_16, gate16=a1_16 if tw else None)
         dz1, dz1_16 = dz1 if tw else (dz1, None)
         if w1.requires_grad:
             ops.conv_wgrad_(dz1, x, w1, s1, dz16=dz1_16, x16=x16 if tw else None)
@@ -145,7 +145,7 @@ class Bottleneck(nn.Module):
                 return None
             d_idn = dz
         # x = relu(previous pre-activation): the gate applies the previous block's ReLU mask in the same epilogue
-        return ops.conv_dgrad(dz1, w1, s1, x.shape[1:3], gate=x, resid=d_idn, twin=tw, dz16=dz1_16)
+        return ops.conv_dgrad(dz1, w1, s1, x.shape[1:3], gate=x, resid=d_idn, twin=tw, dz16=dz1_16, gate16=x16 if tw else None)
 
 
 _BACKWARD_HOOK = None

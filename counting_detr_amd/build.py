@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcdetr_hip.so")
-SOURCES = ["api.hip", "igemm.hip", "igemm_dl.hip", "wgrad_dl.hip", "rcda.hip", "mha.hip", "matcher.hip", "criterion.hip", "elementwise.hip", "glue.hip"]
+SOURCES = ["api.hip", "igemm.hip", "igemm_dl.hip", "rcda.hip", "mha.hip", "matcher.hip", "criterion.hip", "elementwise.hip", "glue.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
 
 

@@ -2302,46 +2302,13 @@ bool wgrad_has_twins(const cdetr_wgrad_desc& d) {
 bool wgrad_is_fast(const cdetr_wgrad_desc& d) { return (d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0; }
 }  // namespace
 
-// wgrad_dl.hip: weight gradients from the bf16 twins with direct-to-LDS operand loads
-bool cdetr_wgrad_dl_eligible(const cdetr_wgrad_desc& d);
-int cdetr_wgrad_dl_launch(const cdetr_wgrad_desc& d, int cfg, long target, hipStream_t st);
-int cdetr_wgrad_dl_group(const cdetr_wgrad_desc* descs, const int* idx, int m, int cfg, long target, hipStream_t st);
-
-namespace {
-// Configuration of the direct-to-LDS weight-gradient kernel for a problem (tile * 100 + (pixels per tile / 32) * 10 + ring depth; tile
-// 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64 output / input channels), or -1 = the register-staged kernels.
-// CDETR_WGRAD_DL (read once): 0 = never, 1 = this rule, >= 100... = force (1000 + cfg) wherever legal (tools/wgrad_dl_sweep.py).
-int wgrad_dl_choice(const cdetr_wgrad_desc& d) {
-    static const int mode = getenv("CDETR_WGRAD_DL") ? atoi(getenv("CDETR_WGRAD_DL")) : 1;
-    if (mode == 0 || wgrad_is_direct(d) || !cdetr_wgrad_dl_eligible(d)) return -1;
-    if (mode >= 1000) return mode - 1000;
-    const int tile = (d.Nout >= 128 && d.Cin >= 128) ? 0 : (d.Nout >= 128 ? 1 : (d.Cin >= 128 ? 2 : 3));
-    return tile * 100 + 13;
-}
-constexpr long WGRAD_DL_TARGET = 768;
-}  // namespace
-
-extern "C" int cdetr_wgrad_dl(const cdetr_wgrad_desc* dp, int32_t cfg, int64_t target, void* stream) {
-    CDETR_CHECK_ARG(dp != nullptr, "cdetr_wgrad_dl: null descriptor");
-    if (int rcv = check_wgrad_desc(*dp)) return rcv;
-    if (dp->P == 0) return CDETR_OK;
-    if (!cdetr_wgrad_dl_eligible(*dp)) {
-        cdetr_set_error("cdetr_wgrad_dl: needs precision 3, dY16 + X16, batch 1, no dbias, channel counts / leading dimensions multiples of 8");
-        return CDETR_ERR_UNSUPPORTED;
-    }
-    return cdetr_wgrad_dl_launch(*dp, cfg, target > 0 ? target : WGRAD_DL_TARGET, reinterpret_cast<hipStream_t>(stream));
-}
-
 extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
     CDETR_CHECK_ARG(dp != nullptr, "cdetr_wgrad: null descriptor");
     cdetr_wgrad_desc d = *dp;
     if (int rcv = check_wgrad_desc(d)) return rcv;
     if (d.P == 0) return CDETR_OK;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    {
-        const int cfg = wgrad_dl_choice(d);
-        if (cfg >= 0) return cdetr_wgrad_dl_launch(d, cfg, WGRAD_DL_TARGET, st);
-    }
+
     if (wgrad_is_direct(d)) {
         int tilesI, tilesJ, per, slices;
         direct_wgrad_plan(d, tilesI, tilesJ, per, slices);
@@ -2469,28 +2436,15 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
     static const int grouping = getenv("CDETR_WGRAD_GROUP") ? atoi(getenv("CDETR_WGRAD_GROUP")) : 1;
     const bool forced = getenv("CDETR_WGRAD_VARIANT") && atoi(getenv("CDETR_WGRAD_VARIANT")) != 0;
     std::vector<int> direct, tr64p, tr64t;                    // tr64t: the same class with bf16 twins (wgrad_tr16_group_kernel)
-    std::vector<std::pair<int, std::vector<int>>> dlc;        // direct-to-LDS classes: (configuration, problems)
     for (int i = 0; i < n; ++i) {
         const cdetr_wgrad_desc& d = descs[i];
         if (int rcv = check_wgrad_desc(d)) return rcv;
         if (d.P == 0) continue;
-        const int dcfg = grouping ? wgrad_dl_choice(d) : -1;
-        if (dcfg >= 0) {
-            size_t k = 0;
-            while (k < dlc.size() && dlc[k].first != dcfg) ++k;
-            if (k == dlc.size()) dlc.push_back({dcfg, {}});
-            dlc[k].second.push_back(i);
-            continue;
-        }
         if (grouping && wgrad_is_direct(d)) direct.push_back(i);
         else if (grouping && wgrad_is_fast(d) && d.precision >= 1 && !forced &&
                  !(d.taps > 1 && d.Nout >= 512 && d.Cin >= 512) && !(d.taps == 1 && (long)d.Nout * d.Cin >= (1L << 20) && d.Cin >= 128))
             (wgrad_has_twins(d) ? tr64t : tr64p).push_back(i);      // = the shapes cdetr_wgrad gives to wgrad_tr_kernel<64, 64>
         else if (int rc1 = cdetr_wgrad(&d, stream)) return rc1;
-    }
-    for (auto& cls : dlc) {                                   // every class's workgroup budget in proportion to its share of the problems
-        const long target = std::max<long>(256, WGRAD_DL_TARGET * (long)cls.second.size() / std::max<size_t>(1, cls.second.size()));
-        if (int rcd = cdetr_wgrad_dl_group(descs, cls.second.data(), (int)cls.second.size(), cls.first, target, st)) return rcd;
     }
     for (size_t c0 = 0; c0 < direct.size(); c0 += WG_MAX) {
         const int m = (int)std::min<size_t>(WG_MAX, direct.size() - c0);

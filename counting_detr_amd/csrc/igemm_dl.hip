@@ -230,13 +230,20 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     const int mw = m0 + wm * 32 * FM;
     // residual / gate rows of every pass: ONE batch of unconditional loads (clamped row / channel, masked use) ahead of the math
     float4 res[NPASS][2], gat[NPASS][2];
+    const __bf16* __restrict__ g16 = d.gate ? reinterpret_cast<const __bf16*>(d.gate16) : nullptr;      // bf16 twin of the gate: same sign, half the bytes
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
         const long mrow = min(mw + p * RPP + rr, d.M - 1);
         res[p][0] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
         res[p][1] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
-        gat[p][0] = d.gate ? *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl0) : make_float4(1.f, 1.f, 1.f, 1.f);
-        gat[p][1] = d.gate ? *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl1) : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (g16) {
+            const uint2 t0 = *reinterpret_cast<const uint2*>(g16 + mrow * d.ldg + nl0), t1 = *reinterpret_cast<const uint2*>(g16 + mrow * d.ldg + nl1);
+            gat[p][0] = make_float4(__uint_as_float(t0.x << 16), __uint_as_float(t0.x & 0xffff0000u), __uint_as_float(t0.y << 16), __uint_as_float(t0.y & 0xffff0000u));
+            gat[p][1] = make_float4(__uint_as_float(t1.x << 16), __uint_as_float(t1.x & 0xffff0000u), __uint_as_float(t1.y << 16), __uint_as_float(t1.y & 0xffff0000u));
+        } else {
+            gat[p][0] = d.gate ? *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl0) : make_float4(1.f, 1.f, 1.f, 1.f);
+            gat[p][1] = d.gate ? *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl1) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
     }
     if constexpr (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4); }
 #pragma unroll
@@ -322,6 +329,7 @@ bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d) {
     if ((reinterpret_cast<uintptr_t>(d.C) & 15) || (reinterpret_cast<uintptr_t>(d.C16) & 7) || (reinterpret_cast<uintptr_t>(d.C16lo) & 7)) return false;
     if (d.resid && ((reinterpret_cast<uintptr_t>(d.resid) & 15) || (d.ldr & 3))) return false;
     if (d.gate && ((reinterpret_cast<uintptr_t>(d.gate) & 15) || (d.ldg & 3))) return false;
+    if (d.gate16 && (reinterpret_cast<uintptr_t>(d.gate16) & 7)) return false;
     if (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15)) return false;
     if (!d.C && !d.C16) return false;
     if (d.C16lo && !d.C16) return false;

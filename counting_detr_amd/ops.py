@@ -80,10 +80,10 @@ def splitk_ws():
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
-             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None, A16lo=None, C16lo=None, dl=None, probe_ws=None, B16=None):
+             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None, A16lo=None, C16lo=None, dl=None, probe_ws=None, B16=None, gate16=None):
     """dl = (tile, stages): run the direct-to-LDS tile kernel with that configuration (cdetr_gemm_dl; tests / sweeps)."""
     d = GemmDesc()
-    d.C16, d.A16, d.A16lo, d.C16lo, d.B16 = ptr(C16), ptr(A16), ptr(A16lo), ptr(C16lo), ptr(B16)
+    d.C16, d.A16, d.A16lo, d.C16lo, d.B16, d.gate16 = ptr(C16), ptr(A16), ptr(A16lo), ptr(C16lo), ptr(B16), ptr(gate16)
     d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION if precision is None else precision
@@ -102,7 +102,7 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
         d.splitk_ws, d.splitk_ws_bytes = ptr(ws), SPLITK_BYTES
     if _GEMM_QUEUE is not None:       # inside gemm_queue(): submitted together by its exit (cdetr_gemm_group)
         _GEMM_QUEUE.append((d, 2.0 * M * N * K * taps * batch, 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
-                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16, A16lo, C16lo, B16), _TERMS[d.precision]))
+                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16, A16lo, C16lo, B16, gate16), _TERMS[d.precision]))
         return
     # compulsory fp32 bytes: input rows once (a strided / dilated conv reads <= M*K of them), weights, output
     fl = 2.0 * M * N * K * taps * batch
@@ -150,7 +150,7 @@ class gemm_queue:
 
 
 def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0,
-              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False, dY16=None, X16=None, dl=None, precision=None):
+              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False, dY16=None, X16=None, precision=None):
     """dY16 / X16: optional bf16 twins of dY / X (same shape and strides in elements): the plain-bf16 kernel reads them instead."""
     d = WgradDesc()
     d.dY16, d.X16 = ptr(dY16), ptr(X16)
@@ -170,10 +170,7 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
     # compulsory bytes: dY and X once, dW read + written (accumulation into the gradient arena)
     fl = 2.0 * P * Nout * Cin * taps * batch
     with _Timed("wgrad", fl, (P, Nout, Cin, taps, -1, batch), 4.0 * (P * Nout + P * Cin + 2 * Nout * Cin * taps) * max(batch, 1), fl * _TERMS[d.precision]):
-        if dl is not None:          # (configuration, workgroup target): the direct-to-LDS kernel, forced (tests / sweeps)
-            check(lib().cdetr_wgrad_dl(C.byref(d), int(dl[0]), int(dl[1]), stream_ptr()), "cdetr_wgrad_dl")
-        else:
-            check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
+        check(lib().cdetr_wgrad(C.byref(d), stream_ptr()), "cdetr_wgrad")
 
 
 _WG_QUEUE = None
@@ -723,7 +720,7 @@ def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=N
     return (y, y16) if twin else y
 
 
-def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False, dz16=None):
+def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False, dz16=None, gate16=None):
     """dx [N,Hin,Win,Cin] = conv_transpose(dz * scale, W) (+ resid), zeroed where gate <= 0.  twin: -> (dx, bf16 copy of dx);
     dz16: the bf16 twin of dz (read instead of dz by the plain-bf16 tile kernels)."""
     Nb, Ho, Wo, Cout = dz.shape
@@ -736,7 +733,8 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
-                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], B16=m[3], precision=bwd_precision(), C16=dx16, A16=dz16)
+                 gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], B16=m[3], precision=bwd_precision(), C16=dx16, A16=dz16,
+                 gate16=gate16 if gate is not None else None)
     else:
         gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
                  gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, precision=bwd_precision(), C16=dx16)

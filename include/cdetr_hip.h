@@ -90,6 +90,9 @@ typedef struct {
                           * pipe from there.  Same arithmetic as splitting the fp32 operand at staging (bit-identical products).       */
     const void* B16;     /* optional, b_layout 0: bf16(B * w_scale), same [N][taps*K] shape and ldb (in elements): what the plain-bf16
                           * (precision 3) direct-to-LDS kernel streams instead of the hi halves of B_split's interleaved groups.   */
+    const void* gate16;  /* optional: bf16 twin of `gate` (same ldg, in elements): the direct-to-LDS kernel tests its sign instead of the fp32
+                          * tensor's (bf16 rounding keeps sign and zero: the ReLU mask is identical) -- half the bytes of the epilogue's
+                          * largest read in the backbone's data gradients.  `gate` must still be given (other kernel classes read it).  */
     void* C16lo;         /* optional: the LO plane of C written by the same epilogue, C16lo = bf16(C - float(C16)) (needs C16): the
                           * next layer's A16lo.  C itself may then be NULL when no consumer reads the fp32 tensor.                     */
 } cdetr_gemm_desc;
@@ -127,10 +130,6 @@ typedef struct {
                        /* Needs both, Nout / Cin / ldy / ldx multiples of 8, 16-byte aligned bases, no dbias; otherwise dY / X are read. */
 } cdetr_wgrad_desc;
 int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
-/* The direct-to-LDS weight-gradient kernel (csrc/wgrad_dl.hip) with an explicit configuration -- what cdetr_wgrad / cdetr_wgrad_group
- * pick themselves for precision 3 with twins; for tests and sweeps.  cfg = tile * 100 + (pixels per LDS tile / 32) * 10 + ring depth,
- * tile 0 = 128x128, 1 = 128x64, 2 = 64x128, 3 = 64x64 (output x input channels); target = workgroups to aim at (0 = default).      */
-int cdetr_wgrad_dl(const cdetr_wgrad_desc* d, int32_t cfg, int64_t target, void* stream);
 /* n INDEPENDENT weight-gradient problems submitted together (same semantics as n cdetr_wgrad calls in any order; problems may
  * accumulate into the same dW / dbias).  Problems of the few-pixel and of the 64x64 transpose-read kernel class run as grouped
  * launches (one kernel for up to 16 problems), the rest one by one.  Replaces: the per-parameter autograd weight-gradient nodes of

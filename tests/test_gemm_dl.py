@@ -127,6 +127,7 @@ def test_dl_conv_dgrad_rows(precision):
         dx16 = torch.empty(Nb, Hin, Win, Cin, device=DEV, dtype=torch.bfloat16)
         ops.gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kh, gate=gate, ldg=Cin, geom=geo, B_split=m[2],
                      B16=m[3] if tile != 3 else None,           # plain bf16: the hi-only weight image, or (tile 3) the hi halves of the split image
+                     gate16=gate.bfloat16() if tile != 0 else None,      # the gate's bf16 twin (same signs) or the fp32 gate itself
                      precision=precision, A16=dh, A16lo=dl_, C16=dx16, dl=(tile, stages))
         ws = (w * sc.view(-1, 1, 1, 1))
         wh, wl = _split_ref(ws)
