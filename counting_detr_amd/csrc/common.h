@@ -12,6 +12,15 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define CDETR_ERR_LAUNCH (-2)
 #define CDETR_ERR_UNSUPPORTED (-3)
 
+// A/B and test knobs that must be re-read on EVERY call (tests switch kernel variants inside one process) cost a getenv per launch;
+// the product path does not pay it: they are consulted only when CDETR_TUNING was set when the library was loaded (tests/conftest.py,
+// the sweep tools).  Knobs that select a fixed configuration for a whole process are plain statics read once.
+#include <stdlib.h>
+static inline const char* cdetr_tune_env(const char* name) {
+    static const bool tuning = getenv("CDETR_TUNING") != nullptr;
+    return tuning ? getenv(name) : nullptr;
+}
+
 // thread-local last-error string (cdetr_last_error)
 void cdetr_set_error(const char* fmt, ...);
 

@@ -1913,7 +1913,7 @@ inline bool gemm_has_a_twin(const cdetr_gemm_desc& d) {
 // cost 2-30 % more time), so its reduction is cut into slices until the grid reaches ~2 workgroups of 8 waves per CU.
 inline int gemm_ksplit(const cdetr_gemm_desc& d, int waves, long tiles, int nkt_all, long tile_bytes, int min_kt = 8) {
     if (!d.splitk_ws || d.batch != 1 || tiles > SPLITK_COUNTERS) return 1;
-    const char* fs = getenv("CDETR_GEMM_SPLITK");           // A/B knob: 0 = never, n = n slices wherever legal
+    const char* fs = cdetr_tune_env("CDETR_GEMM_SPLITK");           // A/B knob: 0 = never, n = n slices wherever legal
     const int force = fs ? atoi(fs) : -1;
     if (force == 0) return 1;
     int S = force > 0 ? force : (int)((256L * 16 / waves) / tiles);
@@ -2002,7 +2002,7 @@ bool gemm_is_direct(const cdetr_gemm_desc& d, int vecA, int vecB) {
     return d.g.mode == CDETR_ROWS_DENSE && (gemm_blocks(d, 64, 64) <= 48 || !(vecA && vecB && (d.K % 32) == 0)) && gemm_blocks(d, 64, 64) < 192;
 }
 bool gemm_is_fewrow_split(const cdetr_gemm_desc& d, int vecA, int vecB) {
-    const char* e = getenv("CDETR_GEMM_FEWROW_SPLIT");      // A/B knob (read per call: only few-row problems get here)
+    const char* e = cdetr_tune_env("CDETR_GEMM_FEWROW_SPLIT");      // A/B knob (tests)
     return !(e && atoi(e) == 0) && d.splitk_ws && d.batch == 1 && vecA && vecB && d.precision >= 1 && d.b_layout == 0 && (d.K % 64) == 0 && (long)d.K * d.taps >= 1024 &&
            d.M >= 256;
 }
@@ -2092,7 +2092,7 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     // tile choice: the largest tile that still yields >= 1.5 waves of workgroups on 256 CUs
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn) * d.batch; };
     // tuning knob (tools/gemm_sweep.py): CDETR_GEMM_VARIANT = 1..4 forces a fast tile, 5 the direct kernel, 6 the generic one
-    const char* force_s = getenv("CDETR_GEMM_VARIANT");
+    const char* force_s = cdetr_tune_env("CDETR_GEMM_VARIANT");
     const int force = force_s ? atoi(force_s) : 0;
     const bool fast_ok = vecA && vecB && (d.K % 32) == 0;
     // CDETR_GEMM_VARIANT (tests / tools/gemm_sweep.py): 3 = 64x64 BK64, 4 = 64x64, 9 = 64x128 (8 waves), 10 = 128x128 (16 waves),
@@ -2337,7 +2337,8 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             // trailing slices exit at once).  MEASURED (profiles/r2_notes.txt): the step's weight gradients 2.04 -> 2.08 ms, i.e. nothing --
             // the re-reads the counters show (3.7x the algorithmic bytes) are served by the 256 MB Infinity Cache at a rate that does not
             // bound the kernel; kept off by default, reachable for A/B runs
-            const int xcd_on = getenv("CDETR_WGRAD_XCD") ? atoi(getenv("CDETR_WGRAD_XCD")) : 0;
+            const char* xe = cdetr_tune_env("CDETR_WGRAD_XCD");
+            const int xcd_on = xe ? atoi(xe) : 0;
             const bool xcd = xcd_on && d.precision >= 1 && max_slices >= 8;
             if (xcd) slices = std::max<long>(8, (slices + 7) / 8 * 8);
             int per = (int)((nktf + slices - 1) / slices);
@@ -2368,7 +2369,7 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
                 hipLaunchKernelGGL((wgrad_fast_kernel<BI, BJ, 0>), grid, block, bytes, st, d, tilesI, tilesJ, per, d.dbias);
             }
         };
-        const char* wf = getenv("CDETR_WGRAD_VARIANT");   // tuning knob: 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64
+        const char* wf = cdetr_tune_env("CDETR_WGRAD_VARIANT");   // tuning knob: 1 = 128x128, 2 = 128x64, 3 = 64x128, 4 = 64x64
         const int wforce = wf ? atoi(wf) : 0;
         if (wforce == 1) launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 128>{});
         else if (wforce == 2) launchf(std::integral_constant<int, 128>{}, std::integral_constant<int, 64>{});
@@ -2434,7 +2435,8 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
     CDETR_CHECK_ARG(n >= 0 && (descs != nullptr || n == 0), "cdetr_wgrad_group: bad arguments");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     static const int grouping = getenv("CDETR_WGRAD_GROUP") ? atoi(getenv("CDETR_WGRAD_GROUP")) : 1;
-    const bool forced = getenv("CDETR_WGRAD_VARIANT") && atoi(getenv("CDETR_WGRAD_VARIANT")) != 0;
+    const char* wfg = cdetr_tune_env("CDETR_WGRAD_VARIANT");
+    const bool forced = wfg && atoi(wfg) != 0;
     std::vector<int> direct, tr64p, tr64t;                    // tr64t: the same class with bf16 twins (wgrad_tr16_group_kernel)
     for (int i = 0; i < n; ++i) {
         const cdetr_wgrad_desc& d = descs[i];
@@ -2485,7 +2487,8 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             it.tilesI = (it.d.Nout + 63) / 64; it.tilesJ = (it.d.Cin + 63) / 64;
             it.per = (int)std::min<long>(per_all, nkt);
             it.nx = it.tilesI * it.tilesJ * it.d.taps; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
-            const int xcd_on = getenv("CDETR_WGRAD_XCD") ? atoi(getenv("CDETR_WGRAD_XCD")) : 0;
+            const char* xe = cdetr_tune_env("CDETR_WGRAD_XCD");
+            const int xcd_on = xe ? atoi(xe) : 0;
             if (xcd_on && it.ny >= 6 && (nkt + 3) / 4 >= 8) {            // XCD-aware slices: a multiple of 8 (see wgrad_tr_kernel)
                 it.ny = (it.ny + 7) / 8 * 8;
                 it.per = (nkt + it.ny - 1) / it.ny;

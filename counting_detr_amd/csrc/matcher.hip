@@ -514,7 +514,7 @@ extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int3
         return CDETR_ERR_UNSUPPORTED;
     }
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (nc_max <= 1024 && getenv("CDETR_LSAP_GENERIC") == nullptr) {
+    if (nc_max <= 1024 && cdetr_tune_env("CDETR_LSAP_GENERIC") == nullptr) {
         // single-wave register-resident solver; nr <= Mmax rows, nc <= nc_max columns
         const size_t state = (size_t)Mmax * 12 + (size_t)nc_max * 12 + 64;
         const size_t with_cost = state + (size_t)Mmax * nc_max * 4;

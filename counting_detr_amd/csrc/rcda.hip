@@ -1318,7 +1318,7 @@ int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st, int hgroups = 
 // sets; with the grouped / prefetched tile loops they no longer do (tools/rcda_bench.py: dS 66 vs 73 us, fwd 50 vs 52 us).
 inline int pick_nw(int L, int NH) {
     (void)L; (void)NH;
-    const char* f = getenv("CDETR_RCDA_NW");
+    const char* f = cdetr_tune_env("CDETR_RCDA_NW");
     if (f) return atoi(f) == 2 ? 2 : 4;
     return 4;
 }

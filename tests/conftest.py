@@ -8,6 +8,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+# the per-call A/B knobs of libcdetr_hip.so (CDETR_GEMM_VARIANT, CDETR_WGRAD_VARIANT, ...) are only consulted when this is set at load time
+os.environ.setdefault("CDETR_TUNING", "1")
 
 
 def pytest_configure(config):

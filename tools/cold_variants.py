@@ -1,5 +1,6 @@
 """Cold-operand timing (see tools/cold_gemm.py) of the tile variants on the hot shapes of the step: CDETR_GEMM_VARIANT is read per call."""
 import os, sys
+os.environ.setdefault("CDETR_TUNING", "1")      # the per-call A/B knobs are only consulted when this is set at load time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from counting_detr_amd import ops

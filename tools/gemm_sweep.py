@@ -1,6 +1,7 @@
 """Time every igemm variant on the GEMM / conv shapes of the 800x800 B=2 step (true GPU time: N back-to-back launches
 between two HIP events).  usage: python tools/gemm_sweep.py [shapes.csv]"""
 import os, sys
+os.environ.setdefault("CDETR_TUNING", "1")      # the per-call A/B knobs are only consulted when this is set at load time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from counting_detr_amd import ops, _ffi

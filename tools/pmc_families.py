@@ -1,4 +1,4 @@
-"""Per-family HBM traffic and SQ-pipe occupancy of one eager bench step from rocprofv3 --pmc passes -> profiles/r2_traffic.json.
+"""Per-family HBM traffic and SQ-pipe occupancy of one eager bench step from rocprofv3 --pmc passes -> profiles/r3_traffic.json.
 
     python tools/pmc_families.py fetch.csv write.csv sq1.csv out.json
 
@@ -14,7 +14,7 @@ import sys
 from collections import defaultdict
 
 FAMILIES = (("igemm_fewrow", ("igemm_direct", "false, 2>(", "true, 2>(")),      # few-row class: the one-wave-per-tile kernel and the two-wave-group tile
-            ("igemm", ("igemm_fast", "igemm_kernel", "igemm_mixed")), ("wgrad", ("wgrad_tr", "wgrad_fast", "wgrad_direct", "wgrad_kernel")),
+            ("igemm", ("igemm_fast", "igemm_kernel", "igemm_mixed", "igemm_dl")), ("wgrad", ("wgrad_tr", "wgrad_fast", "wgrad_direct", "wgrad_kernel")),
             ("rcda_fwd", ("rcda_fwd",)), ("rcda_bwd", ("rcda_bwd", "rcda_dv")), ("mha", ("flash::",)), ("lsap", ("lsap_",)),
             ("layernorm", ("ln_fwd", "ln_bwd")), ("optimizer", ("adamw", "sumsq")), ("weight_mirror", ("weight_mirror",)))
 
@@ -72,7 +72,7 @@ def main():
     out = {"workload": "B=2 800x800 Q=300 bf16x3 fwd / bf16 bwd, one eager step (bench.py --no-graph --steps 1 --warmup 1)",
            "step_equivalents_in_the_profiled_process": nstep, "families_bytes_per_step": fams, "families_bytes_per_kernel_launch": per_launch,
            "detail": detail, "pmc": pmc, "total_bytes_per_step": sum(fams.values()),
-           "source": "profiles/r2_pmc_*.csv summaries: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* in separate passes with "
+           "source": "profiles/r3_pmc_* summaries: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* in separate passes with "
                      "--kernel-trace only; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section), KiB -> bytes; "
                      "tools/pmc_families.py"}
     json.dump(out, open(sys.argv[4], "w"), indent=1)

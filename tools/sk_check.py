@@ -1,5 +1,6 @@
 """Which pass makes the fp32 gradient move when reductions are split 4 ways?  usage: python tools/sk_check.py"""
 import os, sys, torch
+os.environ.setdefault("CDETR_TUNING", "1")      # the per-call A/B knobs are only consulted when this is set at load time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import test_dp_shared_gpu as t
 from counting_detr_amd import ops

@@ -1,5 +1,6 @@
 """Forward intermediates with the reductions split 4 ways vs unsplit (fp32 MFMA mode).  usage: python tools/sk_check3.py"""
 import os, sys, torch
+os.environ.setdefault("CDETR_TUNING", "1")      # the per-call A/B knobs are only consulted when this is set at load time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests")); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import test_dp_shared_gpu as t
 from counting_detr_amd import ops

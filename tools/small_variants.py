@@ -1,4 +1,5 @@
 import os, sys
+os.environ.setdefault("CDETR_TUNING", "1")      # the per-call A/B knobs are only consulted when this is set at load time
 sys.path.insert(0, '.')
 import torch
 from counting_detr_amd import ops

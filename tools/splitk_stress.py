@@ -2,6 +2,7 @@
 counters are reused immediately), every result compared bit-for-bit with the first one of its shape and with the unsplit launch to 1e-5.
 usage: python tools/splitk_stress.py [rounds]"""
 import os, sys
+os.environ.setdefault("CDETR_TUNING", "1")      # the per-call A/B knobs are only consulted when this is set at load time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from counting_detr_amd import ops

@@ -1,6 +1,7 @@
 """Time the tile GEMMs of the B=2 800x800 step with the reduction cut into 1-4 slices (CDETR_GEMM_SPLITK), forward (bf16x3) and
 backward (plain bf16, bf16 twin of A) arithmetic.  usage: python tools/splitk_sweep.py"""
 import os, sys
+os.environ.setdefault("CDETR_TUNING", "1")      # the per-call A/B knobs are only consulted when this is set at load time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from counting_detr_amd import ops, _ffi
