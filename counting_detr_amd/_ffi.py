@@ -110,9 +110,9 @@ def lib():
         L.cdetr_layernorm_fwd_add.restype = C.c_int
         L.cdetr_layernorm_fwd_add.argtypes = [_p] * 10 + [C.c_int32, C.c_int32, C.c_float, _p]
         L.cdetr_layernorm_bwd.restype = C.c_int
-        L.cdetr_layernorm_bwd.argtypes = [_p] * 9 + [C.c_int32, C.c_int32, _p]
+        L.cdetr_layernorm_bwd.argtypes = [_p] * 9 + [C.c_int32, C.c_int32, _p, _p]
         L.cdetr_layernorm_bwd_merge.restype = C.c_int
-        L.cdetr_layernorm_bwd_merge.argtypes = [_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_int32] + [_p] * 8 + [C.c_int32, C.c_int32, _p]
+        L.cdetr_layernorm_bwd_merge.argtypes = [_p] * 7 + [C.c_float, C.c_float, C.c_int32, C.c_int32] + [_p] * 8 + [C.c_int32, C.c_int32, _p, _p]
         L.cdetr_groupnorm_fwd.restype = C.c_int
         L.cdetr_groupnorm_fwd.argtypes = [_p] * 6 + [C.c_int32] * 4 + [C.c_float, _p]
         L.cdetr_groupnorm_bwd.restype = C.c_int

@@ -99,15 +99,24 @@ class Bottleneck(nn.Module):
             return out, outh, outl
         a1 = ops.conv_fwd(x, self.conv1.weight, s1, b1, relu=True, twin=twins)
         a1, a1_16 = a1 if twins else (a1, None)
-        a2 = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True, twin=twins)
-        a2, a2_16 = a2 if twins else (a2, None)
+        # the 3x3's output feeds the EXPANDING 1x1 (K = planes, N = 4 planes): the one shape class where the direct-to-LDS kernel beats the
+        # register-staged one in the split-bf16 forward (tools/dl_sweep.py: 1.05-1.2x) -- its A operand is the smallest tensor of the block, so
+        # the lo plane costs next to nothing; the hi plane is the backward's twin anyway
+        a2l = None
+        if ops.expand_planes() and x.is_cuda:
+            a2, a2_16, a2l = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True, split=True)
+        else:
+            a2 = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True, twin=twins)
+            a2, a2_16 = a2 if twins else (a2, None)
         if self.downsample is not None:
             sd, bd = self.downsample[1].affine()
             idn = ops.conv_fwd(x, self.downsample[0].weight, sd, bd, stride=self.stride)
         else:
             idn = x
-        out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, twin=twin_out)
+        out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, twin=twin_out, xs=(a2_16, a2l) if a2l is not None else None)
         out, out16 = out if twin_out else (out, None)
+        if not twins:
+            a2_16 = None
         if save is not None:
             save.append((x, a1, a2, out, x16, a1_16, a2_16, out16))
         return (out, out16) if twin_out else out

@@ -453,7 +453,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      int rows, int C, const float* __restrict__ g1 = nullptr,
                                                      const float* __restrict__ g2 = nullptr, float* __restrict__ acc1 = nullptr,
                                                      float* __restrict__ acc2 = nullptr, const float* __restrict__ Br = nullptr,
-                                                     const float* __restrict__ Bc = nullptr, float sr = 0.f, float sc = 0.f, int bH = 1, int bW = 1) {
+                                                     const float* __restrict__ Bc = nullptr, float sr = 0.f, float sc = 0.f, int bH = 1, int bW = 1,
+                                                     __bf16* __restrict__ dx16 = nullptr) {
+    // dx16 (C == 256 only): a bf16 twin of dx from the same pass -- the A operand of the plain-bf16 data-gradient GEMM that follows (cdetr_gemm_desc.A16)
     // Br / Bc (with g1; rows = N * bH * bW): two broadcast addends, dy_eff += sr * Br[n, x] + sc * Bc[n, y] (row = (n, y, x)) -- the encoder's
     // cdetr_bcast_add2_sum pass folded in the same way
     // g1 / g2 (C == 256 only): further addends of the incoming gradient, dy_eff = dy + g1 + g2, with acc1 += g1, acc2 += g2 in place -- the
@@ -526,6 +528,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                 o.x = rs[b] * (dg.x - m1 - xh.x * m2) + av[b].x; o.y = rs[b] * (dg.y - m1 - xh.y * m2) + av[b].y;
                 o.z = rs[b] * (dg.z - m1 - xh.z * m2) + av[b].z; o.w = rs[b] * (dg.w - m1 - xh.w * m2) + av[b].w;
                 reinterpret_cast<float4*>(dx + (long)row * C)[lane] = o;
+                if (dx16) {
+                    const f32x2 v0 = {o.x, o.y}, v1 = {o.z, o.w};
+                    uint2 h;
+                    h.x = __builtin_bit_cast(unsigned, __builtin_convertvector(v0, bf16x2));
+                    h.y = __builtin_bit_cast(unsigned, __builtin_convertvector(v1, bf16x2));
+                    reinterpret_cast<uint2*>(dx16 + (long)row * C)[lane] = h;
+                }
             }
         }
     } else
@@ -799,8 +808,9 @@ extern "C" int cdetr_groupnorm_bwd(const float* dy, const float* x, const float*
 }
 
 extern "C" int cdetr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                   const float* add, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, void* stream) {
+                                   const float* add, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, void* dx16, void* stream) {
     CDETR_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && rows >= 0, "cdetr_layernorm_bwd: null pointer");
+    CDETR_CHECK_ARG(!dx16 || C == 256, "cdetr_layernorm_bwd: the bf16 twin of dx exists for C = 256");
     CDETR_CHECK_ARG(C > 0 && (C & 255) == 0 && C <= 1024, "cdetr_layernorm_bwd: C must be a multiple of 256, <= 1024 (got %d)", C);
     if (rows == 0) return CDETR_OK;
     // >= 4 rows per wave amortise the per-workgroup dgamma / dbeta atomics on long inputs; short ones (decoder: 600 rows) are latency
@@ -810,14 +820,14 @@ extern "C" int cdetr_layernorm_bwd(const float* dy, const float* x, const float*
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma,
-                       add, dx, dgamma, dbeta, rows, C);
+                       add, dx, dgamma, dbeta, rows, C, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 1, 1, reinterpret_cast<__bf16*>(dx16));
     return cdetr_launch_status("cdetr_layernorm_bwd");
 }
 
 extern "C" int cdetr_layernorm_bwd_merge(const float* dy, const float* g1, const float* g2, float* acc1, float* acc2, const float* Br,
                                          const float* Bc, float sr, float sc, int32_t H, int32_t W, const float* x,
                                          const float* mean, const float* rstd, const float* gamma, const float* add, float* dx, float* dgamma,
-                                         float* dbeta, int32_t rows, int32_t C, void* stream) {
+                                         float* dbeta, int32_t rows, int32_t C, void* dx16, void* stream) {
     CDETR_CHECK_ARG(dy && g1 && x && mean && rstd && gamma && dx && dgamma && dbeta && rows >= 0 && (g2 || !acc2), "cdetr_layernorm_bwd_merge: bad args");
     CDETR_CHECK_ARG(!Br == !Bc && (!Br || (H > 0 && W > 0 && rows % (H * W) == 0)), "cdetr_layernorm_bwd_merge: Br / Bc come as a pair, rows = N * H * W");
     CDETR_CHECK_ARG(C == 256, "cdetr_layernorm_bwd_merge: C must be 256 (got %d)", C);
@@ -826,7 +836,7 @@ extern "C" int cdetr_layernorm_bwd_merge(const float* dy, const float* g1, const
     int blocks = rows <= 2048 ? (rows + 3) / 4 : (rows + rpb - 1) / rpb;
     if (blocks > 512) blocks = 512;
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma,
-                       add, dx, dgamma, dbeta, rows, C, g1, g2, acc1, acc2, Br, Bc, sr, sc, Br ? H : 1, Br ? W : 1);
+                       add, dx, dgamma, dbeta, rows, C, g1, g2, acc1, acc2, Br, Bc, sr, sc, Br ? H : 1, Br ? W : 1, reinterpret_cast<__bf16*>(dx16));
     return cdetr_launch_status("cdetr_layernorm_bwd_merge");
 }
 

@@ -2064,8 +2064,9 @@ int gemm_dl_choice(const cdetr_gemm_desc& d, int& stages) {
     if (!d.C) return blocks(64, 64) >= 512 && (long)d.K * d.taps >= 2048 && d.N % 128 == 0 ? 0 : 3;   // no fp32 output: only this kernel can run it
     if (blocks(64, 64) < 192) return -1;                                      // few tiles: the split-reduction forms of the register-staged kernels
     if (d.precision == 3) return ((long)d.K * d.taps >= 2048 && d.N % 128 == 0 && blocks(128, 128) >= 128) ? 0 : 3;
-    // split-bf16 x3 with planes given (ops.SPLIT_FWD): where the sweep has it ahead
-    if ((long)d.K * d.taps <= 512 && d.N >= 2 * d.K) return 3;
+    // split-bf16 x3 with planes given: where the sweep has it ahead -- the expanding 1x1 convolutions (K = planes <= 512, N = 4 K), whose
+    // epilogue dominates; 64x128 tiles for the widest one
+    if ((long)d.K * d.taps <= 512 && d.N >= 2 * d.K) return d.N >= 2048 ? 2 : 3;
     return -1;
 }
 }  // namespace

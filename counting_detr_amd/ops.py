@@ -429,21 +429,24 @@ def linear_fwd(x2d, weight, bias=None, relu=False, resid=None, out_scale=1.0, ou
     return y
 
 
-def linear_dgrad(dy2d, weight, gate=None, resid=None):
-    """dx = dy . W   (W [N_out][K_in] read as the n-contiguous operand)"""
+def linear_dgrad(dy2d, weight, gate=None, resid=None, dy16=None, twin=False):
+    """dx = dy . W   (W [N_out][K_in] read as the n-contiguous operand).  dy16: bf16 twin of dy (plain-bf16 backward: the direct-to-LDS
+    kernel reads it instead of dy); twin: -> (dx, bf16 twin of dx from the same epilogue)."""
     M, N = dy2d.shape
     K = weight.shape[1]
     dx = torch.empty((M, K), device=dy2d.device, dtype=torch.float32)
     m = MIRROR.lookup(weight) if MIRROR is not None else None
     if m is not None:
+        dx16 = torch.empty((M, K), device=dy2d.device, dtype=torch.bfloat16) if twin else None
         gemm_raw(dy2d, dy2d.stride(0), m[0], m[1], dx, K, M, K, N, b_layout=0,
                  gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
-                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0), B_split=m[2], B16=m[3], precision=bwd_precision())
-        return dx
+                 resid=resid, ldr=(resid.stride(0) if resid is not None else 0), B_split=m[2], B16=m[3], precision=bwd_precision(),
+                 A16=dy16, C16=dx16)
+        return (dx, dx16) if twin else dx
     gemm_raw(dy2d, dy2d.stride(0), weight, weight.stride(0), dx, K, M, K, N, b_layout=1,
              gate=gate, ldg=(gate.stride(0) if gate is not None else 0),
              resid=resid, ldr=(resid.stride(0) if resid is not None else 0), precision=bwd_precision())
-    return dx
+    return (dx, None) if twin else dx
 
 
 class LinearFn(torch.autograd.Function):
@@ -697,6 +700,16 @@ SPLIT_FWD = os.environ.get("CDETR_SPLIT_FWD", "0") != "0"
 
 def split_forward():
     return SPLIT_FWD and PRECISION == 1
+
+
+EXPAND_PLANES = os.environ.get("CDETR_EXPAND_PLANES", "1") != "0"
+ENC_TWINS = os.environ.get("CDETR_ENC_TWINS", "1") != "0"      # encoder backward: bf16 twins through LayerNorm backward / data-gradient epilogues (A/B)
+
+
+def expand_planes():
+    """Whether a bottleneck's 3x3 convolution also writes the lo plane of its output, so that the expanding 1x1 convolution behind it runs on
+    the direct-to-LDS kernel (split-bf16 forward only; needs the pre-split weight images, i.e. a trainer / inference engine around the model)."""
+    return EXPAND_PLANES and PRECISION == 1 and MIRROR is not None
 
 
 def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False, xs=None, split=False):
@@ -978,25 +991,27 @@ def ln_fwd_add_raw(x2d, weight, bias, eps, a1, a2=None):
     return y, mean, rstd, o1, o2
 
 
-def ln_bwd_raw(dy2d, x2d, mean, rstd, weight, gw, gb, add=None, merge=None, bcast=None):
+def ln_bwd_raw(dy2d, x2d, mean, rstd, weight, gw, gb, add=None, merge=None, bcast=None, twin=False):
     """dx (+ add); dgamma / dbeta accumulate into gw / gb.  merge = (g1, g2 | None, acc1 | None, acc2 | None): the incoming gradient is
     dy2d + g1 + g2 and acc1 += g1, acc2 += g2 in place (cdetr_grad_merge folded in; C = 256).  bcast = (Br, Bc, sr, sc, H, W), with merge:
-    + sr * Br[n,x] + sc * Bc[n,y] as well (cdetr_bcast_add2_sum folded in)."""
+    + sr * Br[n,x] + sc * Bc[n,y] as well (cdetr_bcast_add2_sum folded in).  twin (C = 256): -> (dx, bf16 twin of dx from the same pass)."""
     rows, Cc = x2d.shape
     dx = torch.empty_like(x2d)
+    twin = twin and Cc == 256
+    dx16 = torch.empty(x2d.shape, device=x2d.device, dtype=torch.bfloat16) if twin else None
     if merge is not None and Cc == 256:
         g1, g2, acc1, acc2 = merge
         Br, Bc, sr, sc, bh, bw = bcast if bcast is not None else (None, None, 0.0, 0.0, 1, 1)
         check(lib().cdetr_layernorm_bwd_merge(ptr(dy2d), ptr(g1), ptr(g2), ptr(acc1), ptr(acc2), ptr(Br), ptr(Bc), sr, sc, bh, bw, ptr(x2d),
-                                              ptr(mean), ptr(rstd), ptr(weight), ptr(add), ptr(dx), ptr(gw), ptr(gb), rows, Cc, stream_ptr()),
+                                              ptr(mean), ptr(rstd), ptr(weight), ptr(add), ptr(dx), ptr(gw), ptr(gb), rows, Cc, ptr(dx16), stream_ptr()),
               "cdetr_layernorm_bwd_merge")
-        return dx
+        return (dx, dx16) if twin else dx
     if merge is not None:
         assert bcast is None
         dy2d = grad_merge(dy2d, *merge)
     check(lib().cdetr_layernorm_bwd(ptr(dy2d), ptr(x2d), ptr(mean), ptr(rstd), ptr(weight), ptr(add), ptr(dx), ptr(gw), ptr(gb),
-                                    rows, Cc, stream_ptr()), "cdetr_layernorm_bwd")
-    return dx
+                                    rows, Cc, ptr(dx16), stream_ptr()), "cdetr_layernorm_bwd")
+    return (dx, dx16) if twin else dx
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -1118,20 +1133,26 @@ class EncoderLayerFn(torch.autograd.Function):
         Wip, bip = att.in_proj_weight, att.in_proj_bias
         ln2 = (Y2, mu2, rs2, f.norm2.weight.detach(), grad_buffer(f.norm2.weight), grad_buffer(f.norm2.bias))
         # ---- FFN (post-norm): X2 = LN2(X1 + relu(X1 W1^T + b1) W2^T + b2)
+        # plain-bf16 backward: the LayerNorm backward / the data-gradient epilogues also leave bf16 twins of their outputs, which the next
+        # data-gradient GEMM reads through the direct-to-LDS kernel (igemm_dl.hip) -- the chain dY2 -> dHd -> dX1 -> dY1 -> dO of 5000-row GEMMs
+        tw = ENC_TWINS and bf16_twins() and MIRROR is not None
         if isinstance(dX2, tuple):
             pt, pt2, pt3, pKr, pKc = dX2
-            dY2 = ln_bwd_raw(pt, *ln2, merge=(pt2, pt3, None, None), bcast=(pKr, pKc, 1.0 / H, 1.0 / W, H, W))
+            dY2 = ln_bwd_raw(pt, *ln2, merge=(pt2, pt3, None, None), bcast=(pKr, pKc, 1.0 / H, 1.0 / W, H, W), twin=tw)
         else:
-            dY2 = ln_bwd_raw(dX2.reshape(R, Cc).contiguous(), *ln2)
+            dY2 = ln_bwd_raw(dX2.reshape(R, Cc).contiguous(), *ln2, twin=tw)
+        dY2, dY2h = dY2 if tw else (dY2, None)
         _wg(dY2, Hd, f.linear2.weight, f.linear2.bias, 0, Cc)
-        dHd = linear_dgrad(dY2, f.linear2.weight.detach(), gate=Hd)               # ReLU mask fused in the epilogue
+        dHd = linear_dgrad(dY2, f.linear2.weight.detach(), gate=Hd, dy16=dY2h, twin=tw)               # ReLU mask fused in the epilogue
+        dHd, dHdh = dHd if tw else (dHd, None)
         _wg(dHd, X1, f.linear1.weight, f.linear1.bias, 0, Hd.shape[1])
-        dX1 = linear_dgrad(dHd, f.linear1.weight.detach(), resid=dY2)             # + residual branch
+        dX1 = linear_dgrad(dHd, f.linear1.weight.detach(), resid=dY2, dy16=dHdh)             # + residual branch
         # ---- attention block: X1 = LN1(X + o Wo^T + bo)
-        dY1 = ln_bwd_raw(dX1, Y1, mu1, rs1, layer.norm1.weight.detach(), grad_buffer(layer.norm1.weight), grad_buffer(layer.norm1.bias))
+        dY1 = ln_bwd_raw(dX1, Y1, mu1, rs1, layer.norm1.weight.detach(), grad_buffer(layer.norm1.weight), grad_buffer(layer.norm1.bias), twin=tw)
+        dY1, dY1h = dY1 if tw else (dY1, None)
         o2d = o.view(R, E)
         _wg(dY1, o2d, att.out_proj.weight, att.out_proj.bias, 0, Cc)
-        dO = linear_dgrad(dY1, att.out_proj.weight.detach()).view(N, H * W, E)
+        dO = linear_dgrad(dY1, att.out_proj.weight.detach(), dy16=dY1h).view(N, H * W, E)
         dq_row, dq_col, dk_row, dk_col, dv = rcda_bwd_raw(dO, q_row, q_col, k_row, k_col, v, a_row, a_col, nh, zbuf)
         dq_row2, dq_col2, dv2 = dq_row.view(R, E), dq_col.view(R, E), dv.view(R, E)
         dk_row2, dk_col2 = dk_row.view(N * W, E), dk_col.view(N * H, E)

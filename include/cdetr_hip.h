@@ -190,8 +190,9 @@ int cdetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 int cdetr_layernorm_fwd_add(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                             const float* a1, const float* a2, float* o1, float* o2, int32_t rows, int32_t C, float eps, void* stream);
 int cdetr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                        const float* add, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, void* stream);
-/* the same with the incoming gradient given as a sum, dy + g1 + g2 (g2 optional), and the side effects acc1 += g1, acc2 += g2 (optional, in
+                        const float* add, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C, void* dx16, void* stream);
+/* (dx16: optional bf16 twin of dx, C = 256 -- the A16 operand of the plain-bf16 data-gradient GEMM that consumes dx)
+ * the same with the incoming gradient given as a sum, dy + g1 + g2 (g2 optional), and the side effects acc1 += g1, acc2 += g2 (optional, in
  * place): cdetr_grad_merge folded into the LayerNorm backward that consumes its result (decoder backward: the gradient of a sub-layer input is
  * the residual branch plus one or two projection branches whose values also accumulate into the stack-wide query-position gradients).  Br / Bc
  * (optional pair, rows = N*H*W): two more addends broadcast over the map, + sr * Br[n,x,:] + sc * Bc[n,y,:] -- cdetr_bcast_add2_sum folded in the
@@ -199,7 +200,7 @@ int cdetr_layernorm_bwd(const float* dy, const float* x, const float* mean, cons
 int cdetr_layernorm_bwd_merge(const float* dy, const float* g1, const float* g2, float* acc1, float* acc2, const float* Br, const float* Bc,
                               float sr, float sc, int32_t H, int32_t W, const float* x, const float* mean, const float* rstd,
                               const float* gamma, const float* add, float* dx, float* dgamma, float* dbeta, int32_t rows, int32_t C,
-                              void* stream);
+                              void* dx16, void* stream);
 int cdetr_posadd2(const float* X, const float* Prow, const float* Pcol, float* Qr, float* Qc, int32_t N, int32_t H, int32_t W,
                   int32_t C, void* stream);
 int cdetr_hw_reduce(const float* Xr, const float* Xc, const float* Ar, const float* Ac, float* Or, float* Oc, int32_t N,
