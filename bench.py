@@ -300,7 +300,8 @@ def real_data_leg(dev, precision, batch=2, reps=4):
                      "steps": len(per_size[(H, W)])})
     return {"what": "Trainer.step over batches of 3 image sizes x 7 target-count tuples (2 capacity classes), steady state after the captures",
             "wall_ms_per_step_all_sizes": wall, "new_captures_in_timed_part": tr.cache_stats["captures"] - cap0["captures"],
-            "graphs_cached": len(tr._cache), "per_size": rows, "final_loss": float(out["loss"])}
+            "graphs_cached": len(tr._cache), "per_size": rows, "final_loss": float(out["loss"]),
+            "device_memory_reserved_GB": torch.cuda.memory_reserved() / 2 ** 30}
 
 
 def main(argv=None):

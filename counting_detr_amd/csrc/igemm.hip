@@ -1541,26 +1541,9 @@ __global__ __launch_bounds__(256) void wgrad_tr16_kernel(const cdetr_wgrad_desc 
     wgrad_tr16_body<BI, BJ>(d, tilesI, tilesJ, kt_per_slice, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
 }
 
-// XCD-aware slice placement (ny % 8 == 0, 1-D grid of nx * ny workgroups per batch item): workgroup b runs on XCD b % 8 (private
-// 4 MiB L2 each), and XCD x is given the pixel slices x, x + 8, ... -- every output tile of one slice back to back.  All tiles of a
-// slice read the SAME pixel rows of dY and X (a few hundred KB), so those rows come from HBM / MALL once per slice and are L2 hits for the
-// other tiles; with tiles dealt round-robin over the XCDs every XCD fetched every slice (PMC: 3.7x the algorithmic bytes, the
-// weight gradients ran at HBM speed).  Placement only affects speed.
-__device__ __forceinline__ void wgrad_xcd_slice(int lid, int nx, int& bx, int& by) {
-    const int xcd = lid & 7, j = lid >> 3;
-    bx = j % nx;
-    by = (j / nx) * 8 + xcd;
-}
-
 template <int BI, int BJ, int TERMS = 3>
 __global__ __launch_bounds__(256) void wgrad_tr_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ,
-                                                       const int kt_per_slice, float* __restrict__ dbias, const int nx_xcd) {
-    if (nx_xcd > 0) {      // 1-D grid, XCD-aware slices (never a single slice: ny is a multiple of 8)
-        int bx, by;
-        wgrad_xcd_slice(blockIdx.x, nx_xcd, bx, by);
-        wgrad_tr_body<BI, BJ, TERMS>(d, tilesI, tilesJ, kt_per_slice, dbias, bx, by, blockIdx.z, false);
-        return;
-    }
+                                                       const int kt_per_slice, float* __restrict__ dbias) {
     wgrad_tr_body<BI, BJ, TERMS>(d, tilesI, tilesJ, kt_per_slice, dbias, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
 }
 
@@ -1582,10 +1565,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const WgradGroupArg
     const int per_z = it.nx * it.ny;
     const int z = lb / per_z, l = lb - z * per_z;
     if (z >= it.d.batch) return;                           // padding blocks (every item's count is rounded up to a multiple of 8)
-    int bx, by;
-    if ((it.ny & 7) == 0) wgrad_xcd_slice(l, it.nx, bx, by);   // blk0 and per_z are multiples of 8: l % 8 == blockIdx.x % 8 == the XCD
-    else { bx = l % it.nx; by = l / it.nx; }
-    wgrad_tr_body<BI, BJ, TERMS>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, bx, by, z, false);
+    wgrad_tr_body<BI, BJ, TERMS>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, l % it.nx, l / it.nx, z, false);
 }
 
 template <int BI, int BJ>
@@ -2014,8 +1994,6 @@ bool gemm_is_f44(const cdetr_gemm_desc& d) {
 // small grids (< 2 workgroups of 4 waves per CU): a 64x128 tile shared by 8 waves keeps the wave count and halves the
 // A-operand traffic (tools/split_sweep.py: 6-11 % over 64x64 BK64 on the N = 256 encoder linears)
 bool gemm_is_f24(const cdetr_gemm_desc& d) {
-    static const int on = getenv("CDETR_GEMM_F24") ? atoi(getenv("CDETR_GEMM_F24")) : 3;      // A/B: bit 0 = forward (3 terms), bit 1 = reduced-term backward
-    if (!((d.precision == 1 && (on & 1)) || (d.precision >= 2 && (on & 2)))) return false;
     return d.precision >= 1 && d.b_layout == 0 && (d.N % 128) == 0 && gemm_blocks(d, 64, 64) < 512;
 }
 int check_gemm_desc(const cdetr_gemm_desc& d) {
@@ -2146,13 +2124,11 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
         if (gemm_is_f44(d)) {
             // 128x128 tiles that leave > 1/8 of the CUs idle in a single round: 96x128 tiles (12 waves) when those still fit one round --
             // 5000 x 512 outputs are 160 workgroups of 128 rows but 212 of 96 (each 3/4 of the work)
-            static const int t96 = getenv("CDETR_GEMM_T96") ? atoi(getenv("CDETR_GEMM_T96")) : 1;
             // ... except the longest reductions (3x3 512 -> 512 at 50x50: 144 k-tiles): 128x128 on 8 waves of 64x32 with the reduction cut
             // three ways (480 workgroups) -- 112 -> 101 us bf16x3, 70 -> 65 us bf16 (tools/splitk_sweep.py SWEEP_BIG=1; larger per-wave tiles
             // lose on every other shape of the step, 64x64 per wave on all of them)
-            static const int t128s = getenv("CDETR_GEMM_T128S") ? atoi(getenv("CDETR_GEMM_T128S")) : 1;
-            if (t128s && d.splitk_ws && d.batch == 1 && blocks(128, 128) < 224 && (long)d.K * d.taps >= 4096) return launch_gemm_fast<2, 4, 2, 1, 32>(d, st);
-            if (t96 && blocks(128, 128) < 224 && blocks(96, 128) <= 256) return launch_gemm_fast<3, 4, 1, 1, 32>(d, st);
+            if (d.splitk_ws && d.batch == 1 && blocks(128, 128) < 224 && (long)d.K * d.taps >= 4096) return launch_gemm_fast<2, 4, 2, 1, 32>(d, st);
+            if (blocks(128, 128) < 224 && blocks(96, 128) <= 256) return launch_gemm_fast<3, 4, 1, 1, 32>(d, st);
             return launch_gemm_fast<4, 4, 1, 1, 32>(d, st);
         }
         // small grids (< 2 workgroups of 4 waves per CU): a 64x128 tile shared by 8 waves keeps the wave count and halves the
@@ -2334,22 +2310,12 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             if (slices > max_slices) slices = max_slices;
             if (slices < 1) slices = 1;
             if (slices > 65535) slices = 65535;
-            // XCD-aware slices (wgrad_tr_kernel; CDETR_WGRAD_XCD=1): a multiple of 8 slices whenever >= 8 slices of >= 4 k-tiles exist (empty
-            // trailing slices exit at once).  MEASURED (profiles/r2_notes.txt): the step's weight gradients 2.04 -> 2.08 ms, i.e. nothing --
-            // the re-reads the counters show (3.7x the algorithmic bytes) are served by the 256 MB Infinity Cache at a rate that does not
-            // bound the kernel; kept off by default, reachable for A/B runs
-            const char* xe = cdetr_tune_env("CDETR_WGRAD_XCD");
-            const int xcd_on = xe ? atoi(xe) : 0;
-            const bool xcd = xcd_on && d.precision >= 1 && max_slices >= 8;
-            if (xcd) slices = std::max<long>(8, (slices + 7) / 8 * 8);
             int per = (int)((nktf + slices - 1) / slices);
-            if (!xcd) slices = (nktf + per - 1) / per;
+            slices = (nktf + per - 1) / per;
             const int bytes = (2 * 32 * (BI + 4) + 2 * 32 * (BJ + 4)) * 4;
-            const int nx_xcd = xcd ? tilesI * tilesJ * d.taps : 0;
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
-            if (xcd) grid = dim3((unsigned)(nx_xcd * slices), 1, d.batch);
             // split-bf16: the LDS transpose-read kernel (wgrad_tr_kernel); fp32 MFMA: wgrad_fast_kernel
-            if (wgrad_has_twins(d) && !xcd) {
+            if (wgrad_has_twins(d)) {
                 const int tbytes = 2 * ((BI + BJ) / 32) * (32 * 32 + 32) * 2;   // two buffers of hi planes (padded blocks)
                 if ((rcf = raise_lds(wgrad_tr16_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
                 hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per);
@@ -2357,13 +2323,13 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
                 const int tbytes = 2 * 2 * (BI + BJ) * 32 * 2;
                 if (d.precision == 2) {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ, 2>, tbytes, "cdetr_wgrad"))) return;
-                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 2>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias, nx_xcd);
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 2>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
                 } else if (d.precision == 3) {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ, 1>, tbytes, "cdetr_wgrad"))) return;
-                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 1>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias, nx_xcd);
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ, 1>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
                 } else {
                     if ((rcf = raise_lds(wgrad_tr_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
-                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias, nx_xcd);
+                    hipLaunchKernelGGL((wgrad_tr_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, d.dbias);
                 }
             } else {
                 if ((rcf = raise_lds(wgrad_fast_kernel<BI, BJ, 0>, bytes, "cdetr_wgrad"))) return;
@@ -2488,12 +2454,6 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             it.tilesI = (it.d.Nout + 63) / 64; it.tilesJ = (it.d.Cin + 63) / 64;
             it.per = (int)std::min<long>(per_all, nkt);
             it.nx = it.tilesI * it.tilesJ * it.d.taps; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
-            const char* xe = cdetr_tune_env("CDETR_WGRAD_XCD");
-            const int xcd_on = xe ? atoi(xe) : 0;
-            if (xcd_on && it.ny >= 6 && (nkt + 3) / 4 >= 8) {            // XCD-aware slices: a multiple of 8 (see wgrad_tr_kernel)
-                it.ny = (it.ny + 7) / 8 * 8;
-                it.per = (nkt + it.ny - 1) / it.ny;
-            }
             g.blk0[k + 1] = g.blk0[k] + (it.nx * it.ny * it.d.batch + 7) / 8 * 8;
         }
         // one precision per grouped launch: the group's members come from one backward pass, the first member decides

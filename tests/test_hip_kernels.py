@@ -608,15 +608,11 @@ def test_gemm_variants_ragged_shapes(variant, monkeypatch):
         ops.PRECISION = old
 
 
-@pytest.mark.parametrize("xcd", [0, 1])
 @pytest.mark.parametrize("wvariant", [0, 1, 2, 3, 4])
-def test_wgrad_variants_ragged_shapes(wvariant, xcd, monkeypatch, precision):
-    """Weight-gradient tile variants on pixel counts / channel counts off the tile, with the fused bias gradient, 1x1 and 3x3;
-    xcd = 1: the XCD-aware slice placement of the transpose-read kernel (CDETR_WGRAD_XCD, off by default)."""
+def test_wgrad_variants_ragged_shapes(wvariant, monkeypatch, precision):
+    """Weight-gradient tile variants on pixel counts / channel counts off the tile, with the fused bias gradient, 1x1 and 3x3."""
     from counting_detr_amd import ops
     monkeypatch.setenv("CDETR_WGRAD_VARIANT", str(wvariant))
-    if xcd:
-        monkeypatch.setenv("CDETR_WGRAD_XCD", "1")
     for (P, Nout, Cin) in [(1100, 64, 64), (1500, 132, 68), (2049, 256, 36), (5000, 40, 260)]:
         dY = torch.randn(P, Nout, generator=g(P))
         X = torch.randn(P, Cin, generator=g(P + 1))
