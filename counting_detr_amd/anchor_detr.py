@@ -143,9 +143,8 @@ class SetCriterion(nn.Module):
         logits = out["pred_logits"]
         B, Q = logits.shape[:2]
         aux = outputs.get("aux_outputs")
-        if isinstance(targets, ops.PackedTargets):     # fixed-address buffers + capacity plan (the graph-cached step): counts live on the device
-            if aux:
-                raise NotImplementedError("PackedTargets with aux_outputs: the stacked matching needs tightly packed targets")
+        packed = isinstance(targets, ops.PackedTargets)
+        if packed:     # fixed-address buffers + capacity plan (the graph-cached step): counts live on the device
             plan, tgt_boxes_all, tgt_labels_all = targets.plan, targets.boxes, targets.labels
             sizes = tuple(plan.sizes)
         else:
@@ -153,7 +152,15 @@ class SetCriterion(nn.Module):
             plan = self._plan(sizes, Q, logits.device)
             tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
             tgt_labels_all = torch.cat([t["labels"] for t in targets])
-        if aux:
+        if aux and packed:
+            # capacity plan: the stacked form needs the targets packed tightly L times over (count-dependent offsets); the layers are
+            # matched one after the other with the one device-resident plan instead -- 2 L launches, graph-replayable for any counts
+            layers = list(aux) + [out]
+            L = len(layers)
+            per = [self.matcher.match_device(lo, None, plan, tgt_boxes=tgt_boxes_all) for lo in layers]
+            idx_i, idx_j = torch.cat([r[0] for r in per]), torch.cat([r[1] for r in per])
+            status = torch.cat([r[2] for r in per])
+        elif aux:
             layers = list(aux) + [out]
             L = len(layers)
             plan_all = self._plan(sizes * L, Q, logits.device)

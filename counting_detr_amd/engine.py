@@ -479,9 +479,6 @@ class Trainer:
         return self._entry["out"]
 
     def _capture_entry(self, images, mask, rects, targets, warmup=0):
-        if getattr(self.model, "aux_loss", False):
-            raise NotImplementedError("graph capture with aux_loss=True: the stacked per-layer matching needs tightly packed targets; "
-                                      "use the stream-ordered step (train_step)")
         st = self._make_static(images, mask, rects, targets)
         world = get_world_size()
         hook = _bb._BACKWARD_HOOK
@@ -573,11 +570,12 @@ class Trainer:
         target-capacity class, arithmetic mode); a batch whose key is new is captured first (one dry forward + the capture, ~0.1 s),
         every later batch of that key is three small copies + one graph launch.  FSC-147 images are 384 high and a multiple of 32
         wide after the reference's resize rule (A2/data/fsc147.py:75-77), so an epoch meets a few dozen keys; the least recently
-        used entry is dropped beyond `args.graph_cache_size`.  Falls back to the stream-ordered `train_step` where a capture cannot
-        represent the step (aux_loss=True) or `args.graph_cache` is off.  Returns the step's loss dict (device scalars; valid
+        used entry is dropped beyond `args.graph_cache_size`.  `args.graph_cache` off (--no_graph_cache): the stream-ordered `train_step`.
+        With aux_loss=True the per-layer matchings run as one cost + one assignment launch per layer inside the graph (the stacked
+        single-launch form of the stream-ordered step needs count-dependent offsets).  Returns the step's loss dict (device scalars; valid
         until the same entry is replayed again)."""
         from . import ops
-        if not self._cache_on or not self.flat_g.is_cuda or getattr(self.model, "aux_loss", False):
+        if not self._cache_on or not self.flat_g.is_cuda:
             return self.train_step(samples, rects, targets)
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
         images, mask = nt.decompose()

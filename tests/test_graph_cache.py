@@ -285,3 +285,30 @@ def test_split_plane_forward_equals_default_forward():
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), k
     for k, v in res[0][1].items():
         np.testing.assert_allclose(res[1][1][k], v, rtol=2e-3 if k == "grad_norm" else 1e-4, atol=1e-6, err_msg=k)
+
+
+@gpu
+def test_cached_graph_step_with_aux_losses_equals_eager_step():
+    """aux_loss=True (A2/models/anchor_detr.py:334-350: one Hungarian matching per decoder layer) through the graph cache: the layers are
+    matched one after the other with the device-resident capacity plan; same 31 loss values as the stream-ordered step (whose matchings
+    are one stacked launch), on two batches with different target counts replayed from ONE captured graph."""
+    import counting_detr_amd
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.engine import Trainer
+    from counting_detr_amd.init import seeded_init_
+    args = default_args(device=DEV, num_query_position=100, aux_loss=True)
+    model, crit, _ = counting_detr_amd.build_model(args)
+    seeded_init_(model)
+    model.to(DEV).train()
+    tr = Trainer(model, crit, args, device=DEV)
+    for i, Ts in enumerate([(7, 13), (40, 2)]):
+        images, rects, tg = _batch(2, 96, 128, Ts, seed=60 + i)
+        saved = [t.detach().clone() for t in (tr.flat_p, tr.exp_avg, tr.exp_avg_sq, tr.opt_state)]
+        eo = {k: float(v) for k, v in tr.train_step(images, rects, tg).items()}
+        for dst, src in zip((tr.flat_p, tr.exp_avg, tr.exp_avg_sq, tr.opt_state), saved):
+            dst.copy_(src)
+        go = {k: float(v) for k, v in tr.step(images, rects, tg).items()}
+        assert len(eo) >= 31 and set(eo) == set(go)
+        for k in eo:
+            np.testing.assert_allclose(go[k], eo[k], rtol=1e-4 if k == "grad_norm" else 1e-5, atol=1e-6, err_msg=f"batch {i} {k}")
+    assert tr.cache_stats == {"captures": 1, "steps": 2}
