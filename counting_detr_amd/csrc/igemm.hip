@@ -1536,8 +1536,26 @@ __device__ __forceinline__ void wgrad_tr16_body(const cdetr_wgrad_desc& d, const
     }
 }
 
+// XCD-aware slice placement of the twin-fed weight gradients (1-D grid of nx * ny workgroups, ny % 8 == 0): workgroup b runs on XCD b % 8
+// (private 4 MiB L2 each); XCD x is given the pixel slices x, x + 8, ... and runs every output tile of a slice back to back.  All tiles of a
+// slice read the SAME pixel rows of dY16 / X16, so those rows cross the fabric once per slice instead of once per XCD that happens to hold
+// one of the slice's tiles.  The weight gradients run at ~4 TB/s of counter traffic on 2.2x their algorithmic bytes (profiles/r3_traffic.json):
+// this is the kernel family that IS fabric-bound.  Placement only affects speed.
+__device__ __forceinline__ void wgrad_xcd_slice(int lid, int nx, int& bx, int& by) {
+    const int xcd = lid & 7, j = lid >> 3;
+    bx = j % nx;
+    by = (j / nx) * 8 + xcd;
+}
+
 template <int BI, int BJ>
-__global__ __launch_bounds__(256) void wgrad_tr16_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ, const int kt_per_slice) {
+__global__ __launch_bounds__(256) void wgrad_tr16_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ, const int kt_per_slice,
+                                                         const int nx_xcd) {
+    if (nx_xcd > 0) {      // 1-D grid, XCD-aware slices (never a single slice: ny is a multiple of 8; empty trailing slices exit at once)
+        int bx, by;
+        wgrad_xcd_slice(blockIdx.x, nx_xcd, bx, by);
+        wgrad_tr16_body<BI, BJ>(d, tilesI, tilesJ, kt_per_slice, bx, by, 0, false);
+        return;
+    }
     wgrad_tr16_body<BI, BJ>(d, tilesI, tilesJ, kt_per_slice, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
 }
 
@@ -1577,7 +1595,10 @@ __global__ __launch_bounds__(256) void wgrad_tr16_group_kernel(const WgradGroupA
     const int per_z = it.nx * it.ny;
     const int z = lb / per_z, l = lb - z * per_z;
     if (z >= it.d.batch) return;
-    wgrad_tr16_body<BI, BJ>(it.d, it.tilesI, it.tilesJ, it.per, l % it.nx, l / it.nx, z, false);
+    int bx, by;
+    if (it.pad_) wgrad_xcd_slice(l, it.nx, bx, by);    // (host: ny % 8 == 0, batch 1; blk0 is a multiple of 8: l % 8 == blockIdx.x % 8 == the XCD)
+    else { bx = l % it.nx; by = l / it.nx; }
+    wgrad_tr16_body<BI, BJ>(it.d, it.tilesI, it.tilesJ, it.per, bx, by, z, false);
 }
 
 // ------------------------------------------------------------------------------------------------ direct small GEMMs
@@ -2318,7 +2339,15 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             if (wgrad_has_twins(d)) {
                 const int tbytes = 2 * ((BI + BJ) / 32) * (32 * 32 + 32) * 2;   // two buffers of hi planes (padded blocks)
                 if ((rcf = raise_lds(wgrad_tr16_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
-                hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per);
+                static const int xcd16 = getenv("CDETR_WGRAD_XCD16") ? atoi(getenv("CDETR_WGRAD_XCD16")) : 1;
+                if (xcd16 && d.batch == 1 && slices >= 8 && max_slices >= 8) {      // XCD-aware slices: a multiple of 8 of them, 1-D grid
+                    long s8 = std::min<long>((slices + 7) / 8 * 8, max_slices / 8 * 8);
+                    if (s8 < 8) s8 = 8;
+                    const int per8 = (int)((nktf + s8 - 1) / s8);
+                    const int nx = tilesI * tilesJ * d.taps;
+                    hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ>), dim3((unsigned)(nx * s8)), block, tbytes, st, d, tilesI, tilesJ, per8, nx);
+                } else
+                    hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, 0);
             } else if (d.precision >= 1) {
                 const int tbytes = 2 * 2 * (BI + BJ) * 32 * 2;
                 if (d.precision == 2) {
@@ -2454,6 +2483,12 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             it.tilesI = (it.d.Nout + 63) / 64; it.tilesJ = (it.d.Cin + 63) / 64;
             it.per = (int)std::min<long>(per_all, nkt);
             it.nx = it.tilesI * it.tilesJ * it.d.taps; it.ny = (nkt + it.per - 1) / it.per; it.pad_ = 0;
+            static const int xcd16 = getenv("CDETR_WGRAD_XCD16") ? atoi(getenv("CDETR_WGRAD_XCD16")) : 1;
+            if (twins && xcd16 && it.d.batch == 1 && it.ny >= 6 && (nkt + 3) / 4 >= 8) {      // XCD-aware slices: a multiple of 8 (see wgrad_tr16_kernel)
+                it.ny = (it.ny + 7) / 8 * 8;
+                it.per = (nkt + it.ny - 1) / it.ny;
+                it.pad_ = 1;
+            }
             g.blk0[k + 1] = g.blk0[k] + (it.nx * it.ny * it.d.batch + 7) / 8 * 8;
         }
         // one precision per grouped launch: the group's members come from one backward pass, the first member decides
