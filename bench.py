@@ -252,6 +252,49 @@ def inference_leg(dev, shapes, batch, precision, steps=20):
             "dtype": "forward bf16x3, fp32 accumulate / storage", "steps": steps, "shapes": out}
 
 
+def stage1_leg(dev, precision, points=900, H=800, W=800, steps=20):
+    """BASELINE config 5: 1st-stage pseudo-label generation (point -> box, A1/engine.py:124-187) with 900 anchor points on one 800x800
+    image: forward of the stage-1 model (input_proj, encoder, decoder with 900 queries, wh head), graph replay and stream-ordered."""
+    from counting_detr_amd import ops, stage1
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.engine import build_weight_mirror
+    from counting_detr_amd.init import seeded_init_
+    ops.PRECISION = PRECISIONS[precision]
+    args = default_args(device=str(dev), spatial_prior="defined")
+    model, _, _ = stage1.build(args)
+    seeded_init_(model)
+    model.to(dev).eval()
+    mirror = build_weight_mirror(model, [(n, p) for n, p in model.named_parameters()], dgrad=False)
+    mirror.refresh("fwd")
+    g0 = torch.Generator().manual_seed(5)
+    image = torch.randn(1, 3, H, W, generator=g0).to(dev)
+    pts = (torch.rand(1, points, 2, generator=g0) * 0.9 + 0.05).to(dev)
+    prev, ops.MIRROR = ops.MIRROR, mirror
+    try:
+        with torch.no_grad():
+            run = lambda: stage1.generate_pseudo_boxes(model, image, pts)      # noqa: E731
+            for _ in range(3):
+                boxes = run()
+            torch.cuda.synchronize()
+            dt_e, per_e, _ = timed_steps(run, steps, torch.cuda.synchronize)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=s):
+                boxes = run()
+            for _ in range(3):
+                gr.replay()
+            torch.cuda.synchronize()
+            dt_g, per_g, _ = timed_steps(gr.replay, steps, torch.cuda.synchronize)
+    finally:
+        ops.MIRROR = prev
+    return {"what": f"stage-1 forward (point -> box): {points} anchor points, one {H}x{W} image, pseudo boxes out", "steps": steps,
+            "graph": {"value": steps / dt_g, "unit": "images/s", "ms_per_image": dt_g / steps * 1e3, "step_ms": percentiles(per_g)},
+            "eager": {"value": steps / dt_e, "unit": "images/s", "ms_per_image": dt_e / steps * 1e3},
+            "mean_box_wh": [float(boxes[..., 2].mean()), float(boxes[..., 3].mean())]}
+
+
 def real_data_leg(dev, precision, batch=2, reps=4):
     """The loop main.py runs (engine.train_one_epoch -> Trainer.step: cached HIP graphs keyed by padded image size and target-capacity
     class) on batches shaped like FSC-147 after the reference's resize rule (384 high, widths multiples of 32, A2/data/fsc147.py:75-77)
@@ -556,6 +599,7 @@ def main(argv=None):
             extra_shape(dev, 384, 576, 300, "learned", Ts, a.batch, a.precision)]
     if world == 1 and not a.no_inference:
         res["inference"] = inference_leg(dev, [(800, 800), (384, 576)], a.batch, a.precision)
+        res["stage1_pseudo_labels"] = stage1_leg(dev, a.precision)
     if world == 1 and not a.no_real_data:
         res["real_data_loop"] = real_data_leg(dev, a.precision, a.batch)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
