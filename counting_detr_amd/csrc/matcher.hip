@@ -377,6 +377,48 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
     // column -- positions refer to the `remaining` array) is folded into ONE 32-bit key to minimise next to the value:
     //   unassigned: key = 0x7fffffff - it      assigned: key = 0x80000000 + it      (no candidate: 0xffffffff)
     for (int cur = 0; cur < nr; ++cur) {
+        // ---- fast path: the FIRST scan step of this row (identical arithmetic and tie key) already ends on an unassigned column.  Then
+        // the augmenting path is the single edge (cur, j*): u[cur] += min, no column dual moves (the only visited column is the sink:
+        // delta = min - min = 0), and the row's search state (`remaining`, shortest-path registers, predecessor array) is never looked at
+        // again -- so none of it is set up.  With more columns than rows most rows end here (T = 120 targets on Q = 300 queries: ~80 %);
+        // a row whose nearest column is taken falls through to the full search below, which starts from scratch.
+        {
+            const float* crow0 = cost + (long)cur * nc;
+            const double ui0 = u[cur];
+            const double min0 = 0.0;
+            double bval = INFINITY;
+            unsigned bkey = 0xffffffffu;
+            int best_c = 0;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const bool a = (valid >> c) & 1u;
+                const int jj = a ? lane + 64 * c : 0;
+                const double r = ((min0 + (double)crow0[jj]) - ui0) - v[c];
+                const double s = (a & (r < INFINITY)) ? r : INFINITY;              // the column's shortest-path value after the first step
+                const unsigned p0 = (unsigned)(nc - 1 - (lane + 64 * c));
+                const unsigned k = (r4c[c] == -1) ? (0x7fffffffu - p0) : (0x80000000u + p0);
+                const bool better = a & ((s < bval) | ((s == bval) & (k < bkey)));
+                bval = better ? s : bval;
+                bkey = better ? k : bkey;
+                best_c = better ? c : best_c;
+            }
+            const double my_val = bval;
+            const unsigned my_key = bkey;
+            wave_lexmin<DPP>(bval, bkey);
+            if (bkey != 0xffffffffu && bval != INFINITY && (bkey & 0x80000000u) == 0u) {
+                const bool mine = (my_key == bkey) && (my_val == bval);
+                const int wl = __builtin_ctzll(__ballot(mine));
+                const int jstar = __builtin_amdgcn_readlane(lane + 64 * best_c, wl);
+                if (lane == 0) {
+                    u[cur] = ui0 + bval;
+                    row4col[jstar] = cur;
+                    col4row[cur] = jstar;
+                }
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) r4c[c] = (mine && best_c == c) ? cur : r4c[c];
+                continue;
+            }
+        }
         unsigned sc = 0;                       // visited-column mask of this lane
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
