@@ -44,7 +44,7 @@ class WgradDesc(C.Structure):
 class RcdaFwdDesc(C.Structure):
     _fields_ = [("N", C.c_int32), ("L", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("nh", C.c_int32),
                 ("precision", C.c_int32), ("scale", C.c_float), ("q_row", _p), ("q_col", _p), ("k_row", _p), ("k_col", _p), ("v", _p),
-                ("mask_row", _p), ("mask_col", _p), ("out", _p), ("a_row", _p), ("a_col", _p)]
+                ("mask_row", _p), ("mask_col", _p), ("out", _p), ("a_row", _p), ("a_col", _p), ("ws", _p), ("ws_bytes", C.c_int64)]
 
 
 class RcdaBwdDesc(C.Structure):

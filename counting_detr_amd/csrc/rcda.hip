@@ -323,6 +323,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
 //     per-lane scalar (the form with A_col*A_row as the MFMA operand needs a multiply + bf16 split per element per h);
 //   * V tiles are prefetched PD = 4 iterations ahead (8 registers per tile per thread): an iteration is never bound by
 //     the global-load latency, which is what limited the one-tile-ahead pipeline of rcda_fwd_kernel.
+constexpr int RCDA_WS_COUNTERS = 4096;   // int32 arrival counters at the head of cdetr_rcda_fwd_desc.ws (= SPLITK_COUNTERS of igemm.hip: one scratch serves both)
 constexpr int KSTR = 36;      // LDS row stride (floats) of the projected keys in rcda_scores_mfma: 36 / 4 odd -> conflict-free ds_read_b128
 
 // Score phase on the matrix pipe (split-bf16, H <= 64, W <= 64): S^T = K Q^T per 32-key tile -- A = the projected keys (row = key,
@@ -333,7 +334,8 @@ constexpr int KSTR = 36;      // LDS row stride (floats) of the projected keys i
 // Leaves A_row / A_col in the wave's LDS tiles and saves them, like rcda_scores; ends with the key tiles dead.
 template <int NT, int TW, int TH>
 __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, const FwdSmem& sm, float* smem, float* Srow, float* Scol,
-                                                 int tid, int lane, int i32, int g, int n, int head, int qbase, int q, bool qvalid) {
+                                                 int tid, int lane, int i32, int g, int n, int head, int qbase, int q, bool qvalid,
+                                                 bool save = true) {
     const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
     float* Krow = smem + sm.off_k;             // [W][KSTR]
@@ -442,7 +444,7 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
 
     {
         const int nq = min(QW, L - qbase);   // may be <= 0 for tail waves
-        if (nq > 0) {
+        if (nq > 0 && save) {
             save_rows(Srow, sm.sw, d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
             save_rows(Scol, sm.sh, d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
         }
@@ -480,22 +482,12 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
     const bool qvalid = q < L;
     float* Srow = smem + sm.off_srow + wid * QW * sm.sw;
     float* Scol = smem + sm.off_scol + wid * QW * sm.sh;
-    if (H <= 64) rcda_scores_mfma<NT, (KS + 1) / 2, 2>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
-    else rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
-
-    // ---- hoisted B operand: this lane's A_row row, k-slot j of step s <-> w = 16s + 8g + j
-    bf16x8 bh[KS], bl[KS];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        float x[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int w = 16 * s + 8 * g + j;
-            x[j] = (w < W) ? Srow[i32 * sm.sw + w] : 0.f;
-        }
-        split_bf16x8(x, bh[s], bl[s]);
-    }
-
+    // gridDim.z > 1: the key rows are cut into gridDim.z slices, one workgroup each (the decoder's 2 x 8 x 300 queries are 48 workgroups
+    // stepping through 50 barrier-separated iterations on a 256-CU chip; sliced four ways they are 192 stepping through 13).  Every slice
+    // recomputes the two softmaxes (a few dozen MFMAs); slice 0 saves them.  The partial outputs meet in cdetr_rcda_fwd_desc.ws (below).
+    const int hs = gridDim.z, hz = blockIdx.z;
+    const int hper = (H + hs - 1) / hs;
+    const int hb = hz * hper, he = min(H, hb + hper);
     // ---- V staging: block (wg, cp) = rows w0 = 4wg .. +3, channels 2cp, 2cp+1
     __bf16* VT = reinterpret_cast<__bf16*>(smem + sm.off_k);            // [2][32][VTS]
     // Loads are UNCONDITIONAL (a predicated load sits in its own basic block and the compiler then drains vmcnt every
@@ -509,13 +501,13 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
         const int blk = tid + NT * b;
         const int wg = (blk < NBLK) ? (blk >> 4) : 0, cp = blk & 15;
         vdst[b] = (blk < NBLK) ? (2 * cp) * VTS + 4 * wg : -1;
-        vsrc[b] = d.v + (long)n * H * W * E + head * D + 2 * cp;
+        vsrc[b] = d.v + ((long)n * H + min(hb, H - 1)) * W * E + head * D + 2 * cp;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) vrow[b][kk] = (long)min(4 * wg + kk, W - 1) * E;
     }
     float rv[PD][VB][8];                                    // [kk] -> (x = channel 2cp, y = 2cp+1) as plain scalars
     const long tileE = (long)W * E;
-    int hf = 0;                                             // next tile to fetch; vsrc[] points at it
+    int hf = min(hb, H - 1);                                // next tile to fetch; vsrc[] points at it
     auto vfetch = [&](float (&r)[VB][8]) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < VB; ++b) {
@@ -542,6 +534,22 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
         }
     };
 
+    if (H <= 64) rcda_scores_mfma<NT, (KS + 1) / 2, 2>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid, hz == 0);
+    else rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
+
+    // ---- hoisted B operand: this lane's A_row row, k-slot j of step s <-> w = 16s + 8g + j
+    bf16x8 bh[KS], bl[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        float x[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int w = 16 * s + 8 * g + j;
+            x[j] = (w < W) ? Srow[i32 * sm.sw + w] : 0.f;
+        }
+        split_bf16x8(x, bh[s], bl[s]);
+    }
+
     float outT[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) outT[r] = 0.f;
@@ -554,7 +562,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
     auto step = [&](auto U, int h) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
         vfetch(rv[u]);                                                   // tile h + PD; set u was stashed one iteration ago
-        const float acolh = (h < H) ? Scol[i32 * sm.sh + h] : 0.f;
+        const float acolh = (h < he) ? Scol[i32 * sm.sh + h] : 0.f;
         const __bf16* vt = VT + (u & 1) * 32 * VTS + i32 * VTS + 8 * g;
         f32x16 T = zero;
 #pragma unroll
@@ -568,11 +576,51 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
         vstash(rv[(u + 1) % PD], (u + 1) & 1);                          // tile h+1 -> the buffer tile h-1 used
         __syncthreads();
     };
-    for (int h0 = 0; h0 < H; h0 += PD) {
+    for (int h0 = hb; h0 < he; h0 += PD) {
         step(std::integral_constant<int, 0>{}, h0);
         step(std::integral_constant<int, 1>{}, h0 + 1);
         step(std::integral_constant<int, 2>{}, h0 + 2);
         step(std::integral_constant<int, 3>{}, h0 + 3);
+    }
+    if (hs > 1) {
+        // The slices' partial sums meet in the scratch the split-reduction GEMMs use (same layout: arrival counters, then partials; same
+        // protocol, igemm.hip): park, count in, and the slice that arrives last adds all of them IN SLICE ORDER -- the same sum whichever
+        // slice that is.  Relaxed device-scope atomic stores / loads carry the data across the XCDs' private L2s without a fence.
+        int* cnt = reinterpret_cast<int*>(d.ws);
+        float* wsp = reinterpret_cast<float*>(cnt + RCDA_WS_COUNTERS);
+        const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+        float* mine = wsp + ((long)tile * hs + hz) * 16 * NT + tid;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __hip_atomic_store(mine + r * NT, outT[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem + sm.off_k);          // the V tiles are dead
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old == hs - 1) ? 1 : 0;
+            if (last) __hip_atomic_store(cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // counters stay zero between launches
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        float sum[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+        for (int z = 0; z < hs; ++z) {
+            if (z == hz) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum[r] += outT[r];
+            } else {
+                const float* other = wsp + ((long)tile * hs + z) * 16 * NT + tid;
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[r] = __hip_atomic_load(other + r * NT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum[r] += t[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) outT[r] = sum[r];
     }
     // out^T layout: lane = query i32, register r = channel (r&3) + 8*(r>>2) + 4g
     if (qvalid) {
@@ -1316,6 +1364,24 @@ int launch_rcda_bwd(const cdetr_rcda_bwd_desc& d, hipStream_t st, int hgroups = 
 }
 // waves per workgroup: 4 (128 queries share every staged V tile).  2-wave workgroups used to pay for the short decoder query
 // sets; with the grouped / prefetched tile loops they no longer do (tools/rcda_bench.py: dS 66 vs 73 us, fwd 50 vs 52 us).
+// Key-row slices of the two-step forward (gridDim.z of rcda_fwd2_kernel): enough workgroups that every CU holds two (their
+// barrier-separated iterations then overlap), each slice keeping >= 8 key rows; 1 when the caller gave no scratch.
+inline int fwd2_slices(const cdetr_rcda_fwd_desc& d, int base, int nt, int lds_bytes) {
+    if (!d.ws || base > RCDA_WS_COUNTERS) return 1;
+    int hs;
+    const char* f = cdetr_tune_env("CDETR_RCDA_HS");
+    if (f) hs = atoi(f);
+    else {
+        const int per_cu = lds_bytes > 0 ? std::max(1, std::min(4, (160 * 1024) / lds_bytes)) : 1;
+        (void)per_cu;
+        hs = (200 + base / 2) / base;            // ~200 workgroups (tools/rcda_slices.py: 48 -> 4, 80 -> 3, 112 -> 2 slices are the fastest)
+    }
+    hs = std::min(std::min(hs, 8), d.H / 8);
+    const long avail = (long)d.ws_bytes - (long)RCDA_WS_COUNTERS * 4;
+    while (hs > 1 && (long)base * hs * 16 * nt * 4 > avail) --hs;
+    return hs < 1 ? 1 : hs;
+}
+
 inline int pick_nw(int L, int NH) {
     (void)L; (void)NH;
     const char* f = cdetr_tune_env("CDETR_RCDA_NW");
@@ -1342,12 +1408,15 @@ extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
             int rc;
             if ((rc = set_smem(kern, bytes, "cdetr_rcda_fwd"))) return rc;
             dim3 grid((d.L + QW * NWv - 1) / (QW * NWv), d.N * d.nh), block(64 * NWv);
+            grid.z = fwd2_slices(d, (int)(grid.x * grid.y), 64 * NWv, bytes);
             hipLaunchKernelGGL(kern, grid, block, bytes, st, d);
             return cdetr_launch_status("cdetr_rcda_fwd");
         };
         // 5-wave workgroups (160 queries) when that lands the grid on <= one workgroup per CU and 4 waves do not: the encoder's
         // 2 x 8 x 2500 queries are 320 workgroups of 128 (64 CUs get two) but exactly 256 of 160
-        static const int nw5 = getenv("CDETR_RCDA_NW5") ? atoi(getenv("CDETR_RCDA_NW5")) : 1;
+        static const int nw5_env = getenv("CDETR_RCDA_NW5") ? atoi(getenv("CDETR_RCDA_NW5")) : 1;
+        const char* nw5_t = cdetr_tune_env("CDETR_RCDA_NW5");
+        const int nw5 = nw5_t ? atoi(nw5_t) : nw5_env;
         const long wg4 = (long)((d.L + QW * 4 - 1) / (QW * 4)) * d.N * d.nh, wg5 = (long)((d.L + QW * 5 - 1) / (QW * 5)) * d.N * d.nh;
         if (nw5 && nw == 4 && ks == 4 && wg4 > 256 && wg4 <= 512 && wg5 <= 256) return go(rcda_fwd2_kernel<5, 4>, 5);
         if (nw == 4) {

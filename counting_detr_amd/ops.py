@@ -786,6 +786,7 @@ def maxpool3x3s2(x, split=False):
 
 
 # ----------------------------------------------------------------------------------------------------- RCDA core
+RCDA_SLICES = os.environ.get("CDETR_RCDA_SLICES", "1") != "0"        # key-row slices of the two-step forward (cdetr_rcda_fwd_desc.ws; A/B knob)
 FUSE_RCDA_DQ = os.environ.get("CDETR_RCDA_FUSE_DQ", "1") != "0"     # query gradients inside the dS launch (A/B knob)
 FUSE_RCDA_DK = os.environ.get("CDETR_RCDA_FUSE_DK", "1") != "0"     # key gradients too (split-bf16 mode)
 
@@ -809,6 +810,8 @@ def rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
     d.q_row, d.q_col, d.k_row, d.k_col, d.v = ptr(q_row), ptr(q_col), ptr(k_row), ptr(k_col), ptr(v)
     d.mask_row, d.mask_col = ptr(mask_row), ptr(mask_col)
     d.out, d.a_row, d.a_col = ptr(out), ptr(a_row), ptr(a_col)
+    if RCDA_SLICES:
+        d.ws, d.ws_bytes = ptr(splitk_ws()), SPLITK_BYTES
     # compulsory bytes: both query sets, both key sets, V, the output and the two saved attention maps
     fl = 2.0 * N * nh * L * (H * W * 32 + (H + W) * 32)
     with _Timed("rcda_fwd", fl, None,

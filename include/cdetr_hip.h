@@ -263,6 +263,9 @@ typedef struct {
     const float* q_row; const float* q_col; const float* k_row; const float* k_col; const float* v;
     const uint8_t* mask_row; const uint8_t* mask_col;
     float* out; float* a_row; float* a_col;
+    void* ws;               /* optional scratch (zero-initialised once, >= 16 KB + partial outputs; the kernels leave its counters zero): lets the */
+    int64_t ws_bytes;       /* two-step forward cut the key rows into slices when (N * nh * L / 128) workgroups would not fill the chip; the     */
+                            /* split-reduction scratch of cdetr_gemm_desc.splitk_ws may be passed (launches of one stream do not overlap)      */
 } cdetr_rcda_fwd_desc;
 int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* d, void* stream);
 

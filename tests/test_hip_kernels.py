@@ -237,6 +237,39 @@ def test_rcda_core(N, L, H, W, masked, precision):
         close(a.grad, b.grad, msg=name, rtol=5e-4, atol_scale=tol(precision)["atol_scale"])
 
 
+@pytest.mark.parametrize("N,L,H,W,masked", [(2, 300, 50, 50, False), (2, 77, 17, 5, True), (2, 2500, 50, 50, True), (1, 130, 70, 40, True)])
+@pytest.mark.parametrize("slices", [1, 2, 3, 4, 6, 8])
+def test_rcda_forward_key_row_slices(N, L, H, W, masked, slices, monkeypatch):
+    """cdetr_rcda_fwd_desc.ws: the two-step forward with the key rows cut into `slices` workgroups per query block (partials exchanged
+    through the scratch, summed in slice order by the last arrival) against the fp64 restatement; the saved softmaxes are those of the
+    unsliced launch bit for bit, repeated launches agree bit for bit, and the arrival counters are left zero."""
+    from counting_detr_amd import ops
+    nh, E = 8, 256
+    mk = lambda *s, seed: torch.randn(*s, generator=g(seed))
+    qr, qc, kr, kc, v = mk(N, L, E, seed=1), mk(N, L, E, seed=2), mk(N, W, E, seed=3), mk(N, H, E, seed=4), mk(N, H, W, E, seed=5)
+    mr = mc = None
+    if masked:
+        mr = torch.zeros(N, W, dtype=torch.uint8)
+        mc = torch.zeros(N, H, dtype=torch.uint8)
+        mr[0, W - 2:] = 1
+        mc[0, H - 3:] = 1
+    args = [t.to(DEV) for t in (qr, qc, kr, kc, v)] + [mr.to(DEV) if masked else None, mc.to(DEV) if masked else None, nh]
+    monkeypatch.setattr(ops, "PRECISION", 1)
+    monkeypatch.setattr(ops, "RCDA_SLICES", False)
+    o1, ar1, ac1 = ops.rcda_fwd_raw(*args)
+    monkeypatch.setattr(ops, "RCDA_SLICES", True)
+    monkeypatch.setenv("CDETR_RCDA_HS", str(slices))
+    o2, ar2, ac2 = ops.rcda_fwd_raw(*args)
+    o3, _, _ = ops.rcda_fwd_raw(*args)
+    torch.cuda.synchronize()
+    assert torch.equal(ar1, ar2) and torch.equal(ac1, ac2)
+    assert torch.equal(o2, o3)
+    assert int(ops.splitk_ws()[:4096].abs().sum()) == 0
+    ref = rcda_core_ref(qr.double(), qc.double(), kr.double(), kc.double(), v.double(), mr, mc, nh)
+    close(o2, ref, msg="rcda out, sliced", **tol(1))
+    close(o2, o1, msg="sliced vs unsliced", rtol=1e-5, atol_scale=1e-6)
+
+
 @pytest.mark.parametrize("fuse_dq,fuse_dk", [(False, False), (True, False), (True, True)])
 def test_rcda_backward_fusion_levels_agree(fuse_dq, fuse_dk, monkeypatch, precision):
     """The attention backward with the query / key gradients computed by separate GEMM / weight-gradient launches from the saved
