@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+F="--no-cpu-baseline --no-alt --no-extra --no-inference --no-real-data"
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_t -- python bench.py --mode graph --steps 3 --warmup 2 $F > /dev/null 2>&1
+f=$(find /tmp/prof_t -name "*kernel_trace.csv")
+python tools/step_listing.py $f mask_prep adamw_finish > gpurun_out/step_listing.txt 2>&1
+wc -l gpurun_out/step_listing.txt
