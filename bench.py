@@ -222,7 +222,7 @@ def extra_shape(dev, H, W, queries, prior, Ts, batch, precision, steps=10):
             "steps": steps, "whole_step_tflops": step_gflop_per_image(H, W, Q) * batch / (dt / steps * 1e3), "final_loss": float(q)}
 
 
-def inference_leg(dev, shapes, batch, precision, steps=20):
+def inference_leg(dev, shapes, batch0, precision, steps=20):
     """Forward + counting rule (A2/infer.py:57-81) through engine.InferenceEngine: pre-split weight images built once, one captured
     HIP graph per shape, replayed `steps` times after 3 warm-ups.  images/s per shape, plus the eager (stream-ordered) rate."""
     import counting_detr_amd
@@ -236,7 +236,8 @@ def inference_leg(dev, shapes, batch, precision, steps=20):
     seeded_init_(model)
     model.to(dev).eval()
     out = []
-    for (H, W) in shapes:
+    for shp in shapes:
+        (H, W), batch = shp[:2], (shp[2] if len(shp) > 2 else batch0)       # a third entry overrides the images per launch
         images, rects, _ = synthetic_batch(batch, H, W, (1,), seed=7, device=dev)
         row = {"image": [H, W], "images_per_gpu": batch, "queries": 300}
         for tag, graphs in (("graph", True), ("eager", False)):
@@ -598,7 +599,7 @@ def main(argv=None):
             # a typical FSC-147 image after the resize rule (A2/data/fsc147.py:75-77)
             extra_shape(dev, 384, 576, 300, "learned", Ts, a.batch, a.precision)]
     if world == 1 and not a.no_inference:
-        res["inference"] = inference_leg(dev, [(800, 800), (384, 576)], a.batch, a.precision)
+        res["inference"] = inference_leg(dev, [(800, 800), (384, 576), (800, 800, 8), (384, 576, 16)], a.batch, a.precision)
         res["stage1_pseudo_labels"] = stage1_leg(dev, a.precision)
     if world == 1 and not a.no_real_data:
         res["real_data_loop"] = real_data_leg(dev, a.precision, a.batch)
