@@ -488,6 +488,25 @@ def main(argv=None):
         f[1] += e0.elapsed_time(e1) * 1e-3
         f[2] += 1
         f[3] += nbytes
+    # the same leg with the weight gradients submitted at the END of the backward instead of beside the data-gradient chain: the family
+    # times of kernels that do not share the chip with another stream (the product runs the overlapped form: ops.WGRAD_EVERY)
+    unoverlapped = None
+    if ops.WGRAD_EVERY:
+        every, ops.WGRAD_EVERY = ops.WGRAD_EVERY, 0
+        ops.PROFILE = []
+        for _ in range(reps):
+            trainer._fwd_bwd(im, mk, rects, targets, nb)
+        torch.cuda.synchronize()
+        f2 = {}
+        for family, flops, e0, e1, tag, nbytes, issued in ops.PROFILE:
+            f = f2.setdefault(family, [0.0, 0.0, 0])
+            f[0] += flops; f[1] += e0.elapsed_time(e1) * 1e-3; f[2] += 1
+        ops.WGRAD_EVERY = every
+        dense_ = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
+        unoverlapped = {k: {"tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / dense_, "ms_per_step": v[1] / reps * 1e3,
+                            "avg_launch_us": v[1] / max(v[2], 1) * 1e6} for k, v in f2.items() if v[1] > 0}
+        unoverlapped["note"] = ("the same launches with ops.WGRAD_EVERY = 0 (weight gradients after the data-gradient chain, nothing shares the chip): "
+                                "per-kernel figures without the stretch of running beside another stream; the step itself is slower that way")
     ops.PROFILE = None
     if os.environ.get("CDETR_BENCH_SHAPES") and rank == 0:
         rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
@@ -541,7 +560,7 @@ def main(argv=None):
                 "kernel": "the tile GEMM kernels (igemm_fast_kernel / igemm_dl_kernel: conv fwd / dgrad / linears of > 48 output tiles) -- algorithmic "
                           "FLOPs 2*M*N*K*taps per launch; the few-row GEMMs (decoder, positional MLPs, heads: launch-latency class, igemm_direct_kernel) "
                           "are the separate family igemm_fewrow",
-                "avg_launch_us": ig[1] / max(ig[2], 1) * 1e6, "families": kern,
+                "avg_launch_us": ig[1] / max(ig[2], 1) * 1e6, "families": kern, "unoverlapped": unoverlapped,
                 "whole_step_tflops": gflop_img * a.batch / ms_per_step, "whole_step_frac": gflop_img * a.batch / ms_per_step / dense,
                 "step_gflop_per_image": gflop_img,
                 "pmc": (tj or {}).get("pmc")}

@@ -206,9 +206,11 @@ WGRAD_ASYNC = int(_os.environ.get("CDETR_WGRAD_ASYNC", "1"))
 # Measured (one MI355X, B=2 800x800, same box, ms/step): everything at the end 10.95 | one overlapped submission per backbone segment
 # (layer4 / layer3 / layer2) 10.87 | every 3 blocks 10.95 | every block 11.02 (small groups lose the grouped launch) | encoder / decoder
 # layers overlapped as well 11.13-11.25 (their chains are latency-bound: a concurrent kernel slows every link).
-# Default: OFF.  The best setting buys 0.07 ms (0.7 %) and stretches every data-gradient kernel it runs beside (rocprofv3: the 64x64 dgrad
-# tiles 30.9 -> 43 us average), which muddies the per-kernel roofline accounting for less than the box-to-box spread of the step time.
-WGRAD_EVERY = int(_os.environ.get("CDETR_WGRAD_EVERY", "0"))       # backbone: blocks per overlapped submission (100: one per segment; 0 = at the end)
+# Round 2 left this off (0.07 ms then).  With the round-3 kernels (twin-fed weight gradients, direct-to-LDS data gradients) one overlapped
+# submission per backbone segment is worth 0.10-0.20 ms (same-lease A/B: 9.79 -> 9.69 and 9.70 -> 9.50 ms; every 2 blocks 9.73; encoder /
+# decoder stacks as well 9.81): ON.  The kernels that run beside each other stretch (tile GEMM family 4.66 -> 4.97 ms of summed launch
+# time, weight gradients 1.43 -> 1.55), so bench.py reports the family figures as they run AND with the overlap off (roofline.unoverlapped).
+WGRAD_EVERY = int(_os.environ.get("CDETR_WGRAD_EVERY", "100"))     # backbone: blocks per overlapped submission (100: one per segment; 0 = at the end)
 WGRAD_STACKS = int(_os.environ.get("CDETR_WGRAD_STACKS", "0"))     # encoder / decoder: per-layer overlapped submissions
 _WG_SIDE = {}
 _WG_INFLIGHT = []
