@@ -97,6 +97,17 @@ class Bottleneck(nn.Module):
             if save is not None:
                 save.append((x, a1, a2, out, x16, a1h, a2h, outh))
             return out, outh, outl
+        idn, br = x, None
+        if self.downsample is not None:       # the shortcut convolution: beside conv1 -> conv2 (ops.fork_branch), joined before the residual add
+            sd, bd = self.downsample[1].affine()
+            wd = self.downsample[0].weight
+            if ops.BRANCH_BESIDE and x.is_cuda:
+                Hd, Wd = (x.shape[1] - 1) // self.stride + 1, (x.shape[2] - 1) // self.stride + 1
+                idn = torch.empty((x.shape[0], Hd, Wd, wd.shape[0]), device=x.device, dtype=torch.float32)
+                with ops.fork_branch() as br:
+                    ops.conv_fwd(x, wd, sd, bd, stride=self.stride, out=idn)
+            else:
+                idn = ops.conv_fwd(x, wd, sd, bd, stride=self.stride)
         a1 = ops.conv_fwd(x, self.conv1.weight, s1, b1, relu=True, twin=twins)
         a1, a1_16 = a1 if twins else (a1, None)
         # the 3x3's output feeds the EXPANDING 1x1 (K = planes, N = 4 planes): the one shape class where the direct-to-LDS kernel beats the
@@ -108,11 +119,8 @@ class Bottleneck(nn.Module):
         else:
             a2 = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True, twin=twins)
             a2, a2_16 = a2 if twins else (a2, None)
-        if self.downsample is not None:
-            sd, bd = self.downsample[1].affine()
-            idn = ops.conv_fwd(x, self.downsample[0].weight, sd, bd, stride=self.stride)
-        else:
-            idn = x
+        if br is not None:
+            br.join()
         out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, twin=twin_out, xs=(a2_16, a2l) if a2l is not None else None)
         out, out16 = out if twin_out else (out, None)
         if not twins:
@@ -131,6 +139,16 @@ class Bottleneck(nn.Module):
         s3, _ = self.bn3.affine()
         w1, w2, w3 = self.conv1.weight, self.conv2.weight, self.conv3.weight
         st, dl = self.stride, self.dilation
+        d_idn, br = dz, None
+        if self.downsample is not None and need_dx:      # the shortcut's data gradient: beside the main branch's chain, joined before the last add
+            wd0 = self.downsample[0].weight
+            sd0, _ = self.downsample[1].affine()
+            if ops.BRANCH_BESIDE and dz.is_cuda:
+                d_idn = torch.empty(x.shape, device=dz.device, dtype=torch.float32)
+                with ops.fork_branch() as br:
+                    ops.conv_dgrad(dz, wd0, sd0, x.shape[1:3], stride=st, dz16=dz16, out=d_idn)
+            else:
+                d_idn = ops.conv_dgrad(dz, wd0, sd0, x.shape[1:3], stride=st, dz16=dz16)
         if w3.requires_grad:
             ops.conv_wgrad_(dz, a2, w3, s3, dz16=dz16, x16=a2_16 if tw else None)
         dz2 = ops.conv_dgrad(dz, w3, s3, a2.shape[1:3], gate=a2, twin=tw, dz16=dz16, gate16=a2_16 if tw else None)      # masked by relu(a2)
@@ -146,13 +164,10 @@ class Bottleneck(nn.Module):
             sd, _ = self.downsample[1].affine()
             if wd.requires_grad:
                 ops.conv_wgrad_(dz, x, wd, sd, stride=st, dz16=dz16, x16=x16 if tw else None)
-            if not need_dx:
-                return None
-            d_idn = ops.conv_dgrad(dz, wd, sd, x.shape[1:3], stride=st, dz16=dz16)
-        else:
-            if not need_dx:
-                return None
-            d_idn = dz
+        if not need_dx:
+            return None
+        if br is not None:
+            br.join()
         # x = relu(previous pre-activation): the gate applies the previous block's ReLU mask in the same epilogue
         return ops.conv_dgrad(dz1, w1, s1, x.shape[1:3], gate=x, resid=d_idn, twin=tw, dz16=dz1_16, gate16=x16 if tw else None)
 

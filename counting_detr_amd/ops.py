@@ -251,6 +251,34 @@ def wgrad_join(stream=None):
             del _WG_INFLIGHT[:]
 
 
+# A bottleneck's shortcut convolution (and its data gradient) depends on nothing in the block's main branch until the residual add: it runs
+# on a side stream beside conv1 -> conv2 (a parallel branch of the captured graph).  The output buffer is allocated by the caller on ITS
+# stream before the fork, so no tensor changes allocator streams.
+BRANCH_BESIDE = int(_os.environ.get("CDETR_BRANCH_BESIDE", "1"))
+_BR_SIDE = {}
+
+
+class fork_branch:
+    """with fork_branch() as br: <launches on the side stream, ordered after everything issued so far> ... br.join() before the first consumer."""
+
+    def __enter__(self):
+        main = torch.cuda.current_stream()
+        side = _BR_SIDE.get(main.device)
+        if side is None:
+            side = _BR_SIDE[main.device] = torch.cuda.Stream(device=main.device)
+        side.wait_stream(main)
+        self.side, self.ctx = side, torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        self.event = self.side.record_event()
+        return self.ctx.__exit__(*exc)
+
+    def join(self):
+        torch.cuda.current_stream().wait_event(self.event)
+
+
 def colsum_(X2d, out):
     """out[n] += sum_m X2d[m][n]"""
     M, N = X2d.shape
@@ -714,7 +742,7 @@ def expand_planes():
     return EXPAND_PLANES and PRECISION == 1 and MIRROR is not None
 
 
-def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False, xs=None, split=False):
+def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False, xs=None, split=False, out=None):
     """x [N,H,W,Cin] NHWC -> [N,Ho,Wo,Cout]; weight logical [Cout,Cin,kh,kw] in channels_last memory.
     y = relu?( conv(x, W) * scale[c] + bias[c] + resid )   (A2/models/resnet.py:140-160 + backbone.py:50-60).
     twin: -> (y, bf16 copy of y written by the same epilogue).  split: -> (y, hi, lo) = y with its split-bf16 planes.
@@ -723,7 +751,7 @@ def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=N
     Cout, Cin_w, kh, kw = weight.shape
     assert Cin_w == Cin and x.is_contiguous()
     g, Ho, Wo = conv_geom_fwd(H, W, kh, kw, stride, pad, dil)
-    y = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    y = out if out is not None else torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
     y16 = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if (twin or split) else None
     ylo = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if split else None
     sp = MIRROR.lookup_fwd(weight, scale) if MIRROR is not None else None
@@ -735,7 +763,7 @@ def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=N
     return (y, y16) if twin else y
 
 
-def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False, dz16=None, gate16=None):
+def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False, dz16=None, gate16=None, out=None):
     """dx [N,Hin,Win,Cin] = conv_transpose(dz * scale, W) (+ resid), zeroed where gate <= 0.  twin: -> (dx, bf16 copy of dx);
     dz16: the bf16 twin of dz (read instead of dz by the plain-bf16 tile kernels)."""
     Nb, Ho, Wo, Cout = dz.shape
@@ -743,7 +771,7 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     Hin, Win = in_hw
     dense = kh == 1 and kw == 1 and stride == 1 and pad == 0
     g = _geom() if dense else _geom(_ffi.ROWS_CONV_DGRAD, Ho, Wo, Hin, Win, kh, kw, stride, pad, dil)
-    dx = torch.empty((Nb, Hin, Win, Cin), device=dz.device, dtype=torch.float32)
+    dx = out if out is not None else torch.empty((Nb, Hin, Win, Cin), device=dz.device, dtype=torch.float32)
     dx16 = torch.empty((Nb, Hin, Win, Cin), device=dz.device, dtype=torch.bfloat16) if twin else None
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
     if m is not None:     # FrozenBN scale is folded into the mirror
