@@ -491,8 +491,9 @@ def main(argv=None):
     # the same leg with the weight gradients submitted at the END of the backward instead of beside the data-gradient chain: the family
     # times of kernels that do not share the chip with another stream (the product runs the overlapped form: ops.WGRAD_EVERY)
     unoverlapped = None
-    if ops.WGRAD_EVERY:
+    if ops.WGRAD_EVERY or ops.BRANCH_BESIDE:
         every, ops.WGRAD_EVERY = ops.WGRAD_EVERY, 0
+        beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0
         ops.PROFILE = []
         for _ in range(reps):
             trainer._fwd_bwd(im, mk, rects, targets, nb)
@@ -501,12 +502,15 @@ def main(argv=None):
         for family, flops, e0, e1, tag, nbytes, issued in ops.PROFILE:
             f = f2.setdefault(family, [0.0, 0.0, 0])
             f[0] += flops; f[1] += e0.elapsed_time(e1) * 1e-3; f[2] += 1
-        ops.WGRAD_EVERY = every
+        ops.WGRAD_EVERY, ops.BRANCH_BESIDE = every, beside
         dense_ = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         unoverlapped = {k: {"tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / dense_, "ms_per_step": v[1] / reps * 1e3,
                             "avg_launch_us": v[1] / max(v[2], 1) * 1e6} for k, v in f2.items() if v[1] > 0}
-        unoverlapped["note"] = ("the same launches with ops.WGRAD_EVERY = 0 (weight gradients after the data-gradient chain, nothing shares the chip): "
-                                "per-kernel figures without the stretch of running beside another stream; the step itself is slower that way")
+        unoverlapped["note"] = ("the same launches with ops.WGRAD_EVERY = 0 and ops.BRANCH_BESIDE = 0 (weight gradients after the data-gradient chain, shortcut "
+                                "convolutions in line: nothing shares the chip): per-kernel figures without the stretch of running beside another stream -- "
+                                "the step is 0.2-0.3 ms slower that way.  roofline.achieved / frac / families are the launches AS THEY RUN in the product "
+                                "(two streams share the chip during the backbone's backward and at its three shortcut convolutions: every kernel there "
+                                "takes longer, their sum takes less)")
     ops.PROFILE = None
     if os.environ.get("CDETR_BENCH_SHAPES") and rank == 0:
         rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])

@@ -10,6 +10,10 @@ F="--no-cpu-baseline --no-alt --no-extra --no-inference --no-real-data"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k -- python bench.py --steps 20 --warmup 5 $F > $O/bench_prof.log 2>&1
 find /tmp/prof_k -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats.csv \;
 python tools/kernel_stats.py $O/bench_kernel_stats.csv 70 > $O/kernel_summary.txt 2>&1
+# the same with nothing sharing the chip (weight gradients after the chain, shortcut convolutions in line): backs roofline.unoverlapped
+CDETR_WGRAD_EVERY=0 CDETR_BRANCH_BESIDE=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_k0 -- python bench.py --steps 20 --warmup 5 $F > $O/bench_prof0.log 2>&1
+find /tmp/prof_k0 -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats_unoverlapped.csv \;
+python tools/kernel_stats.py $O/bench_kernel_stats_unoverlapped.csv 40 > $O/kernel_summary_unoverlapped.txt 2>&1
 B="python bench.py --steps 1 --warmup 1 --no-graph $F"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_f -- $B > $O/pmc_fetch.log 2>&1
 find /tmp/prof_f -name "*counter_collection.csv" -exec cp {} /tmp/fetch.csv \;
