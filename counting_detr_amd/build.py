@@ -40,12 +40,15 @@ def build_lib(force=False, verbose=True):
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
     procs = []
+    headers = [d for d in _deps() if d.endswith(".h")]
     for s in SOURCES:
         src = os.path.join(CSRC, s)
         if not os.path.exists(src):
             continue
         obj = os.path.join(LIBDIR, s.replace(".hip", ".o"))
         objs.append(obj)
+        if not force and os.path.exists(obj) and all(os.path.getmtime(obj) > os.path.getmtime(d) for d in [src] + headers):
+            continue                                # this object is newer than its source and every header: keep it
         cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)

@@ -26,6 +26,13 @@ def invalidate_caches(model):
             m._stem_w4 = None
         if hasattr(m, "_stem_wr"):
             m._stem_wr = None
+    # captured steps / forwards hold the addresses of those tables: their owners (engine.Trainer, engine.InferenceEngine) drop them
+    for ref in list(model.__dict__.get("_graph_cache_owners", [])):
+        owner = ref()
+        if owner is None:
+            model.__dict__["_graph_cache_owners"].remove(ref)
+        else:
+            owner.clear_graph_cache()
 
 
 def _read(path_or_dict):

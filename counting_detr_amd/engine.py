@@ -173,11 +173,15 @@ class Trainer:
         self.epoch = 0
         self._entry = None                      # capture() / replay(): the explicitly captured step
         self._cap_stream = None
-        self._cache = {}                        # step(): captured steps by (image shape, target capacity, arithmetic), LRU order
+        self._cache = {}                        # step(): captured steps by (image shape, exemplar shape, target capacity, arithmetic), LRU order
+        self._pool = None                       # ONE graph memory pool for every cached step (entries never run concurrently)
         self._cache_on = bool(getattr(args, "graph_cache", True))
         self._cache_size = int(getattr(args, "graph_cache_size", 32))
         self.cache_stats = {"captures": 0, "steps": 0}
         self.mirror = self._build_mirror(named)
+        import weakref
+        owners = model.__dict__.setdefault("_graph_cache_owners", [])      # checkpoint.invalidate_caches -> clear_graph_cache
+        owners.append(weakref.ref(self))
         self.exchange = FlatGradExchange(self.flat_g, self.seg_bounds)
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
         self.sync_replicas()
@@ -478,8 +482,26 @@ class Trainer:
         self._entry = self._capture_entry(images, mask, rects, targets, warmup)
         return self._entry["out"]
 
+    def counts_on_device(self):
+        """Whether a captured step serves OTHER target counts than the ones it was captured with: only the fused criterion
+        (ops.CriterionFn, the default four losses) reads the counts from the device tables of the capacity plan; the tensor-op
+        composition (`criterion.fused = False`, CDETR_FUSED_CRITERION=0, or another `losses` list) builds its index tensors from the
+        host-side counts, which a capture would freeze."""
+        c = self.criterion
+        return bool(getattr(c, "fused", False)) and list(getattr(c, "losses", [])) == ["labels", "boxes", "cardinality", "vars"]
+
+    def clear_graph_cache(self):
+        """Drop every captured step.  Captured graphs hold the ADDRESSES of value-derived device tables (FrozenBN folds, padded stem
+        images): anything that rebuilds them (checkpoint.invalidate_caches: checkpoint loads, replica broadcast) calls this."""
+        if self._cache or self._entry is not None:
+            if self.flat_g.is_cuda:
+                torch.cuda.synchronize()
+            self._cache.clear()
+            self._entry = None
+
     def _capture_entry(self, images, mask, rects, targets, warmup=0):
         st = self._make_static(images, mask, rects, targets)
+        st["sizes"] = tuple(len(t["boxes"]) for t in targets)
         world = get_world_size()
         hook = _bb._BACKWARD_HOOK
         _bb.set_backward_hook(None)                # no collectives inside the capture
@@ -515,6 +537,11 @@ class Trainer:
         mode = {"capture_error_mode": "thread_local"} if world > 1 else {}
         g_a = torch.cuda.CUDAGraph()
         segs = None
+        # every cached step allocates from ONE pool: a step's activations are dead when the next graph launch starts (same stream, the
+        # returned loss scalars stay allocated while their entry lives), so N cached shapes cost the memory of the largest, not the sum
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        mode["pool"] = self._pool
         if not segmented:
             with torch.cuda.graph(g_a, stream=s, **mode):
                 out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
@@ -526,16 +553,22 @@ class Trainer:
             segs = []
             for seg in (1, 2, 3):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=g_a.pool(), stream=s, **mode):
+                with torch.cuda.graph(g, stream=s, **mode):
                     self._trunk_segment(seg, last=(seg == 3))
                 segs.append(g)
             g_b = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_b, pool=g_a.pool(), stream=s, **mode):
+            with torch.cuda.graph(g_b, stream=s, **mode):
                 out["grad_norm"] = self._optimizer_step()
         return g_a, segs, g_b, out
 
     def _load_entry(self, e, images, mask, rects, targets):
         st = e["st"]
+        if tuple(rects.shape) != tuple(st["rects"].shape) or tuple(images.shape) != tuple(st["images"].shape):
+            raise ValueError(f"captured step holds images {tuple(st['images'].shape)} / exemplars {tuple(st['rects'].shape)}, "
+                             f"got {tuple(images.shape)} / {tuple(rects.shape)}")
+        if not self.counts_on_device() and tuple(len(t["boxes"]) for t in targets) != st["sizes"]:
+            raise ValueError("this criterion (not the fused four-loss kernel) freezes the target counts into a captured step: "
+                             f"captured {st['sizes']}, got {tuple(len(t['boxes']) for t in targets)}")
         st["images"].copy_(images)
         st["mask"].copy_(mask)
         st["rects"].copy_(rects)
@@ -575,18 +608,28 @@ class Trainer:
         single-launch form of the stream-ordered step needs count-dependent offsets).  Returns the step's loss dict (device scalars; valid
         until the same entry is replayed again)."""
         from . import ops
-        if not self._cache_on or not self.flat_g.is_cuda:
+        if not self._cache_on or not self.flat_g.is_cuda or not self.counts_on_device():
+            # (a criterion that reads the counts on the host would replay the captured batch's matching layout: stream-ordered step)
             return self.train_step(samples, rects, targets)
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
         images, mask = nt.decompose()
         cap = self.target_capacity(max([len(t["boxes"]) for t in targets], default=0))
-        key = (tuple(images.shape), cap, ops.PRECISION, ops.PRECISION_BWD)
+        key = (tuple(images.shape), tuple(rects.shape), cap, ops.PRECISION, ops.PRECISION_BWD)
         e = self._cache.pop(key, None)
         if e is None:
             while len(self._cache) >= max(self._cache_size, 1):
                 torch.cuda.synchronize()           # nothing of the entry being dropped is still running
                 self._cache.pop(next(iter(self._cache)))
-            e = self._capture_entry(images, mask, rects, targets)
+            while True:
+                try:
+                    e = self._capture_entry(images, mask, rects, targets)
+                    break
+                except torch.OutOfMemoryError:     # a new shape does not fit beside the cached ones: drop the least recently used, retry
+                    if not self._cache:
+                        raise
+                    torch.cuda.synchronize()
+                    self._cache.pop(next(iter(self._cache)))
+                    torch.cuda.empty_cache()
             self.cache_stats["captures"] += 1
         else:
             self._load_entry(e, images, mask, rects, targets)
@@ -668,8 +711,17 @@ class InferenceEngine:
         self.mirror = build_weight_mirror(model, named, dgrad=False) if (self.device.type == "cuda" and p0 is not None) else None
         self._cache = {}
         self._stream = None
+        self._pool = None                # one graph memory pool for all shapes (graphs never run concurrently; outputs stay allocated)
         self.stats = {"captures": 0, "calls": 0}
+        import weakref
+        model.__dict__.setdefault("_graph_cache_owners", []).append(weakref.ref(self))
         self.refresh_weights()
+
+    def clear_graph_cache(self):
+        if self._cache:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize()
+            self._cache.clear()
 
     def refresh_weights(self):
         """Call after loading / changing the model's weights: rebuilds the forward weight images (and drops the graphs' cached folds)."""
@@ -711,7 +763,9 @@ class InferenceEngine:
             self._stream.wait_stream(torch.cuda.current_stream())
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=self._stream):
+            if self._pool is None:
+                self._pool = torch.cuda.graph_pool_handle()
+            with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
                 out = self._run(*st)
             e = (g, st, out)
             self.stats["captures"] += 1

@@ -66,6 +66,10 @@ def main(args):
         print(f"backbone: {n} tensors from {args.pretrained_backbone}")
 
     checkpoint = None
+    if args.auto_resume and not args.resume:                            # A1/main.py:217-221: continue from the output directory's last checkpoint
+        last = os.path.join(args.output_dir, "detr_retrain.pth")
+        if os.path.isfile(last):
+            args.resume = last
     if args.resume:                                                     # A2/main.py:195-209
         checkpoint, _, _ = ckpt_io.resume_model(model, args.resume, skip_mismatch=args.resume_skip_mismatch)
 

@@ -211,16 +211,22 @@ def g3_block():
 
 
 # ----------------------------------------------------------------------------- G4 matcher + G5 criterion
-def g45_matcher_criterion():
+G45_CASES = [("q300_t37", 300, (37,), False), ("q576_t200", 576, (200,), False), ("q900_t56", 900, (56,), False),
+             ("q300_t450", 300, (450,), False), ("q900_t900", 900, (900,), False), ("b2_q40", 40, (7, 13), False),
+             ("b2_q300", 300, (37, 120), False), ("negvar", 50, (9,), True), ("t0", 30, (0, 5), False)]
+# FSC-147 images hold up to 3731 objects (A2/data/fsc147.py:80-84 feeds every one of them to the matcher, A2/models/matcher.py:229-247):
+# the target-capacity classes 1024 / 2048 / 3800 of the device matcher and criterion are pinned by these
+G45_LARGE_T = [("q300_t3000", 300, (3000,), False), ("q576_t3731", 576, (3731,), False), ("q900_t3000", 900, (3000,), False),
+               ("b2_q300_t2100", 300, (37, 2100), False), ("q300_t1100", 300, (1100,), False)]
+
+
+def g45_matcher_criterion(cases=G45_CASES, fname="g45_matcher_criterion.npz"):
     from models.anchor_detr import SetCriterion
     from models.matcher import OriginalHungarianMatcher
     matcher = OriginalHungarianMatcher(2, 5, 2)
     wd = {"loss_ce": 2, "loss_bbox": 5, "loss_giou": 2, "loss_variance": 2}
     crit = SetCriterion(1, matcher, wd, ["labels", "boxes", "cardinality", "vars"], focal_alpha=0.25)
     d = {}
-    cases = [("q300_t37", 300, (37,), False), ("q576_t200", 576, (200,), False), ("q900_t56", 900, (56,), False),
-             ("q300_t450", 300, (450,), False), ("q900_t900", 900, (900,), False), ("b2_q40", 40, (7, 13), False),
-             ("b2_q300", 300, (37, 120), False), ("negvar", 50, (9,), True), ("t0", 30, (0, 5), False)]
     for name, Q, Ts, neg in cases:
         g = gen(1000 + Q + sum(Ts))
         B = len(Ts)
@@ -256,7 +262,11 @@ def g45_matcher_criterion():
         for k, v in losses.items():
             put(d, f"{name}/L_{k}", v)
         put(d, f"{name}/B", np.array(B))
-    np.savez_compressed(os.path.join(OUT, "g45_matcher_criterion.npz"), **d)
+    np.savez_compressed(os.path.join(OUT, fname), **d)
+
+
+def g45_large_t():
+    g45_matcher_criterion(G45_LARGE_T, "g45_large_t.npz")
 
 
 # ----------------------------------------------------------------------------- G6 end-to-end tiny
@@ -337,8 +347,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     install_stubs()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g6", "g8"]
-    fns = {"g1": g1_rcda, "g2": g2_pos, "g3": g3_block, "g45": g45_matcher_criterion, "g6": g6_e2e, "g8": g8_count}
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g45", "g45L", "g6", "g8"]
+    fns = {"g1": g1_rcda, "g2": g2_pos, "g3": g3_block, "g45": g45_matcher_criterion, "g45L": g45_large_t, "g6": g6_e2e, "g8": g8_count}
     for w in which:
         fns[w]()
         print("wrote", w)

@@ -88,7 +88,8 @@ def _batch(B, H, W, Ts, seed):
 
 
 @gpu
-@pytest.mark.parametrize("Ts,cap", [((7, 13), 128), ((0, 31), 128), ((100, 3), 100), ((130, 40), 512), ((250, 0), 512)])
+@pytest.mark.parametrize("Ts,cap", [((7, 13), 128), ((0, 31), 128), ((100, 3), 100), ((130, 40), 512), ((250, 0), 512),
+                                    ((600, 40), 1024), ((1024, 1024), 1024), ((2000, 3), 2048), ((1025, 0), 2048), ((3731, 100), 3800), ((2049, 3800), 3800)])
 def test_capacity_plan_equals_exact_plan_on_device(Ts, cap):
     """Device matcher + fused criterion on PackedTargets with a capacity plan == on the reference's list of dicts with the exact
     plan: Hungarian indices bit-exact (rows beyond min(Q, T) are not part of the contract), every loss equal."""
@@ -142,6 +143,32 @@ def test_cached_graph_steps_equal_eager_steps_on_varied_batches():
     # keys: (128x160, cap 100) x3 [7,13 / 64,0 / 1,100], (96x128, 100) x2, (64x96, 100), (128x160, cap 512) -> 4 captures for 7 steps
     assert tr.cache_stats == {"captures": 4, "steps": 7}
     assert sorted(e["replays"] for e in tr._cache.values()) == [1, 1, 2, 3]
+
+
+@gpu
+def test_cached_graph_steps_with_crowded_images():
+    """FSC-147's crowded images (up to 3731 targets per image, A2/data/fsc147.py:80-84): the capacity classes 1024 / 2048 / 3800 of
+    the captured step (cost-matrix slots b * Q * Tcap in the [Q][T] layout, the one-workgroup LDS solver) == the stream-ordered
+    step with the exact plan; the 2048 graph is replayed with other counts."""
+    from counting_detr_amd.engine import Trainer
+    model, crit, args = _build(Q=100)
+    tr = Trainer(model, crit, args, device=DEV)
+    seq = [((2, 64, 96), (1100, 5)), ((2, 64, 96), (37, 2100)), ((2, 64, 96), (3731, 0)), ((2, 64, 96), (1500, 1025)), ((2, 64, 96), (600, 1024))]
+    state = lambda: [t.detach().clone() for t in (tr.flat_p, tr.exp_avg, tr.exp_avg_sq, tr.opt_state)]      # noqa: E731
+    for i, ((B, H, W), Ts) in enumerate(seq):
+        images, rects, tg = _batch(B, H, W, Ts, seed=300 + i)
+        saved = state()
+        eo = {k: float(v) for k, v in tr.train_step(images, rects, tg).items()}
+        p_eager = tr.flat_p.detach().clone()
+        for dst, src in zip((tr.flat_p, tr.exp_avg, tr.exp_avg_sq, tr.opt_state), saved):
+            dst.copy_(src)
+        go = {k: float(v) for k, v in tr.step(images, rects, tg).items()}
+        torch.cuda.synchronize()
+        for k in eo:
+            np.testing.assert_allclose(go[k], eo[k], rtol=1e-4 if k == "grad_norm" else 1e-5, atol=1e-6, err_msg=f"step {i} {k}")
+        diff = (tr.flat_p - p_eager).abs()
+        assert float(diff.max()) <= 2.1e-4 and float((diff > 2e-6).float().mean()) < 2e-3, f"step {i}"
+    assert tr.cache_stats == {"captures": 3, "steps": 5}          # classes 2048 (x2), 3800 (x2), 1024
 
 
 @gpu

@@ -323,13 +323,20 @@ def test_multihead_rcda_module_vs_oracle(precision):
 
 # ----------------------------------------------------------------------------------------------------- matcher
 G45 = ["q300_t37", "q576_t200", "q900_t56", "q300_t450", "q900_t900", "b2_q40", "b2_q300", "t0"]
+# FSC-147's crowded images (up to 3731 targets, A2/data/fsc147.py:80-84 -> A2/models/matcher.py:229-247): reference vectors of
+# oracle/gen_golden.py g45L; they reach the LDS-resident solver's column limit and the [Q][T] (T > Q) layout at every query count
+G45L = ["q300_t3000", "q576_t3731", "q900_t3000", "b2_q300_t2100", "q300_t1100"]
 
 
-@pytest.mark.parametrize("name", G45)
+def _g45_file(name):
+    return "g45_large_t.npz" if name in G45L else "g45_matcher_criterion.npz"
+
+
+@pytest.mark.parametrize("name", G45 + G45L)
 def test_matcher_golden(golden, name):
     """Device cost + device LSAP reproduce the REFERENCE's Hungarian indices bit-exactly (golden vectors)."""
     from counting_detr_amd.matcher import OriginalHungarianMatcher
-    z = golden("g45_matcher_criterion.npz")
+    z = golden(_g45_file(name))
     B = int(z[f"{name}/B"])
     outs = {k: torch.from_numpy(z[f"{name}/{k}"]).to(DEV) for k in ("pred_logits", "pred_boxes")}
     tg = []
@@ -343,13 +350,13 @@ def test_matcher_golden(golden, name):
         assert np.array_equal(idx[b][1].numpy(), z[f"{name}/idx_j{b}"]), f"idx_j image {b}"
 
 
-@pytest.mark.parametrize("name", ["q300_t37", "q576_t200", "q900_t56", "q300_t450", "q900_t900", "b2_q40", "b2_q300", "negvar", "t0"])
+@pytest.mark.parametrize("name", ["q300_t37", "q576_t200", "q900_t56", "q300_t450", "q900_t900", "b2_q40", "b2_q300", "negvar", "t0"] + G45L)
 @pytest.mark.parametrize("fused", [False, True])
 def test_criterion_golden(golden, name, fused):
     """SetCriterion (fused kernel and tensor-op composition) vs the REFERENCE's losses and input gradients (golden vectors)."""
     from counting_detr_amd.anchor_detr import SetCriterion
     from counting_detr_amd.matcher import OriginalHungarianMatcher
-    z = golden("g45_matcher_criterion.npz")
+    z = golden(_g45_file(name))
     B = int(z[f"{name}/B"])
     outs = {k: torch.from_numpy(z[f"{name}/{k}"]).to(DEV).requires_grad_(True) for k in ("pred_logits", "pred_boxes", "pred_vars")}
     tg = []
@@ -392,7 +399,9 @@ def test_match_cost_values(golden):
 @pytest.mark.parametrize("Q,T,kind", [(300, 37, "float"), (64, 64, "ties"), (50, 120, "ties"), (120, 50, "ints"),
                                       (900, 900, "float"), (300, 1500, "float"), (7, 1, "float"), (300, 120, "float"),
                                       (300, 120, "ties"), (300, 120, "ints"), (576, 200, "ties"), (130, 128, "ties"),
-                                      (65, 64, "ints"), (320, 319, "ties"), (512, 3, "ints"), (1000, 64, "ties")])
+                                      (65, 64, "ints"), (320, 319, "ties"), (512, 3, "ints"), (1000, 64, "ties"),
+                                      (300, 3000, "float"), (300, 3731, "ints"), (576, 3731, "float"), (900, 3000, "ties"),
+                                      (300, 3800, "float"), (900, 2049, "ints")])
 def test_lsap_vs_scipy(Q, T, kind):
     """The device solver returns scipy's (row_ind, col_ind), ties included, when fed the same matrix."""
     from scipy.optimize import linear_sum_assignment

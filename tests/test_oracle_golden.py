@@ -82,11 +82,12 @@ def test_g3_bottleneck(golden, name):
 
 
 G45 = ["q300_t37", "q576_t200", "q900_t56", "q300_t450", "q900_t900", "b2_q40", "b2_q300", "negvar", "t0"]
+G45L = ["q300_t3000", "q576_t3731", "q900_t3000", "b2_q300_t2100", "q300_t1100"]      # FSC-147's crowded images (up to 3731 targets)
 
 
-@pytest.mark.parametrize("name", G45)
+@pytest.mark.parametrize("name", G45 + G45L)
 def test_g45_matcher_criterion(golden, name):
-    z = golden("g45_matcher_criterion.npz")
+    z = golden("g45_large_t.npz" if name in G45L else "g45_matcher_criterion.npz")
     B = int(z[f"{name}/B"])
     outs = {k: T(z[f"{name}/{k}"]).clone().requires_grad_(True) for k in ("pred_logits", "pred_boxes", "pred_vars")}
     tg = []
