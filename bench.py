@@ -209,12 +209,13 @@ def extra_shape(dev, H, W, queries, prior, Ts, batch, precision, steps=10):
     tr = build_trainer(dev, queries, prior, precision)
     images, rects, targets = synthetic_batch(batch, H, W, Ts, seed=0, device=dev)
     tr.capture(images, rects, targets, warmup=1)
+    rp = (lambda: tr.replay(pipelined=True)) if tr._entry.get("fs") is not None else tr.replay      # one batch of look-ahead, like the main line
     for _ in range(3):
-        tr.replay()
+        rp()
 
     def bar():
         torch.cuda.synchronize()
-    dt, per, out = timed_steps(tr.replay, steps, bar)
+    dt, per, out = timed_steps(rp, steps, bar)
     q = out["loss"]
     Q = tr.model.transformer.num_position * tr.model.transformer.num_pattern
     return {"image": [H, W], "queries": Q, "spatial_prior": prior, "targets": list(Ts), "images_per_gpu": batch,
@@ -369,6 +370,9 @@ def main(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip the extra shapes (grid-576 queries, 384x576 image)")
     ap.add_argument("--no-inference", action="store_true", help="skip the inference leg (forward + counting rule, graph replay)")
     ap.add_argument("--no-real-data", action="store_true", help="skip the graph-cache leg (variable image sizes / target counts)")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="graph mode: run the frozen stage (stem + layer1) of a batch inside its own step instead of beside the previous step's "
+                         "matcher / backward (engine.Trainer: frozen-stage prefetch)")
     a = ap.parse_args(argv)
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -398,6 +402,8 @@ def main(argv=None):
     from counting_detr_amd import ops
     H, W = a.size
     Ts = (37, 120)
+    if a.no_prefetch:
+        os.environ["CDETR_FROZEN_PREFETCH"] = "0"
     trainer = build_trainer(dev, a.queries, a.prior, a.precision)
     Q = a.queries if a.prior == "learned" else int(round(a.queries ** 0.5)) ** 2
     images, rects, targets = synthetic_batch(a.batch, H, W, Ts, seed=1000 * rank, device=dev)
@@ -442,7 +448,12 @@ def main(argv=None):
     elif mode == "graph":
         trainer.capture(images, rects, targets, warmup=1)
     a.no_graph = (mode == "eager")
-    step = eager_step if mode == "eager" else trainer.replay
+    # graph replay of a fixed batch, one step of look-ahead: every step ALSO computes the frozen stage (stem + layer1: no trainable
+    # parameter, no gradient) for the step that follows, beside its own Hungarian solve / backward -- what main.py's loop does with the
+    # next batch of the loader.  Work per step is unchanged (one frozen stage + one trainable step); --no-prefetch runs it in line.
+    pipelined = mode == "graph" and trainer._entry is not None and trainer._entry.get("fs") is not None
+    graph_step = (lambda: trainer.replay(pipelined=True)) if pipelined else trainer.replay
+    step = eager_step if mode == "eager" else graph_step
     for _ in range(a.warmup):
         out = step()
     if world > 1:
@@ -578,13 +589,27 @@ def main(argv=None):
                       "images_per_gpu": a.batch, "global_batch": a.batch * world, "parallelism": f"dp{world}",
                       "graph": not a.no_graph, "mode_probe_ms": probe, "precision": a.precision,
                       "precision_backward": ({1: "bf16x3", 2: "bf16x2", 3: "bf16"}[ops.PRECISION_BWD] if a.precision != "fp32" else "fp32"),
-                      "final_loss": loss},
+                      "final_loss": loss,
+                      "frozen_stage_prefetch": bool(pipelined and mode != "eager")},
            "step_ms": percentiles(per_step),
            "per_rank_ms_per_step": per_rank_ms,
            "scaling_note": ("measured on %d ranks" % world) if world > 1 else
                            "single-GPU line; no N > 1 scaling curve has been measured for this repo yet (one-GPU leases only: the driver's "
                            "SCALE run is the first RCCL execution of the N > 1 path)",
            "roofline": roofline}
+    if pipelined and mode != "eager":
+        # the same captured step with its frozen stage in line (no look-ahead): short run on the same box, for transparency
+        for _ in range(3):
+            trainer.replay()
+        dtn, pern, _ = timed_steps(trainer.replay, 10, barrier)
+        res["frozen_stage_prefetch"] = {
+            "what": "graph replay with one batch of look-ahead: a step also runs the frozen stage (stem + max-pool + layer1: no trainable parameter, "
+                    "the images need no gradient -- A2/models/backbone.py:93-95) of the batch that FOLLOWS, as its own graph on its own stream "
+                    "released between the step's [forward] and [matcher + criterion + backward + optimizer] graphs, i.e. beside the Hungarian "
+                    "solve (one wavefront per image, chip idle) and the latency-bound start of the backward.  Work per step is unchanged: one "
+                    "frozen stage + one trainable step; `value` is timed this way (main.py's loop does the same with the loader's next batch)",
+            "in_line_ms_per_step": dtn / 10 * 1e3, "in_line_step_ms": percentiles(pern), "prefetched_ms_per_step": ms_per_step,
+            "hits": trainer.prefetch_stats["hits"], "in_line_runs": trainer.prefetch_stats["inline"]}
     if world > 1:
         ex = torch.tensor([sum(exposed) / max(len(exposed), 1) if exposed else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)

@@ -27,7 +27,7 @@ class GemmDesc(C.Structure):
                 ("B", _p), ("ldb", C.c_int64), ("sB", C.c_int64),
                 ("C", _p), ("ldc", C.c_int64), ("sC", C.c_int64),
                 ("w_scale", _p), ("bias", _p), ("resid", _p), ("ldr", C.c_int64), ("gate", _p), ("ldg", C.c_int64),
-                ("g", ConvGeom), ("B_split", _p), ("batch_inner", C.c_int32), ("pad_", C.c_int32),
+                ("g", ConvGeom), ("B_split", _p), ("batch_inner", C.c_int32), ("flags", C.c_int32),
                 ("sA2", C.c_int64), ("sB2", C.c_int64), ("sC2", C.c_int64), ("A16", _p), ("C16", _p),
                 ("splitk_ws", _p), ("splitk_ws_bytes", C.c_int64), ("A16lo", _p), ("B16", _p), ("gate16", _p), ("C16lo", _p)]
 

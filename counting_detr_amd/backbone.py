@@ -70,12 +70,13 @@ class Bottleneck(nn.Module):
         self.downsample = nn.Sequential(ConvW(inplanes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)) if has_down else None
         self.stride, self.dilation = stride, dilation
 
-    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False, xlo=None, split=False, last=False):
+    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False, xlo=None, split=False, last=False, out_to=None):
         """twins: every activation a weight gradient of this block will read (a1, a2) and the block's output (the next block's x) also
         leave their producing epilogue as a bf16 copy (ops.bf16_twins); x16 = the twin of x, from the previous block.
         twin_out: only the output gets a twin (the last frozen block in front of the trainable ones).
         split: every activation leaves its epilogue as split-bf16 planes hi | lo (ops.split_forward: the operand format of the
-        direct-to-LDS tile kernel); x16 / xlo = the planes of x; the hi planes double as the backward's twins.  -> (out, hi, lo)."""
+        direct-to-LDS tile kernel); x16 / xlo = the planes of x; the hi planes double as the backward's twins.  -> (out, hi, lo).
+        out_to = (y, y16): caller-owned buffers the block's output (and its twin) are written to (fixed addresses: ResNetBody.frozen_stage)."""
         twin_out = twin_out or twins
         s1, b1 = self.bn1.affine()
         s2, b2 = self.bn2.affine()
@@ -121,7 +122,8 @@ class Bottleneck(nn.Module):
             a2, a2_16 = a2 if twins else (a2, None)
         if br is not None:
             br.join()
-        out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, twin=twin_out, xs=(a2_16, a2l) if a2l is not None else None)
+        out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, twin=twin_out, xs=(a2_16, a2l) if a2l is not None else None,
+                           out=out_to[0] if out_to is not None else None, out16=out_to[1] if out_to is not None else None)
         out, out16 = out if twin_out else (out, None)
         if not twins:
             a2_16 = None
@@ -151,11 +153,13 @@ class Bottleneck(nn.Module):
                 d_idn = ops.conv_dgrad(dz, wd0, sd0, x.shape[1:3], stride=st, dz16=dz16)
         if w3.requires_grad:
             ops.conv_wgrad_(dz, a2, w3, s3, dz16=dz16, x16=a2_16 if tw else None)
-        dz2 = ops.conv_dgrad(dz, w3, s3, a2.shape[1:3], gate=a2, twin=tw, dz16=dz16, gate16=a2_16 if tw else None)      # masked by relu(a2)
+        # dz2 / dz1 are read by the next data gradient and one weight gradient only -- plain-bf16 contractions fed by the twin: no fp32 copy
+        dz2 = ops.conv_dgrad(dz, w3, s3, a2.shape[1:3], gate=a2, twin=tw, dz16=dz16, gate16=a2_16 if tw else None, twin_only=True)      # masked by relu(a2)
         dz2, dz2_16 = dz2 if tw else (dz2, None)
         if w2.requires_grad:
             ops.conv_wgrad_(dz2, a1, w2, s2, stride=st, pad=dl, dil=dl, dz16=dz2_16, x16=a1_16 if tw else None)
-        dz1 = ops.conv_dgrad(dz2, w2, s2, a1.shape[1:3], stride=st, pad=dl, dil=dl, gate=a1, twin=tw, dz16=dz2_16, gate16=a1_16 if tw else None)
+        dz1 = ops.conv_dgrad(dz2, w2, s2, a1.shape[1:3], stride=st, pad=dl, dil=dl, gate=a1, twin=tw, dz16=dz2_16, gate16=a1_16 if tw else None,
+                             twin_only=True)
         dz1, dz1_16 = dz1 if tw else (dz1, None)
         if w1.requires_grad:
             ops.conv_wgrad_(dz1, x, w1, s1, dz16=dz1_16, x16=x16 if tw else None)
@@ -285,6 +289,7 @@ class ResNetBody(nn.Module):
             setattr(self, f"layer{li}", nn.Sequential(*blocks))
         self._stem_w4 = None
         self._stem_wr = None
+        self.frozen_input = None      # see forward_nhwc
         self.stem_packed = True       # row-packed stem (stem_rows); False = one tap per filter element (stem_weight4)
 
     def stem_weight4(self):
@@ -327,12 +332,12 @@ class ResNetBody(nn.Module):
         ops.gemm_raw(xp, 4, wr, 7 * 32, y, 64, B * Ho * Wo, 64, 32, taps=7, w_scale=s, bias=b, relu=True, geom=g)
         return y
 
-    def forward_nhwc(self, images):
-        """images [B,3,H,W] (NCHW, as the reference API) -> layer4 features NHWC [B,H/16,W/16,2048]."""
+    def frozen_stage(self, images, twins, out_to=None):
+        """The part of the trunk that never trains and whose input needs no gradient (A2/models/backbone.py:93-95: conv1 + layer1
+        frozen): stem + max-pool + layer1, images [B,3,H,W] -> (x NHWC [B,H/4,W/4,256], bf16 twin of x or None, lo plane or None).
+        It depends on nothing a training step updates, so a trainer may run it for the NEXT batch while the current step is in its
+        latency-bound phases (engine.Trainer: frozen-stage prefetch).  out_to = (x, x16) caller-owned output buffers."""
         B, _, H, W = images.shape
-        blocks = list(self.layer2) + list(self.layer3) + list(self.layer4)
-        train = torch.is_grad_enabled() and any(p.requires_grad for blk in blocks for p in blk.parameters())
-        twins = train and ops.bf16_twins()            # layer1's output is layer2's first weight-gradient operand: it gets a twin too
         with torch.no_grad():
             if self.stem_packed:
                 x = self.stem_rows(images)
@@ -344,16 +349,41 @@ class ResNetBody(nn.Module):
             split = ops.split_forward() and images.is_cuda
             x16 = xlo = None
             if split:
+                assert out_to is None
                 x, x16, xlo = ops.maxpool3x3s2(x, split=True)
                 for blk in self.layer1:
                     x, x16, xlo = blk.forward_fused(x, x16=x16, xlo=xlo, split=True)
             else:
                 x = ops.maxpool3x3s2(x)
                 for i, blk in enumerate(self.layer1):
-                    if twins and i == len(self.layer1) - 1:
-                        x, x16 = blk.forward_fused(x, twin_out=True)
+                    if i == len(self.layer1) - 1 and (twins or out_to is not None):
+                        x, x16 = blk.forward_fused(x, twin_out=True, out_to=out_to)
                     else:
                         x = blk.forward_fused(x)
+        return x, x16, xlo
+
+    @staticmethod
+    def frozen_out_hw(H, W):
+        """Spatial size of the frozen stage's output: 7x7 / 2 stem (pad 3), then 3x3 / 2 max-pool (pad 1)."""
+        return ((H - 1) // 2 + 1 - 1) // 2 + 1, ((W - 1) // 2 + 1 - 1) // 2 + 1
+
+    def frozen_stage_is_frozen(self):
+        return not any(p.requires_grad for m in (self.conv1, self.layer1) for p in m.parameters())
+
+    def forward_nhwc(self, images):
+        """images [B,3,H,W] (NCHW, as the reference API) -> layer4 features NHWC [B,H/16,W/16,2048].
+        `self.frozen_input` = (x, x16) (set by a trainer around its captured forward): the frozen stage's output for THESE images has
+        already been computed into those buffers (frozen_stage(..., out_to=...)) -- it is not run again."""
+        B, _, H, W = images.shape
+        blocks = list(self.layer2) + list(self.layer3) + list(self.layer4)
+        train = torch.is_grad_enabled() and any(p.requires_grad for blk in blocks for p in blk.parameters())
+        twins = train and ops.bf16_twins()            # layer1's output is layer2's first weight-gradient operand: it gets a twin too
+        split = ops.split_forward() and images.is_cuda
+        if self.frozen_input is not None:
+            (x, x16), xlo = self.frozen_input, None
+            assert tuple(x.shape) == (B,) + self.frozen_out_hw(H, W) + (256,) and not split, (tuple(x.shape), (B, H, W))
+        else:
+            x, x16, xlo = self.frozen_stage(images, twins)
         anchor = self.layer4[-1].conv3.weight
         if train:
             return _TrunkFn.apply(x, anchor, blocks, x16, xlo)

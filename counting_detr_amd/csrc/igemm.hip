@@ -2017,10 +2017,17 @@ bool gemm_is_f44(const cdetr_gemm_desc& d) {
 bool gemm_is_f24(const cdetr_gemm_desc& d) {
     return d.precision >= 1 && d.b_layout == 0 && (d.N % 128) == 0 && gemm_blocks(d, 64, 64) < 512;
 }
+}  // namespace
+bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d);      // igemm_dl.hip
+namespace {
 int check_gemm_desc(const cdetr_gemm_desc& d) {
     CDETR_CHECK_ARG(d.M >= 0 && d.N > 0 && d.K > 0 && d.taps > 0 && d.batch > 0, "cdetr_gemm: bad sizes M=%d N=%d K=%d taps=%d batch=%d",
                     d.M, d.N, d.K, d.taps, d.batch);
-    CDETR_CHECK_ARG(d.A && d.B && d.C, "cdetr_gemm: null A/B/C");
+    CDETR_CHECK_ARG((d.A || d.A16) && d.B && (d.C || d.C16 || ((d.flags & CDETR_GEMM_C_GROUPS) && d.C16lo)), "cdetr_gemm: null A / B / output");
+    // C == nullptr: the fp32 output is not wanted (an inner gradient of a bottleneck that only the next bf16 contraction reads): only the
+    // direct-to-LDS kernel writes the bf16 twin alone -- the problem must be eligible for it (cdetr_gemm_dl_eligible)
+    // (likewise A == NULL: the operand exists as its twin A16 only)
+    CDETR_CHECK_ARG((d.C && d.A && !d.flags) || cdetr_gemm_dl_eligible(d), "cdetr_gemm: A == NULL / C == NULL need A16 / C16 and direct-to-LDS-eligible operands (A16, B16 / B_split, K %% 64 == 0)");
     CDETR_CHECK_ARG(d.b_layout == 0 || d.b_layout == 1, "cdetr_gemm: b_layout %d", d.b_layout);
     if (d.g.mode == CDETR_ROWS_DENSE) {
         CDETR_CHECK_ARG(d.taps == 1, "cdetr_gemm: dense rows need taps == 1");
@@ -2095,6 +2102,11 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     const char* force_s = cdetr_tune_env("CDETR_GEMM_VARIANT");
     const int force = force_s ? atoi(force_s) : 0;
     const bool fast_ok = vecA && vecB && (d.K % 32) == 0;
+    if (!d.C || !d.A || d.flags) { // grouped operands, twin-only output / operand: the direct-to-LDS kernel is the only one that handles it (check_gemm_desc made sure it can)
+        int stages = 3;
+        const int tile = gemm_dl_choice(d, stages);
+        return cdetr_gemm_dl_launch(d, tile >= 0 ? tile : 3, stages, st);
+    }
     // CDETR_GEMM_VARIANT (tests / tools/gemm_sweep.py): 3 = 64x64 BK64, 4 = 64x64, 9 = 64x128 (8 waves), 10 = 128x128 (16 waves),
     // 13 = 96x128 (12 waves) -- the tiles of the default dispatch --, 5 = the few-row kernel, 6 = the generic kernel
     if (force == 9 && fast_ok) return launch_gemm_fast<2, 4, 1, 1, 32>(d, st);
@@ -2263,9 +2275,15 @@ extern "C" int cdetr_gemm_group(const cdetr_gemm_desc* descs, int32_t n, void* s
 }
 
 namespace {
+bool wgrad_has_twins(const cdetr_wgrad_desc& d);
+bool wgrad_is_direct(const cdetr_wgrad_desc& d);
+bool wgrad_is_fast(const cdetr_wgrad_desc& d);
 int check_wgrad_desc(const cdetr_wgrad_desc& d) {
     CDETR_CHECK_ARG(d.P >= 0 && d.Nout > 0 && d.Cin > 0 && d.taps > 0 && d.batch > 0, "cdetr_wgrad: bad sizes");
-    CDETR_CHECK_ARG(d.dY && d.X && d.dW, "cdetr_wgrad: null pointer");
+    CDETR_CHECK_ARG((d.dY || d.dY16) && d.X && d.dW, "cdetr_wgrad: null pointer");
+    // dY == NULL: the gradient exists as its bf16 twin only (cdetr_gemm_desc.C == NULL upstream): the twin-fed tile kernel must be the one that runs
+    CDETR_CHECK_ARG(d.dY || (wgrad_has_twins(d) && wgrad_is_fast(d) && !wgrad_is_direct(d)),
+                    "cdetr_wgrad: dY == NULL needs dY16 + X16, plain-bf16 products and a problem of the tile-kernel class");
     CDETR_CHECK_ARG(aligned16(d.dY) && aligned16(d.X) && (d.sY & 3) == 0 && (d.sX & 3) == 0 && (d.sY2 & 3) == 0 && (d.sX2 & 3) == 0, "cdetr_wgrad: dY/X must be 16-byte aligned");
     if (d.g.mode == CDETR_ROWS_DENSE) {
         CDETR_CHECK_ARG(d.taps == 1, "cdetr_wgrad: dense rows need taps == 1");

@@ -40,7 +40,10 @@ struct DlCfg {
 
 // PROBE: wave 0 of every workgroup stamps s_memtime at its phase boundaries into cdetr_gemm_desc.splitk_ws (8 x uint64 per workgroup:
 // start, prologue issued, first tile landed, k-loop done, epilogue operands loaded, stores issued) -- tools/dl_probe.py.
-template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false>
+// EARLY: the epilogue's operands (bias, residual rows, gate rows -- nothing the k-loop computes) are requested BEFORE the first operand
+// tile, so their HBM round trip (2.9 of a 64 x 64 / K = 256 workgroup's 11.7 us in the phase probe, profiles/r3_dl_probe_v1.txt) runs under
+// the k-loop; loads complete in issue order, so the counted vmcnt waits of the ring stay valid (the older loads have landed by then).
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true>
 __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN) {
     using Cf = DlCfg<FM, FN, TERMS, STAGES>;
     unsigned long long* probe = PROBE ? reinterpret_cast<unsigned long long*>(d.splitk_ws) + (long)blockIdx.x * 8 : nullptr;
@@ -73,12 +76,47 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     const int K = d.K, taps = d.taps;
     const int nkt_tap = K / KT, nkt = nkt_tap * taps;
 
+    // ---------------------------------------------------------------- epilogue geometry + its operand loads
+    // (the accumulators are transposed through LDS at the end so that LR = 4 FN lanes hold 8 consecutive channels each of ONE row)
+    constexpr int LDW = 32 * FN + 4;                            // floats per staged row
+    constexpr int LR = 4 * FN;                                  // lanes per output row (8 channels each)
+    constexpr int RPP = 64 / LR;                                // rows per pass of the wave
+    constexpr int NPASS = 32 * FM / RPP;
+    static_assert(32 * FM * LDW * 4 * 4 <= Cf::LDS, "the staging tiles fit the ring");
+    const int rr = lane / LR, cc = (lane % LR) * 8;
+    const int n = n0 + wn * 32 * FN + cc;
+    const bool v0 = n < d.N, v1 = n + 4 < d.N;                  // the two 4-channel halves of this lane's 8 channels (N % 4 == 0)
+    const int nl0 = min(n, d.N - 4), nl1 = min(n + 4, d.N - 4);
+    const int mw = m0 + wm * 32 * FM;
+    const __bf16* __restrict__ g16 = d.gate ? reinterpret_cast<const __bf16*>(d.gate16) : nullptr;      // bf16 twin of the gate: same sign, half the bytes
+    float4 bia[2], res[NPASS][2];
+    uint2 gat16[NPASS][2];
+    // residual / gate-twin rows of every pass: ONE batch of unconditional loads (clamped row / channel, masked use).  An fp32 gate without
+    // a twin (not a product configuration: the kernel's operands ARE twins) is fetched in the epilogue: twice the registers for the k-loop
+    auto load_epilogue_operands = [&]() __attribute__((always_inline)) {
+        bia[0] = d.bias ? *reinterpret_cast<const float4*>(d.bias + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bia[1] = d.bias ? *reinterpret_cast<const float4*>(d.bias + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int p = 0; p < NPASS; ++p) {
+            const long mrow = min(mw + p * RPP + rr, d.M - 1);
+            res[p][0] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            res[p][1] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            gat16[p][0] = g16 ? *reinterpret_cast<const uint2*>(g16 + mrow * d.ldg + nl0) : make_uint2(0x3f803f80u, 0x3f803f80u);
+            gat16[p][1] = g16 ? *reinterpret_cast<const uint2*>(g16 + mrow * d.ldg + nl1) : make_uint2(0x3f803f80u, 0x3f803f80u);
+        }
+    };
+    if constexpr (EARLY) load_epilogue_operands();
+
     // ---------------------------------------------------------------- loader state: which 16 bytes this lane fetches
     const int prow = tid >> 3;                                  // row inside a 32-row pass (one pass = one load per thread)
     const int chunk = (tid & 7) ^ ((tid >> 4) & 7);             // logical chunk behind LDS slot (tid & 7) of row prow (+ 32 j)
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(dl_zero_page) + (tid & 7) * 16;
-    const __bf16* Apl = reinterpret_cast<const __bf16*>((TERMS == 3 && (chunk >> 2)) ? d.A16lo : d.A16);
-    const int a_kk = (TERMS == 3) ? (chunk & 3) * 8 : chunk * 8;
+    // A: interleaved groups [hi 32 | lo 32] (A_split: one full line per row and k-tile), or the hi / lo planes (two half lines)
+    const bool a_il = TERMS == 3 && (d.flags & CDETR_GEMM_A_GROUPS);
+    const __bf16* Apl = reinterpret_cast<const __bf16*>((TERMS == 3 && (chunk >> 2) && !a_il) ? d.A16lo : d.A16);
+    const int a_kk = a_il ? chunk * 8 : (TERMS == 3) ? (chunk & 3) * 8 : chunk * 8;
+    const long a_ld = a_il ? 2 * d.lda : d.lda;                  // row stride in bf16 elements
+    const int a_kb = a_il ? 4 : 2;                              // bytes along k per k-value
     RowCoord arow[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) arow[j] = decode_row(d.g, m0 + j * 32 + prow, d.M);
@@ -89,7 +127,7 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const long row = gather_row(d.g, arow[j], tap);
-            ap[j] = row >= 0 ? reinterpret_cast<const unsigned char*>(Apl + row * d.lda + a_kk) : zero;
+            ap[j] = row >= 0 ? reinterpret_cast<const unsigned char*>(Apl + row * a_ld + a_kk) : zero;
             amask |= (row >= 0 ? 1u : 0u) << j;
         }
     };
@@ -105,7 +143,7 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     }
     const int bshift = (TERMS == 1 && d.B16) ? 1 : 2;           // log2(bytes per k of the weight image)
     auto issue = [&](int stage, int tap, int kc) __attribute__((always_inline)) {
-        const int koa = kc * 2;                                 // bytes along k of the A planes
+        const int koa = kc * a_kb;                              // bytes along k of the A planes / groups
         const long kob = ((long)tap * K + kc) << bshift;        // bytes along (tap, k) of the weight image
         unsigned char* la = smem + stage * A_STAGE + w * 1024;
         unsigned char* lb = smem + STAGES * A_STAGE + stage * B_STAGE + w * 1024;
@@ -199,11 +237,6 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     // gate loads and the C / C16 / C16lo stores are full 128- / 256-byte row segments (8 rows per instruction) instead of 16 bytes
     // in each of 32 rows.  Staging rows are padded by 16 bytes: the float4 writes of 8 consecutive lanes (8 rows, same column) and
     // the row-major float4 reads both spread over the banks.
-    constexpr int LDW = 32 * FN + 4;                            // floats per staged row
-    constexpr int LR = 4 * FN;                                  // lanes per output row (8 channels each)
-    constexpr int RPP = 64 / LR;                                // rows per pass of the wave
-    constexpr int NPASS = 32 * FM / RPP;
-    static_assert(32 * FM * LDW * 4 * 4 <= Cf::LDS, "the staging tiles fit the ring");
     __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring
     float* stg = reinterpret_cast<float*>(smem) + w * (32 * FM * LDW);
 #pragma unroll
@@ -216,35 +249,20 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
                     make_float4(acc[b][a][4 * q], acc[b][a][4 * q + 1], acc[b][a][4 * q + 2], acc[b][a][4 * q + 3]);
     float* __restrict__ C = d.C;
     __bf16* __restrict__ C16 = reinterpret_cast<__bf16*>(d.C16);
-    __bf16* __restrict__ C16lo = reinterpret_cast<__bf16*>(d.C16lo);
-    const int rr = lane / LR, cc = (lane % LR) * 8;
-    const int n = n0 + wn * 32 * FN + cc;
-    const bool v0 = n < d.N, v1 = n + 4 < d.N;                  // the two 4-channel halves of this lane's 8 channels (N % 4 == 0)
-    const int nl0 = min(n, d.N - 4), nl1 = min(n + 4, d.N - 4);
-    float bias8[8];
-    {
-        const float4 b0 = d.bias ? *reinterpret_cast<const float4*>(d.bias + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 b1 = d.bias ? *reinterpret_cast<const float4*>(d.bias + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
-        bias8[0] = b0.x; bias8[1] = b0.y; bias8[2] = b0.z; bias8[3] = b0.w; bias8[4] = b1.x; bias8[5] = b1.y; bias8[6] = b1.z; bias8[7] = b1.w;
-    }
-    const int mw = m0 + wm * 32 * FM;
-    // residual / gate rows of every pass: ONE batch of unconditional loads (clamped row / channel, masked use) ahead of the math
-    float4 res[NPASS][2], gat[NPASS][2];
-    const __bf16* __restrict__ g16 = d.gate ? reinterpret_cast<const __bf16*>(d.gate16) : nullptr;      // bf16 twin of the gate: same sign, half the bytes
+    const bool c_il = d.flags & CDETR_GEMM_C_GROUPS;
+    __bf16* __restrict__ C16lo = c_il ? nullptr : reinterpret_cast<__bf16*>(d.C16lo);
+    unsigned char* __restrict__ Cil = c_il ? reinterpret_cast<unsigned char*>(d.C16lo) : nullptr;       // (N % 32 == 0: a lane's 8 channels never straddle a group)
+    if constexpr (!EARLY) load_epilogue_operands();
+    float4 gat32[NPASS][2];
+    if (d.gate && !g16) {
 #pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-        const long mrow = min(mw + p * RPP + rr, d.M - 1);
-        res[p][0] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        res[p][1] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g16) {
-            const uint2 t0 = *reinterpret_cast<const uint2*>(g16 + mrow * d.ldg + nl0), t1 = *reinterpret_cast<const uint2*>(g16 + mrow * d.ldg + nl1);
-            gat[p][0] = make_float4(__uint_as_float(t0.x << 16), __uint_as_float(t0.x & 0xffff0000u), __uint_as_float(t0.y << 16), __uint_as_float(t0.y & 0xffff0000u));
-            gat[p][1] = make_float4(__uint_as_float(t1.x << 16), __uint_as_float(t1.x & 0xffff0000u), __uint_as_float(t1.y << 16), __uint_as_float(t1.y & 0xffff0000u));
-        } else {
-            gat[p][0] = d.gate ? *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl0) : make_float4(1.f, 1.f, 1.f, 1.f);
-            gat[p][1] = d.gate ? *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl1) : make_float4(1.f, 1.f, 1.f, 1.f);
+        for (int p = 0; p < NPASS; ++p) {
+            const long mrow = min(mw + p * RPP + rr, d.M - 1);
+            gat32[p][0] = *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl0);
+            gat32[p][1] = *reinterpret_cast<const float4*>(d.gate + mrow * d.ldg + nl1);
         }
     }
+    const float bias8[8] = {bia[0].x, bia[0].y, bia[0].z, bia[0].w, bia[1].x, bia[1].y, bia[1].z, bia[1].w};
     if constexpr (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(4); }
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
@@ -254,7 +272,13 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
         const float4 s1 = *reinterpret_cast<const float4*>(stg + row * LDW + cc + 4);
         const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
         const float re[8] = {res[p][0].x, res[p][0].y, res[p][0].z, res[p][0].w, res[p][1].x, res[p][1].y, res[p][1].z, res[p][1].w};
-        const float ga[8] = {gat[p][0].x, gat[p][0].y, gat[p][0].z, gat[p][0].w, gat[p][1].x, gat[p][1].y, gat[p][1].z, gat[p][1].w};
+        float ga[8] = {__uint_as_float(gat16[p][0].x << 16), __uint_as_float(gat16[p][0].x & 0xffff0000u), __uint_as_float(gat16[p][0].y << 16),
+                       __uint_as_float(gat16[p][0].y & 0xffff0000u), __uint_as_float(gat16[p][1].x << 16), __uint_as_float(gat16[p][1].x & 0xffff0000u),
+                       __uint_as_float(gat16[p][1].y << 16), __uint_as_float(gat16[p][1].y & 0xffff0000u)};
+        if (d.gate && !g16) {
+            const float4 t0 = gat32[p][0], t1 = gat32[p][1];
+            ga[0] = t0.x; ga[1] = t0.y; ga[2] = t0.z; ga[3] = t0.w; ga[4] = t1.x; ga[5] = t1.y; ga[6] = t1.z; ga[7] = t1.w;
+        }
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -272,6 +296,11 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
             if (C) {
                 *reinterpret_cast<float4*>(C + o) = make_float4(v[0], v[1], v[2], v[3]);
                 if (v1) *reinterpret_cast<float4*>(C + o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            }
+            if (Cil) {          // interleaved groups: 8 consecutive channels = 16 bytes of the hi half + 16 bytes of the lo half of one group
+                unsigned char* gp = Cil + ((long)m * d.ldc + (n & ~31)) * 4 + (n & 31) * 2;
+                *reinterpret_cast<u32x4*>(gp) = h;
+                *reinterpret_cast<u32x4*>(gp + 64) = l;
             }
             if (C16) {
                 if (v1 && ((o & 7) == 0)) {
@@ -292,11 +321,11 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     if constexpr (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6); }
 }
 
-template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false>
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true>
 int launch_dl(const cdetr_gemm_desc& d, hipStream_t st) {
     using Cf = DlCfg<FM, FN, TERMS, STAGES>;
     const int tilesM = (d.M + Cf::BM - 1) / Cf::BM, tilesN = (d.N + Cf::BN - 1) / Cf::BN;
-    auto kern = igemm_dl_kernel<FM, FN, TERMS, STAGES, PROBE>;
+    auto kern = igemm_dl_kernel<FM, FN, TERMS, STAGES, PROBE, EARLY>;
     if (Cf::LDS > 64 * 1024) {
         static bool raised = false;                             // per instantiation
         if (!raised) {
@@ -322,7 +351,11 @@ bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d) {
     if (!d.B_split && !(d.precision == 3 && d.B16)) return false;
     if (d.B16 && ((reinterpret_cast<uintptr_t>(d.B16) & 15) || (d.ldb & 7))) return false;
     if (d.precision != 1 && d.precision != 3) return false;
-    if (d.precision == 1 && !d.A16lo) return false;
+    const bool a_groups = d.flags & CDETR_GEMM_A_GROUPS, c_groups = d.flags & CDETR_GEMM_C_GROUPS;
+    if ((a_groups || c_groups) && d.precision != 1) return false;
+    if (d.precision == 1 && !d.A16lo && !a_groups) return false;
+    if (a_groups && (d.lda & 31)) return false;
+    if (c_groups && (!d.C16lo || (reinterpret_cast<uintptr_t>(d.C16lo) & 15) || (d.ldc & 31) || (d.N & 31))) return false;
     const int KT = d.precision == 1 ? 32 : 64;
     if (d.K % KT != 0 || (d.lda & 7) != 0 || (d.ldb & 31) != 0 || (d.N & 3) != 0 || (d.ldc & 3) != 0) return false;
     if ((reinterpret_cast<uintptr_t>(d.A16) & 15) || (reinterpret_cast<uintptr_t>(d.A16lo) & 15) || (reinterpret_cast<uintptr_t>(d.B_split) & 15)) return false;
@@ -331,21 +364,28 @@ bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d) {
     if (d.gate && ((reinterpret_cast<uintptr_t>(d.gate) & 15) || (d.ldg & 3))) return false;
     if (d.gate16 && (reinterpret_cast<uintptr_t>(d.gate16) & 7)) return false;
     if (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15)) return false;
-    if (!d.C && !d.C16) return false;
-    if (d.C16lo && !d.C16) return false;
+    if (!d.C && !d.C16 && !c_groups) return false;
+    if (d.C16lo && !d.C16 && !c_groups) return false;
     return true;
 }
 
 // tile: 0 = 128x128, 1 = 128x64 (rows x channels), 2 = 64x128, 3 = 64x64; stages 2..4
 int cdetr_gemm_dl_launch(const cdetr_gemm_desc& d, int tile, int stages, hipStream_t st) {
     const bool x3 = d.precision == 1;
+    static const bool late = getenv("CDETR_DL_LATE_EPILOGUE") != nullptr;       // A/B: epilogue operands fetched after the k-loop (round 3)
     if (stages >= 100) {                                        // phase probe (tools/dl_probe.py): splitk_ws receives the time stamps
         if (!d.splitk_ws) { cdetr_set_error("cdetr_gemm_dl: the phase probe writes into splitk_ws"); return CDETR_ERR_ARG; }
-        if (tile == 0 && stages == 103) return x3 ? launch_dl<2, 2, 3, 3, true>(d, st) : launch_dl<2, 2, 1, 3, true>(d, st);
-        if (tile == 3 && stages == 103) return x3 ? launch_dl<1, 1, 3, 3, true>(d, st) : launch_dl<1, 1, 1, 3, true>(d, st);
-        if (tile == 1 && stages == 103) return x3 ? launch_dl<2, 1, 3, 3, true>(d, st) : launch_dl<2, 1, 1, 3, true>(d, st);
+#define DL_PROBE(FM, FN)                                                                                                  \
+    return late ? (x3 ? launch_dl<FM, FN, 3, 3, true, false>(d, st) : launch_dl<FM, FN, 1, 3, true, false>(d, st))         \
+                : (x3 ? launch_dl<FM, FN, 3, 3, true>(d, st) : launch_dl<FM, FN, 1, 3, true>(d, st))
+        if (tile == 0 && stages == 103) { DL_PROBE(2, 2); }
+        if (tile == 3 && stages == 103) { DL_PROBE(1, 1); }
+        if (tile == 1 && stages == 103) { DL_PROBE(2, 1); }
+#undef DL_PROBE
     }
-#define DL_GO(FM, FN, S) return x3 ? launch_dl<FM, FN, 3, S>(d, st) : launch_dl<FM, FN, 1, S>(d, st)
+#define DL_GO(FM, FN, S)                                                                                            \
+    return late ? (x3 ? launch_dl<FM, FN, 3, S, false, false>(d, st) : launch_dl<FM, FN, 1, S, false, false>(d, st)) \
+                : (x3 ? launch_dl<FM, FN, 3, S>(d, st) : launch_dl<FM, FN, 1, S>(d, st))
     switch (tile * 8 + stages) {
         case 0 * 8 + 2: DL_GO(2, 2, 2);
         case 0 * 8 + 3: DL_GO(2, 2, 3);

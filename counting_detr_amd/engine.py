@@ -175,6 +175,11 @@ class Trainer:
         self._cap_stream = None
         self._cache = {}                        # step(): captured steps by (image shape, exemplar shape, target capacity, arithmetic), LRU order
         self._pool = None                       # ONE graph memory pool for every cached step (entries never run concurrently)
+        import os as _os
+        self._prefetch_on = bool(getattr(args, "frozen_prefetch", True)) and _os.environ.get("CDETR_FROZEN_PREFETCH", "1") != "0"
+        self._frozen = {}                       # image shape -> frozen-stage buffers + graph (see "frozen-stage prefetch")
+        self._pf_stream = self._pf_pool = None
+        self.prefetch_stats = {"hits": 0, "inline": 0}
         self._cache_on = bool(getattr(args, "graph_cache", True))
         self._cache_size = int(getattr(args, "graph_cache_size", 32))
         self.cache_stats = {"captures": 0, "steps": 0}
@@ -349,20 +354,28 @@ class Trainer:
             return torch.clamp(t / get_world_size(), min=1)[0]
         return max(nb, 1.0)
 
-    def _fwd_bwd(self, images, mask, rects, targets, num_boxes, defer_trunk=False):
-        """zero-grad + weight images + forward + criterion + backward.  `defer_trunk`: stop the backward at the backbone (the
-        gradient w.r.t. layer4's output is parked in `self._trunk_pending`, a backbone.TrunkBackward) -- the caller runs the
-        three backbone segments itself (`_trunk_segment`)."""
+    def _forward(self, images, mask, rects):
+        """Forward weight images + model forward.  Leaves ops.MIRROR armed: `_loss_backward` (or `_trunk_segment(last=True)`) disarms it."""
         from .misc import NestedTensor
         from . import ops
-        # weight images, armed for this step only: the forward operands now; the data-gradient operands and the gradient arena's
-        # zero-fill are not needed before the backward starts, so they run on a side stream UNDER the criterion -- the Hungarian solve
-        # is one wavefront per image for ~0.3 ms, the rest of the chip is idle there (in a captured step: a parallel graph branch)
         if self.mirror is not None:
             self.mirror.refresh("fwd")
         ops.MIRROR = self.mirror
         try:
             outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
+        except BaseException:
+            ops.MIRROR = None
+            raise
+        return outputs
+
+    def _loss_backward(self, outputs, targets, num_boxes, defer_trunk=False):
+        """zero-grad + data-gradient weight images (side stream, under the criterion) + criterion + backward.  `defer_trunk`: stop the
+        backward at the backbone (the gradient w.r.t. layer4's output is parked in `self._trunk_pending`, a backbone.TrunkBackward) --
+        the caller runs the three backbone segments itself (`_trunk_segment`)."""
+        from . import ops
+        # the data-gradient operands and the gradient arena's zero-fill are not needed before the backward starts, so they run on a side
+        # stream UNDER the criterion -- the Hungarian solve is one wavefront per image for ~0.3 ms (in a captured step: a parallel graph branch)
+        try:
             main = torch.cuda.current_stream() if self.flat_g.is_cuda else None
             if main is not None:
                 if self._side is None:
@@ -397,6 +410,10 @@ class Trainer:
         out = {k: v.detach() for k, v in loss_dict.items()}
         out["loss"] = losses.detach()
         return out
+
+    def _fwd_bwd(self, images, mask, rects, targets, num_boxes, defer_trunk=False):
+        """zero-grad + weight images + forward + criterion + backward (stream-ordered step and warm-ups)."""
+        return self._loss_backward(self._forward(images, mask, rects), targets, num_boxes, defer_trunk)
 
     def _trunk_segment(self, seg, last=False):
         """Backward of one backbone segment (1 = layer4, 2 = layer3, 3 = layer2) of a deferred trunk backward."""
@@ -499,6 +516,101 @@ class Trainer:
             self._cache.clear()
             self._entry = None
 
+    # ------------------------------------------------------------------ frozen-stage prefetch
+    # The stem + layer1 (A2/models/backbone.py:93-95: frozen, and the images need no gradient) of batch i+1 depends on nothing step i
+    # updates.  It is an HBM-bound 0.6 ms at two 800x800 images; the step has a window where the chip is all but idle (the Hungarian
+    # solve: one wavefront per image for ~0.3 ms, then the latency-bound decoder / encoder backward).  So a captured step is TWO graphs,
+    # [forward] | [matcher + criterion + backward (+ optimizer)], and between their launches the frozen stage of the NEXT batch -- its own
+    # small graph per image shape, on its own stream, with its own graph memory pool and split-reduction scratch -- is released behind an
+    # event: it runs beside the solve.  Its fp32 output goes straight into the buffer the next forward reads (this step's forward is done
+    # with it; the backward reads the bf16 twin only), the twin into a staging copy that the next step moves over (41 MB, ~15 us).
+    # A batch that was not announced (first step, another object than the announced one) runs its frozen stage in line, as before.
+    def _prefetch_ok(self):
+        from . import ops
+        body = self.model.backbone.body
+        return (self._prefetch_on and self.flat_g.is_cuda and body.frozen_stage_is_frozen() and ops.bf16_twins()
+                and not ops.split_forward())
+
+    def _frozen_for(self, shape):
+        """Static buffers + captured graph of the frozen stage for one padded image shape."""
+        from . import ops
+        shape = tuple(shape)
+        fs = self._frozen.get(shape)
+        if fs is not None:
+            return fs
+        body = self.model.backbone.body
+        B, _, H, W = shape
+        h, w = body.frozen_out_hw(H, W)
+        dev = self.device
+        fs = {"images": torch.zeros(shape, device=dev), "x": torch.empty((B, h, w, 256), device=dev),
+              "x16": torch.empty((B, h, w, 256), device=dev, dtype=torch.bfloat16),
+              "x16s": torch.empty((B, h, w, 256), device=dev, dtype=torch.bfloat16), "token": None, "keep": None}
+        if self._pf_stream is None:
+            # (a HIP CU-masked stream -- hipExtStreamCreateWithCUMask, leaving 16-64 CUs to the step's own latency-bound chain -- was tried:
+            # with such a queue alive EVERY launch of the process slowed down, 9.3 -> 19 ms per step, in-line replays included:
+            # profiles/r4_prefetch_ab.txt; an ordinary stream it is)
+            self._pf_stream = torch.cuda.Stream(device=dev)
+            self._pf_pool = torch.cuda.graph_pool_handle()      # NOT the steps' pool: this graph runs beside a step's backward
+        ps = self._pf_stream
+        prev = ops.MIRROR
+        ops.MIRROR = self.mirror
+        beside = ops.BRANCH_BESIDE
+        try:
+            if self.mirror is not None:
+                self.mirror.refresh("fwd")                      # the frozen layers' pre-split images (rewritten, unchanged, by every step)
+            ps.wait_stream(torch.cuda.current_stream())
+            beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0    # a LINEAR graph: every node runs on the (CU-masked) stream it is launched on
+            with torch.cuda.stream(ps):
+                body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))       # lazily cached tables exist before the capture
+            torch.cuda.current_stream().wait_stream(ps)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            mode = {"capture_error_mode": "thread_local"} if get_world_size() > 1 else {}
+            with torch.cuda.graph(g, pool=self._pf_pool, stream=ps, **mode):
+                body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))
+        finally:
+            ops.MIRROR = prev
+            ops.BRANCH_BESIDE = beside
+        fs["graph"] = g
+        self._frozen[shape] = fs
+        return fs
+
+    @staticmethod
+    def _token(obj):
+        """Identity of a batch as the caller hands it over: the image tensor object itself ([B,3,H,W], or a NestedTensor's `.tensors`)
+        and its version counter -- an announced batch is recognised when the very same, unmodified tensor comes back.  None: a list of
+        images (padded into a fresh tensor on arrival) cannot be announced."""
+        t = obj.tensors if hasattr(obj, "tensors") else obj
+        if not torch.is_tensor(t) or t.dim() != 4 or not t.is_cuda:
+            return None
+        return (id(t), t._version, t.data_ptr())
+
+    def _frozen_ready(self, e, token):
+        """Make the frozen stage's output for the entry's current images available in fs['x'] / fs['x16'] (main stream)."""
+        fs = e["fs"]
+        main = torch.cuda.current_stream()
+        main.wait_stream(self._pf_stream)                       # whatever was prefetched has landed
+        if token is None or fs["token"] != token:               # not announced: in line
+            fs["images"].copy_(e["st"]["images"])
+            fs["graph"].replay()
+            self.prefetch_stats["inline"] += 1
+        else:
+            self.prefetch_stats["hits"] += 1
+        fs["token"] = fs["keep"] = None
+        fs["x16"].copy_(fs["x16s"])
+
+    def _prefetch(self, images, token, keep):
+        """Release the frozen stage of the announced next batch behind everything issued so far on the current stream."""
+        fs = self._frozen_for(images.shape)
+        ps = self._pf_stream
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        ps.wait_event(ev)
+        with torch.cuda.stream(ps):
+            fs["images"].copy_(images, non_blocking=True)
+            fs["graph"].replay()
+        fs["token"], fs["keep"] = token, keep                   # (`keep`: the announced object stays alive, so its id cannot be re-used)
+
     def _capture_entry(self, images, mask, rects, targets, warmup=0):
         st = self._make_static(images, mask, rects, targets)
         st["sizes"] = tuple(len(t["boxes"]) for t in targets)
@@ -508,11 +620,20 @@ class Trainer:
         # CDETR_SEGMENTED_GRAPH=1: the five-graph form on ONE rank (no collectives): what the segmentation itself costs (tools / DESIGN section 7)
         import os
         segmented = world > 1 or os.environ.get("CDETR_SEGMENTED_GRAPH", "0") == "1"
+        body = self.model.backbone.body
+        fs = self._frozen_for(images.shape) if self._prefetch_ok() else None
         try:
-            g_a, segs, g_b, out = self._capture_graphs(st, world, warmup, segmented)
+            if fs is not None:                     # the captured forward reads the frozen stage's output from fixed buffers
+                fs["images"].copy_(st["images"])
+                fs["graph"].replay()
+                fs["x16"].copy_(fs["x16s"])
+                fs["token"] = None
+                body.frozen_input = (fs["x"], fs["x16"])
+            g_f, g_a, segs, g_b, out = self._capture_graphs(st, world, warmup, segmented)
         finally:                                   # a failed capture must leave the stream-ordered step intact
             _bb.set_backward_hook(hook)
-        return {"g_a": g_a, "segs": segs, "g_b": g_b, "st": st, "out": out, "replays": 0}
+            body.frozen_input = None
+        return {"g_f": g_f, "g_a": g_a, "segs": segs, "g_b": g_b, "st": st, "out": out, "replays": 0, "fs": fs, "loads": 0}
 
     def _capture_graphs(self, st, world, warmup, segmented):
         self._dry_run(st)
@@ -535,21 +656,25 @@ class Trainer:
         # ANOTHER thread invalidates a capture in progress.  "thread_local" confines the check to the capturing thread, so a rank can
         # capture at any time -- ranks meet different image sizes at different steps, a rendezvous here would deadlock.
         mode = {"capture_error_mode": "thread_local"} if world > 1 else {}
-        g_a = torch.cuda.CUDAGraph()
-        segs = None
         # every cached step allocates from ONE pool: a step's activations are dead when the next graph launch starts (same stream, the
         # returned loss scalars stay allocated while their entry lives), so N cached shapes cost the memory of the largest, not the sum
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         mode["pool"] = self._pool
+        # [forward] | [criterion + backward ...]: two graphs, so that the next batch's frozen stage can be released between their launches
+        g_f = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_f, stream=s, **mode):
+            outputs = self._forward(st["images"], st["mask"], st["rects"])
+        g_a = torch.cuda.CUDAGraph()
+        segs = None
         if not segmented:
             with torch.cuda.graph(g_a, stream=s, **mode):
-                out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
+                out = self._loss_backward(outputs, st["targets"], st["num_boxes"])
                 out["grad_norm"] = self._optimizer_step()
             g_b = None
         else:                                      # (capturing records work, it does not run it)
             with torch.cuda.graph(g_a, stream=s, **mode):
-                out = self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"], defer_trunk=True)
+                out = self._loss_backward(outputs, st["targets"], st["num_boxes"], defer_trunk=True)
             segs = []
             for seg in (1, 2, 3):
                 g = torch.cuda.CUDAGraph()
@@ -559,7 +684,8 @@ class Trainer:
             g_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_b, stream=s, **mode):
                 out["grad_norm"] = self._optimizer_step()
-        return g_a, segs, g_b, out
+        del outputs
+        return g_f, g_a, segs, g_b, out
 
     def _load_entry(self, e, images, mask, rects, targets):
         st = e["st"]
@@ -574,9 +700,20 @@ class Trainer:
         st["rects"].copy_(rects)
         st["targets"].load(targets)
         self._load_num_boxes(st, targets)
+        e["loads"] += 1
 
-    def _replay_entry(self, e):
+    def _replay_entry(self, e, token=None, next_samples=None):
+        """token: identity of the batch now in the entry's static buffers (None: unknown -> the frozen stage runs in line).
+        next_samples: the batch the caller will hand to the NEXT step (the same object), or None."""
         e["replays"] += 1
+        if e["fs"] is not None:
+            self._frozen_ready(e, token)
+        e["g_f"].replay()
+        if e["fs"] is not None and next_samples is not None:
+            tok = self._token(next_samples)
+            if tok is not None:
+                nxt = next_samples.tensors if hasattr(next_samples, "tensors") else next_samples
+                self._prefetch(nxt, tok, nxt)
         e["g_a"].replay()
         if e["g_b"] is not None:
             self.exchange.segment_done(0)          # everything above the backbone is final: first bucket leaves now
@@ -587,25 +724,53 @@ class Trainer:
             e["g_b"].replay()
         return e["out"]
 
-    def replay(self, samples=None, rects=None, targets=None):
+    def replay(self, samples=None, rects=None, targets=None, next_samples=None, pipelined=False):
         """Run the captured step; with arguments, on a NEW batch of the captured image size whose target counts fit the captured
-        capacity class (copied into the graph's static inputs first)."""
+        capacity class (copied into the graph's static inputs first).  `next_samples`: the batch object that will be passed to the next
+        `replay` / `step` call -- its frozen stage (stem + layer1) is computed beside this step's matcher / backward.
+        `pipelined=True` (no new batch): the captured batch is replayed step after step and every step also computes the frozen stage
+        for the following one (the benchmark's fixed-batch loop: same work per step, one step of look-ahead)."""
         e = self._entry
+        token = None
         if samples is not None:
             nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
             images, mask = nt.decompose()
             self._load_entry(e, images, mask, rects, targets)
-        return self._replay_entry(e)
+            token = self._token(samples)
+        elif pipelined and e["fs"] is not None:
+            token = ("entry", id(e), e["loads"])
+            out = self._replay_pipelined(e, token)
+            return out
+        return self._replay_entry(e, token, next_samples)
+
+    def _replay_pipelined(self, e, token):
+        e["replays"] += 1
+        self._frozen_ready(e, token)
+        e["g_f"].replay()
+        fs = e["fs"]
+        self._prefetch(e["st"]["images"], token, None)          # the "next batch" of a fixed-batch loop is the captured one
+        assert self._frozen_for(e["st"]["images"].shape) is fs
+        e["g_a"].replay()
+        if e["g_b"] is not None:
+            self.exchange.segment_done(0)
+            for seg, g in zip((1, 2, 3), e["segs"]):
+                g.replay()
+                self.exchange.segment_done(seg)
+            self.exchange.finish()
+            e["g_b"].replay()
+        return e["out"]
 
     # ------------------------------------------------------------------ graph cache: the step the data loader drives
-    def step(self, samples, rects, targets):
+    def step(self, samples, rects, targets, next_samples=None):
         """One training step on an arbitrary batch at graph-replay speed: captured steps are cached by (padded image size, batch,
         target-capacity class, arithmetic mode); a batch whose key is new is captured first (one dry forward + the capture, ~0.1 s),
-        every later batch of that key is three small copies + one graph launch.  FSC-147 images are 384 high and a multiple of 32
+        every later batch of that key is three small copies + the graph launches.  FSC-147 images are 384 high and a multiple of 32
         wide after the reference's resize rule (A2/data/fsc147.py:75-77), so an epoch meets a few dozen keys; the least recently
         used entry is dropped beyond `args.graph_cache_size`.  `args.graph_cache` off (--no_graph_cache): the stream-ordered `train_step`.
         With aux_loss=True the per-layer matchings run as one cost + one assignment launch per layer inside the graph (the stacked
-        single-launch form of the stream-ordered step needs count-dependent offsets).  Returns the step's loss dict (device scalars; valid
+        single-launch form of the stream-ordered step needs count-dependent offsets).
+        `next_samples`: the batch object the NEXT call will receive as `samples` (a look-ahead of one batch, engine.train_one_epoch does
+        it): its frozen stage runs beside this step's matcher / backward.  Returns the step's loss dict (device scalars; valid
         until the same entry is replayed again)."""
         from . import ops
         if not self._cache_on or not self.flat_g.is_cuda or not self.counts_on_device():
@@ -616,10 +781,13 @@ class Trainer:
         cap = self.target_capacity(max([len(t["boxes"]) for t in targets], default=0))
         key = (tuple(images.shape), tuple(rects.shape), cap, ops.PRECISION, ops.PRECISION_BWD)
         e = self._cache.pop(key, None)
+        token = self._token(samples)
         if e is None:
             while len(self._cache) >= max(self._cache_size, 1):
                 torch.cuda.synchronize()           # nothing of the entry being dropped is still running
                 self._cache.pop(next(iter(self._cache)))
+            fs0 = self._frozen.get(tuple(images.shape))
+            pre = fs0 is not None and fs0["token"] == token
             while True:
                 try:
                     e = self._capture_entry(images, mask, rects, targets)
@@ -631,11 +799,13 @@ class Trainer:
                     self._cache.pop(next(iter(self._cache)))
                     torch.cuda.empty_cache()
             self.cache_stats["captures"] += 1
+            token = None                           # (the capture recomputed the frozen stage itself; whatever was prefetched is spent)
+            del pre
         else:
             self._load_entry(e, images, mask, rects, targets)
         self._cache[key] = e                       # most recently used last
         self.cache_stats["steps"] += 1
-        return self._replay_entry(e)
+        return self._replay_entry(e, token, next_samples)
 
 
 def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
@@ -659,10 +829,21 @@ def train_one_epoch(trainer, data_loader, epoch, print_freq=100, log=print):
             log({"nonfinite_steps": bad, "iteration": it, **(vals or {})})
             sys.exit(1)
 
+    def lookahead(loader):                     # (batch, next batch or None): the trainer runs the next batch's frozen stage beside this step
+        prev = None
+        for cur in loader:
+            if prev is not None:
+                yield prev, cur
+            prev = cur
+        if prev is not None:
+            yield prev, None
+
     it = -1
-    for it, ret in enumerate(data_loader):
+    for it, (ret, nxt) in enumerate(lookahead(data_loader)):
         samples = NestedTensor(ret["image"], ret["mask"]) if "mask" in ret else ret["image"]     # data.collate pads + masks
-        out = trainer.step(samples, ret["ex_rects"], ret["targets"])       # cached HIP graph per padded size / target-capacity class
+        nxt_img = nxt["image"] if (nxt is not None and torch.is_tensor(nxt.get("image"))) else None
+        # cached HIP graph per padded size / target-capacity class; the next batch's image tensor is announced (frozen-stage prefetch)
+        out = trainer.step(samples, ret["ex_rects"], ret["targets"], next_samples=nxt_img)
         if keys is None:
             keys = sorted(k for k, v in out.items() if torch.is_tensor(v))
             acc = torch.zeros(len(keys), device=trainer.device, dtype=torch.float32)

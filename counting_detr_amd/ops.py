@@ -80,10 +80,15 @@ def splitk_ws():
 
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
-             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None, A16lo=None, C16lo=None, dl=None, probe_ws=None, B16=None, gate16=None):
+             batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None, A16lo=None, C16lo=None, dl=None, probe_ws=None, B16=None, gate16=None,
+             A_split=None, C_split=None):
     """dl = (tile, stages): run the direct-to-LDS tile kernel with that configuration (cdetr_gemm_dl; tests / sweeps)."""
     d = GemmDesc()
     d.C16, d.A16, d.A16lo, d.C16lo, d.B16, d.gate16 = ptr(C16), ptr(A16), ptr(A16lo), ptr(C16lo), ptr(B16), ptr(gate16)
+    if A_split is not None:        # interleaved groups [hi 32 | lo 32] travel in the A16 / C16lo fields under a flag (include/cdetr_hip.h)
+        d.A16, d.flags = ptr(A_split), d.flags | 1
+    if C_split is not None:
+        d.C16lo, d.flags = ptr(C_split), d.flags | 2
     d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION if precision is None else precision
@@ -102,7 +107,7 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
         d.splitk_ws, d.splitk_ws_bytes = ptr(ws), SPLITK_BYTES
     if _GEMM_QUEUE is not None:       # inside gemm_queue(): submitted together by its exit (cdetr_gemm_group)
         _GEMM_QUEUE.append((d, 2.0 * M * N * K * taps * batch, 4.0 * (M * K + N * K * taps + M * N) * max(batch, 1),
-                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16, A16lo, C16lo, B16, gate16), _TERMS[d.precision]))
+                            (A, B, Cout, bias, w_scale, resid, gate, B_split, C16, A16, A16lo, C16lo, B16, gate16, A_split, C_split), _TERMS[d.precision]))
         return
     # compulsory fp32 bytes: input rows once (a strided / dilated conv reads <= M*K of them), weights, output
     fl = 2.0 * M * N * K * taps * batch
@@ -263,9 +268,10 @@ class fork_branch:
 
     def __enter__(self):
         main = torch.cuda.current_stream()
-        side = _BR_SIDE.get(main.device)
+        key = (main.device, main.cuda_stream)     # one side stream per parent stream: its split-reduction scratch (splitk_ws) is not shared
+        side = _BR_SIDE.get(key)                  # with a step that runs concurrently on another stream (the frozen-stage prefetch)
         if side is None:
-            side = _BR_SIDE[main.device] = torch.cuda.Stream(device=main.device)
+            side = _BR_SIDE[key] = torch.cuda.Stream(device=main.device)
         side.wait_stream(main)
         self.side, self.ctx = side, torch.cuda.stream(side)
         self.ctx.__enter__()
@@ -295,6 +301,15 @@ def relu_mask(y, dy, scale=1.0, twin=False):
         return dz, dz16
     check(lib().cdetr_relu_mask(ptr(y), ptr(dy), ptr(dz), dy.numel(), scale, stream_ptr()), "cdetr_relu_mask")
     return dz
+
+
+def split_groups(x):
+    """fp32 [..., K] (K % 32 == 0) -> its interleaved split-bf16 form [..., K/32, 64] bf16: per group of 32 values [hi 32 | lo 32]
+    (cdetr_gemm_desc.A_split / B_split; tensor ops: tests and sweeps -- the product's producers write it from their epilogues)."""
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    sh = x.shape[:-1] + (x.shape[-1] // 32, 32)
+    return torch.cat([hi.view(sh), lo.view(sh)], dim=-1).contiguous()
 
 
 def split_planes(x):
@@ -742,7 +757,7 @@ def expand_planes():
     return EXPAND_PLANES and PRECISION == 1 and MIRROR is not None
 
 
-def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False, xs=None, split=False, out=None):
+def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False, xs=None, split=False, out=None, out16=None):
     """x [N,H,W,Cin] NHWC -> [N,Ho,Wo,Cout]; weight logical [Cout,Cin,kh,kw] in channels_last memory.
     y = relu?( conv(x, W) * scale[c] + bias[c] + resid )   (A2/models/resnet.py:140-160 + backbone.py:50-60).
     twin: -> (y, bf16 copy of y written by the same epilogue).  split: -> (y, hi, lo) = y with its split-bf16 planes.
@@ -752,7 +767,7 @@ def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=N
     assert Cin_w == Cin and x.is_contiguous()
     g, Ho, Wo = conv_geom_fwd(H, W, kh, kw, stride, pad, dil)
     y = out if out is not None else torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    y16 = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if (twin or split) else None
+    y16 = out16 if out16 is not None else (torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if (twin or split) else None)
     ylo = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if split else None
     sp = MIRROR.lookup_fwd(weight, scale) if MIRROR is not None else None
     xh, xl = xs if xs is not None else (None, None)
@@ -763,17 +778,30 @@ def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=N
     return (y, y16) if twin else y
 
 
-def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False, dz16=None, gate16=None, out=None):
+TWIN_ONLY = os.environ.get("CDETR_TWIN_ONLY", "1") != "0"      # inner gradients of a bottleneck leave their kernel as the bf16 twin alone (A/B)
+
+
+def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resid=None, twin=False, dz16=None, gate16=None, out=None,
+               twin_only=False):
     """dx [N,Hin,Win,Cin] = conv_transpose(dz * scale, W) (+ resid), zeroed where gate <= 0.  twin: -> (dx, bf16 copy of dx);
-    dz16: the bf16 twin of dz (read instead of dz by the plain-bf16 tile kernels)."""
-    Nb, Ho, Wo, Cout = dz.shape
+    dz16: the bf16 twin of dz (read instead of dz by the plain-bf16 tile kernels).
+    twin_only (with twin): nothing reads the fp32 gradient (every consumer is a plain-bf16 contraction fed by the twin) -> (None, twin)
+    when the problem runs on the direct-to-LDS kernel (cdetr_gemm_desc.C == NULL); otherwise both are written as usual.
+    `dz` may then be None as well (its shape comes from dz16)."""
+    Nb, Ho, Wo, Cout = (dz if dz is not None else dz16).shape
     Cout_w, Cin, kh, kw = weight.shape
     Hin, Win = in_hw
     dense = kh == 1 and kw == 1 and stride == 1 and pad == 0
     g = _geom() if dense else _geom(_ffi.ROWS_CONV_DGRAD, Ho, Wo, Hin, Win, kh, kw, stride, pad, dil)
-    dx = out if out is not None else torch.empty((Nb, Hin, Win, Cin), device=dz.device, dtype=torch.float32)
-    dx16 = torch.empty((Nb, Hin, Win, Cin), device=dz.device, dtype=torch.bfloat16) if twin else None
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
+    # (the consumers must be twin-fed too: the direct-to-LDS data gradient and the tile-class weight gradient -- more than 1024 rows,
+    # 8-channel granularity: csrc/igemm.hip wgrad_has_twins / wgrad_is_direct; a few-row problem keeps its fp32 gradient)
+    no_fp32 = (twin_only and twin and TWIN_ONLY and out is None and m is not None and m[3] is not None and dz16 is not None
+               and bwd_precision() == 3 and Cout % 64 == 0 and Cin % 64 == 0 and Nb * Hin * Win > 1024
+               and os.environ.get("CDETR_WGRAD_TWINS", "1") != "0")
+    assert dz is not None or (m is not None and dz16 is not None), "a gradient that exists as a twin only needs the weight images"
+    dx = out if out is not None else (None if no_fp32 else torch.empty((Nb, Hin, Win, Cin), device=dz16.device if dz is None else dz.device, dtype=torch.float32))
+    dx16 = torch.empty((Nb, Hin, Win, Cin), device=(dz16 if dz is None else dz).device, dtype=torch.bfloat16) if twin else None
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
                  gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], B16=m[3], precision=bwd_precision(), C16=dx16, A16=dz16,
@@ -788,9 +816,10 @@ TWIN_EXPERIMENT = os.environ.get("CDETR_TWIN_EXP", "0") == "1"      # tools only
 
 
 def conv_wgrad_(dz, x, weight, scale, stride=1, pad=0, dil=1, dz16=None, x16=None):
+    """dz may be None when the gradient exists as its twin only (conv_dgrad(twin_only=True))."""
     if TWIN_EXPERIMENT and dz16 is None and bwd_precision() == 3:
         dz16, x16 = dz.to(torch.bfloat16), x.to(torch.bfloat16)
-    Nb, Ho, Wo, Cout = dz.shape
+    Nb, Ho, Wo, Cout = (dz if dz is not None else dz16).shape
     _, H, W, Cin = x.shape
     kh, kw = weight.shape[2:]
     g, Ho2, Wo2 = conv_geom_fwd(H, W, kh, kw, stride, pad, dil)

@@ -57,9 +57,11 @@ typedef struct {
                           3 = plain bf16: both operands rounded, 1 MFMA.  2 / 3 are meant for the BACKWARD passes (data / weight
                           gradients); kernels without a reduced-term form (few-row GEMMs, n-contiguous operands) run them as 1. */
     float out_scale;
-    const float* A; int64_t lda, sA;
+    const float* A; int64_t lda, sA; /* A may be NULL under the same conditions as C below (the operand exists as its bf16 twin A16 only) */
     const float* B; int64_t ldb, sB;
-    float* C; int64_t ldc, sC;
+    float* C; int64_t ldc, sC; /* C may be NULL when C16 is given and the operands are in the direct-to-LDS kernel's formats (A16, B16 or
+                                * B_split, K % 64 == 0, 16-byte aligned): only the bf16 copy is written -- an inner activation gradient of
+                                * a bottleneck is read by nothing but the next bf16 contractions */
     const float* w_scale;
     const float* bias;
     const float* resid; int64_t ldr;
@@ -70,7 +72,8 @@ typedef struct {
                           * the byte offsets of (n, tap, k-group) equal those of the fp32 operand (ldb applies unchanged);
                           * written by cdetr_weight_mirror.  Kernels that cannot use it read B / w_scale instead.          */
     int32_t batch_inner; /* 0: batch item z sits at z*s.  > 0: z = outer*batch_inner + inner sits at inner*s + outer*s2      */
-    int32_t pad_;        /* (e.g. heads inside images: one launch for the per-head GEMMs of every image)                  */
+    int32_t flags;       /* (e.g. heads inside images: one launch for the per-head GEMMs of every image)
+                          * flags: CDETR_GEMM_A_GROUPS / CDETR_GEMM_C_GROUPS below (0 = none)                                       */
     int64_t sA2, sB2, sC2;
     const void* A16;     /* optional: a bf16 TWIN of A (same lda / batch strides, in elements): with precision 3 the tile kernels read it
                           * instead of A -- half the operand bytes, no conversion at staging.  Needs lda and the strides to be multiples
@@ -96,6 +99,14 @@ typedef struct {
     void* C16lo;         /* optional: the LO plane of C written by the same epilogue, C16lo = bf16(C - float(C16)) (needs C16): the
                           * next layer's A16lo.  C itself may then be NULL when no consumer reads the fp32 tensor.                     */
 } cdetr_gemm_desc;
+/* cdetr_gemm_desc.flags (direct-to-LDS kernel, precision 1):
+ * CDETR_GEMM_A_GROUPS: A16 holds A pre-split in INTERLEAVED groups, the format of B_split -- row m = [K/32 groups][hi 32 bf16 | lo 32 bf16],
+ *   i.e. the byte offset of (m, k-group) equals that of the fp32 operand (lda applies unchanged, 4 bytes per element; lda % 32 == 0; A16lo
+ *   unused).  A k-tile of the kernel is then ONE full 128-byte line per row; with the planes A16 / A16lo it is two half lines.
+ * CDETR_GEMM_C_GROUPS: C16lo receives C in the same interleaved form ([N/32 groups][hi 32 | lo 32] per row, ldc applies unchanged,
+ *   N % 32 == 0, ldc % 32 == 0) -- the next layer's grouped A operand; C16 (the plain hi twin) stays optional.                       */
+#define CDETR_GEMM_A_GROUPS 1
+#define CDETR_GEMM_C_GROUPS 2
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 /* The direct-to-LDS tile kernel (csrc/igemm_dl.hip) with an explicit configuration -- what cdetr_gemm picks by itself for problems
  * whose operands are given pre-split (A16 [+ A16lo] and B_split); for tests and tile sweeps.  tile: 0 = 128x128, 1 = 128x64,

@@ -156,3 +156,36 @@ def test_dl_is_what_cdetr_gemm_picks_for_presplit_operands():
     ops.gemm_raw(x, K, w, K, y_old, N, M, N, K, B_split=sp, precision=1)
     assert torch.equal(y_auto, y_forced)
     np.testing.assert_allclose(y_auto.cpu().numpy(), y_old.cpu().numpy(), rtol=0, atol=2e-5 * float(y_old.abs().max()))
+
+
+def test_twin_only_output_through_cdetr_gemm():
+    """cdetr_gemm_desc.C == NULL (an inner gradient of a bottleneck: nothing reads its fp32 copy): the direct-to-LDS kernel writes the
+    bf16 twin alone, bit-identical to the twin of the full call, whatever the problem size; without direct-to-LDS operands the call is
+    refused, not run; the twin-fed weight-gradient kernel accepts dY == NULL the same way."""
+    from counting_detr_amd import ops
+    for (M, N, K) in [(5000, 256, 1024), (300, 64, 128)]:          # the second one is below the kernel's usual size threshold
+        dz = torch.randn(M, K, generator=g(M)).to(DEV)
+        w = (torch.randn(K, N, generator=g(K)) / K ** 0.5).to(DEV)          # logical [Cout = K][Cin = N]
+        gate = torch.randn(M, N, generator=g(3)).to(DEV)
+        mir = ops.WeightMirror([(w, None)], [])
+        mir.refresh("bwd")
+        m = mir.lookup(w, None)
+        dz16 = dz.bfloat16()
+        full, full16, only16 = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV, dtype=torch.bfloat16), torch.zeros(M, N, device=DEV, dtype=torch.bfloat16)
+        kw = dict(gate=gate, ldg=N, B_split=m[2], B16=m[3], precision=3, A16=dz16, gate16=gate.bfloat16())
+        ops.gemm_raw(dz, K, m[0], m[1], full, N, M, N, K, C16=full16, dl=(3, 3), **kw)
+        ops.gemm_raw(None, K, m[0], m[1], None, N, M, N, K, C16=only16, **kw)          # neither the fp32 operand nor the fp32 result exists
+        assert torch.equal(only16, full16) and torch.equal(full16, full.bfloat16())
+        with pytest.raises(RuntimeError):                                       # no twin of A: not a direct-to-LDS problem -> refused
+            ops.gemm_raw(dz, K, m[0], m[1], None, N, M, N, K, C16=only16, gate=gate, ldg=N, B_split=m[2], precision=3)
+    # weight gradient from twins only
+    P, Nout, Cin = 5000, 256, 128
+    dY, X = torch.randn(P, Nout, generator=g(1)).to(DEV), torch.randn(P, Cin, generator=g(2)).to(DEV)
+    dW1, dW2 = torch.zeros(Nout, Cin, device=DEV), torch.zeros(Nout, Cin, device=DEV)
+    ops.wgrad_raw(dY, Nout, X, Cin, dW1, Cin, P, Nout, Cin, dY16=dY.bfloat16(), X16=X.bfloat16(), precision=3)
+    ops.wgrad_raw(None, Nout, X, Cin, dW2, Cin, P, Nout, Cin, dY16=dY.bfloat16(), X16=X.bfloat16(), precision=3)
+    ref = dY.bfloat16().double().t() @ X.bfloat16().double()
+    assert (dW2.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    np.testing.assert_allclose(dW1.cpu().numpy(), dW2.cpu().numpy(), rtol=0, atol=1e-5 * float(ref.abs().max()))     # (atomic accumulation order)
+    with pytest.raises(RuntimeError):
+        ops.wgrad_raw(None, Nout, X, Cin, dW2, Cin, P, Nout, Cin, dY16=dY.bfloat16(), precision=3)       # no X twin

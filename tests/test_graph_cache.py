@@ -172,6 +172,67 @@ def test_cached_graph_steps_with_crowded_images():
 
 
 @gpu
+def test_frozen_stage_prefetch_equals_the_in_line_step():
+    """engine.Trainer's frozen-stage prefetch: announcing the next batch (`next_samples`) makes its stem + layer1 run beside the
+    current step's matcher / backward; the training trajectory is the one of the trainer that runs them in line (same losses step by
+    step, same parameters to atomic-order noise) -- over batches of changing shapes, an announced batch that does not come (another
+    tensor arrives: in-line run), a batch modified after it was announced (version counter: in-line run), and un-announced steps."""
+    from counting_detr_amd.engine import Trainer
+    trs = []
+    for on in (True, False):
+        model, crit, args = _build(Q=100)
+        args.frozen_prefetch = on
+        trs.append(Trainer(model, crit, args, device=DEV))
+    ta, tb = trs
+    assert ta._prefetch_ok() and not tb._prefetch_ok()
+    shapes = [(2, 64, 96), (2, 64, 96), (2, 96, 128), (2, 64, 96), (2, 64, 96), (2, 64, 96), (2, 96, 128)]
+    batches = [_batch(B, H, W, (5 + i, 20 - i), seed=500 + i) for i, (B, H, W) in enumerate(shapes)]
+    decoy = _batch(2, 64, 96, (3, 3), seed=999)[0]
+    for i, (images, rects, tg) in enumerate(batches):
+        nxt = batches[i + 1][0] if i + 1 < len(batches) else None
+        if i == 3:
+            nxt = decoy                                   # announced, never delivered
+        if i == 5:
+            nxt = None                                    # not announced
+        oa = ta.step(images, rects, tg, next_samples=nxt)
+        if i == 1:
+            batches[2][0].add_(0.25)                      # the announced batch changes before it is delivered: its prefetched stage is stale
+        ob = tb.step(images, rects, tg)
+        torch.cuda.synchronize()
+        for k in ob:
+            np.testing.assert_allclose(float(oa[k]), float(ob[k]), rtol=3e-3 if i else (2e-4 if k == "grad_norm" else 1e-5), atol=1e-6, err_msg=f"step {i} {k}")
+            # (two trainers drift apart by the atomic-order noise of their updates; a STALE frozen stage -- the batch of step 2 was shifted by
+            # 0.25 after it was announced -- would move the losses by O(1))
+    diff = (ta.flat_p - tb.flat_p).abs()
+    assert float(diff.max()) <= 1e-3 and float((diff > 1e-5).float().mean()) < 1e-2
+    # steps 1, 3 (same shape as announced) hit; 2 was modified, 4 got another tensor than announced, 6 was not announced; 0 is the first
+    # step; every first meeting of a key (steps 0 and 2) recomputes in line inside the capture
+    assert ta.prefetch_stats["hits"] == 3, ta.prefetch_stats          # steps 1, 3, 5
+    assert tb.prefetch_stats == {"hits": 0, "inline": 0}
+
+
+@gpu
+def test_pipelined_replay_equals_plain_replay():
+    """Trainer.replay(pipelined=True) (bench.py's fixed-batch loop: every step computes the frozen stage for the following one) ==
+    Trainer.replay() step by step."""
+    from counting_detr_amd.engine import Trainer
+    outs = []
+    for pipelined in (True, False):
+        model, crit, args = _build(Q=100)
+        tr = Trainer(model, crit, args, device=DEV)
+        tr.capture(*_batch(2, 96, 128, (7, 30), seed=5), warmup=0)
+        losses = []
+        for _ in range(4):
+            losses.append(float(tr.replay(pipelined=pipelined)["loss"]))
+        torch.cuda.synchronize()
+        outs.append((losses, tr.flat_p.detach().clone(), dict(tr.prefetch_stats)))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-4)
+    assert outs[0][0][-1] < outs[0][0][0]                 # it trains
+    assert outs[0][2] == {"hits": 3, "inline": 1} and outs[1][2] == {"hits": 0, "inline": 4}
+    assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-3
+
+
+@gpu
 def test_graph_cache_evicts_least_recently_used():
     from counting_detr_amd.engine import Trainer
     model, crit, args = _build(Q=100)

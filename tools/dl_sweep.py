@@ -10,6 +10,7 @@ import torch
 from counting_detr_amd import ops, _ffi
 
 DEV = "cuda"
+GROUPS = os.environ.get("DL_SWEEP_GROUPS", "0") == "1"      # also time the interleaved-groups operand format (forward only)
 CONFIGS = [(0, 2), (0, 3), (1, 2), (1, 3), (1, 4), (2, 3), (3, 3), (3, 4)]
 # (M rows, N, K, taps, conv geometry (H, W, stride, pad, dil) or None, epilogue with residual)
 FWD = [(80000, 64, 64, 1, None, False), (80000, 64, 64, 9, (200, 200, 1, 1, 1), False), (80000, 256, 64, 1, None, True),
@@ -58,10 +59,21 @@ def run(shape, precision, mult=1):
 
     def old(i):
         ops.gemm_raw(As[i], K, w4, taps * K, Cs[i], N, M, N, K, taps=taps, bias=bias, relu=True, resid=Rs[i] if resid else None, ldr=N, geom=g,
-                     B_split=sp, precision=precision, A16=Ah[i] if precision == 3 else None, C16=C16[i], C16lo=C16l[i] if C16l else None)
+                     B_split=sp, precision=precision, A16=Ah[i] if precision == 3 else None, C16=C16[i],
+                     C16lo=C16l[i] if (C16l and not GROUPS) else None)      # (GROUPS: what the product's forward writes: fp32 + the hi twin = 6 bytes per element, like the grouped form)
     row = {}
     os.environ["CDETR_GEMM_DL"] = "0"
     row["old"] = bench(old, nsets)
+    if GROUPS and precision == 1:
+        # round 4: the activation stored ONCE as interleaved groups [hi 32 | lo 32] (the format of B_split) instead of fp32 + planes: A read
+        # as full 128-byte lines per k-tile, C written as groups (+ the plain hi twin the weight gradients read), no fp32 tensor at all
+        Ag = [ops.split_groups(a) for a in As]
+        Cg = [torch.empty(M, N // 32, 64, device=DEV, dtype=torch.bfloat16) for _ in range(nsets)] if N % 32 == 0 else None
+        for tile, stages in CONFIGS:
+            def grp(i):
+                ops.gemm_raw(None, K, w4, taps * K, None if Cg else Cs[i], N, M, N, K, taps=taps, bias=bias, relu=True, resid=Rs[i] if resid else None, ldr=N,
+                             geom=g, B_split=sp, precision=1, A_split=Ag[i], C16=C16[i], C_split=Cg[i] if Cg else None, dl=(tile, stages))
+            row[("g", tile, stages)] = bench(grp, nsets)
     for tile, stages in CONFIGS:
         def new(i):
             ops.gemm_raw(As[i], K, w4, taps * K, Cs[i], N, M, N, K, taps=taps, bias=bias, relu=True, resid=Rs[i] if resid else None, ldr=N, geom=g,
@@ -83,13 +95,20 @@ if __name__ == "__main__":
             continue
         print(f"== {tag}: precision {precision} ({'bf16x3' if precision == 1 else 'bf16'}), M x{mult}; us per launch (TF algorithmic)")
         print("%-34s %14s | " % ("M N K taps", "reg-staged") + " ".join("%13s" % f"{names[t]}/{s}" for t, s in CONFIGS))
-        tot_old = tot_best = 0.0
+        tot_old = tot_best = tot_g = tot_gonly = 0.0
         for sh in FWD:
             row, fl = run(sh, precision, mult)
-            best = min((v, k) for k, v in row.items() if k != "old")
+            best = min((v, k) for k, v in row.items() if k != "old" and k[0] != "g")
             tot_old += row["old"]
             tot_best += min(best[0], row["old"])
             cells = " ".join(("%7.1f (%4.0f)" % (row[c], fl / row[c] / 1e6)) if c in row else "%13s" % "-" for c in CONFIGS)
             print("%-34s %7.1f (%4.0f) | %s   best %s/%d x%.2f" % (str(sh[:4]), row["old"], fl / row["old"] / 1e6, cells, names[best[1][0]], best[1][1],
                                                                   row["old"] / best[0]), flush=True)
-        print(f"sum: reg-staged {tot_old:.0f} us, best-of {tot_best:.0f} us")
+            if any(k[0] == "g" for k in row if k != "old"):
+                cells = " ".join(("%7.1f (%4.0f)" % (row[("g",) + c], fl / row[("g",) + c] / 1e6)) if ("g",) + c in row else "%13s" % "-" for c in CONFIGS)
+                bg = min((v, k) for k, v in row.items() if k != "old" and k[0] == "g")
+                tot_g += min(bg[0], row["old"])
+                tot_gonly += bg[0]
+                print("%-34s %14s | %s   best %s/%d x%.2f vs reg-staged, x%.2f vs planes" % ("   ... interleaved groups", "", cells, names[bg[1][1]], bg[1][2],
+                                                                                             row["old"] / bg[0], best[0] / bg[0]), flush=True)
+        print(f"sum: reg-staged {tot_old:.0f} us, best-of {tot_best:.0f} us" + (f", interleaved groups: best-of-with-reg-staged {tot_g:.0f} us, groups everywhere {tot_gonly:.0f} us" if tot_g else ""))
