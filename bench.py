@@ -313,21 +313,22 @@ def real_data_leg(dev, precision, batch=2, reps=4):
         Ts = counts[r % len(counts)] if r % 7 else (180, 20)                      # every 7th batch falls into the next capacity class (128 < T <= Q)
         images, rects, targets = synthetic_batch(batch, H, W, Ts, seed=300 + r, device=dev)
         batches.append(((H, W), Ts, images, rects, targets))
-    for b in batches:                                                            # first meeting of every key: captures
-        tr.step(b[2], b[3], b[4])
+    nxt = lambda i: batches[i + 1][2] if i + 1 < len(batches) else None      # noqa: E731  (the look-ahead engine.train_one_epoch does)
+    for i, b in enumerate(batches):                                              # first meeting of every key: captures
+        tr.step(b[2], b[3], b[4], next_samples=nxt(i))
     torch.cuda.synchronize()
     cap0 = dict(tr.cache_stats)
     per_size = {}
     evs = []
-    for b in batches:
+    for i, b in enumerate(batches):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        out = tr.step(b[2], b[3], b[4])
+        out = tr.step(b[2], b[3], b[4], next_samples=nxt(i))
         e1.record()
         evs.append((b[0], e0, e1))
     t0 = time.perf_counter()
-    for b in batches:
-        out = tr.step(b[2], b[3], b[4])
+    for i, b in enumerate(batches):
+        out = tr.step(b[2], b[3], b[4], next_samples=nxt(i))
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / len(batches) * 1e3
     for sz, e0, e1 in evs:
@@ -336,16 +337,17 @@ def real_data_leg(dev, precision, batch=2, reps=4):
     for (H, W) in sizes:
         images, rects, targets = synthetic_batch(batch, H, W, (37, 120), seed=1, device=dev)
         tr.capture(images, rects, targets, warmup=0)
+        rp = (lambda: tr.replay(pipelined=True)) if tr._entry.get("fs") is not None else tr.replay
         for _ in range(3):
-            tr.replay()
-        dt, per, _ = timed_steps(tr.replay, 10, torch.cuda.synchronize)
+            rp()
+        dt, per, _ = timed_steps(rp, 10, torch.cuda.synchronize)
         fixed = dt / 10 * 1e3
         cached = sorted(per_size[(H, W)])[len(per_size[(H, W)]) // 2]
         rows.append({"image": [H, W], "cached_step_ms_median": cached, "fixed_replay_ms": fixed, "ratio": cached / fixed,
                      "steps": len(per_size[(H, W)])})
     return {"what": "Trainer.step over batches of 3 image sizes x 7 target-count tuples (2 capacity classes), steady state after the captures",
             "wall_ms_per_step_all_sizes": wall, "new_captures_in_timed_part": tr.cache_stats["captures"] - cap0["captures"],
-            "graphs_cached": len(tr._cache), "per_size": rows, "final_loss": float(out["loss"]),
+            "graphs_cached": len(tr._cache), "per_size": rows, "final_loss": float(out["loss"]), "frozen_stage_prefetch": dict(tr.prefetch_stats),
             "device_memory_reserved_GB": torch.cuda.memory_reserved() / 2 ** 30}
 
 
@@ -484,8 +486,9 @@ def main(argv=None):
     from counting_detr_amd.misc import nested_tensor_from_tensor_list
     im, mk = nested_tensor_from_tensor_list(images).decompose()
     reps = 2
-    for _ in range(reps):
-        trainer._fwd_bwd(im, mk, rects, targets, nb)
+    with ops.arithmetic(*trainer.arith):
+        for _ in range(reps):
+            trainer._fwd_bwd(im, mk, rects, targets, nb)
     torch.cuda.synchronize()
     fam = {}
     shapes = {}
@@ -506,8 +509,9 @@ def main(argv=None):
         every, ops.WGRAD_EVERY = ops.WGRAD_EVERY, 0
         beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0
         ops.PROFILE = []
-        for _ in range(reps):
-            trainer._fwd_bwd(im, mk, rects, targets, nb)
+        with ops.arithmetic(*trainer.arith):
+            for _ in range(reps):
+                trainer._fwd_bwd(im, mk, rects, targets, nb)
         torch.cuda.synchronize()
         f2 = {}
         for family, flops, e0, e1, tag, nbytes, issued in ops.PROFILE:
@@ -623,6 +627,7 @@ def main(argv=None):
         # the same step in the other arithmetic mode (short run, same launch mode), for transparency
         alt = "fp32" if a.precision != "fp32" else "bf16x3"
         ops.PRECISION = PRECISIONS[alt]
+        own, trainer.arith = trainer.arith, (PRECISIONS[alt], trainer.arith[1])      # (the trainer computes in ITS arithmetic, not the module default)
         if a.no_graph:
             alt_step = eager_step
         else:
@@ -638,6 +643,7 @@ def main(argv=None):
         dta = (time.perf_counter() - t1) / 5
         res["alt_precision"] = {"precision": alt, "value": a.batch / dta, "unit": "images/s", "ms_per_step": dta * 1e3, "steps": 5}
         ops.PRECISION = PRECISIONS[a.precision]
+        trainer.arith = own
     if world == 1 and not a.no_extra:
         del trainer
         torch.cuda.empty_cache()

@@ -69,7 +69,7 @@ class MirrorItem(C.Structure):
 EXPORTS = ["cdetr_gemm", "cdetr_gemm_dl", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_layernorm_bwd_merge", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
            "cdetr_hw_reduce", "cdetr_bcast_add2", "cdetr_bcast_add2_sum", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_maxpool3x3s2_split", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_mask_prep", "cdetr_stem_pack", "cdetr_exemplar_fwd", "cdetr_exemplar_bwd", "cdetr_aggr_weight_fwd", "cdetr_aggr_weight_bwd",
-           "cdetr_box_head_fwd", "cdetr_box_head_bwd", "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version"]
+           "cdetr_box_head_fwd", "cdetr_box_head_bwd", "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version", "cdetr_delay", "cdetr_flag_signal", "cdetr_flag_wait"]
 
 _lib = None
 
@@ -89,6 +89,12 @@ def lib():
         for name in ("cdetr_gemm", "cdetr_wgrad", "cdetr_rcda_fwd", "cdetr_rcda_bwd"):
             getattr(L, name).restype = C.c_int
             getattr(L, name).argtypes = [_p, _p]
+        L.cdetr_delay.restype = C.c_int
+        L.cdetr_delay.argtypes = [C.c_int32, _p]
+        L.cdetr_flag_signal.restype = C.c_int
+        L.cdetr_flag_signal.argtypes = [_p, _p]
+        L.cdetr_flag_wait.restype = C.c_int
+        L.cdetr_flag_wait.argtypes = [_p, _p, C.c_int32, _p]
         L.cdetr_gemm_group.restype = C.c_int
         L.cdetr_gemm_group.argtypes = [_p, C.c_int32, _p]
         L.cdetr_wgrad_group.restype = C.c_int

@@ -124,6 +124,7 @@ class SetCriterion(nn.Module):
         self._nb_cache = {}
         self._w6_cache = {}
         self._plans = {}            # (target counts, Q, device) -> MatchPlan (device offset tables built once: graph-safe)
+        self._pre = None            # (cost matrices, the logits they belong to): pre_match()
 
     # -- matched (batch, query, target-row) index tensors on the device
     def _matched(self, idx_i, idx_j, plan):
@@ -132,6 +133,25 @@ class SetCriterion(nn.Module):
         sidx = torch.cat([idx_i[b, :m] for b, m in enumerate(plan.M)])
         tidx = torch.cat([idx_j[b, :m] + plan.tgt_off_host[b] for b, m in enumerate(plan.M)])
         return bidx, sidx, tidx
+
+    def _targets_of(self, targets, Q, device):
+        if isinstance(targets, ops.PackedTargets):     # fixed-address buffers + capacity plan (the graph-cached step): counts live on the device
+            return targets.plan, targets.boxes, targets.labels, True
+        sizes = tuple(len(t["boxes"]) for t in targets)
+        return (self._plan(sizes, Q, device), torch.cat([t["boxes"] for t in targets]).to(torch.float32),
+                torch.cat([t["labels"] for t in targets]), False)
+
+    @torch.no_grad()
+    def pre_match(self, outputs, targets):
+        """The Hungarian cost matrices of the last layer, ahead of `forward` (which then starts with the assignment solve itself): the
+        trainer captures this as its own small graph so that work for the next batch can be released exactly when the solve starts.
+        -> False when the configuration matches several layers (aux_loss): nothing is computed ahead then."""
+        if outputs.get("aux_outputs"):
+            return False
+        logits = outputs["pred_logits"]
+        plan, tgt_boxes, _, _ = self._targets_of(targets, logits.shape[1], logits.device)
+        self._pre = (self.matcher.cost_device(outputs, plan, tgt_boxes), logits)
+        return True
 
     def forward(self, outputs, targets, num_boxes=None):
         """`num_boxes`: optional precomputed normaliser (device scalar) -- the data-parallel trainer all-reduces the target
@@ -143,15 +163,10 @@ class SetCriterion(nn.Module):
         logits = out["pred_logits"]
         B, Q = logits.shape[:2]
         aux = outputs.get("aux_outputs")
-        packed = isinstance(targets, ops.PackedTargets)
-        if packed:     # fixed-address buffers + capacity plan (the graph-cached step): counts live on the device
-            plan, tgt_boxes_all, tgt_labels_all = targets.plan, targets.boxes, targets.labels
-            sizes = tuple(plan.sizes)
-        else:
-            sizes = tuple(len(t["boxes"]) for t in targets)
-            plan = self._plan(sizes, Q, logits.device)
-            tgt_boxes_all = torch.cat([t["boxes"] for t in targets]).to(torch.float32)
-            tgt_labels_all = torch.cat([t["labels"] for t in targets])
+        plan, tgt_boxes_all, tgt_labels_all, packed = self._targets_of(targets, Q, logits.device)
+        sizes = tuple(plan.sizes)
+        pre, self._pre = self._pre, None
+        cost = pre[0] if (pre is not None and pre[1] is logits) else None
         if aux and packed:
             # capacity plan: the stacked form needs the targets packed tightly L times over (count-dependent offsets); the layers are
             # matched one after the other with the one device-resident plan instead -- 2 L launches, graph-replayable for any counts
@@ -168,7 +183,7 @@ class SetCriterion(nn.Module):
             idx_i, idx_j, status, _ = self.matcher.match_device(stacked, None, plan_all, tgt_boxes=tgt_boxes_all.repeat(L, 1))
         else:
             layers, L = [out], 1
-            idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan, tgt_boxes=tgt_boxes_all)
+            idx_i, idx_j, status, _ = self.matcher.match_device(out, targets, plan, tgt_boxes=tgt_boxes_all, cost=cost)
         if self.check_status and bool((status != 0).any()):
             raise ValueError("invalid or infeasible matching cost matrix")
         if num_boxes is not None:

@@ -243,6 +243,46 @@ extern "C" int cdetr_mask_prep(const uint8_t* mask, int32_t B, int32_t H, int32_
     return cdetr_launch_status("cdetr_mask_prep");
 }
 
+// Cross-stream ordering WITHOUT a host-visible event: a one-thread "signal" kernel in one stream's chain bumps a counter in device memory, a
+// one-wave "wait" kernel at the head of another stream's work sleeps until it sees the bump (or a timeout).  engine.Trainer releases the next
+// batch's frozen stage with it at the moment the Hungarian solve of the current step is about to start: the solve keeps its whole cost matrix
+// in LDS (~144 KB = one compute unit's LDS) and must be resident BEFORE the stem / layer1 workgroups flood every CU, and an event cannot be
+// recorded in the middle of a captured graph.  `seen` is the waiter's own count of bumps consumed (self-healing: it adopts the counter's value),
+// the timeout makes a missing signal (or a waiter that shares its hardware queue with the signalling chain) a delay, never a hang.
+namespace {
+__global__ void flag_signal_kernel(int* flag) { __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void flag_wait_kernel(const int* flag, int* seen, long timeout_ticks) {
+    const int want = *seen + 1;
+    const long t0 = wall_clock64();
+    int cur;
+    while ((cur = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - want < 0 && wall_clock64() - t0 < timeout_ticks)
+        __builtin_amdgcn_s_sleep(16);
+    if (threadIdx.x == 0) *seen = (cur - want >= 0) ? cur : want;
+}
+__global__ void delay_kernel(long ticks) {
+    const long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+}  // namespace
+extern "C" int cdetr_flag_signal(int32_t* flag, void* stream) {
+    CDETR_CHECK_ARG(flag != nullptr, "cdetr_flag_signal: null flag");
+    hipLaunchKernelGGL(flag_signal_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), flag);
+    return cdetr_launch_status("cdetr_flag_signal");
+}
+extern "C" int cdetr_flag_wait(const int32_t* flag, int32_t* seen, int32_t timeout_us, void* stream) {
+    CDETR_CHECK_ARG(flag && seen && timeout_us >= 0 && timeout_us <= 100000, "cdetr_flag_wait: bad args (timeout 0 .. 100000 us)");
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), flag, seen, (long)timeout_us * 100);   // wall_clock64: 100 MHz
+    return cdetr_launch_status("cdetr_flag_wait");
+}
+// One idle wavefront for `us` microseconds (s_sleep between reads of the 100 MHz wall clock): holds a stream back without occupying the chip
+// (the stream-concurrency probe of engine.Trainer).
+extern "C" int cdetr_delay(int32_t us, void* stream) {
+    CDETR_CHECK_ARG(us >= 0 && us <= 100000, "cdetr_delay: 0 .. 100000 us");
+    if (us == 0) return CDETR_OK;
+    hipLaunchKernelGGL(delay_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), (long)us * 100);      // wall_clock64: 100 MHz
+    return cdetr_launch_status("cdetr_delay");
+}
+
 extern "C" int cdetr_stem_pack(const float* images, float* xp, int32_t B, int32_t H, int32_t W, int32_t Ha, int32_t Wa, int32_t pad_y,
                                int32_t pad_x, void* stream) {
     CDETR_CHECK_ARG(images && xp && B > 0 && H > 0 && W > 0 && Ha >= H + pad_y && Wa >= W + pad_x && pad_y >= 0 && pad_x >= 0 &&

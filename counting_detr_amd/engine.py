@@ -117,8 +117,24 @@ def build_weight_mirror(model, named, dgrad=True):
     return ops.WeightMirror(entries, fwd) if (entries or fwd) else None
 
 
+def _scoped(fn):
+    """Run a Trainer / InferenceEngine method under the engine's own arithmetic (ops.arithmetic)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **k):
+        from . import ops
+        with ops.arithmetic(*self.arith):
+            return fn(self, *a, **k)
+    return wrapper
+
+
 class Trainer:
-    def __init__(self, model, criterion, args, device=None):
+    def __init__(self, model, criterion, args, device=None, precision=None, precision_bwd=None):
+        """precision / precision_bwd: the matrix-core arithmetic this trainer computes in (ops.PRECISION / PRECISION_BWD codes); default:
+        the module defaults at construction time.  Every step, capture and replay of the trainer runs under them (ops.arithmetic)."""
+        from . import ops as _ops
+        self.arith = (int(_ops.PRECISION if precision is None else precision), int(_ops.PRECISION_BWD if precision_bwd is None else precision_bwd))
         self.model, self.criterion, self.args = model, criterion, args
         self.device = torch.device(device or args.device)
         self.max_norm = args.clip_max_norm
@@ -177,8 +193,11 @@ class Trainer:
         self._pool = None                       # ONE graph memory pool for every cached step (entries never run concurrently)
         import os as _os
         self._prefetch_on = bool(getattr(args, "frozen_prefetch", True)) and _os.environ.get("CDETR_FROZEN_PREFETCH", "1") != "0"
+        self._pf_timeout_us = int(_os.environ.get("CDETR_PF_TIMEOUT_US", getattr(args, "frozen_prefetch_timeout_us", 400)))   # flag wait (chain layout)
+        self._pf_delay_us = int(_os.environ.get("CDETR_PF_DELAY_US", 0))        # "single" layout only: fixed delay in front of the prefetched stage
+        self._pf_eager = _os.environ.get("CDETR_PF_EAGER", "0") == "1"
         self._frozen = {}                       # image shape -> frozen-stage buffers + graph (see "frozen-stage prefetch")
-        self._pf_stream = self._pf_pool = None
+        self._pf_stream = self._pf_pool = self._wg_stream = None
         self.prefetch_stats = {"hits": 0, "inline": 0}
         self._cache_on = bool(getattr(args, "graph_cache", True))
         self._cache_size = int(getattr(args, "graph_cache_size", 32))
@@ -368,32 +387,26 @@ class Trainer:
             raise
         return outputs
 
-    def _loss_backward(self, outputs, targets, num_boxes, defer_trunk=False):
-        """zero-grad + data-gradient weight images (side stream, under the criterion) + criterion + backward.  `defer_trunk`: stop the
-        backward at the backbone (the gradient w.r.t. layer4's output is parked in `self._trunk_pending`, a backbone.TrunkBackward) --
-        the caller runs the three backbone segments itself (`_trunk_segment`)."""
+    def _zero_and_mirror(self):
+        """What the backward needs and nothing before it does: the gradient arena zeroed, the data-gradient weight images refreshed."""
+        self.flat_g.zero_()
+        if self.mirror is not None:
+            self.mirror.refresh("bwd")
+
+    def _criterion_forward(self, outputs, targets, num_boxes):
+        """Hungarian solve + the six losses -> (loss dict, weighted total)   (A2/engine.py:35-37)."""
+        loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
+        wd = self.criterion.weight_dict
+        losses = getattr(self.criterion, "last_total", None)       # fused criterion: the weighted total came out of the same launch
+        if losses is None:
+            losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)      # A2/engine.py:37
+        return loss_dict, losses
+
+    def _backward(self, losses, defer_trunk=False):
+        """losses.backward().  `defer_trunk`: stop at the backbone (the gradient w.r.t. layer4's output is parked in
+        `self._trunk_pending`, a backbone.TrunkBackward) -- the caller runs the three backbone segments itself (`_trunk_segment`)."""
         from . import ops
-        # the data-gradient operands and the gradient arena's zero-fill are not needed before the backward starts, so they run on a side
-        # stream UNDER the criterion -- the Hungarian solve is one wavefront per image for ~0.3 ms (in a captured step: a parallel graph branch)
         try:
-            main = torch.cuda.current_stream() if self.flat_g.is_cuda else None
-            if main is not None:
-                if self._side is None:
-                    self._side = torch.cuda.Stream(device=self.device)
-                self._side.wait_stream(main)
-                with torch.cuda.stream(self._side):
-                    self.flat_g.zero_()
-                    if self.mirror is not None:
-                        self.mirror.refresh("bwd")
-            else:
-                self.flat_g.zero_()
-            loss_dict = self.criterion(outputs, targets, num_boxes=num_boxes)
-            if main is not None:
-                main.wait_stream(self._side)
-            wd = self.criterion.weight_dict
-            losses = getattr(self.criterion, "last_total", None)       # fused criterion: the weighted total came out of the same launch
-            if losses is None:
-                losses = sum(loss_dict[k] * wd[k] for k in loss_dict if k in wd)      # A2/engine.py:37
             with ops.wgrad_queue():      # small parameter gradients outside the fused layer nodes (heads, positional MLPs): grouped
                 if defer_trunk:
                     with _bb.defer_trunk_backward() as d:
@@ -405,6 +418,29 @@ class Trainer:
             if not defer_trunk:
                 ops.MIRROR = None
         ops.wgrad_join()             # parameter gradients that ran beside the backward (ops.wgrad_flush(overlap=True))
+
+    def _loss_backward(self, outputs, targets, num_boxes, defer_trunk=False):
+        """zero-grad + data-gradient weight images (side stream, under the criterion) + criterion + backward."""
+        from . import ops
+        # the data-gradient operands and the gradient arena's zero-fill are not needed before the backward starts, so they run on a side
+        # stream UNDER the criterion -- the Hungarian solve is one wavefront per image for ~0.3 ms
+        try:
+            main = torch.cuda.current_stream() if self.flat_g.is_cuda else None
+            if main is not None:
+                if self._side is None:
+                    self._side = torch.cuda.Stream(device=self.device)
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side):
+                    self._zero_and_mirror()
+            else:
+                self._zero_and_mirror()
+            loss_dict, losses = self._criterion_forward(outputs, targets, num_boxes)
+            if main is not None:
+                main.wait_stream(self._side)
+        except BaseException:
+            ops.MIRROR = None
+            raise
+        self._backward(losses, defer_trunk)
         # detached: a returned loss that still references the autograd graph keeps its AccumulateGrad nodes (and their stream) alive
         # into the next step -- a later graph capture on another stream then records a cross-stream dependency and fails
         out = {k: v.detach() for k, v in loss_dict.items()}
@@ -435,6 +471,7 @@ class Trainer:
         out["grad_norm"] = self._optimizer_step()
         return out
 
+    @_scoped
     def train_step(self, samples, rects, targets):
         """Eager step.  samples: [B,3,H,W] tensor, list of [3,h,w] tensors, or NestedTensor.  Returns device scalars.
         With world_size > 1 the gradient all-reduce runs as 4 buckets on a side stream, overlapped with backward."""
@@ -485,6 +522,7 @@ class Trainer:
         else:
             st["num_boxes"].fill_(float(nb))
 
+    @_scoped
     def capture(self, samples, rects, targets, warmup=0):
         """Capture (record, not run) the step for these image shapes; `replay()` executes it -- on the captured batch, or on any new
         batch of the same padded image size whose target counts fit the captured capacity class (`target_capacity`).
@@ -545,13 +583,10 @@ class Trainer:
         fs = {"images": torch.zeros(shape, device=dev), "x": torch.empty((B, h, w, 256), device=dev),
               "x16": torch.empty((B, h, w, 256), device=dev, dtype=torch.bfloat16),
               "x16s": torch.empty((B, h, w, 256), device=dev, dtype=torch.bfloat16), "token": None, "keep": None}
-        if self._pf_stream is None:
-            # (a HIP CU-masked stream -- hipExtStreamCreateWithCUMask, leaving 16-64 CUs to the step's own latency-bound chain -- was tried:
-            # with such a queue alive EVERY launch of the process slowed down, 9.3 -> 19 ms per step, in-line replays included:
-            # profiles/r4_prefetch_ab.txt; an ordinary stream it is)
-            self._pf_stream = torch.cuda.Stream(device=dev)
-            self._pf_pool = torch.cuda.graph_pool_handle()      # NOT the steps' pool: this graph runs beside a step's backward
-        ps = self._pf_stream
+        # (a HIP CU-masked stream -- hipExtStreamCreateWithCUMask, leaving 16-64 CUs to the step's own latency-bound chain -- was tried:
+        # with such a queue alive EVERY launch of the process slowed down, 9.3 -> 19 ms per step, in-line replays included:
+        # profiles/r4_prefetch_ab_cumask.txt; an ordinary stream it is)
+        ps, _ = self._side_streams()
         prev = ops.MIRROR
         ops.MIRROR = self.mirror
         beside = ops.BRANCH_BESIDE
@@ -599,16 +634,30 @@ class Trainer:
         fs["token"] = fs["keep"] = None
         fs["x16"].copy_(fs["x16s"])
 
-    def _prefetch(self, images, token, keep):
-        """Release the frozen stage of the announced next batch behind everything issued so far on the current stream."""
+    def _prefetch(self, images, token, keep, ordered=False):
+        """Release the frozen stage of the announced next batch behind everything issued so far on the current stream (`ordered`: the
+        prefetch stream is already ordered behind it and has idled its delay)."""
         fs = self._frozen_for(images.shape)
         ps = self._pf_stream
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        ps.wait_event(ev)
+        if not ordered:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            ps.wait_event(ev)
         with torch.cuda.stream(ps):
             fs["images"].copy_(images, non_blocking=True)
-            fs["graph"].replay()
+            if self._pf_delay_us > 0 and not ordered:     # the solve first (it needs a whole CU's LDS), the flood of stem / layer1 workgroups after it
+                from . import _ffi
+                _ffi.check(_ffi.lib().cdetr_delay(self._pf_delay_us, _ffi.stream_ptr()), "cdetr_delay")
+            if self._pf_eager:                 # stream-ordered launches instead of the graph (A/B: CDETR_PF_EAGER)
+                from . import ops
+                prev, ops.MIRROR = ops.MIRROR, self.mirror
+                beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0
+                try:
+                    self.model.backbone.body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))
+                finally:
+                    ops.MIRROR, ops.BRANCH_BESIDE = prev, beside
+            else:
+                fs["graph"].replay()
         fs["token"], fs["keep"] = token, keep                   # (`keep`: the announced object stays alive, so its id cannot be re-used)
 
     def _capture_entry(self, images, mask, rects, targets, warmup=0):
@@ -617,8 +666,17 @@ class Trainer:
         world = get_world_size()
         hook = _bb._BACKWARD_HOOK
         _bb.set_backward_hook(None)                # no collectives inside the capture
-        # CDETR_SEGMENTED_GRAPH=1: the five-graph form on ONE rank (no collectives): what the segmentation itself costs (tools / DESIGN section 7)
+        # layout of a captured step (args.graph_layout / CDETR_GRAPH_LAYOUT):
+        #   "chain" (default): LINEAR graphs only -- hipGraphLaunch enqueues a single-chain graph in ~0.05 ms of host time, a graph with
+        #       parallel branches in 3-4 ms (measured, profiles/r4_host_cost.txt: the round-3 step spent 8.6 ms of HOST time per 9.4 ms step in
+        #       its launches, i.e. ran within a few percent of host-bound and hid device-side gains) -- and concurrency comes from SEPARATE
+        #       linear graphs on side streams, ordered by events between the launches: [zero-fill + data-gradient weight images, then the next
+        #       batch's frozen stage] under the Hungarian solve, each backbone segment's weight gradients beside the next segment's data-gradient
+        #       chain; with world_size > 1 the gradient buckets' all-reduces sit between the same pieces.
+        #   "single": round 3's form -- [forward] | [everything else] with in-graph branches (world_size > 1 / CDETR_SEGMENTED_GRAPH=1: the
+        #       backbone's backward as three more sub-graphs).
         import os
+        layout = os.environ.get("CDETR_GRAPH_LAYOUT", getattr(self.args, "graph_layout", "chain"))
         segmented = world > 1 or os.environ.get("CDETR_SEGMENTED_GRAPH", "0") == "1"
         body = self.model.backbone.body
         fs = self._frozen_for(images.shape) if self._prefetch_ok() else None
@@ -629,13 +687,18 @@ class Trainer:
                 fs["x16"].copy_(fs["x16s"])
                 fs["token"] = None
                 body.frozen_input = (fs["x"], fs["x16"])
-            g_f, g_a, segs, g_b, out = self._capture_graphs(st, world, warmup, segmented)
+            if layout == "chain":
+                e = self._capture_chain(st, world, warmup)
+            else:
+                (g_f, g_p), g_a, segs, g_b, out = self._capture_graphs(st, world, warmup, segmented)
+                e = {"g_f": g_f, "g_p": g_p, "g_a": g_a, "segs": segs, "g_b": g_b, "out": out}
         finally:                                   # a failed capture must leave the stream-ordered step intact
             _bb.set_backward_hook(hook)
             body.frozen_input = None
-        return {"g_f": g_f, "g_a": g_a, "segs": segs, "g_b": g_b, "st": st, "out": out, "replays": 0, "fs": fs, "loads": 0}
+        e.update({"layout": layout, "st": st, "replays": 0, "fs": fs, "loads": 0})
+        return e
 
-    def _capture_graphs(self, st, world, warmup, segmented):
+    def _capture_warmup(self, st, world, warmup):
         self._dry_run(st)
         if self._cap_stream is None:               # ONE capture stream per trainer: per-stream scratch (ops.splitk_ws) exists once
             self._cap_stream = torch.cuda.Stream(device=self.device)
@@ -661,10 +724,133 @@ class Trainer:
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         mode["pool"] = self._pool
+        return s, mode
+
+    def _concurrent(self, a, b):
+        """Do kernels of stream `b` run while a long kernel occupies stream `a`?  (HIP maps streams onto a few hardware queues -- four by
+        default --, and two streams of one queue never overlap: measured, not assumed.)"""
+        from . import _ffi
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(a):
+            e0.record(a)
+            _ffi.check(_ffi.lib().cdetr_delay(600, _ffi.stream_ptr()), "cdetr_delay")
+        b.wait_event(e0)
+        with torch.cuda.stream(b):
+            _ffi.check(_ffi.lib().cdetr_delay(1, _ffi.stream_ptr()), "cdetr_delay")
+            e1.record(b)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) < 0.3           # b's kernel was through while a's 0.6 ms were still running
+
+    def _side_streams(self):
+        """pf: zero-fill + data-gradient weight images + the next batch's frozen stage; wg: weight gradients beside the data-gradient chain.
+        Both must overlap the stream the steps are replayed on (the current one at the first call) and each other: candidates are probed."""
+        if self._pf_stream is None:
+            main = torch.cuda.current_stream()
+            cands = [torch.cuda.Stream(device=self.device) for _ in range(8)]
+            ok = [c for c in cands if self._concurrent(main, c)]
+            pf = ok[0] if ok else cands[0]
+            rest = [c for c in ok[1:] if self._concurrent(pf, c)]
+            wg = rest[0] if rest else next(c for c in cands if c is not pf)
+            self._pf_stream, self._wg_stream = pf, wg
+            self.side_stream_probe = {"overlap_main": len(ok), "of": len(cands), "wg_overlaps_pf": bool(rest)}
+            self._pf_pool = torch.cuda.graph_pool_handle()      # NOT the steps' pool: the frozen-stage graph runs beside a step's backward
+            self._sig = torch.zeros(2, dtype=torch.int32, device=self.device)       # [signal counter, signals the prefetch stream has consumed]
+        return self._pf_stream, self._wg_stream
+
+    def _capture_chain(self, st, world, warmup):
+        """The step as a chain of LINEAR graphs (see _capture_entry) on the main stream: F forward + cost matrices | B Hungarian solve +
+        criterion + the backward down to the backbone | S1 S2 S3 the backbone's segments | O clip + AdamW.  Beside them: Z (zero-fill +
+        data-gradient weight images) on the prefetch stream, released by the previous step's O (it runs beside the start of F; B waits for
+        it); the next batch's frozen stage on the same stream, released by F (beside the solve); W0 (every parameter gradient above the
+        backbone) and W1 W2 W3 (a backbone segment's) on the weight-gradient stream, each released by the main piece that produced its
+        operands and running beside the pieces that follow; O waits for them."""
+        from . import ops
+        s, mode = self._capture_warmup(st, world, warmup)
+        pf, wg = self._side_streams()
+        G = torch.cuda.CUDAGraph
+        keep_beside, keep_every = ops.BRANCH_BESIDE, ops.WGRAD_EVERY
+        ops.BRANCH_BESIDE, ops.WGRAD_EVERY = 0, 0          # no fork inside a capture: every graph is one chain
+        e = {}
+        try:
+            e["F"] = G()
+            with torch.cuda.graph(e["F"], stream=s, **mode):
+                outputs = self._forward(st["images"], st["mask"], st["rects"])
+                if hasattr(self.criterion, "pre_match"):    # the cost matrices close the forward piece: the next piece STARTS with the solve
+                    self.criterion.pre_match(outputs, st["targets"])
+            e["Z"] = G()
+            with torch.cuda.graph(e["Z"], stream=pf, **mode):
+                self._zero_and_mirror()
+            # every parameter gradient above the backbone (heads, decoder, encoder, projection) is collected instead of submitted inside B:
+            # they become W0 on the weight-gradient stream, beside the backbone's data-gradient chain
+            held = []                                       # operands of the side-stream weight gradients: alive until every main piece that may
+            outer = ops.wgrad_queue()                       # run beside them has been captured (its tensors must not take their memory)
+            outer.__enter__()
+            ops.WG_DEFER_NESTED = True
+            try:
+                e["B"] = G()                                # solve + criterion + the backward down to the backbone
+                with torch.cuda.graph(e["B"], stream=s, **mode):
+                    from . import _ffi                      # "the solve is next": releases the prefetch stream (cdetr_flag_wait)
+                    _ffi.check(_ffi.lib().cdetr_flag_signal(self._sig.data_ptr(), _ffi.stream_ptr()), "cdetr_flag_signal")
+                    loss_dict, losses = self._criterion_forward(outputs, st["targets"], st["num_boxes"])
+                    self._backward(losses, defer_trunk=True)
+                e["W0"] = None
+                if ops._WG_QUEUE:
+                    held.append([x[2] for x in ops._WG_QUEUE])
+                    e["W0"] = G()
+                    with torch.cuda.graph(e["W0"], stream=wg, **mode):
+                        ops.wgrad_flush()
+            finally:
+                ops.WG_DEFER_NESTED = False
+                outer.__exit__(None, None, None)
+            out = {k: v.detach() for k, v in loss_dict.items()}
+            out["loss"] = losses.detach()
+            e["S"], e["W"] = [], []
+            for seg in (1, 2, 3):
+                q = ops.wgrad_queue()
+                q.__enter__()
+                try:
+                    g = G()
+                    with torch.cuda.graph(g, stream=s, **mode):
+                        if self._trunk_pending is not None:
+                            self._trunk_pending.run(seg)
+                    gw = None
+                    if ops._WG_QUEUE:
+                        held.append([x[2] for x in ops._WG_QUEUE])
+                        gw = G()
+                        with torch.cuda.graph(gw, stream=wg, **mode):
+                            ops.wgrad_flush()
+                finally:
+                    q.__exit__(None, None, None)
+                e["S"].append(g)
+                e["W"].append(gw)
+            ops.MIRROR = None
+            self._trunk_pending = None
+            e["O"] = G()
+            with torch.cuda.graph(e["O"], stream=s, **mode):
+                out["grad_norm"] = self._optimizer_step()
+            del held, outputs, losses, loss_dict
+        finally:
+            ops.BRANCH_BESIDE, ops.WGRAD_EVERY = keep_beside, keep_every
+            ops.MIRROR = None
+        e["out"] = out
+        return e
+
+    def _capture_graphs(self, st, world, warmup, segmented):
+        s, mode = self._capture_warmup(st, world, warmup)
         # [forward] | [criterion + backward ...]: two graphs, so that the next batch's frozen stage can be released between their launches
         g_f = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_f, stream=s, **mode):
             outputs = self._forward(st["images"], st["mask"], st["rects"])
+        # with a frozen-stage prefetch: the cost matrices as a third small graph -- the prefetch is released behind IT, i.e. at the moment the
+        # assignment solve starts (a flood of stem / layer1 workgroups released earlier delays the start of every small launch before the solve)
+        g_p = None
+        if self.model.backbone.body.frozen_input is not None and hasattr(self.criterion, "pre_match"):
+            g_p = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_p, stream=s, **mode):
+                ok = self.criterion.pre_match(outputs, st["targets"])
+            if not ok:
+                g_p = None
         g_a = torch.cuda.CUDAGraph()
         segs = None
         if not segmented:
@@ -685,7 +871,7 @@ class Trainer:
             with torch.cuda.graph(g_b, stream=s, **mode):
                 out["grad_norm"] = self._optimizer_step()
         del outputs
-        return g_f, g_a, segs, g_b, out
+        return (g_f, g_p), g_a, segs, g_b, out
 
     def _load_entry(self, e, images, mask, rects, targets):
         st = e["st"]
@@ -708,22 +894,80 @@ class Trainer:
         e["replays"] += 1
         if e["fs"] is not None:
             self._frozen_ready(e, token)
-        e["g_f"].replay()
+        announce = None
         if e["fs"] is not None and next_samples is not None:
             tok = self._token(next_samples)
             if tok is not None:
-                nxt = next_samples.tensors if hasattr(next_samples, "tensors") else next_samples
-                self._prefetch(nxt, tok, nxt)
-        e["g_a"].replay()
-        if e["g_b"] is not None:
-            self.exchange.segment_done(0)          # everything above the backbone is final: first bucket leaves now
-            for seg, g in zip((1, 2, 3), e["segs"]):
-                g.replay()
-                self.exchange.segment_done(seg)
+                announce = (next_samples.tensors if hasattr(next_samples, "tensors") else next_samples, tok)
+        return self._run_entry(e, announce)
+
+    def _run_entry(self, e, announce):
+        """announce = (image tensor of the next batch, its token) or None."""
+        from . import _ffi
+        dp = get_world_size() > 1
+        if e["layout"] != "chain":
+            e["g_f"].replay()
+            if e["g_p"] is not None:
+                e["g_p"].replay()
+            if announce is not None:
+                self._prefetch(announce[0], announce[1], announce[0])
+            e["g_a"].replay()
+            if e["g_b"] is not None:
+                self.exchange.segment_done(0)          # everything above the backbone is final: first bucket leaves now
+                for seg, g in zip((1, 2, 3), e["segs"]):
+                    g.replay()
+                    self.exchange.segment_done(seg)
+                self.exchange.finish()
+                e["g_b"].replay()
+            return e["out"]
+        main = torch.cuda.current_stream()
+        pf, wg = self._side_streams()
+        # Z needs the optimizer step of the previous call to be done and nothing else: behind everything issued so far, beside F
+        ev0 = torch.cuda.Event()
+        ev0.record(main)
+        pf.wait_event(ev0)
+        with torch.cuda.stream(pf):
+            e["Z"].replay()
+            evz = torch.cuda.Event()
+            evz.record(pf)
+        e["F"].replay()
+        if announce is not None:
+            # the next batch's frozen stage: behind F (event) AND behind the signal kernel that opens B -- the solve keeps its cost matrix in
+            # LDS (a whole compute unit's worth) and must be resident before the stem / layer1 workgroups take every CU
+            evf = torch.cuda.Event()
+            evf.record(main)
+            pf.wait_event(evf)
+            with torch.cuda.stream(pf):
+                _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr(), self._sig.data_ptr() + 4, self._pf_timeout_us, _ffi.stream_ptr()),
+                           "cdetr_flag_wait")
+            self._prefetch(announce[0], announce[1], announce[0], ordered=True)
+        main.wait_event(evz)
+        e["B"].replay()
+        if e["W0"] is not None:                        # the parameter gradients above the backbone: beside the backbone's data-gradient chain
+            evb = torch.cuda.Event()
+            evb.record(main)
+            wg.wait_event(evb)
+            with torch.cuda.stream(wg):
+                e["W0"].replay()
+        if dp:
+            self.exchange.segment_done(0, also=wg if e["W0"] is not None else None)      # first bucket: everything above the backbone
+        for seg, g, gw in zip((1, 2, 3), e["S"], e["W"]):
+            g.replay()
+            if gw is not None:
+                evs = torch.cuda.Event()
+                evs.record(main)
+                wg.wait_event(evs)
+                with torch.cuda.stream(wg):
+                    gw.replay()
+            if dp:
+                self.exchange.segment_done(seg, also=wg if gw is not None else None)
+        main.wait_stream(wg)
+        if dp:
             self.exchange.finish()
-            e["g_b"].replay()
+        e["O"].replay()
         return e["out"]
 
+    @_scoped
     def replay(self, samples=None, rects=None, targets=None, next_samples=None, pipelined=False):
         """Run the captured step; with arguments, on a NEW batch of the captured image size whose target counts fit the captured
         capacity class (copied into the graph's static inputs first).  `next_samples`: the batch object that will be passed to the next
@@ -739,28 +983,13 @@ class Trainer:
             token = self._token(samples)
         elif pipelined and e["fs"] is not None:
             token = ("entry", id(e), e["loads"])
-            out = self._replay_pipelined(e, token)
-            return out
+            e["replays"] += 1
+            self._frozen_ready(e, token)
+            return self._run_entry(e, (e["st"]["images"], token))      # the "next batch" of a fixed-batch loop is the captured one
         return self._replay_entry(e, token, next_samples)
 
-    def _replay_pipelined(self, e, token):
-        e["replays"] += 1
-        self._frozen_ready(e, token)
-        e["g_f"].replay()
-        fs = e["fs"]
-        self._prefetch(e["st"]["images"], token, None)          # the "next batch" of a fixed-batch loop is the captured one
-        assert self._frozen_for(e["st"]["images"].shape) is fs
-        e["g_a"].replay()
-        if e["g_b"] is not None:
-            self.exchange.segment_done(0)
-            for seg, g in zip((1, 2, 3), e["segs"]):
-                g.replay()
-                self.exchange.segment_done(seg)
-            self.exchange.finish()
-            e["g_b"].replay()
-        return e["out"]
-
     # ------------------------------------------------------------------ graph cache: the step the data loader drives
+    @_scoped
     def step(self, samples, rects, targets, next_samples=None):
         """One training step on an arbitrary batch at graph-replay speed: captured steps are cached by (padded image size, batch,
         target-capacity class, arithmetic mode); a batch whose key is new is captured first (one dry forward + the capture, ~0.1 s),
@@ -779,7 +1008,7 @@ class Trainer:
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
         images, mask = nt.decompose()
         cap = self.target_capacity(max([len(t["boxes"]) for t in targets], default=0))
-        key = (tuple(images.shape), tuple(rects.shape), cap, ops.PRECISION, ops.PRECISION_BWD)
+        key = (tuple(images.shape), tuple(rects.shape), cap) + self.arith
         e = self._cache.pop(key, None)
         token = self._token(samples)
         if e is None:
@@ -883,7 +1112,9 @@ class InferenceEngine:
     `engine(samples, rects)` -> (counts [B] int64, keep [B,Q] bool, outputs dict, reference points, prob [B,Q]); the tensors are the graph's
     static outputs: valid until the same shape runs again (clone to keep)."""
 
-    def __init__(self, model, threshold=0.5, graphs=True, max_graphs=48, device=None):
+    def __init__(self, model, threshold=0.5, graphs=True, max_graphs=48, device=None, precision=None):
+        from . import ops as _ops
+        self.arith = (int(_ops.PRECISION if precision is None else precision), int(_ops.PRECISION_BWD))      # (ops.arithmetic: this engine's own)
         self.model, self.threshold, self.graphs, self.max_graphs = model, threshold, graphs, max_graphs
         p0 = next(model.parameters(), None)
         self.device = torch.device(device) if device is not None else (p0.device if p0 is not None else torch.device("cpu"))
@@ -904,6 +1135,7 @@ class InferenceEngine:
                 torch.cuda.synchronize()
             self._cache.clear()
 
+    @_scoped
     def refresh_weights(self):
         """Call after loading / changing the model's weights: rebuilds the forward weight images (and drops the graphs' cached folds)."""
         from .checkpoint import invalidate_caches
@@ -924,6 +1156,7 @@ class InferenceEngine:
         counts, keep, prob = count_from_logits(outputs["pred_logits"], self.threshold)
         return counts, keep, outputs, ref, prob
 
+    @_scoped
     @torch.no_grad()
     def __call__(self, samples, rects):
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)

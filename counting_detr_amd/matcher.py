@@ -16,16 +16,24 @@ class OriginalHungarianMatcher(nn.Module):
         assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
 
     @torch.no_grad()
-    def match_device(self, outputs, targets, plan=None, tgt_boxes=None):
-        """-> (idx_i [B,Mmax], idx_j [B,Mmax] int64 device, status [B] int32 device, plan).  `tgt_boxes`: the targets' boxes already
-        concatenated in plan order (the criterion needs the same tensor: one concatenation per step instead of two)."""
+    def cost_device(self, outputs, plan, tgt_boxes):
+        """The cost matrices of A2/models/matcher.py:229-242, per image, in the solver's layout (ops.match_cost)."""
         logits, boxes = outputs["pred_logits"], outputs["pred_boxes"]
+        return ops.match_cost(logits.detach().float(), boxes.detach().float(), tgt_boxes, plan, float(self.cost_class),
+                              float(self.cost_bbox), float(self.cost_giou))
+
+    @torch.no_grad()
+    def match_device(self, outputs, targets, plan=None, tgt_boxes=None, cost=None):
+        """-> (idx_i [B,Mmax], idx_j [B,Mmax] int64 device, status [B] int32 device, plan).  `tgt_boxes`: the targets' boxes already
+        concatenated in plan order (the criterion needs the same tensor: one concatenation per step instead of two).  `cost`: the cost
+        matrices when they were computed ahead (`cost_device`; SetCriterion.pre_match)."""
+        logits = outputs["pred_logits"]
         B, Q = logits.shape[:2]
         if plan is None:
             plan = ops.MatchPlan([len(t["boxes"]) for t in targets], Q, logits.device)
-        tgt = tgt_boxes if tgt_boxes is not None else torch.cat([t["boxes"] for t in targets]).to(torch.float32)
-        cost = ops.match_cost(logits.detach().float(), boxes.detach().float(), tgt, plan, float(self.cost_class),
-                              float(self.cost_bbox), float(self.cost_giou))
+        if cost is None:
+            tgt = tgt_boxes if tgt_boxes is not None else torch.cat([t["boxes"] for t in targets]).to(torch.float32)
+            cost = self.cost_device(outputs, plan, tgt)
         idx_i, idx_j, status = ops.lsap(cost, plan)
         return idx_i, idx_j, status, plan
 

@@ -36,6 +36,28 @@ def bwd_precision():
     return PRECISION_BWD if PRECISION == 1 else PRECISION
 
 
+class arithmetic:
+    """`with ops.arithmetic(precision, precision_bwd):` -- the arithmetic an ENGINE owns, in force for the calls it makes.  engine.Trainer and
+    engine.InferenceEngine take theirs at construction and enter this scope around every forward / backward / capture they run, so two
+    engines of different arithmetic (a split-bf16 trainer and an fp32-MFMA evaluator) live in one process without leaking into each other;
+    the module-level PRECISION / PRECISION_BWD remain the defaults of code that runs outside any engine (kernel tests, tools).
+    Scopes nest; a backward runs on the autograd engine's thread while the calling thread holds the scope (module globals: visible there)."""
+
+    def __init__(self, precision, precision_bwd=None):
+        self.want = (int(precision), int(PRECISION_BWD if precision_bwd is None else precision_bwd))
+
+    def __enter__(self):
+        global PRECISION, PRECISION_BWD
+        self.saved = (PRECISION, PRECISION_BWD)
+        PRECISION, PRECISION_BWD = self.want
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION, PRECISION_BWD
+        PRECISION, PRECISION_BWD = self.saved
+        return False
+
+
 class _Timed:
     def __init__(self, family, flops, tag=None, nbytes=0.0, issued=None):
         self.family, self.flops, self.tag, self.nbytes = family, flops, tag, nbytes     # nbytes: compulsory (algorithmic) HBM bytes of the launch
@@ -181,12 +203,18 @@ def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom
 _WG_QUEUE = None
 
 
+WG_DEFER_NESTED = False      # a nested wgrad_queue() hands its problems to the enclosing one instead of submitting them (see below)
+
+
 class wgrad_queue:
     """Context manager: PARAMETER-gradient calls (`_wg`) issued inside are queued and submitted as ONE cdetr_wgrad_group call on
     exit (grouped launches).  Legal because a layer's parameter gradients are independent of each other and nothing inside a
     backward reads the gradient buffers -- only the optimizer / gradient exchange do, after the block.  The operand tensors
     are kept alive until the flush.  Weight-gradient-shaped contractions whose result the backward itself consumes (the RCDA
-    key gradients) are never deferred."""
+    key gradients) are never deferred.
+    With `WG_DEFER_NESTED` set, a queue that closes INSIDE another one passes its problems up instead of submitting them: the trainer's
+    chain layout collects every parameter gradient of the backward above the backbone in its own outer queue and submits them as a
+    separate graph on the weight-gradient stream (engine.Trainer._capture_chain)."""
 
     def __enter__(self):
         global _WG_QUEUE
@@ -197,7 +225,11 @@ class wgrad_queue:
     def __exit__(self, et, ev, tb):
         global _WG_QUEUE
         if et is None:
-            wgrad_flush()
+            if WG_DEFER_NESTED and self.prev is not None:
+                self.prev.extend(_WG_QUEUE)
+                del _WG_QUEUE[:]
+            else:
+                wgrad_flush()
         _WG_QUEUE = self.prev
         return False
 
@@ -550,6 +582,74 @@ class LinearFn(torch.autograd.Function):
             wgrad_raw(dy2d, dy2d.stride(0), x2d, x2d.stride(0), gw, gw.stride(0), dy2d.shape[0], w.shape[0], x2d.shape[1],
                       dbias=gb, may_defer=True)       # parameter gradient: queued when the trainer runs backward under wgrad_queue()
         return dx, None, None, None, None, None, d_resid, None
+
+
+FUSED_HEADS = os.environ.get("CDETR_FUSED_HEADS", "1") != "0"      # the three heads as one autograd node (A/B)
+
+
+class HeadsFn(torch.autograd.Function):
+    """The three heads on one decoder state (A2/models/transformer.py:79-107,193-213): class Linear(256, ncls) and the two 3-layer MLPs
+    (boxes: 4 outputs, variances: 2) as ONE autograd node with a hand-scheduled backward.
+    Forward: three grouped launches (the layers of one depth run together).  Backward: depth by depth, the two MLPs' data gradients of a
+    depth in one grouped launch with the ReLU mask of the layer below as the epilogue's gate (no mask pass), the three input gradients
+    chained through residual epilogues and ONE add -- 6 launches where the per-layer autograd nodes took 15; parameter gradients are
+    queued (ops.wgrad_queue) like every other one of the step.
+    params = (cls_w, cls_b, [w, b] x 3 of the box MLP, [w, b] x 3 of the variance MLP)."""
+
+    @staticmethod
+    def forward(ctx, x, *params):
+        shp = x.shape
+        x2d = x.reshape(-1, shp[-1])
+        if x2d.stride(-1) != 1 or (x2d.stride(0) & 3) or (x2d.data_ptr() & 15):
+            x2d = x2d.contiguous()
+        P = [p.detach() for p in params]
+        cw, cb, box, var = P[0], P[1], P[2:8], P[8:14]
+        with gemm_queue():
+            cls = linear_fwd(x2d, cw, cb)
+            h1b = linear_fwd(x2d, box[0], box[1], relu=True)
+            h1v = linear_fwd(x2d, var[0], var[1], relu=True)
+        with gemm_queue():
+            h2b = linear_fwd(h1b, box[2], box[3], relu=True)
+            h2v = linear_fwd(h1v, var[2], var[3], relu=True)
+        with gemm_queue():
+            ob = linear_fwd(h2b, box[4], box[5])
+            ov = linear_fwd(h2v, var[4], var[5])
+        ctx.params = params
+        ctx.save_for_backward(x2d, h1b, h2b, h1v, h2v)
+        ctx.xshape = shp
+        lead = shp[:-1]
+        return cls.reshape(*lead, -1), ob.reshape(*lead, -1), ov.reshape(*lead, -1)
+
+    @staticmethod
+    def backward(ctx, d_cls, d_box, d_var):
+        x2d, h1b, h2b, h1v, h2v = ctx.saved_tensors
+        params = ctx.params
+        P = [p.detach() for p in params]
+        cw, box, var = P[0], P[2:8], P[8:14]
+        d_cls, d_box, d_var = (t.reshape(-1, t.shape[-1]).contiguous() for t in (d_cls, d_box, d_var))
+        with gemm_queue():
+            g2b = linear_dgrad(d_box, box[4], gate=h2b)             # masked by relu(h2): the gradient w.r.t. the second layer's pre-activation
+            g2v = linear_dgrad(d_var, var[4], gate=h2v)
+        with gemm_queue():
+            g1b = linear_dgrad(g2b, box[2], gate=h1b)
+            g1v = linear_dgrad(g2v, var[2], gate=h1v)
+        dxc = linear_dgrad(d_cls, cw)
+        with gemm_queue():
+            dxb = linear_dgrad(g1b, box[0], resid=dxc)
+            dxv = linear_dgrad(g1v, var[0])
+        dx = add2(dxb, dxv)[0] if ctx.needs_input_grad[0] else None
+
+        def wg(dy, xin, w, b):
+            if w.requires_grad:
+                gw = grad_buffer(w)
+                gb = grad_buffer(b) if (b is not None and b.requires_grad) else None
+                wgrad_raw(dy, dy.stride(0), xin, xin.stride(0), gw, gw.stride(0), dy.shape[0], gw.shape[0], xin.shape[1], dbias=gb, may_defer=True)
+        wg(d_cls, x2d, params[0], params[1])
+        for (dy3, dy2, dy1, h2, h1, off) in ((d_box, g2b, g1b, h2b, h1b, 2), (d_var, g2v, g1v, h2v, h1v, 8)):
+            wg(dy3, h2, params[off + 4], params[off + 5])
+            wg(dy2, h1, params[off + 2], params[off + 3])
+            wg(dy1, x2d, params[off], params[off + 1])
+        return (dx.reshape(ctx.xshape) if dx is not None else None,) + (None,) * len(params)
 
 
 def linear(x, weight, bias=None, relu=False, resid=None, out_scale=1.0, rows=None):

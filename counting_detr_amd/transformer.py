@@ -354,7 +354,11 @@ class Transformer(nn.Module):
         # the heads are ONE module aliased over the layers (:104-107): with aux losses all layers go through them in one pass
         lids = list(range(len(self.decoder_layers))) if self.all_layer_heads else [last]
         output = layer_outs[last] if len(lids) == 1 else torch.stack([layer_outs[i] for i in lids])      # [(Ld,) B, Q, C]
-        if self.stage == 2:
+        if self.stage == 2 and output.is_cuda and torch.is_grad_enabled() and ops.FUSED_HEADS:
+            ce, be, ve = self.cls_embed[last], self.bbox_embed[last], self.bbox_variance[last]
+            hp = [ce.weight, ce.bias] + [t for l in be.layers for t in (l.weight, l.bias)] + [t for l in ve.layers for t in (l.weight, l.bias)]
+            outputs_class, tmp, var = ops.HeadsFn.apply(output, *hp)       # one autograd node: 6 backward launches instead of 15
+        elif self.stage == 2:
             outputs_class, tmp, var = mlps_levelwise([self.cls_embed[last], self.bbox_embed[last], self.bbox_variance[last]], output)
         else:
             ce = self.cls_embed[last]

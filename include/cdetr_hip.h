@@ -366,6 +366,16 @@ int cdetr_criterion_bwd(const float* g6, const float* g_total, const float* loss
 
 const char* cdetr_last_error(void);
 int cdetr_abi_version(void);
+/* Stream plumbing of the trainer (no reference counterpart: the reference runs one stream and drains it every step, A2/engine.py:33-57).
+ * cdetr_delay: one idle wavefront for `us` microseconds -- holds `stream` back without occupying the chip (stream-concurrency probe).
+ * cdetr_flag_signal / cdetr_flag_wait: ordering between two streams from INSIDE captured graphs, where no event can be recorded: the signal
+ *   (one thread) adds 1 to *flag; the wait (one thread, at the head of the other stream's work) sleeps until *flag has passed *seen -- its own
+ *   count of consumed signals, updated by the kernel -- or `timeout_us` has gone by (a missing signal costs a delay, never a hang).
+ *   engine.Trainer releases the next batch's frozen stage (A2/models/backbone.py:93-95) the moment the Hungarian solve of the current step
+ *   (A2/models/matcher.py:243-247) is about to start: the solve needs one whole compute unit's LDS for its cost matrix.                   */
+int cdetr_delay(int32_t us, void* stream);
+int cdetr_flag_signal(int32_t* flag, void* stream);
+int cdetr_flag_wait(const int32_t* flag, int32_t* seen, int32_t timeout_us, void* stream);
 
 /* ---- glue (csrc/glue.hip): the small steps between the GEMMs, one launch each -------------------------------------------------
  * cdetr_mask_prep: padding mask [B][H][W] (bytes, non-zero = padding) -> m [B][h][w] (nearest-neighbour down-sampling,

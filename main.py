@@ -73,7 +73,7 @@ def main(args):
     if args.resume:                                                     # A2/main.py:195-209
         checkpoint, _, _ = ckpt_io.resume_model(model, args.resume, skip_mismatch=args.resume_skip_mismatch)
 
-    trainer = Trainer(model, criterion, args, device=device)           # 3 lr groups + flat AdamW (A2/main.py:157-189); syncs replicas
+    trainer = Trainer(model, criterion, args, device=device)           # 3 lr groups + flat AdamW (A2/main.py:157-189); syncs replicas; owns its arithmetic
     if checkpoint is not None and (args.resume_optimizer or args.auto_resume) and checkpoint.get("optimizer"):
         # opt-in (the reference loads weights only and starts at --start_epoch, A2/main.py:195-209): continue an interrupted run
         trainer.load_state_dict(checkpoint["optimizer"], checkpoint.get("lr_scheduler"))

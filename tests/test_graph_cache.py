@@ -189,6 +189,8 @@ def test_frozen_stage_prefetch_equals_the_in_line_step():
     batches = [_batch(B, H, W, (5 + i, 20 - i), seed=500 + i) for i, (B, H, W) in enumerate(shapes)]
     decoy = _batch(2, 64, 96, (3, 3), seed=999)[0]
     for i, (images, rects, tg) in enumerate(batches):
+        for dst, src in zip((ta.flat_p, ta.exp_avg, ta.exp_avg_sq, ta.opt_state), (tb.flat_p, tb.exp_avg, tb.exp_avg_sq, tb.opt_state)):
+            dst.copy_(src)                                # both trainers take every step from the same state: no drift to allow for
         nxt = batches[i + 1][0] if i + 1 < len(batches) else None
         if i == 3:
             nxt = decoy                                   # announced, never delivered
@@ -200,11 +202,9 @@ def test_frozen_stage_prefetch_equals_the_in_line_step():
         ob = tb.step(images, rects, tg)
         torch.cuda.synchronize()
         for k in ob:
-            np.testing.assert_allclose(float(oa[k]), float(ob[k]), rtol=3e-3 if i else (2e-4 if k == "grad_norm" else 1e-5), atol=1e-6, err_msg=f"step {i} {k}")
-            # (two trainers drift apart by the atomic-order noise of their updates; a STALE frozen stage -- the batch of step 2 was shifted by
-            # 0.25 after it was announced -- would move the losses by O(1))
+            np.testing.assert_allclose(float(oa[k]), float(ob[k]), rtol=2e-4 if k == "grad_norm" else 2e-5, atol=1e-6, err_msg=f"step {i} {k}")
     diff = (ta.flat_p - tb.flat_p).abs()
-    assert float(diff.max()) <= 1e-3 and float((diff > 1e-5).float().mean()) < 1e-2
+    assert float(diff.max()) <= 2.1e-4 and float((diff > 2e-6).float().mean()) < 2e-3
     # steps 1, 3 (same shape as announced) hit; 2 was modified, 4 got another tensor than announced, 6 was not announced; 0 is the first
     # step; every first meeting of a key (steps 0 and 2) recomputes in line inside the capture
     assert ta.prefetch_stats["hits"] == 3, ta.prefetch_stats          # steps 1, 3, 5
@@ -226,7 +226,7 @@ def test_pipelined_replay_equals_plain_replay():
             losses.append(float(tr.replay(pipelined=pipelined)["loss"]))
         torch.cuda.synchronize()
         outs.append((losses, tr.flat_p.detach().clone(), dict(tr.prefetch_stats)))
-    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-4)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=3e-3)          # (two runs drift apart by the atomic-order noise of their updates)
     assert outs[0][0][-1] < outs[0][0][0]                 # it trains
     assert outs[0][2] == {"hits": 3, "inline": 1} and outs[1][2] == {"hits": 0, "inline": 4}
     assert float((outs[0][1] - outs[1][1]).abs().max()) <= 1e-3
@@ -319,32 +319,40 @@ def test_inference_engine_graph_equals_eager_forward():
 
 
 @gpu
-def test_segmented_graph_equals_single_graph(monkeypatch):
-    """The five-sub-graph form of the captured step (what world_size > 1 replays, with the bucketed all-reduces between the
-    sub-graphs) on ONE rank == the single-graph step: same losses bit for bit (the forward and the matching are deterministic),
-    same gradient norm and parameters to the atomic-order noise of the weight-gradient reductions."""
+def test_graph_layouts_agree(monkeypatch):
+    """The captured step's layouts -- "chain" (default: linear graphs only, side work as separate graphs on side streams), "single" (round
+    3: [forward] | [the rest with in-graph branches]) and "single" with the backbone's backward as three more sub-graphs (what
+    world_size > 1 replayed in round 3) -- are the same step: same losses bit for bit on the first step (the forward and the matching
+    are deterministic), same gradient norm and parameters to the atomic-order noise of the weight-gradient reductions."""
     from counting_detr_amd.engine import Trainer
     images, rects, tg = _batch(2, 128, 160, (7, 13), seed=21)
     res = []
-    for seg in ("0", "1"):
+    for layout, seg in (("single", "0"), ("single", "1"), ("chain", "0")):
+        monkeypatch.setenv("CDETR_GRAPH_LAYOUT", layout)
         monkeypatch.setenv("CDETR_SEGMENTED_GRAPH", seg)
         model, crit, args = _build(Q=100)
         tr = Trainer(model, crit, args, device=DEV)
         tr.capture(images, rects, tg, warmup=0)
-        assert (tr._entry["segs"] is not None) == (seg == "1")
+        e = tr._entry
+        assert e["layout"] == layout
+        if layout == "single":
+            assert (e["segs"] is not None) == (seg == "1")
+        else:
+            assert len(e["S"]) == 3 and all(w is not None for w in e["W"]) and e["W0"] is not None
         outs = []
         for _ in range(3):
             outs.append({k: float(v) for k, v in tr.replay().items()})
         torch.cuda.synchronize()
         res.append((outs, tr.flat_p.detach().clone()))
-    (o0, p0), (o1, p1) = res
-    for k in o0[0]:
-        if k != "grad_norm":
-            assert o0[0][k] == o1[0][k], k                      # first step: identical weights -> identical forward, matching and losses
-        for a, b in zip(o0, o1):
-            np.testing.assert_allclose(b[k], a[k], rtol=2e-3, atol=1e-6, err_msg=k)
-    diff = (p0 - p1).abs()
-    assert float(diff.max()) <= 6.5e-4 and float((diff > 1e-5).float().mean()) < 1e-2      # 3 AdamW steps of <= lr each on near-zero gradients
+    (o0, p0) = res[0]
+    for (o1, p1) in res[1:]:
+        for k in o0[0]:
+            if k != "grad_norm":
+                assert o0[0][k] == o1[0][k], k                      # first step: identical weights -> identical forward, matching and losses
+            for a, b in zip(o0, o1):
+                np.testing.assert_allclose(b[k], a[k], rtol=2e-3, atol=1e-6, err_msg=k)
+        diff = (p0 - p1).abs()
+        assert float(diff.max()) <= 6.5e-4 and float((diff > 1e-5).float().mean()) < 1e-2      # 3 AdamW steps of <= lr each on near-zero gradients
 
 
 @gpu
@@ -400,3 +408,39 @@ def test_cached_graph_step_with_aux_losses_equals_eager_step():
         for k in eo:
             np.testing.assert_allclose(go[k], eo[k], rtol=1e-4 if k == "grad_norm" else 1e-5, atol=1e-6, err_msg=f"batch {i} {k}")
     assert tr.cache_stats == {"captures": 1, "steps": 2}
+
+
+@gpu
+def test_two_engines_of_different_arithmetic_in_one_process():
+    """A split-bf16 Trainer and an fp32-MFMA InferenceEngine (another model) interleaved in one process: each computes in the arithmetic
+    it was built with (ops.arithmetic scopes; the module defaults are untouched) -- the evaluator's outputs are bit-identical to the ones
+    it produces alone, the trainer's first-step losses too."""
+    from counting_detr_amd import ops
+    from counting_detr_amd.engine import InferenceEngine, Trainer
+    default = (ops.PRECISION, ops.PRECISION_BWD)
+    images, rects, tg = _batch(2, 96, 128, (7, 13), seed=77)
+
+    def build_pair():
+        model, crit, args = _build(Q=100)
+        tr = Trainer(model, crit, args, device=DEV, precision=1, precision_bwd=3)
+        model2, _, _ = _build(Q=100)
+        return tr, InferenceEngine(model2, precision=0)
+    tr, ev = build_pair()
+    alone_ev = [t.clone() for t in (ev(images, rects)[2]["pred_logits"], ev(images, rects)[2]["pred_boxes"])]
+    tr2, ev2 = build_pair()
+    alone_tr = {k: float(v) for k, v in tr2.step(images, rects, tg).items()}
+    tr3, ev3 = build_pair()
+    assert tr3.arith == (1, 3) and ev3.arith[0] == 0
+    o1 = ev3(images, rects)[2]
+    mixed_ev = [o1["pred_logits"].clone(), o1["pred_boxes"].clone()]
+    mixed_tr = {k: float(v) for k, v in tr3.step(images, rects, tg).items()}
+    o2 = ev3(images, rects)[2]
+    for a, b, c in zip(alone_ev, mixed_ev, (o2["pred_logits"], o2["pred_boxes"])):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for k, v in alone_tr.items():
+        if k != "grad_norm":
+            assert mixed_tr[k] == v, k
+    assert (ops.PRECISION, ops.PRECISION_BWD) == default
+    # and the two arithmetics really differ: the fp32-MFMA evaluator of the TRAINER's weights is not bit-equal to a split-bf16 one
+    e_a, e_b = InferenceEngine(tr3.model, precision=0), InferenceEngine(tr3.model, precision=1)
+    assert not torch.equal(e_a(images, rects)[2]["pred_boxes"], e_b(images, rects)[2]["pred_boxes"])

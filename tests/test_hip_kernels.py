@@ -1109,3 +1109,35 @@ def test_layernorm_backward_with_merged_addends(N, H, W):
     ye.backward(tot)
     dx = run(True, True, False)[0]
     close(dx, xe.grad + add.double().cpu(), rtol=5e-5, atol_scale=5e-5, msg="merged vs fp64")
+
+
+def test_fused_heads_node_equals_per_layer_nodes():
+    """ops.HeadsFn (the class / box / variance heads of A2/models/transformer.py:79-107 as one autograd node, hand-scheduled backward
+    with the ReLU masks in the data-gradient epilogues) == the per-layer LinearFn nodes: outputs bit-identical (the same launches),
+    input gradient and every parameter gradient equal to the reduced-term arithmetic's noise."""
+    from counting_detr_amd import ops
+    from counting_detr_amd.transformer import MLP, Linear, mlps_levelwise
+    torch.manual_seed(0)
+    ce, be, ve = Linear(256, 2).to(DEV), MLP(256, 256, 4, 3).to(DEV), MLP(256, 256, 2, 3).to(DEV)
+    x = torch.randn(2, 300, 256, device=DEV)
+    ups = [torch.randn(2, 300, n, device=DEV) for n in (2, 4, 2)]
+    res = []
+    for fused in (False, True):
+        for p in list(ce.parameters()) + list(be.parameters()) + list(ve.parameters()):
+            p.grad = torch.zeros_like(p)
+        xi = x.clone().requires_grad_(True)
+        if fused:
+            hp = [ce.weight, ce.bias] + [t for l in be.layers for t in (l.weight, l.bias)] + [t for l in ve.layers for t in (l.weight, l.bias)]
+            outs = ops.HeadsFn.apply(xi, *hp)
+        else:
+            outs = mlps_levelwise([ce, be, ve], xi)
+        with ops.wgrad_queue():
+            torch.autograd.backward(list(outs), ups)
+        res.append(([o.detach().clone() for o in outs], xi.grad.clone(),
+                    [p.grad.clone() for p in list(ce.parameters()) + list(be.parameters()) + list(ve.parameters())]))
+    (o0, dx0, g0), (o1, dx1, g1) = res
+    for a, b in zip(o0, o1):
+        assert torch.equal(a, b)
+    close(dx1, dx0, rtol=1e-5, msg="dx")
+    for i, (a, b) in enumerate(zip(g0, g1)):
+        close(b, a, rtol=1e-5, msg=f"param grad {i}")

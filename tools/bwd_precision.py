@@ -14,7 +14,9 @@ res = {}
 for tag, prec, bwd in (("fp32", "fp32", 1), ("bf16x3", "bf16x3", 1), ("bf16x2", "bf16x3", 2), ("bf16x1", "bf16x3", 3)):
     tr = build_trainer(dev, 300, "learned", prec)
     ops.PRECISION_BWD = bwd
-    out = tr._fwd_bwd(im, mk, rects, targets, nb)
+    tr.arith = (tr.arith[0], bwd)                 # the trainer owns its arithmetic (ops.arithmetic)
+    with ops.arithmetic(*tr.arith):
+        out = tr._fwd_bwd(im, mk, rects, targets, nb)
     torch.cuda.synchronize()
     g = tr.flat_g.detach().double().clone()
     tr.capture(images, rects, targets, warmup=1)
