@@ -243,10 +243,11 @@ def inference_leg(dev, shapes, batch0, precision, steps=20):
         row = {"image": [H, W], "images_per_gpu": batch, "queries": 300}
         for tag, graphs in (("graph", True), ("eager", False)):
             eng = InferenceEngine(model, graphs=graphs)
+            # (graph mode, one batch of look-ahead like infer.py's loop: the next batch's frozen stage runs beside this batch's encoder / decoder)
             for _ in range(3):
-                counts = eng(images, rects)[0]
+                counts = eng(images, rects, next_samples=images)[0]
             torch.cuda.synchronize()
-            dt, per, _ = timed_steps(lambda: eng(images, rects), steps, torch.cuda.synchronize)
+            dt, per, _ = timed_steps(lambda: eng(images, rects, next_samples=images), steps, torch.cuda.synchronize)
             row[tag] = {"value": batch * steps / dt, "unit": "images/s", "ms_per_batch": dt / steps * 1e3, "step_ms": percentiles(per)}
         row["counts"] = [int(c) for c in counts]
         out.append(row)

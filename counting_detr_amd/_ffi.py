@@ -94,7 +94,7 @@ def lib():
         L.cdetr_flag_signal.restype = C.c_int
         L.cdetr_flag_signal.argtypes = [_p, _p]
         L.cdetr_flag_wait.restype = C.c_int
-        L.cdetr_flag_wait.argtypes = [_p, _p, C.c_int32, _p]
+        L.cdetr_flag_wait.argtypes = [_p, _p, C.c_int32, C.c_int32, _p]
         L.cdetr_gemm_group.restype = C.c_int
         L.cdetr_gemm_group.argtypes = [_p, C.c_int32, _p]
         L.cdetr_wgrad_group.restype = C.c_int

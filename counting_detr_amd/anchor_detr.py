@@ -78,6 +78,8 @@ class AnchorDETR(nn.Module):
             samples = nested_tensor_from_tensor_list(samples)
         images, mask = samples.decompose()
         x, mi = self.backbone.features(images, mask)                          # NHWC [B,h,w,2048] + everything derived from the mask
+        if ops.AFTER_BACKBONE is not None:
+            ops.AFTER_BACKBONE()
         per_image = self.backbone.exemplar_mode == "per_image"
         if CONCAT_FREE:     # the exemplar product folds into the projection weight: no [B,h,w,4096] tensor
             src = self.aggr_input_proj[0]((x, rects, mi.extent, per_image))

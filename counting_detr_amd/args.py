@@ -74,6 +74,14 @@ def get_args_parser():
     p.add_argument("--no_graph_cache", dest="graph_cache", action="store_false",
                    help="train with the stream-ordered step instead of cached HIP graphs (one per padded image size / target-capacity class)")
     p.add_argument("--graph_cache_size", default=32, type=int, help="captured steps kept alive (least recently used is dropped)")
+    p.add_argument("--graph_layout", default="chain", choices=["chain", "single"],
+                   help="captured step: chain = linear graphs + side-stream graphs (host cost 0.3 ms per step); single = round 3's two graphs with "
+                        "in-graph branches (8.7 ms of host time per step)")
+    p.add_argument("--no_frozen_prefetch", dest="frozen_prefetch", action="store_false",
+                   help="run the frozen stem + layer1 of a batch inside its own step instead of beside the previous step's Hungarian solve")
+    p.add_argument("--captured_allreduce", action="store_true",
+                   help="world_size > 1: the four gradient buckets' all-reduces as captured graphs on the exchange stream instead of host-issued "
+                        "RCCL calls (untested on N > 1 GPUs: for the first multi-GPU A/B)")
     p.add_argument("--bwd_precision", default=None, choices=["bf16", "bf16x2", "bf16x3"],
                    help="arithmetic of the backward contractions (default bf16 = 1 MFMA per product, gradient error 4.7e-3 of its norm; "
                         "bf16x3 = the forward's split arithmetic, 1.6e-3; DESIGN section 3).  Same as CDETR_PRECISION_BWD=3/2/1")

@@ -357,7 +357,9 @@ class ResNetBody(nn.Module):
                 x = ops.maxpool3x3s2(x)
                 for i, blk in enumerate(self.layer1):
                     if i == len(self.layer1) - 1 and (twins or out_to is not None):
-                        x, x16 = blk.forward_fused(x, twin_out=True, out_to=out_to)
+                        want16 = twins or (out_to is not None and out_to[1] is not None)      # (inference: out_to = (x, None), no twin)
+                        r = blk.forward_fused(x, twin_out=want16, out_to=out_to)
+                        x, x16 = r if want16 else (r, None)
                     else:
                         x = blk.forward_fused(x)
         return x, x16, xlo

@@ -251,13 +251,15 @@ extern "C" int cdetr_mask_prep(const uint8_t* mask, int32_t B, int32_t H, int32_
 // the timeout makes a missing signal (or a waiter that shares its hardware queue with the signalling chain) a delay, never a hang.
 namespace {
 __global__ void flag_signal_kernel(int* flag) { __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ void flag_wait_kernel(const int* flag, int* seen, long timeout_ticks) {
+__global__ void flag_wait_kernel(const int* flag, int* seen, long timeout_ticks, long post_ticks) {
     const int want = *seen + 1;
     const long t0 = wall_clock64();
     int cur;
     while ((cur = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) - want < 0 && wall_clock64() - t0 < timeout_ticks)
         __builtin_amdgcn_s_sleep(16);
     if (threadIdx.x == 0) *seen = (cur - want >= 0) ? cur : want;
+    const long t1 = wall_clock64();                    // the signalling chain's NEXT kernel gets a head start before this stream's work begins
+    while (wall_clock64() - t1 < post_ticks) __builtin_amdgcn_s_sleep(16);
 }
 __global__ void delay_kernel(long ticks) {
     const long t0 = wall_clock64();
@@ -269,9 +271,11 @@ extern "C" int cdetr_flag_signal(int32_t* flag, void* stream) {
     hipLaunchKernelGGL(flag_signal_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), flag);
     return cdetr_launch_status("cdetr_flag_signal");
 }
-extern "C" int cdetr_flag_wait(const int32_t* flag, int32_t* seen, int32_t timeout_us, void* stream) {
-    CDETR_CHECK_ARG(flag && seen && timeout_us >= 0 && timeout_us <= 100000, "cdetr_flag_wait: bad args (timeout 0 .. 100000 us)");
-    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), flag, seen, (long)timeout_us * 100);   // wall_clock64: 100 MHz
+extern "C" int cdetr_flag_wait(const int32_t* flag, int32_t* seen, int32_t timeout_us, int32_t post_us, void* stream) {
+    CDETR_CHECK_ARG(flag && seen && timeout_us >= 0 && timeout_us <= 100000 && post_us >= 0 && post_us <= 1000,
+                    "cdetr_flag_wait: bad args (timeout 0 .. 100000 us, post 0 .. 1000 us)");
+    hipLaunchKernelGGL(flag_wait_kernel, dim3(1), dim3(1), 0, reinterpret_cast<hipStream_t>(stream), flag, seen, (long)timeout_us * 100,
+                       (long)post_us * 100);            // wall_clock64: 100 MHz
     return cdetr_launch_status("cdetr_flag_wait");
 }
 // One idle wavefront for `us` microseconds (s_sleep between reads of the 100 MHz wall clock): holds a stream back without occupying the chip

@@ -41,7 +41,29 @@ class FlatGradExchange:
         self.flat_g, self.seg_bounds = flat_g, list(seg_bounds)
         self.stream = torch.cuda.Stream() if (flat_g.is_cuda and is_dist_avail_and_initialized()) else None
         self.launched = []
+        self.graphs = None      # capture_buckets(): the bucket all-reduces as captured graphs
         self.probe = None       # a list: finish() appends (compute-side event, comm-side event) per step -> exposed_ms()
+
+    def capture_buckets(self, pool=None):
+        """The four bucket all-reduces as captured graphs on the exchange stream (RCCL collectives are capturable): `segment_done` then
+        replays graph `seg` instead of calling into the process group -- one `hipGraphLaunch` per bucket instead of RCCL's host-side
+        enqueue.  Selectable (engine.Trainer: args.captured_allreduce / CDETR_CAPTURED_ALLREDUCE=1) next to the default host-issued form so
+        that the first multi-GPU run can A/B them; never exercised on N > 1 GPUs in this repository's history."""
+        if self.stream is None:
+            return False
+        graphs = []
+        for seg in range(len(self.seg_bounds) - 1):
+            lo, hi = self.seg_bounds[seg], self.seg_bounds[seg + 1]
+            if hi <= lo:
+                graphs.append(None)
+                continue
+            g = torch.cuda.CUDAGraph()
+            kw = {"pool": pool} if pool is not None else {}
+            with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local", **kw):
+                dist.all_reduce(self.flat_g[lo:hi])
+            graphs.append(g)
+        self.graphs = graphs
+        return True
 
     def segment_done(self, seg, also=None):
         """also: a second stream whose work so far (parameter gradients running beside the backward) the bucket depends on."""
@@ -57,7 +79,11 @@ class FlatGradExchange:
             if also is not None:
                 self.stream.wait_stream(also)
             with torch.cuda.stream(self.stream):
-                dist.all_reduce(buf)
+                g = self.graphs[seg] if self.graphs else None
+                if g is not None:
+                    g.replay()
+                else:
+                    dist.all_reduce(buf)
         else:
             dist.all_reduce(buf)
 
@@ -194,8 +220,12 @@ class Trainer:
         import os as _os
         self._prefetch_on = bool(getattr(args, "frozen_prefetch", True)) and _os.environ.get("CDETR_FROZEN_PREFETCH", "1") != "0"
         self._pf_timeout_us = int(_os.environ.get("CDETR_PF_TIMEOUT_US", getattr(args, "frozen_prefetch_timeout_us", 400)))   # flag wait (chain layout)
+        self._captured_allreduce = _os.environ.get("CDETR_CAPTURED_ALLREDUCE", "1" if getattr(args, "captured_allreduce", False) else "0") == "1"
+        self._z_late = _os.environ.get("CDETR_Z_LATE", "1") != "0"               # Z released by the backbone-forward-done signal instead of at step start
+        self._pf_post_us = int(_os.environ.get("CDETR_PF_POST_US", 30))          # head start of the solve over the prefetched stage's workgroups
         self._pf_delay_us = int(_os.environ.get("CDETR_PF_DELAY_US", 0))        # "single" layout only: fixed delay in front of the prefetched stage
         self._pf_eager = _os.environ.get("CDETR_PF_EAGER", "0") == "1"
+        self._tail_inline = float(_os.environ.get("CDETR_TAIL_INLINE", getattr(args, "wgrad_tail_inline", 1.0)))   # share of layer2's weight gradients kept on the main stream
         self._frozen = {}                       # image shape -> frozen-stage buffers + graph (see "frozen-stage prefetch")
         self._pf_stream = self._pf_pool = self._wg_stream = None
         self.prefetch_stats = {"hits": 0, "inline": 0}
@@ -755,7 +785,8 @@ class Trainer:
             self._pf_stream, self._wg_stream = pf, wg
             self.side_stream_probe = {"overlap_main": len(ok), "of": len(cands), "wg_overlaps_pf": bool(rest)}
             self._pf_pool = torch.cuda.graph_pool_handle()      # NOT the steps' pool: the frozen-stage graph runs beside a step's backward
-            self._sig = torch.zeros(2, dtype=torch.int32, device=self.device)       # [signal counter, signals the prefetch stream has consumed]
+            # [solve-is-next counter, consumed | backbone-forward-done counter, consumed]   (cdetr_flag_signal / cdetr_flag_wait)
+            self._sig = torch.zeros(4, dtype=torch.int32, device=self.device)
         return self._pf_stream, self._wg_stream
 
     def _capture_chain(self, st, world, warmup):
@@ -774,10 +805,16 @@ class Trainer:
         e = {}
         try:
             e["F"] = G()
-            with torch.cuda.graph(e["F"], stream=s, **mode):
-                outputs = self._forward(st["images"], st["mask"], st["rects"])
-                if hasattr(self.criterion, "pre_match"):    # the cost matrices close the forward piece: the next piece STARTS with the solve
-                    self.criterion.pre_match(outputs, st["targets"])
+            from . import _ffi
+            sig2 = self._sig.data_ptr() + 8                  # "the backbone's forward is done": releases Z under the encoder / decoder
+            ops.AFTER_BACKBONE = (lambda: _ffi.check(_ffi.lib().cdetr_flag_signal(sig2, _ffi.stream_ptr()), "cdetr_flag_signal")) if self._z_late else None
+            try:
+                with torch.cuda.graph(e["F"], stream=s, **mode):
+                    outputs = self._forward(st["images"], st["mask"], st["rects"])
+                    if hasattr(self.criterion, "pre_match"):    # the cost matrices close the forward piece: the next piece STARTS with the solve
+                        self.criterion.pre_match(outputs, st["targets"])
+            finally:
+                ops.AFTER_BACKBONE = None
             e["Z"] = G()
             with torch.cuda.graph(e["Z"], stream=pf, **mode):
                 self._zero_and_mirror()
@@ -814,6 +851,14 @@ class Trainer:
                     with torch.cuda.graph(g, stream=s, **mode):
                         if self._trunk_pending is not None:
                             self._trunk_pending.run(seg)
+                        if seg == 3 and ops._WG_QUEUE and self._tail_inline > 0:
+                            # the LAST segment's weight gradients have nothing left to run beside: the main stream would idle while the
+                            # weight-gradient stream works off its backlog -- the problems whose operands came last stay on the main stream
+                            q_all = list(ops._WG_QUEUE)
+                            k = int(round(len(q_all) * (1.0 - self._tail_inline)))
+                            ops._WG_QUEUE[:] = q_all[k:]
+                            ops.wgrad_flush()
+                            ops._WG_QUEUE[:] = q_all[:k]
                     gw = None
                     if ops._WG_QUEUE:
                         held.append([x[2] for x in ops._WG_QUEUE])
@@ -834,6 +879,8 @@ class Trainer:
             ops.BRANCH_BESIDE, ops.WGRAD_EVERY = keep_beside, keep_every
             ops.MIRROR = None
         e["out"] = out
+        if world > 1 and self.exchange.graphs is None and self._captured_allreduce:
+            self.exchange.capture_buckets()
         return e
 
     def _capture_graphs(self, st, world, warmup, segmented):
@@ -927,6 +974,8 @@ class Trainer:
         ev0.record(main)
         pf.wait_event(ev0)
         with torch.cuda.stream(pf):
+            if self._z_late:                           # (zero-fill + weight images are floods: beside the latency-bound encoder / decoder, not the backbone)
+                _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr() + 8, self._sig.data_ptr() + 12, 4000, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
             e["Z"].replay()
             evz = torch.cuda.Event()
             evz.record(pf)
@@ -938,7 +987,7 @@ class Trainer:
             evf.record(main)
             pf.wait_event(evf)
             with torch.cuda.stream(pf):
-                _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr(), self._sig.data_ptr() + 4, self._pf_timeout_us, _ffi.stream_ptr()),
+                _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr(), self._sig.data_ptr() + 4, self._pf_timeout_us, self._pf_post_us, _ffi.stream_ptr()),
                            "cdetr_flag_wait")
             self._prefetch(announce[0], announce[1], announce[0], ordered=True)
         main.wait_event(evz)
@@ -1105,14 +1154,44 @@ def count_from_logits(pred_logits, threshold=0.5):
     return keep.sum(-1), keep, prob
 
 
+def probe_side_stream(main, device, n=8):
+    """A stream whose kernels really run beside `main`'s (HIP maps streams onto a few hardware queues; two streams of one queue never
+    overlap): candidates are probed with a long idle kernel on `main` and a short one on the candidate."""
+    from . import _ffi
+
+    def concurrent(a, b):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(a):
+            e0.record(a)
+            _ffi.check(_ffi.lib().cdetr_delay(600, _ffi.stream_ptr()), "cdetr_delay")
+        b.wait_event(e0)
+        with torch.cuda.stream(b):
+            _ffi.check(_ffi.lib().cdetr_delay(1, _ffi.stream_ptr()), "cdetr_delay")
+            e1.record(b)
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) < 0.3
+    cands = [torch.cuda.Stream(device=device) for _ in range(n)]
+    for c in cands:
+        if concurrent(main, c):
+            return c, True
+    return cands[0], False
+
+
 class InferenceEngine:
     """Forward + counting rule (A2/infer.py:57-81) at graph-replay speed: pre-split forward weight images built ONCE (the
     weights do not change), one captured HIP graph per padded image shape (val / test images are resized to multiples of
     `scale_factor`, A2/data/fsc147.py:150-152 -- a few dozen shapes), replayed with three small input copies.
     `engine(samples, rects)` -> (counts [B] int64, keep [B,Q] bool, outputs dict, reference points, prob [B,Q]); the tensors are the graph's
-    static outputs: valid until the same shape runs again (clone to keep)."""
+    static outputs: valid until the same shape runs again (clone to keep).
+    The captured forward is a LINEAR graph (no in-graph forks: 0.1 ms of host time per launch instead of 2.7; +4-6 % images/s).
+    `prefetch=True` + `engine(samples, rects, next_samples=nxt)` announces the batch of the NEXT call (the same tensor object): its frozen
+    stage (stem + max-pool + layer1, throughput-bound) runs on a side stream beside this call's latency-bound encoder / decoder -- released
+    by a signal kernel that the captured forward carries right behind its backbone.  Measured (profiles/r4_inference_prefetch.txt): 2.5 %
+    SLOWER than the plain linear graph (510 vs 522 img/s at 800x800, 787 vs 812 at 384x576) -- the inference forward has no window like the
+    training step's Hungarian solve, the flood only stretches the encoder / decoder chain -- so it is OFF by default; bit-identical either way."""
 
-    def __init__(self, model, threshold=0.5, graphs=True, max_graphs=48, device=None, precision=None):
+    def __init__(self, model, threshold=0.5, graphs=True, max_graphs=48, device=None, precision=None, prefetch=False):
         from . import ops as _ops
         self.arith = (int(_ops.PRECISION if precision is None else precision), int(_ops.PRECISION_BWD))      # (ops.arithmetic: this engine's own)
         self.model, self.threshold, self.graphs, self.max_graphs = model, threshold, graphs, max_graphs
@@ -1124,16 +1203,20 @@ class InferenceEngine:
         self._cache = {}
         self._stream = None
         self._pool = None                # one graph memory pool for all shapes (graphs never run concurrently; outputs stay allocated)
-        self.stats = {"captures": 0, "calls": 0}
+        import os
+        self._prefetch_on = bool(prefetch) and os.environ.get("CDETR_FROZEN_PREFETCH", "1") != "0" and hasattr(model, "backbone")
+        self._frozen, self._pf_stream, self._pf_pool, self._sig = {}, None, None, None
+        self.stats = {"captures": 0, "calls": 0, "prefetch_hits": 0}
         import weakref
         model.__dict__.setdefault("_graph_cache_owners", []).append(weakref.ref(self))
         self.refresh_weights()
 
     def clear_graph_cache(self):
-        if self._cache:
+        if self._cache or self._frozen:
             if self.device.type == "cuda":
                 torch.cuda.synchronize()
             self._cache.clear()
+            self._frozen.clear()
 
     @_scoped
     def refresh_weights(self):
@@ -1143,6 +1226,7 @@ class InferenceEngine:
         if self.mirror is not None:
             self.mirror.refresh("fwd")
         self._cache.clear()
+        self._frozen.clear()
 
     @torch.no_grad()
     def _run(self, images, mask, rects):
@@ -1156,14 +1240,51 @@ class InferenceEngine:
         counts, keep, prob = count_from_logits(outputs["pred_logits"], self.threshold)
         return counts, keep, outputs, ref, prob
 
+    # ---- frozen-stage prefetch (see the class docstring; the training-side twin is Trainer._frozen_for / _prefetch)
+    def _frozen_for(self, shape):
+        from . import ops
+        shape = tuple(shape)
+        fs = self._frozen.get(shape)
+        if fs is not None:
+            return fs
+        body = self.model.backbone.body
+        B, _, H, W = shape
+        h, w = body.frozen_out_hw(H, W)
+        if self._pf_stream is None:
+            self._pf_stream, _ = probe_side_stream(torch.cuda.current_stream(), self.device)
+            self._pf_pool = torch.cuda.graph_pool_handle()
+            self._sig = torch.zeros(2, dtype=torch.int32, device=self.device)
+        ps = self._pf_stream
+        fs = {"images": torch.zeros(shape, device=self.device), "x": torch.empty((B, h, w, 256), device=self.device),
+              "xs": torch.empty((B, h, w, 256), device=self.device), "token": None, "keep": None}
+        prev, ops.MIRROR = ops.MIRROR, self.mirror
+        beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0
+        try:
+            ps.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(ps):
+                body.frozen_stage(fs["images"], False, out_to=(fs["xs"], None))
+            torch.cuda.current_stream().wait_stream(ps)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self._pf_pool, stream=ps):
+                body.frozen_stage(fs["images"], False, out_to=(fs["xs"], None))
+        finally:
+            ops.MIRROR, ops.BRANCH_BESIDE = prev, beside
+        fs["graph"] = g
+        self._frozen[shape] = fs
+        return fs
+
     @_scoped
     @torch.no_grad()
-    def __call__(self, samples, rects):
+    def __call__(self, samples, rects, next_samples=None):
+        from . import _ffi, ops
         nt = samples if hasattr(samples, "decompose") else nested_tensor_from_tensor_list(samples)
         images, mask = nt.decompose()
         self.stats["calls"] += 1
         if not self.graphs or not images.is_cuda:
             return self._run(images, mask, rects)
+        body = self.model.backbone.body if self._prefetch_on else None
+        fs = self._frozen_for(images.shape) if (body is not None and not ops.split_forward()) else None
         key = (tuple(images.shape), tuple(rects.shape))
         e = self._cache.pop(key, None)
         if e is None:
@@ -1171,23 +1292,64 @@ class InferenceEngine:
                 torch.cuda.synchronize()
                 self._cache.pop(next(iter(self._cache)))
             st = (images.clone(), mask.clone(), rects.clone())
-            self._run(*st)                             # lazily cached tables of this shape exist before the capture
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=self.device)
-            self._stream.wait_stream(torch.cuda.current_stream())
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            if self._pool is None:
-                self._pool = torch.cuda.graph_pool_handle()
-            with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
-                out = self._run(*st)
+            beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0      # a LINEAR graph: hipGraphLaunch enqueues it in ~0.1 ms of host time (2.7 ms with forks)
+            try:
+                if fs is not None:                     # the captured forward reads the frozen stage's output from a fixed buffer
+                    fs["images"].copy_(st[0])
+                    fs["graph"].replay()
+                    fs["x"].copy_(fs["xs"])
+                    fs["token"] = None
+                    body.frozen_input = (fs["x"], None)
+                    sig = self._sig
+                    ops.AFTER_BACKBONE = lambda: _ffi.check(_ffi.lib().cdetr_flag_signal(sig.data_ptr(), _ffi.stream_ptr()), "cdetr_flag_signal")
+                self._run(*st)                         # lazily cached tables of this shape exist before the capture
+                self._stream.wait_stream(torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                if self._pool is None:
+                    self._pool = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
+                    out = self._run(*st)
+            finally:
+                ops.BRANCH_BESIDE = beside
+                if fs is not None:
+                    body.frozen_input = None
+                    ops.AFTER_BACKBONE = None
             e = (g, st, out)
             self.stats["captures"] += 1
+            token = None
         else:
             e[1][0].copy_(images)
             e[1][1].copy_(mask)
             e[1][2].copy_(rects)
+            token = Trainer._token(samples)
         self._cache[key] = e
+        if fs is not None:
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._pf_stream)
+            if token is None or fs["token"] != token:
+                fs["images"].copy_(e[1][0])
+                fs["graph"].replay()
+            else:
+                self.stats["prefetch_hits"] += 1
+            fs["token"] = fs["keep"] = None
+            fs["x"].copy_(fs["xs"])                    # the forward reads x; the staging copy is free for the next batch's stage
+            tok = Trainer._token(next_samples) if next_samples is not None else None
+            if tok is not None:
+                nxt = next_samples.tensors if hasattr(next_samples, "tensors") else next_samples
+                f2 = self._frozen_for(nxt.shape)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                self._pf_stream.wait_event(ev)
+                with torch.cuda.stream(self._pf_stream):
+                    # behind the copy above (event) and behind this call's backbone (signal kernel in the captured forward; the timeout only
+                    # bounds how long a missing signal can hold the stage back)
+                    _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr(), self._sig.data_ptr() + 4, 5000, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
+                    f2["images"].copy_(nxt, non_blocking=True)
+                    f2["graph"].replay()
+                f2["token"], f2["keep"] = tok, nxt
         e[0].replay()
         return e[2]
 

@@ -492,6 +492,7 @@ class WeightMirror:
         return out
 
 
+AFTER_BACKBONE = None      # optional callable: AnchorDETR.forward calls it right after the backbone (engine.InferenceEngine's release signal)
 MIRROR = None      # set by engine.Trainer; None -> data gradients read the weight itself as the n-contiguous operand
 
 

@@ -375,7 +375,7 @@ int cdetr_abi_version(void);
  *   (A2/models/matcher.py:243-247) is about to start: the solve needs one whole compute unit's LDS for its cost matrix.                   */
 int cdetr_delay(int32_t us, void* stream);
 int cdetr_flag_signal(int32_t* flag, void* stream);
-int cdetr_flag_wait(const int32_t* flag, int32_t* seen, int32_t timeout_us, void* stream);
+int cdetr_flag_wait(const int32_t* flag, int32_t* seen, int32_t timeout_us, int32_t post_us, void* stream);   /* post_us: idle on after the signal */
 
 /* ---- glue (csrc/glue.hip): the small steps between the GEMMs, one launch each -------------------------------------------------
  * cdetr_mask_prep: padding mask [B][H][W] (bytes, non-zero = padding) -> m [B][h][w] (nearest-neighbour down-sampling,

@@ -36,11 +36,22 @@ def infer(model, criterion, data_loader, device, output_dir, split="test", thres
     predictions = {"categories": [{"name": "fg", "id": 1}], "images": [], "annotations": []}
     anno_id = 1
     pred_counts, gt_counts, loss_sum, n_img = [], [], {}, 0
-    for ret in data_loader:
-        image, mask = ret["image"].to(device), ret["mask"].to(device)
+    def lookahead(loader):          # (batch on the device, the next batch's image tensor or None): the engine runs the next image's frozen
+        prev = None                 # stage (stem + layer1) beside this image's encoder / decoder
+        for cur in loader:
+            cur = dict(cur)
+            cur["image"], cur["mask"] = cur["image"].to(device), cur["mask"].to(device)
+            if prev is not None:
+                yield prev, cur["image"]
+            prev = cur
+        if prev is not None:
+            yield prev, None
+
+    for ret, next_image in lookahead(data_loader):
+        image, mask = ret["image"], ret["mask"]
         rects = ret["ex_rects"].to(device)
         targets = [{k: v.to(device) for k, v in t.items()} for t in ret["targets"]]
-        _, keep, outputs, ref_points, prob = engine(NestedTensor(image, mask), rects)            # forward + :75-81
+        _, keep, outputs, ref_points, prob = engine(NestedTensor(image, mask), rects, next_samples=next_image)      # forward + :75-81
         loss_dict = criterion(outputs, targets)
         for k, v in loss_dict.items():
             loss_sum[k] = loss_sum.get(k, 0.0) + float(v) * len(targets)

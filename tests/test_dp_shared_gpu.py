@@ -10,6 +10,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 pytestmark = pytest.mark.gpu
 
 H = W = 256
@@ -149,3 +151,37 @@ def test_graph_cache_with_ranks_meeting_shapes_in_different_orders():
     assert torch.equal(r0["p"], r1["p"]), "replicas diverged"
     assert r0["stats"] == {"captures": 3, "steps": 5} and r1["stats"] == {"captures": 3, "steps": 5}
     assert all(l == l and abs(l) < 1e4 for l in r0["losses"] + r1["losses"])
+
+
+@pytest.mark.gpu
+def test_bucket_allreduces_can_be_captured_by_rccl(tmp_path):
+    """FlatGradExchange.capture_buckets (the selectable captured form of the gradient exchange, --captured_allreduce): RCCL's all-reduce is
+    recorded into HIP graphs on the exchange stream and replayed -- on a ONE-rank NCCL group (the only kind a one-GPU box can form: the sum
+    over one rank is the identity), which exercises the capture / replay mechanics, not the wire."""
+    import subprocess
+    import sys
+    script = tmp_path / "cap.py"
+    script.write_text('''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29711")
+dist.init_process_group("nccl", rank=0, world_size=1)
+from counting_detr_amd.engine import FlatGradExchange
+g = torch.arange(1000, dtype=torch.float32, device="cuda")
+ex = FlatGradExchange(g, [0, 400, 400, 900, 1000])
+dist.all_reduce(g)                       # communicator set up outside any capture
+torch.cuda.synchronize()
+assert ex.capture_buckets() and [x is not None for x in ex.graphs] == [True, False, True, True]
+ref = g.clone()
+for x in ex.graphs:
+    if x is not None:
+        with torch.cuda.stream(ex.stream):
+            x.replay()
+torch.cuda.synchronize()
+assert torch.equal(g, ref)
+print("captured-ok")
+dist.destroy_process_group()
+''' % ROOT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
+    assert "captured-ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

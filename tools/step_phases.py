@@ -8,21 +8,28 @@ import sys
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0")))
 rows.sort()
-# the last complete step: from the last stem_pack that is followed by an adamw_finish
-starts = [i for i, r in enumerate(rows) if "stem_pack" in r[2]]
+# a step = the kernels between two adamw_finish launches; which one: argv[3] counts from the end (default 2: the last but one full step --
+# bench.py's timed (pipelined) steps come before its in-line comparison steps, pass a larger number to look at those)
 ends = [i for i, r in enumerate(rows) if "adamw_finish" in r[2]]
-s0 = e0 = None
-for s in reversed(starts):
-    e = next((x for x in ends if x > s), None)
-    if e is not None:
-        s0, e0 = s, e
-        break
-# the gradient arena's zero-fill / weight images precede stem_pack in a captured step: walk back to the previous adamw_finish
-prev_end = max([x for x in ends if x < s0], default=-1)
-step = rows[prev_end + 1:e0 + 1]
-markers = [("backbone fwd", "stem_pack"), ("proj + encoder fwd", "gn_fwd"), ("decoder fwd + heads", "flash::fwd"), ("matcher + criterion", "match_cost"),
+back = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+e0 = ends[-back]
+prev_end = ends[-back - 1]
+allq = rows[prev_end + 1:e0 + 1]
+# round 4 ("chain" layout): the step's main chain is one hardware queue; side work (zero-fill + weight images, the NEXT batch's frozen
+# stage, the weight gradients) runs on other queues beside it -- phases are cut on the main queue, the side queues are summarised
+counts = {}
+for r in allq:
+    counts[r[3]] = counts.get(r[3], 0) + 1
+mainq = max(counts, key=counts.get)
+step = [r for r in allq if r[3] == mainq]
+side = {}
+for r in allq:
+    if r[3] != mainq:
+        side.setdefault(r[3], []).append(r)
+first = "stem_pack" if any("stem_pack" in r[2] for r in step) else step[0][2][:40]
+markers = [("backbone fwd", first), ("proj + encoder fwd", "gn_fwd"), ("decoder fwd + heads", "flash::fwd"), ("matcher + criterion", "match_cost"),
            ("heads + decoder bwd", "criterion_bwd"), ("encoder bwd", "rcda_bwd_kernel<2, 5"), ("proj + backbone bwd", "gn_bwd"), ("clip + AdamW", "sumsq")]
 idx = []
 for name, key in markers:
@@ -46,6 +53,15 @@ for j, (name, i) in enumerate(idx):
         top[k] = top.get(k, 0) + (r[1] - r[0]) / 1e6
     tops = ", ".join("%s %.2f" % (k, v) for k, v in sorted(top.items(), key=lambda kv: -kv[1])[:4])
     out.append("  %-26s launches %4d  kernel %.3f ms  wall %.3f ms   | %s" % (name, len(seg), kt, wall, tops))
+t00 = allq[0][0]
+for q, v in sorted(side.items()):
+    names = {}
+    for r in v:
+        k = r[2].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")[:36]
+        names[k] = names.get(k, 0) + (r[1] - r[0]) / 1e6
+    tops = ", ".join("%s %.2f" % (k, x) for k, x in sorted(names.items(), key=lambda kv: -kv[1])[:4])
+    out.append("  side queue %-15s launches %4d  kernel %.3f ms  from %.3f to %.3f ms of the step | %s" %
+               (q, len(v), sum(r[1] - r[0] for r in v) / 1e6, (v[0][0] - t00) / 1e6, (v[-1][1] - t00) / 1e6, tops))
 txt = "\n".join(out)
 print(txt)
 if len(sys.argv) > 2:
