@@ -30,9 +30,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense bf16 MFMA; the split-bf16 mode spends 3 bf16 MFMAs per algorithmic product
 PRECISIONS = {"bf16x3": 1, "fp32": 0}
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r3_traffic.json")
-if not os.path.exists(TRAFFIC_JSON):
-    TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r2_traffic.json")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (4, 3, 2)) if os.path.exists(p)), "")
 
 
 def step_gflop_per_image(H, W, Q):
@@ -609,10 +607,12 @@ def main(argv=None):
         dtn, pern, _ = timed_steps(trainer.replay, 10, barrier)
         res["frozen_stage_prefetch"] = {
             "what": "graph replay with one batch of look-ahead: a step also runs the frozen stage (stem + max-pool + layer1: no trainable parameter, "
-                    "the images need no gradient -- A2/models/backbone.py:93-95) of the batch that FOLLOWS, as its own graph on its own stream "
-                    "released between the step's [forward] and [matcher + criterion + backward + optimizer] graphs, i.e. beside the Hungarian "
-                    "solve (one wavefront per image, chip idle) and the latency-bound start of the backward.  Work per step is unchanged: one "
-                    "frozen stage + one trainable step; `value` is timed this way (main.py's loop does the same with the loader's next batch)",
+                    "the images need no gradient -- A2/models/backbone.py:93-95) of the batch that FOLLOWS, as its own linear graph on its own "
+                    "(probed-concurrent) stream, released by a signal kernel at the head of the step's [Hungarian solve + criterion + backward] "
+                    "graph: it runs beside the solve (one wavefront per image, chip otherwise idle).  Work per step is unchanged: one frozen "
+                    "stage + one trainable step; `value` is timed this way (main.py's loop does the same with the loader's next batch); "
+                    "in_line_*: the same captured step with the stage run inside it (no look-ahead)",
+            "graph_layout": trainer._entry.get("layout"), "side_streams": getattr(trainer, "side_stream_probe", None),
             "in_line_ms_per_step": dtn / 10 * 1e3, "in_line_step_ms": percentiles(pern), "prefetched_ms_per_step": ms_per_step,
             "hits": trainer.prefetch_stats["hits"], "in_line_runs": trainer.prefetch_stats["inline"]}
     if world > 1:
