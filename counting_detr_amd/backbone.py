@@ -70,34 +70,15 @@ class Bottleneck(nn.Module):
         self.downsample = nn.Sequential(ConvW(inplanes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)) if has_down else None
         self.stride, self.dilation = stride, dilation
 
-    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False, xlo=None, split=False, last=False, out_to=None):
+    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False, out_to=None):
         """twins: every activation a weight gradient of this block will read (a1, a2) and the block's output (the next block's x) also
         leave their producing epilogue as a bf16 copy (ops.bf16_twins); x16 = the twin of x, from the previous block.
         twin_out: only the output gets a twin (the last frozen block in front of the trainable ones).
-        split: every activation leaves its epilogue as split-bf16 planes hi | lo (ops.split_forward: the operand format of the
-        direct-to-LDS tile kernel); x16 / xlo = the planes of x; the hi planes double as the backward's twins.  -> (out, hi, lo).
         out_to = (y, y16): caller-owned buffers the block's output (and its twin) are written to (fixed addresses: ResNetBody.frozen_stage)."""
         twin_out = twin_out or twins
         s1, b1 = self.bn1.affine()
         s2, b2 = self.bn2.affine()
         s3, b3 = self.bn3.affine()
-        if split:
-            xs = (x16, xlo) if (x16 is not None and xlo is not None) else None
-            a1, a1h, a1l = ops.conv_fwd(x, self.conv1.weight, s1, b1, relu=True, split=True, xs=xs)
-            a2, a2h, a2l = ops.conv_fwd(a1, self.conv2.weight, s2, b2, stride=self.stride, pad=self.dilation, dil=self.dilation, relu=True,
-                                        split=True, xs=(a1h, a1l))
-            if self.downsample is not None:
-                sd, bd = self.downsample[1].affine()
-                idn = ops.conv_fwd(x, self.downsample[0].weight, sd, bd, stride=self.stride, xs=xs)
-            else:
-                idn = x
-            if last:        # the trunk's output feeds the projection as fp32 only: no planes
-                out, outh, outl = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, xs=(a2h, a2l)), None, None
-            else:
-                out, outh, outl = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, split=True, xs=(a2h, a2l))
-            if save is not None:
-                save.append((x, a1, a2, out, x16, a1h, a2h, outh))
-            return out, outh, outl
         idn, br = x, None
         if self.downsample is not None:       # the shortcut convolution: beside conv1 -> conv2 (ops.fork_branch), joined before the residual add
             sd, bd = self.downsample[1].affine()
@@ -228,15 +209,12 @@ class _TrunkFn(torch.autograd.Function):
     """layer2..layer4 as one autograd node (explicit backward schedule instead of ~100 tiny autograd nodes)."""
 
     @staticmethod
-    def forward(ctx, x, anchor, blocks, x16, xlo=None):
+    def forward(ctx, x, anchor, blocks, x16):
         saved = []
         twins = x16 is not None
-        split_mode = xlo is not None
         with torch.no_grad():
             for blk in blocks:
-                if split_mode:      # split-bf16 planes travel with the activation (their hi planes are the backward's twins)
-                    x, x16, xlo = blk.forward_fused(x, saved, x16=x16, xlo=xlo, split=True, last=blk is blocks[-1])
-                elif twins:
+                if twins:
                     x, x16 = blk.forward_fused(x, saved, x16=x16, twins=True)
                 else:
                     x = blk.forward_fused(x, saved)
@@ -256,7 +234,7 @@ class _TrunkFn(torch.autograd.Function):
         if _DEFER is not None:                       # the trainer runs the segments itself (graph replay with bucketed exchange)
             _DEFER.append(TrunkBackward(blocks, saved, dz, dz16))
             ctx.saved_acts = None
-            return None, None, None, None, None
+            return None, None, None, None
         hook = _BACKWARD_HOOK
         if hook is not None:
             hook(0)          # autograd runs this node last: every gradient above the backbone is final
@@ -266,7 +244,7 @@ class _TrunkFn(torch.autograd.Function):
             if hook is not None:
                 hook(seg)    # layer4 / layer3 / layer2 done
         ctx.saved_acts = None
-        return None, None, None, None, None
+        return None, None, None, None
 
 
 class ResNetBody(nn.Module):
@@ -334,7 +312,7 @@ class ResNetBody(nn.Module):
 
     def frozen_stage(self, images, twins, out_to=None):
         """The part of the trunk that never trains and whose input needs no gradient (A2/models/backbone.py:93-95: conv1 + layer1
-        frozen): stem + max-pool + layer1, images [B,3,H,W] -> (x NHWC [B,H/4,W/4,256], bf16 twin of x or None, lo plane or None).
+        frozen): stem + max-pool + layer1, images [B,3,H,W] -> (x NHWC [B,H/4,W/4,256], bf16 twin of x or None).
         It depends on nothing a training step updates, so a trainer may run it for the NEXT batch while the current step is in its
         latency-bound phases (engine.Trainer: frozen-stage prefetch).  out_to = (x, x16) caller-owned output buffers."""
         B, _, H, W = images.shape
@@ -346,23 +324,16 @@ class ResNetBody(nn.Module):
                 x[..., :3] = images.permute(0, 2, 3, 1)
                 s, b = self.bn1.affine()
                 x = ops.conv_fwd(x, self.stem_weight4(), s, b, stride=2, pad=3, relu=True)
-            split = ops.split_forward() and images.is_cuda
-            x16 = xlo = None
-            if split:
-                assert out_to is None
-                x, x16, xlo = ops.maxpool3x3s2(x, split=True)
-                for blk in self.layer1:
-                    x, x16, xlo = blk.forward_fused(x, x16=x16, xlo=xlo, split=True)
-            else:
-                x = ops.maxpool3x3s2(x)
-                for i, blk in enumerate(self.layer1):
-                    if i == len(self.layer1) - 1 and (twins or out_to is not None):
-                        want16 = twins or (out_to is not None and out_to[1] is not None)      # (inference: out_to = (x, None), no twin)
-                        r = blk.forward_fused(x, twin_out=want16, out_to=out_to)
-                        x, x16 = r if want16 else (r, None)
-                    else:
-                        x = blk.forward_fused(x)
-        return x, x16, xlo
+            x16 = None
+            x = ops.maxpool3x3s2(x)
+            for i, blk in enumerate(self.layer1):
+                if i == len(self.layer1) - 1 and (twins or out_to is not None):
+                    want16 = twins or (out_to is not None and out_to[1] is not None)      # (inference: out_to = (x, None), no twin)
+                    r = blk.forward_fused(x, twin_out=want16, out_to=out_to)
+                    x, x16 = r if want16 else (r, None)
+                else:
+                    x = blk.forward_fused(x)
+        return x, x16
 
     @staticmethod
     def frozen_out_hw(H, W):
@@ -380,21 +351,17 @@ class ResNetBody(nn.Module):
         blocks = list(self.layer2) + list(self.layer3) + list(self.layer4)
         train = torch.is_grad_enabled() and any(p.requires_grad for blk in blocks for p in blk.parameters())
         twins = train and ops.bf16_twins()            # layer1's output is layer2's first weight-gradient operand: it gets a twin too
-        split = ops.split_forward() and images.is_cuda
         if self.frozen_input is not None:
-            (x, x16), xlo = self.frozen_input, None
-            assert tuple(x.shape) == (B,) + self.frozen_out_hw(H, W) + (256,) and not split, (tuple(x.shape), (B, H, W))
+            x, x16 = self.frozen_input
+            assert tuple(x.shape) == (B,) + self.frozen_out_hw(H, W) + (256,), (tuple(x.shape), (B, H, W))
         else:
-            x, x16, xlo = self.frozen_stage(images, twins)
+            x, x16 = self.frozen_stage(images, twins)
         anchor = self.layer4[-1].conv3.weight
         if train:
-            return _TrunkFn.apply(x, anchor, blocks, x16, xlo)
+            return _TrunkFn.apply(x, anchor, blocks, x16)
         with torch.no_grad():
             for blk in blocks:
-                if split:
-                    x, x16, xlo = blk.forward_fused(x, x16=x16, xlo=xlo, split=True, last=blk is blocks[-1])
-                else:
-                    x = blk.forward_fused(x)
+                x = blk.forward_fused(x)
         return x
 
 

@@ -39,6 +39,7 @@ __device__ __forceinline__ void block_sum(float v, float* wred, float* red, int 
 }
 
 __global__ __launch_bounds__(256) void criterion_fwd_kernel(const cdetr_criterion_desc d) {
+    __builtin_amdgcn_s_setprio(3);                   // one workgroup on the step's critical path (see lsap_wave_kernel)
     extern __shared__ int tcls[];                    // [B*Q] target class of every query (num_classes = no object)
     __shared__ float wred[4 * NRED], red[NRED];
     __shared__ int card[64];                         // per-image count of "object" queries (B <= 64)

@@ -2027,7 +2027,7 @@ int check_gemm_desc(const cdetr_gemm_desc& d) {
     // C == nullptr: the fp32 output is not wanted (an inner gradient of a bottleneck that only the next bf16 contraction reads): only the
     // direct-to-LDS kernel writes the bf16 twin alone -- the problem must be eligible for it (cdetr_gemm_dl_eligible)
     // (likewise A == NULL: the operand exists as its twin A16 only)
-    CDETR_CHECK_ARG((d.C && d.A && !d.flags) || cdetr_gemm_dl_eligible(d), "cdetr_gemm: A == NULL / C == NULL need A16 / C16 and direct-to-LDS-eligible operands (A16, B16 / B_split, K %% 64 == 0)");
+    CDETR_CHECK_ARG((d.C && d.A && !(d.flags & (CDETR_GEMM_A_GROUPS | CDETR_GEMM_C_GROUPS))) || cdetr_gemm_dl_eligible(d), "cdetr_gemm: A == NULL / C == NULL need A16 / C16 and direct-to-LDS-eligible operands (A16, B16 / B_split, K %% 64 == 0)");
     CDETR_CHECK_ARG(d.b_layout == 0 || d.b_layout == 1, "cdetr_gemm: b_layout %d", d.b_layout);
     if (d.g.mode == CDETR_ROWS_DENSE) {
         CDETR_CHECK_ARG(d.taps == 1, "cdetr_gemm: dense rows need taps == 1");
@@ -2102,7 +2102,7 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     const char* force_s = cdetr_tune_env("CDETR_GEMM_VARIANT");
     const int force = force_s ? atoi(force_s) : 0;
     const bool fast_ok = vecA && vecB && (d.K % 32) == 0;
-    if (!d.C || !d.A || d.flags) { // grouped operands, twin-only output / operand: the direct-to-LDS kernel is the only one that handles it (check_gemm_desc made sure it can)
+    if (!d.C || !d.A || (d.flags & (CDETR_GEMM_A_GROUPS | CDETR_GEMM_C_GROUPS))) { // grouped operands, twin-only output / operand: the direct-to-LDS kernel is the only one that handles it (check_gemm_desc made sure it can)
         int stages = 3;
         const int tile = gemm_dl_choice(d, stages);
         return cdetr_gemm_dl_launch(d, tile >= 0 ? tile : 3, stages, st);

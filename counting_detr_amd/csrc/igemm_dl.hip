@@ -53,6 +53,7 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
         }
     };
     stamp(0);
+    if (d.flags & CDETR_GEMM_PRIO) __builtin_amdgcn_s_setprio(2);      // main-chain launch beside another stream's flood: first at the instruction arbiter
     constexpr int BM = Cf::BM, BN = Cf::BN, NA = Cf::NA, NB = Cf::NB, KT = Cf::KT;
     constexpr int A_STAGE = Cf::A_STAGE, B_STAGE = Cf::B_STAGE;
     constexpr int NI = NA + NB;                                // loads per wave per k-tile
@@ -351,7 +352,7 @@ bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d) {
     if (!d.B_split && !(d.precision == 3 && d.B16)) return false;
     if (d.B16 && ((reinterpret_cast<uintptr_t>(d.B16) & 15) || (d.ldb & 7))) return false;
     if (d.precision != 1 && d.precision != 3) return false;
-    const bool a_groups = d.flags & CDETR_GEMM_A_GROUPS, c_groups = d.flags & CDETR_GEMM_C_GROUPS;
+    const bool a_groups = d.flags & CDETR_GEMM_A_GROUPS, c_groups = d.flags & CDETR_GEMM_C_GROUPS;      // (CDETR_GEMM_PRIO: any problem)
     if ((a_groups || c_groups) && d.precision != 1) return false;
     if (d.precision == 1 && !d.A16lo && !a_groups) return false;
     if (a_groups && (d.lda & 31)) return false;

@@ -89,6 +89,7 @@ __global__ __launch_bounds__(NT) void lsap_kernel(const float* __restrict__ cost
                                                   const int* __restrict__ tgt_off, int Q, int Mmax, int64_t* __restrict__ idx_i,
                                                   int64_t* __restrict__ idx_j, int* __restrict__ status, int nc_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __builtin_amdgcn_s_setprio(3);         // (critical-path kernel that may share its SIMDs with another stream's throughput work)
     const int b = blockIdx.x;
     const int T = tgt_off[b + 1] - tgt_off[b];
     const bool transpose = T < Q;
@@ -295,8 +296,11 @@ template <int CPL, bool COST_LDS, bool DPP = true>
 __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__ cost_all, const int64_t* __restrict__ cost_off,
                                                        const int* __restrict__ tgt_off, int Q, int Mmax,
                                                        int64_t* __restrict__ idx_i, int64_t* __restrict__ idx_j,
-                                                       int* __restrict__ status) {
+                                                       int* __restrict__ status, int prio) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    // one wave on the step's critical path, possibly sharing its SIMD with throughput work of another stream (the trainer runs the next
+    // batch's frozen stage beside the solve): highest wave priority at the instruction arbiter
+    if (prio) __builtin_amdgcn_s_setprio(3);
     const int b = blockIdx.x;
     const int T = tgt_off[b + 1] - tgt_off[b];
     const bool transpose = T < Q;
@@ -564,7 +568,8 @@ extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int3
         const size_t wb = cost_lds ? with_cost : state;
         auto go = [&](auto kern) {
             if (wb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wb);
-            hipLaunchKernelGGL(kern, dim3(B), dim3(64), wb, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status);
+            static const int prio = getenv("CDETR_LSAP_PRIO") ? atoi(getenv("CDETR_LSAP_PRIO")) : 1;      // A/B: s_setprio 3 in the solve
+            hipLaunchKernelGGL(kern, dim3(B), dim3(64), wb, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status, prio);
         };
         // columns per lane = ceil(nc_max / 64): the per-iteration column scan is unrolled exactly that far
         if (nc_max <= 128) { if (cost_lds) go(lsap_wave_kernel<2, true>); else go(lsap_wave_kernel<2, false>); }

@@ -596,8 +596,7 @@ class Trainer:
     def _prefetch_ok(self):
         from . import ops
         body = self.model.backbone.body
-        return (self._prefetch_on and self.flat_g.is_cuda and body.frozen_stage_is_frozen() and ops.bf16_twins()
-                and not ops.split_forward())
+        return self._prefetch_on and self.flat_g.is_cuda and body.frozen_stage_is_frozen() and ops.bf16_twins()
 
     def _frozen_for(self, shape):
         """Static buffers + captured graph of the frozen stage for one padded image shape."""
@@ -1292,7 +1291,7 @@ class InferenceEngine:
         if not self.graphs or not images.is_cuda:
             return self._run(images, mask, rects)
         body = self.model.backbone.body if self._prefetch_on else None
-        fs = self._frozen_for(images.shape) if (body is not None and not ops.split_forward()) else None
+        fs = self._frozen_for(images.shape) if body is not None else None
         key = (tuple(images.shape), tuple(rects.shape))
         e = self._cache.pop(key, None)
         if e is None:

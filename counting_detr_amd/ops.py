@@ -103,7 +103,7 @@ def splitk_ws():
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
              batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None, A16lo=None, C16lo=None, dl=None, probe_ws=None, B16=None, gate16=None,
-             A_split=None, C_split=None):
+             A_split=None, C_split=None, prio=False):
     """dl = (tile, stages): run the direct-to-LDS tile kernel with that configuration (cdetr_gemm_dl; tests / sweeps)."""
     d = GemmDesc()
     d.C16, d.A16, d.A16lo, d.C16lo, d.B16, d.gate16 = ptr(C16), ptr(A16), ptr(A16lo), ptr(C16lo), ptr(B16), ptr(gate16)
@@ -111,6 +111,8 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
         d.A16, d.flags = ptr(A_split), d.flags | 1
     if C_split is not None:
         d.C16lo, d.flags = ptr(C_split), d.flags | 2
+    if prio:
+        d.flags |= 4                # CDETR_GEMM_PRIO
     d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION if precision is None else precision
@@ -248,7 +250,6 @@ WGRAD_ASYNC = int(_os.environ.get("CDETR_WGRAD_ASYNC", "1"))
 # decoder stacks as well 9.81): ON.  The kernels that run beside each other stretch (tile GEMM family 4.66 -> 4.97 ms of summed launch
 # time, weight gradients 1.43 -> 1.55), so bench.py reports the family figures as they run AND with the overlap off (roofline.unoverlapped).
 WGRAD_EVERY = int(_os.environ.get("CDETR_WGRAD_EVERY", "100"))     # backbone: blocks per overlapped submission (100: one per segment; 0 = at the end)
-WGRAD_STACKS = int(_os.environ.get("CDETR_WGRAD_STACKS", "0"))     # encoder / decoder: per-layer overlapped submissions
 _WG_SIDE = {}
 _WG_INFLIGHT = []
 
@@ -836,18 +837,6 @@ def conv_geom_fwd(Hin, Win, kh, kw, stride, pad, dil):
 TWINS = os.environ.get("CDETR_TWINS", "1") != "0"
 
 
-# Forward activations of the backbone also leave their producing epilogue as split-bf16 planes (hi | lo) -- the operand format of the
-# direct-to-LDS tile kernel (csrc/igemm_dl.hip): the next convolution copies its tiles HBM -> LDS without touching a register.
-# Measured (tools/dl_sweep.py): ahead only on the epilogue-dominated 1x1 convolutions, behind on the long reductions, and every producer
-# pays 2 more bytes per element for the lo plane: OFF by default (the plain-bf16 data gradients DO use the direct-to-LDS kernel, fed by
-# the bf16 twins that exist anyway).
-SPLIT_FWD = os.environ.get("CDETR_SPLIT_FWD", "0") != "0"
-
-
-def split_forward():
-    return SPLIT_FWD and PRECISION == 1
-
-
 EXPAND_PLANES = os.environ.get("CDETR_EXPAND_PLANES", "1") != "0"
 ENC_TWINS = os.environ.get("CDETR_ENC_TWINS", "1") != "0"      # encoder backward: bf16 twins through LayerNorm backward / data-gradient epilogues (A/B)
 
@@ -879,6 +868,7 @@ def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=N
     return (y, y16) if twin else y
 
 
+DGRAD_PRIO = os.environ.get("CDETR_DGRAD_PRIO", "1") != "0"     # the backbone's data gradients at raised wave priority (they share the chip with the weight gradients)
 TWIN_ONLY = os.environ.get("CDETR_TWIN_ONLY", "1") != "0"      # inner gradients of a bottleneck leave their kernel as the bf16 twin alone (A/B)
 
 
@@ -906,20 +896,15 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
                  gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], B16=m[3], precision=bwd_precision(), C16=dx16, A16=dz16,
-                 gate16=gate16 if gate is not None else None)
+                 gate16=gate16 if gate is not None else None, prio=DGRAD_PRIO)
     else:
         gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
                  gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, precision=bwd_precision(), C16=dx16)
     return (dx, dx16) if twin else dx
 
 
-TWIN_EXPERIMENT = os.environ.get("CDETR_TWIN_EXP", "0") == "1"      # tools only: bf16 twins made by tensor casts, to time the twin-fed kernel alone
-
-
 def conv_wgrad_(dz, x, weight, scale, stride=1, pad=0, dil=1, dz16=None, x16=None):
     """dz may be None when the gradient exists as its twin only (conv_dgrad(twin_only=True))."""
-    if TWIN_EXPERIMENT and dz16 is None and bwd_precision() == 3:
-        dz16, x16 = dz.to(torch.bfloat16), x.to(torch.bfloat16)
     Nb, Ho, Wo, Cout = (dz if dz is not None else dz16).shape
     _, H, W, Cin = x.shape
     kh, kw = weight.shape[2:]
@@ -1379,8 +1364,6 @@ class EncoderStackFn(torch.autograd.Function):
                 c = ctx.ctxs[li]
                 dX, accR, accC = EncoderLayerFn._backward(c, dX, accR, accC, zall[li * zn:(li + 1) * zn], defer_out=(li > 0 and ENC_DEFER))[:3]
                 c.saved_tensors = None
-                if WGRAD_STACKS:
-                    wgrad_flush(overlap=True)   # this layer's parameter gradients run beside the next layer's chain
         ctx.ctxs = None
         return dX, accR, accC, None, None, None, None, None
 
@@ -1559,8 +1542,6 @@ class DecoderStackFn(torch.autograd.Function):
                 ga1 = linear_dgrad(dqk.view(M, 2 * E), Ws[0:2 * E])
                 t = linear_dgrad(dvs.view(M, E), Ws[2 * E:3 * E], resid=dY2)
             pend_t, pend_g = t, ga1                                            # d(x) = t + ga1 and d(qpos) += ga1: formed by the consumer
-            if li % 2 == 0 and WGRAD_STACKS:
-                wgrad_flush(overlap=True)       # two layers' parameter gradients (26 small problems) beside the next layers' chain
         dx = grad_merge(pend_t, pend_g, None, acc_p, None)                     # the first layer's input gradient leaves the node: merged for real
         if ctx.own_means:        # memory also fed the two key means: broadcast their gradients back in the same pass
             dMem = bcast_add2(dMem.view(N, H, W, E), dKrm, dKcm, 1.0 / H, 1.0 / W)

@@ -107,6 +107,9 @@ typedef struct {
  *   N % 32 == 0, ldc % 32 == 0) -- the next layer's grouped A operand; C16 (the plain hi twin) stays optional.                       */
 #define CDETR_GEMM_A_GROUPS 1
 #define CDETR_GEMM_C_GROUPS 2
+/* CDETR_GEMM_PRIO: the launch's waves run at raised instruction priority (s_setprio): for launches of a step's MAIN chain that share the
+ *   chip with another stream's throughput work (the backbone's data gradients beside the weight gradients); results are unaffected.   */
+#define CDETR_GEMM_PRIO 4
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 /* The direct-to-LDS tile kernel (csrc/igemm_dl.hip) with an explicit configuration -- what cdetr_gemm picks by itself for problems
  * whose operands are given pre-split (A16 [+ A16lo] and B_split); for tests and tile sweeps.  tile: 0 = 128x128, 1 = 128x64,

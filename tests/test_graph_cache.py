@@ -381,34 +381,6 @@ def test_graph_layouts_agree(monkeypatch):
 
 
 @gpu
-def test_split_plane_forward_equals_default_forward():
-    """ops.SPLIT_FWD (every backbone activation also leaves its epilogue as bf16 hi | lo planes; the expanding 1x1 convolutions read them
-    through the direct-to-LDS kernel) is the same network: forward outputs within the split product's error, a train step with the same
-    losses.  Off by default (measured: no net gain, tools/dl_sweep.py) -- this keeps the path honest."""
-    from counting_detr_amd import ops
-    from counting_detr_amd.engine import Trainer
-    images, rects, tg = _batch(2, 160, 192, (7, 13), seed=5)
-    res = []
-    old = ops.SPLIT_FWD
-    try:
-        for flag in (False, True):
-            ops.SPLIT_FWD = flag
-            model, crit, args = _build(Q=100)
-            with torch.no_grad():
-                out, _ = model(images, rects=rects)
-            tr = Trainer(model, crit, args, device=DEV)
-            losses = {k: float(v) for k, v in tr.train_step(images, rects, tg).items()}
-            res.append((out, losses))
-    finally:
-        ops.SPLIT_FWD = old
-    for k in ("pred_logits", "pred_boxes", "pred_vars"):
-        a, b = res[1][0][k], res[0][0][k]
-        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()), k
-    for k, v in res[0][1].items():
-        np.testing.assert_allclose(res[1][1][k], v, rtol=2e-3 if k == "grad_norm" else 1e-4, atol=1e-6, err_msg=k)
-
-
-@gpu
 def test_cached_graph_step_with_aux_losses_equals_eager_step():
     """aux_loss=True (A2/models/anchor_detr.py:334-350: one Hungarian matching per decoder layer) through the graph cache: the layers are
     matched one after the other with the device-resident capacity plan; same 31 loss values as the stream-ordered step (whose matchings
