@@ -591,11 +591,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 }
 
 // Encoder prologue: Qr[n,y,x,:] = X + Prow[n,x,:], Qc[n,y,x,:] = X + Pcol[n,y,:]  (A2/models/transformer.py:248-255)
-__global__ __launch_bounds__(256) void posadd2_kernel(const float* __restrict__ X, const float* __restrict__ Prow,
-                                                      const float* __restrict__ Pcol, float* __restrict__ Qr, float* __restrict__ Qc,
-                                                      int N, int H, int W, int C4) {
+__device__ __forceinline__ void posadd2_body(const float* __restrict__ X, const float* __restrict__ Prow, const float* __restrict__ Pcol,
+                                             float* __restrict__ Qr, float* __restrict__ Qc, int N, int H, int W, int C4, int blk, int nblk) {
     const long total = (long)N * H * W * C4;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)blk * 256 + threadIdx.x; idx < total; idx += (long)nblk * 256) {
         const int c = (int)(idx % C4);
         long t = idx / C4;
         const int xw = (int)(t % W); t /= W;
@@ -607,6 +606,11 @@ __global__ __launch_bounds__(256) void posadd2_kernel(const float* __restrict__ 
         reinterpret_cast<float4*>(Qr)[idx] = make_float4(v.x + pr.x, v.y + pr.y, v.z + pr.z, v.w + pr.w);
         reinterpret_cast<float4*>(Qc)[idx] = make_float4(v.x + pc.x, v.y + pc.y, v.z + pc.z, v.w + pc.w);
     }
+}
+__global__ __launch_bounds__(256) void posadd2_kernel(const float* __restrict__ X, const float* __restrict__ Prow,
+                                                      const float* __restrict__ Pcol, float* __restrict__ Qr, float* __restrict__ Qc,
+                                                      int N, int H, int W, int C4) {
+    posadd2_body(X, Prow, Pcol, Qr, Qc, N, H, W, C4, blockIdx.x, gridDim.x);
 }
 
 // Decoder glue (A2/models/transformer.py:366-403): O1 = T + A, O2 = T + B (B / O2 optional) in one pass.
@@ -680,11 +684,10 @@ __global__ __launch_bounds__(256) void sine_embed_bwd_kernel(const float* __rest
 //   blocks [N*W, N*W+N*H): Oc[n,y,:] = scale_c * sum_x X[n,y,x,:] (+ Ac[n,y,:])
 // forward: X = src, scale = 1/H, 1/W, addend = positional embeddings (k_row / k_col inputs, mean-before-project);
 // backward: X = a logit-gradient map, scale = 1 (sum over the broadcast axis).  Xc (second map) may differ from Xr.
-__global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict__ Xr, const float* __restrict__ Xc,
-                                                        const float* __restrict__ Ar, const float* __restrict__ Ac,
-                                                        float* __restrict__ Or, float* __restrict__ Oc, int N, int H, int W, int C,
-                                                        float scale_r, float scale_c) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ void hw_reduce_body(const float* __restrict__ Xr, const float* __restrict__ Xc,
+                                               const float* __restrict__ Ar, const float* __restrict__ Ac,
+                                               float* __restrict__ Or, float* __restrict__ Oc, int N, int H, int W, int C,
+                                               float scale_r, float scale_c, const int b) {
     const int c = threadIdx.x;          // C <= 256 handled per pass
     if (C == 256) {
         // thread = (channel quad, 1 of 4 interleaved slices of the reduced axis): 16-byte loads, 4 independent accumulation chains per
@@ -738,6 +741,22 @@ __global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict_
             Oc[(long)r * C + cc] = s;
         }
     }
+}
+__global__ __launch_bounds__(256) void hw_reduce_kernel(const float* __restrict__ Xr, const float* __restrict__ Xc,
+                                                        const float* __restrict__ Ar, const float* __restrict__ Ac,
+                                                        float* __restrict__ Or, float* __restrict__ Oc, int N, int H, int W, int C,
+                                                        float scale_r, float scale_c) {
+    hw_reduce_body(Xr, Xc, Ar, Ac, Or, Oc, N, H, W, C, scale_r, scale_c, blockIdx.x);
+}
+// The encoder layer's prologue as ONE launch (two independent passes over the same source, A2/models/transformer.py:246-252 + the
+// mean-before-project keys): workgroups [0, N (W + H)) form the key means, the rest the two positional adds.
+__global__ __launch_bounds__(256) void posadd2_hw_reduce_kernel(const float* __restrict__ X, const float* __restrict__ Prow,
+                                                                const float* __restrict__ Pcol, float* __restrict__ Qr,
+                                                                float* __restrict__ Qc, float* __restrict__ Kr, float* __restrict__ Kc,
+                                                                int N, int H, int W, int C, float scale_r, float scale_c) {
+    const int nred = N * (W + H);
+    if ((int)blockIdx.x < nred) hw_reduce_body(X, X, Prow, Pcol, Kr, Kc, N, H, W, C, scale_r, scale_c, blockIdx.x);
+    else posadd2_body(X, Prow, Pcol, Qr, Qc, N, H, W, C / 4, blockIdx.x - nred, gridDim.x - nred);
 }
 
 // out[n,y,x,:] = T[n,y,x,:] + sr * Br[n,x,:] + sc * Bc[n,y,:]   (backward of the two key means: broadcast back)
@@ -855,6 +874,15 @@ extern "C" int cdetr_hw_reduce(const float* Xr, const float* Xc, const float* Ar
     hipLaunchKernelGGL(hw_reduce_kernel, dim3(N * (W + H)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), Xr, Xc, Ar, Ac, Or,
                        Oc, N, H, W, C, scale_r, scale_c);
     return cdetr_launch_status("cdetr_hw_reduce");
+}
+
+extern "C" int cdetr_posadd2_hw_reduce(const float* X, const float* Prow, const float* Pcol, float* Qr, float* Qc, float* Kr, float* Kc,
+                                       int32_t N, int32_t H, int32_t W, int32_t C, float scale_r, float scale_c, void* stream) {
+    CDETR_CHECK_ARG(X && Prow && Pcol && Qr && Qc && Kr && Kc && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "cdetr_posadd2_hw_reduce: bad args");
+    const long n4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(posadd2_hw_reduce_kernel, dim3(N * (W + H) + grid_for(n4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, Prow,
+                       Pcol, Qr, Qc, Kr, Kc, N, H, W, C, scale_r, scale_c);
+    return cdetr_launch_status("cdetr_posadd2_hw_reduce");
 }
 
 extern "C" int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc, float* out, int32_t N, int32_t H, int32_t W,

@@ -10,6 +10,7 @@ A2/infer.py:27-122, re-designed for one-process-per-GPU data parallelism on MI35
   * the step issues no host sync (device matcher, device loss normaliser), so it can be captured in a HIP graph.
 """
 import math
+import os
 import sys
 
 import torch
@@ -217,15 +218,14 @@ class Trainer:
         self._cap_stream = None
         self._cache = {}                        # step(): captured steps by (image shape, exemplar shape, target capacity, arithmetic), LRU order
         self._pool = None                       # ONE graph memory pool for every cached step (entries never run concurrently)
-        import os as _os
-        self._prefetch_on = bool(getattr(args, "frozen_prefetch", True)) and _os.environ.get("CDETR_FROZEN_PREFETCH", "1") != "0"
-        self._pf_timeout_us = int(_os.environ.get("CDETR_PF_TIMEOUT_US", getattr(args, "frozen_prefetch_timeout_us", 400)))   # flag wait (chain layout)
-        self._captured_allreduce = _os.environ.get("CDETR_CAPTURED_ALLREDUCE", "1" if getattr(args, "captured_allreduce", False) else "0") == "1"
-        self._z_late = _os.environ.get("CDETR_Z_LATE", "1") != "0"               # Z released by the backbone-forward-done signal instead of at step start
-        self._pf_post_us = int(_os.environ.get("CDETR_PF_POST_US", 30))          # head start of the solve over the prefetched stage's workgroups
-        self._pf_delay_us = int(_os.environ.get("CDETR_PF_DELAY_US", 0))        # "single" layout only: fixed delay in front of the prefetched stage
-        self._pf_eager = _os.environ.get("CDETR_PF_EAGER", "0") == "1"
-        self._tail_inline = float(_os.environ.get("CDETR_TAIL_INLINE", getattr(args, "wgrad_tail_inline", 1.0)))   # share of layer2's weight gradients kept on the main stream
+        self._prefetch_on = bool(getattr(args, "frozen_prefetch", True)) and os.environ.get("CDETR_FROZEN_PREFETCH", "1") != "0"
+        self._pf_timeout_us = int(os.environ.get("CDETR_PF_TIMEOUT_US", getattr(args, "frozen_prefetch_timeout_us", 400)))   # flag wait (chain layout)
+        self._captured_allreduce = os.environ.get("CDETR_CAPTURED_ALLREDUCE", "1" if getattr(args, "captured_allreduce", False) else "0") == "1"
+        self._z_late = os.environ.get("CDETR_Z_LATE", "1") != "0"               # Z released by the backbone-forward-done signal instead of at step start
+        self._pf_post_us = int(os.environ.get("CDETR_PF_POST_US", 30))          # head start of the solve over the prefetched stage's workgroups
+        self._pf_delay_us = int(os.environ.get("CDETR_PF_DELAY_US", 0))        # "single" layout only: fixed delay in front of the prefetched stage
+        self._pf_eager = os.environ.get("CDETR_PF_EAGER", "0") == "1"
+        self._tail_inline = float(os.environ.get("CDETR_TAIL_INLINE", getattr(args, "wgrad_tail_inline", 1.0)))   # share of layer2's weight gradients kept on the main stream
         self._frozen = {}                       # image shape -> frozen-stage buffers + graph (see "frozen-stage prefetch")
         self._pf_stream = self._pf_pool = self._wg_stream = None
         self.prefetch_stats = {"hits": 0, "inline": 0}
@@ -704,7 +704,6 @@ class Trainer:
         #       chain; with world_size > 1 the gradient buckets' all-reduces sit between the same pieces.
         #   "single": round 3's form -- [forward] | [everything else] with in-graph branches (world_size > 1 / CDETR_SEGMENTED_GRAPH=1: the
         #       backbone's backward as three more sub-graphs).
-        import os
         layout = os.environ.get("CDETR_GRAPH_LAYOUT", getattr(self.args, "graph_layout", "chain"))
         segmented = world > 1 or os.environ.get("CDETR_SEGMENTED_GRAPH", "0") == "1"
         body = self.model.backbone.body
@@ -776,9 +775,8 @@ class Trainer:
         Both must overlap the stream the steps are replayed on (the current one at the first call) and each other: candidates are probed."""
         if self._pf_stream is None:
             main = torch.cuda.current_stream()
-            import os as _os
             prio = 0
-            if _os.environ.get("CDETR_SIDE_PRIORITY", "normal") == "low":      # A/B: side work yields to the main chain at dispatch
+            if os.environ.get("CDETR_SIDE_PRIORITY", "normal") == "low":      # A/B: side work yields to the main chain at dispatch
                 try:
                     prio = max(torch.cuda.Stream.priority_range())
                 except Exception:
@@ -798,11 +796,12 @@ class Trainer:
 
     def _capture_chain(self, st, world, warmup):
         """The step as a chain of LINEAR graphs (see _capture_entry) on the main stream: F forward + cost matrices | B Hungarian solve +
-        criterion + the backward down to the backbone | S1 S2 S3 the backbone's segments | O clip + AdamW.  Beside them: Z (zero-fill +
-        data-gradient weight images) on the prefetch stream, released by the previous step's O (it runs beside the start of F; B waits for
-        it); the next batch's frozen stage on the same stream, released by F (beside the solve); W0 (every parameter gradient above the
-        backbone) and W1 W2 W3 (a backbone segment's) on the weight-gradient stream, each released by the main piece that produced its
-        operands and running beside the pieces that follow; O waits for them."""
+        criterion + the backward down to the backbone | S12 layer4 + layer3 | S3 layer2 | O clip + AdamW (world_size > 1: S1 | S2 | S3).  Beside them: Z (zero-fill +
+        data-gradient weight images) on the prefetch stream, released by the previous step's O (it runs beside the encoder / decoder forward, behind the
+        backbone-done signal kernel of F; B waits for it); the next batch's frozen stage on the same stream, released by F and the signal
+        kernel that opens B (beside the solve); W0 (every parameter gradient above the backbone) and W12 (layer4 + layer3's) on the
+        weight-gradient stream, each released by the main piece that produced its operands and running beside the pieces that follow
+        (layer2's stay on the main stream: nothing is left to run beside them); O waits for them."""
         from . import ops
         s, mode = self._capture_warmup(st, world, warmup)
         pf, wg = self._side_streams()
@@ -850,15 +849,21 @@ class Trainer:
             out = {k: v.detach() for k, v in loss_dict.items()}
             out["loss"] = losses.detach()
             e["S"], e["W"] = [], []
-            for seg in (1, 2, 3):
+            # main-stream pieces of the backbone's backward: layer4 | layer3 | layer2, one per gradient bucket (world_size > 1: the all-reduces
+            # are issued at the boundaries).  Merging the first two ([layer4 + layer3] | [layer2], CDETR_S_PIECES=2: one boundary fewer) is
+            # SLOWER by 0.10 ms in three same-lease pairs (profiles/r4_ab_launches.txt): layer4's weight gradients then start a piece later.
+            pieces = ((1, 2), (3,)) if (world == 1 and os.environ.get("CDETR_S_PIECES") == "2") else ((1,), (2,), (3,))
+            e["pieces"] = pieces
+            for segs in pieces:
                 q = ops.wgrad_queue()
                 q.__enter__()
                 try:
                     g = G()
                     with torch.cuda.graph(g, stream=s, **mode):
-                        if self._trunk_pending is not None:
-                            self._trunk_pending.run(seg)
-                        if seg == 3 and ops._WG_QUEUE and self._tail_inline > 0:
+                        for seg in segs:
+                            if self._trunk_pending is not None:
+                                self._trunk_pending.run(seg)
+                        if segs[-1] == 3 and ops._WG_QUEUE and self._tail_inline > 0:
                             # the LAST segment's weight gradients have nothing left to run beside: the main stream would idle while the
                             # weight-gradient stream works off its backlog -- the problems whose operands came last stay on the main stream
                             q_all = list(ops._WG_QUEUE)
@@ -1007,7 +1012,7 @@ class Trainer:
                 e["W0"].replay()
         if dp:
             self.exchange.segment_done(0, also=wg if e["W0"] is not None else None)      # first bucket: everything above the backbone
-        for seg, g, gw in zip((1, 2, 3), e["S"], e["W"]):
+        for segs, g, gw in zip(e["pieces"], e["S"], e["W"]):
             g.replay()
             if gw is not None:
                 evs = torch.cuda.Event()
@@ -1016,7 +1021,8 @@ class Trainer:
                 with torch.cuda.stream(wg):
                     gw.replay()
             if dp:
-                self.exchange.segment_done(seg, also=wg if gw is not None else None)
+                for seg in segs:
+                    self.exchange.segment_done(seg, also=wg if gw is not None else None)
         main.wait_stream(wg)
         if dp:
             self.exchange.finish()
@@ -1210,7 +1216,6 @@ class InferenceEngine:
         self._cache = {}
         self._stream = None
         self._pool = None                # one graph memory pool for all shapes (graphs never run concurrently; outputs stay allocated)
-        import os
         self._prefetch_on = bool(prefetch) and os.environ.get("CDETR_FROZEN_PREFETCH", "1") != "0" and hasattr(model, "backbone")
         self._frozen, self._pf_stream, self._pf_pool, self._sig = {}, None, None, None
         self.stats = {"captures": 0, "calls": 0, "prefetch_hits": 0}

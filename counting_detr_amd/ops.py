@@ -586,6 +586,57 @@ class LinearFn(torch.autograd.Function):
         return dx, None, None, None, None, None, d_resid, None
 
 
+class PosMlpFn(torch.autograd.Function):
+    """Linear -> ReLU -> Linear (adapt_pos1d / adapt_pos2d, A2/models/transformer.py:73-74) applied to SEVERAL inputs at once, as one
+    autograd node: forward = two grouped launches (first layers, second layers), backward = one grouped launch for the data gradients through
+    the second layer with the ReLU mask as the epilogue's gate, one for the first layer of the inputs that need a gradient (the sine
+    embeddings of the anchor points; mask positions need none) -- instead of (data gradient, mask pass, data gradient) per input.
+    args = (w0, b0, w2, b2, *xs) -> tuple of outputs."""
+
+    @staticmethod
+    def forward(ctx, w0, b0, w2, b2, *xs):
+        W0, B0, W2, B2 = w0.detach(), b0.detach(), w2.detach(), b2.detach()
+        x2 = []
+        for x in xs:
+            t = x.reshape(-1, x.shape[-1])
+            if t.stride(-1) != 1 or (t.stride(0) & 3) or (t.data_ptr() & 15):
+                t = t.contiguous()
+            x2.append(t)
+        with gemm_queue():
+            hs = [linear_fwd(t, W0, B0, relu=True) for t in x2]
+        with gemm_queue():
+            ys = [linear_fwd(h, W2, B2) for h in hs]
+        ctx.params = (w0, b0, w2, b2)
+        ctx.n = len(xs)
+        ctx.shapes = [x.shape for x in xs]
+        ctx.save_for_backward(*x2, *hs)
+        return tuple(y.reshape(*x.shape[:-1], y.shape[-1]) for y, x in zip(ys, xs))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x2, hs = saved[:n], saved[n:]
+        w0, b0, w2, b2 = ctx.params
+        W0, W2 = w0.detach(), w2.detach()
+        live = [i for i in range(n) if dys[i] is not None]
+        d2 = {i: dys[i].reshape(-1, dys[i].shape[-1]).contiguous() for i in live}
+        with gemm_queue():
+            dh = {i: linear_dgrad(d2[i], W2, gate=hs[i]) for i in live}          # masked by relu(h): the gradient w.r.t. the first layer's pre-activation
+        need = [i for i in live if ctx.needs_input_grad[4 + i]]
+        dx = {}
+        if need:
+            with gemm_queue():
+                dx = {i: linear_dgrad(dh[i], W0) for i in need}
+        for i in live:
+            for (dy, xin, w, b) in ((d2[i], hs[i], w2, b2), (dh[i], x2[i], w0, b0)):
+                if w.requires_grad:
+                    gw = grad_buffer(w)
+                    gb = grad_buffer(b) if b.requires_grad else None
+                    wgrad_raw(dy, dy.stride(0), xin, xin.stride(0), gw, gw.stride(0), dy.shape[0], gw.shape[0], xin.shape[1], dbias=gb, may_defer=True)
+        return (None, None, None, None) + tuple(dx[i].reshape(ctx.shapes[i]) if i in dx else None for i in range(n))
+
+
 FUSED_HEADS = os.environ.get("CDETR_FUSED_HEADS", "1") != "0"      # the three heads as one autograd node (A/B)
 
 
@@ -1193,6 +1244,17 @@ def posadd2(X, Prow, Pcol):
     return Qr, Qc
 
 
+def posadd2_hw_reduce(X, Prow, Pcol):
+    """posadd2(X, Prow, Pcol) and hw_reduce(X, X, Prow, Pcol, 1/H, 1/W) in one launch -> (Qr, Qc, Kr, Kc)."""
+    N, H, W, Cc = X.shape
+    Qr, Qc = torch.empty_like(X), torch.empty_like(X)
+    Kr = torch.empty((N, W, Cc), device=X.device, dtype=torch.float32)
+    Kc = torch.empty((N, H, Cc), device=X.device, dtype=torch.float32)
+    check(lib().cdetr_posadd2_hw_reduce(ptr(X), ptr(Prow), ptr(Pcol), ptr(Qr), ptr(Qc), ptr(Kr), ptr(Kc), N, H, W, Cc, 1.0 / H, 1.0 / W,
+                                        stream_ptr()), "cdetr_posadd2_hw_reduce")
+    return Qr, Qc, Kr, Kc
+
+
 def hw_reduce(Xr, Xc, Ar, Ac, scale_r, scale_c):
     N, H, W, Cc = Xr.shape
     Or = torch.empty((N, W, Cc), device=Xr.device, dtype=torch.float32)
@@ -1242,8 +1304,7 @@ class EncoderLayerFn(torch.autograd.Function):
         Wi, bi = att.in_proj_weight.detach(), att.in_proj_bias.detach()
         X = src.contiguous()
         Prow, Pcol = posemb_row.contiguous(), posemb_col.contiguous()
-        Qr, Qc = posadd2(X, Prow, Pcol)
-        Kr, Kc = hw_reduce(X, X, Prow, Pcol, 1.0 / H, 1.0 / W)
+        Qr, Qc, Kr, Kc = posadd2_hw_reduce(X, Prow, Pcol)       # positional adds + key means: one launch
         with gemm_queue():           # the five in-projections are independent: one grouped submission
             q_row = linear_fwd(Qr.view(R, Cc), Wi[0:E], bi[0:E]).view(N, H * W, E)
             q_col = linear_fwd(Qc.view(R, Cc), Wi[E:2 * E], bi[E:2 * E]).view(N, H * W, E)

@@ -86,6 +86,8 @@ def pos_mlp_many(mlp, xs):
     (ops.gemm_queue), then the second ones."""
     if not (xs[0].is_cuda and torch.is_grad_enabled()):
         return [mlp(x) for x in xs]
+    if ops.FUSED_HEADS:             # one autograd node: the ReLU masks ride in the data-gradient epilogues of its backward
+        return list(ops.PosMlpFn.apply(mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, *xs))
     with ops.gemm_queue():
         hs = [mlp[0](x, relu=True) for x in xs]
     with ops.gemm_queue():
@@ -335,7 +337,7 @@ class Transformer(nn.Module):
                     self.taps[f"enc{li}"] = memory.detach()
 
         # query positional terms do not depend on the layer (the reference recomputes them in every layer, :366-379)
-        query_pos = self.adapt_pos2d(pos2posemb2d(reference_points))
+        query_pos = pos_mlp_many(self.adapt_pos2d, [pos2posemb2d(reference_points)])[0]
         last = len(self.decoder_layers) - 1
         if self.fused_decoder and src.is_cuda:
             args = (tgt, query_pos, query_pos_x, query_pos_y, memory, None, None, mask_row, mask_col, list(self.decoder_layers),

@@ -219,6 +219,10 @@ int cdetr_posadd2(const float* X, const float* Prow, const float* Pcol, float* Q
                   int32_t C, void* stream);
 int cdetr_hw_reduce(const float* Xr, const float* Xc, const float* Ar, const float* Ac, float* Or, float* Oc, int32_t N,
                     int32_t H, int32_t W, int32_t C, float scale_r, float scale_c, void* stream);
+/* cdetr_posadd2 and cdetr_hw_reduce(X, X, Prow, Pcol, ...) of one encoder layer as ONE launch (both read the same source and nothing of each
+ * other: A2/models/transformer.py:246-252): Qr / Qc = X + Prow / Pcol (broadcast), Kr / Kc = mean over H / W of X, scaled, + Prow / Pcol. */
+int cdetr_posadd2_hw_reduce(const float* X, const float* Prow, const float* Pcol, float* Qr, float* Qc, float* Kr, float* Kc, int32_t N,
+                            int32_t H, int32_t W, int32_t C, float scale_r, float scale_c, void* stream);
 int cdetr_bcast_add2(const float* T, const float* Br, const float* Bc, float* out, int32_t N, int32_t H, int32_t W, int32_t C,
                      float sr, float sc, void* stream);
 /* the same with up to two further addends of T's shape (T2, T3; NULL = absent): out = T + T2 + T3 + sr*Br + sc*Bc -- sibling data gradients

@@ -1141,3 +1141,50 @@ def test_fused_heads_node_equals_per_layer_nodes():
     close(dx1, dx0, rtol=1e-5, msg="dx")
     for i, (a, b) in enumerate(zip(g0, g1)):
         close(b, a, rtol=1e-5, msg=f"param grad {i}")
+
+
+def test_encoder_prologue_single_launch():
+    """cdetr_posadd2_hw_reduce == cdetr_posadd2 + cdetr_hw_reduce (bit for bit: the same device bodies), also on a non-square map and a
+    channel count that takes the generic path."""
+    from counting_detr_amd import ops
+    for (N, H, W, Cc) in [(2, 50, 50, 256), (1, 24, 36, 256), (2, 7, 5, 64)]:
+        g = torch.Generator().manual_seed(H * W)
+        X = torch.randn(N, H, W, Cc, generator=g).to(DEV)
+        Pr, Pc = torch.randn(N, W, Cc, generator=g).to(DEV), torch.randn(N, H, Cc, generator=g).to(DEV)
+        Qr, Qc = ops.posadd2(X, Pr, Pc)
+        Kr, Kc = ops.hw_reduce(X, X, Pr, Pc, 1.0 / H, 1.0 / W)
+        q1, q2, k1, k2 = ops.posadd2_hw_reduce(X, Pr, Pc)
+        assert torch.equal(q1, Qr) and torch.equal(q2, Qc) and torch.equal(k1, Kr) and torch.equal(k2, Kc)
+        close(k1, X.mean(1) + Pr, rtol=1e-5)
+        close(k2, X.mean(2) + Pc, rtol=1e-5)
+
+
+def test_fused_pos_mlp_node_equals_per_layer_nodes():
+    """ops.PosMlpFn (Linear -> ReLU -> Linear over several inputs, one autograd node) == the per-layer LinearFn nodes: same outputs, input
+    gradients (only where one is needed) and parameter gradients."""
+    from counting_detr_amd import ops
+    from counting_detr_amd.transformer import PosMLP
+    torch.manual_seed(1)
+    mlp = PosMLP(256).to(DEV)
+    xs0 = [torch.randn(2, 50, 256, device=DEV), torch.randn(2, 37, 256, device=DEV), torch.randn(2, 300, 256, device=DEV)]
+    ups = [torch.randn_like(x) for x in xs0]
+    res = []
+    for fused in (False, True):
+        for p in mlp.parameters():
+            p.grad = torch.zeros_like(p)
+        xs = [xs0[0].clone(), xs0[1].clone(), xs0[2].clone().requires_grad_(True)]
+        old, ops.FUSED_HEADS = ops.FUSED_HEADS, fused
+        try:
+            from counting_detr_amd.transformer import pos_mlp_many
+            ys = pos_mlp_many(mlp, xs)
+            with ops.wgrad_queue():
+                torch.autograd.backward(ys, ups)
+        finally:
+            ops.FUSED_HEADS = old
+        res.append(([y.detach().clone() for y in ys], xs[2].grad.clone(), [p.grad.clone() for p in mlp.parameters()]))
+    (y0, dx0, g0), (y1, dx1, g1) = res
+    for a, b in zip(y0, y1):
+        assert torch.equal(a, b)
+    close(dx1, dx0, rtol=1e-5, msg="dx")
+    for i, (a, b) in enumerate(zip(g0, g1)):
+        close(b, a, rtol=1e-5, msg=f"param grad {i}")
