@@ -10,7 +10,6 @@ __device__ __attribute__((aligned(256))) unsigned int dl_zero_page[64];      // 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* gbl_vp;
-typedef const __attribute__((address_space(1))) u32x4* gbl_u32x4p;
 
 __device__ __forceinline__ void wait_vm(int n) {              // counted wait: at most n of this wave's loads still in flight
     switch (n) {

@@ -43,13 +43,7 @@ struct DlCfg {
 // EARLY: the epilogue's operands (bias, residual rows, gate rows -- nothing the k-loop computes) are requested BEFORE the first operand
 // tile, so their HBM round trip (2.9 of a 64 x 64 / K = 256 workgroup's 11.7 us in the phase probe, profiles/r3_dl_probe_v1.txt) runs under
 // the k-loop; loads complete in issue order, so the counted vmcnt waits of the ring stay valid (the older loads have landed by then).
-// REGD > 0: the same tiles, LDS image and epilogue with the operand tiles travelling HBM / L2 -> VGPR -> LDS (`global_load_dwordx4` +
-// `ds_write_b128` at the lane-linear addresses the DMA would have written) through a ring of REGD register sets: tile t + 1 is committed to
-// LDS slot (t + 1) & 1 right after the barrier that publishes tile t, its set is refilled with tile t + 1 + REGD (REGD k-steps of flight
-// time), two LDS slots.  Why: one `global_load_lds_dwordx4` retires ~1 KiB per ~55 cycles per CU whatever the tile or the number of
-// resident workgroups (k-steps of 16 / 24 / 32 KB take 0.38 / 0.54 / 0.73 us in the phase probe; splitting K over more workgroups does
-// not help) -- the vector-memory path into registers is wider.
-template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true, int REGD = 0>
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true>
 __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN) {
     using Cf = DlCfg<FM, FN, TERMS, STAGES>;
     unsigned long long* probe = PROBE ? reinterpret_cast<unsigned long long*>(d.splitk_ws) + (long)blockIdx.x * 8 : nullptr;
@@ -65,7 +59,6 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     constexpr int NI = NA + NB;                                // loads per wave per k-tile
     static_assert(TERMS == 3 || TERMS == 1, "split-bf16 x3 or plain bf16");
     static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
-    static_assert(REGD == 0 || (STAGES == 2 && !PROBE), "register staging: two LDS slots, no phase probe");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];       // the ONLY LDS object (a second one makes hipcc drain vmcnt before every ds_read)
 
     const int tid = threadIdx.x;
@@ -163,25 +156,6 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
             __builtin_amdgcn_global_load_lds((gbl_vp)(bp[j] + kob), (lds_vp)(lb + j * 4096), 16, 0, 0);
     };
 
-    // register staging: set q of the ring holds the NI pieces of one tile
-    u32x4 rg[REGD > 0 ? REGD : 1][NI];
-    auto fetch = [&](int set, int tap, int kc, bool live) __attribute__((always_inline)) {
-        const int koa = kc * a_kb;
-        const long kob = ((long)tap * K + kc) << bshift;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) rg[set][j] = *(gbl_u32x4p)(live ? ap[j] + (((amask >> j) & 1u) ? koa : 0) : zero);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) rg[set][NA + j] = *(gbl_u32x4p)(live ? bp[j] + kob : zero);
-    };
-    auto commit = [&](int set, int slot) __attribute__((always_inline)) {
-        unsigned char* la = smem + slot * A_STAGE + w * 1024 + lane * 16;
-        unsigned char* lb = smem + STAGES * A_STAGE + slot * B_STAGE + w * 1024 + lane * 16;
-#pragma unroll
-        for (int j = 0; j < NA; ++j) *reinterpret_cast<u32x4*>(la + j * 4096) = rg[set][j];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) *reinterpret_cast<u32x4*>(lb + j * 4096) = rg[set][NA + j];
-    };
-
     // ---------------------------------------------------------------- fragment addresses
     const int fx = (i32 >> 1) & 7;
     int xo[4], wo[4];
@@ -235,62 +209,25 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
         }
     };
     set_tap(0);
-    if constexpr (REGD > 0) {
-        // Every fetch and commit below is UNCONDITIONAL (a tile past the end reads the zero page and is committed to a slot nobody reads
-        // again): no control flow around a vector-memory instruction, so the compiler's vmcnt bookkeeping stays exact -- at a join of
-        // "fetched" and "not fetched" it would wait for the newest set as well and the ring would be one deep whatever REGD says.
-        auto fetch_next = [&](int set) __attribute__((always_inline)) {
-            fetch(set, f_tap, f_kc, f_idx < nkt);
-            ++f_idx;
-            f_kc += KT;
-            if (f_kc == K) {
-                f_kc = 0;
-                ++f_tap;
-                if (f_tap < taps) set_tap(f_tap);
-            }
-        };
-        auto step = [&](int kt, int q) __attribute__((always_inline)) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's pieces of tile kt are written
-            __builtin_amdgcn_s_barrier();                       // tile kt is complete in slot kt & 1; everyone is done reading the other slot
-            __builtin_amdgcn_sched_barrier(0);
-            commit((q + 1) % REGD, (kt + 1) & 1);               // tile kt + 1 (in flight since step kt + 1 - REGD) -> the other slot
-            fetch_next((q + 1) % REGD);                         // tile kt + 1 + REGD -> the set just drained
-            compute(kt & 1);
-            __builtin_amdgcn_sched_barrier(0);
-        };
 #pragma unroll
-        for (int q = 0; q < REGD; ++q) fetch_next(q);           // tile q -> set q
-        commit(0, 0);
-        fetch_next(0);                                          // tile REGD -> set 0
-        int kt = 0;
-        for (; kt + REGD <= nkt; kt += REGD) {
-#pragma unroll
-            for (int q = 0; q < REGD; ++q) step(kt + q, q);
-        }
-#pragma unroll
-        for (int q = 0; q < REGD - 1; ++q)
-            if (kt + q < nkt) step(kt + q, q);
-    } else {
-#pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s)
-            if (s < nkt) issue_next(s);
-        stamp(1);
-        int st = 0, sn = STAGES - 1;                                 // stage of the tile being computed / of the tile being issued
-        for (int kt = 0; kt < nkt; ++kt) {
-            // tiles kt .. min(kt + STAGES - 2, nkt - 1) are in flight; tile kt must have landed (this wave's pieces), the others may fly on
-            const int fly = min(STAGES - 2, nkt - 1 - kt);
-            if (fly >= 2) wait_vm(2 * NI);
-            else if (fly == 1) wait_vm(NI);
-            else wait_vm(0);
-            __builtin_amdgcn_s_barrier();                           // every wave's pieces of tile kt are in LDS; everyone is done reading slot sn
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (PROBE) { if (kt == 0) stamp(2); }
-            if (f_idx < nkt) issue_next(sn);
-            compute(st);
-            __builtin_amdgcn_sched_barrier(0);
-            st = (st + 1 == STAGES) ? 0 : st + 1;
-            sn = (sn + 1 == STAGES) ? 0 : sn + 1;
-        }
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nkt) issue_next(s);
+    stamp(1);
+    int st = 0, sn = STAGES - 1;                                 // stage of the tile being computed / of the tile being issued
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tiles kt .. min(kt + STAGES - 2, nkt - 1) are in flight; tile kt must have landed (this wave's pieces), the others may fly on
+        const int fly = min(STAGES - 2, nkt - 1 - kt);
+        if (fly >= 2) wait_vm(2 * NI);
+        else if (fly == 1) wait_vm(NI);
+        else wait_vm(0);
+        __builtin_amdgcn_s_barrier();                           // every wave's pieces of tile kt are in LDS; everyone is done reading slot sn
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PROBE) { if (kt == 0) stamp(2); }
+        if (f_idx < nkt) issue_next(sn);
+        compute(st);
+        __builtin_amdgcn_sched_barrier(0);
+        st = (st + 1 == STAGES) ? 0 : st + 1;
+        sn = (sn + 1 == STAGES) ? 0 : sn + 1;
     }
     mfma_drain(acc);
     stamp(3);
@@ -385,11 +322,11 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     if constexpr (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6); }
 }
 
-template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true, int REGD = 0>
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true>
 int launch_dl(const cdetr_gemm_desc& d, hipStream_t st) {
     using Cf = DlCfg<FM, FN, TERMS, STAGES>;
     const int tilesM = (d.M + Cf::BM - 1) / Cf::BM, tilesN = (d.N + Cf::BN - 1) / Cf::BN;
-    auto kern = igemm_dl_kernel<FM, FN, TERMS, STAGES, PROBE, EARLY, REGD>;
+    auto kern = igemm_dl_kernel<FM, FN, TERMS, STAGES, PROBE, EARLY>;
     if (Cf::LDS > 64 * 1024) {
         static bool raised = false;                             // per instantiation
         if (!raised) {
@@ -450,18 +387,6 @@ int cdetr_gemm_dl_launch(const cdetr_gemm_desc& d, int tile, int stages, hipStre
 #define DL_GO(FM, FN, S)                                                                                            \
     return late ? (x3 ? launch_dl<FM, FN, 3, S, false, false>(d, st) : launch_dl<FM, FN, 1, S, false, false>(d, st)) \
                 : (x3 ? launch_dl<FM, FN, 3, S>(d, st) : launch_dl<FM, FN, 1, S>(d, st))
-#define DL_REG(FM, FN, R) return x3 ? launch_dl<FM, FN, 3, 2, false, true, R>(d, st) : launch_dl<FM, FN, 1, 2, false, true, R>(d, st)
-    switch (tile * 100 + stages) {                              // stages 12 / 22: register-staged operand tiles, ring of 1 / 2 register sets
-        case 0 * 100 + 12: DL_REG(2, 2, 1);
-        case 1 * 100 + 12: DL_REG(2, 1, 1);
-        case 1 * 100 + 22: DL_REG(2, 1, 2);
-        case 2 * 100 + 12: DL_REG(1, 2, 1);
-        case 2 * 100 + 22: DL_REG(1, 2, 2);
-        case 3 * 100 + 12: DL_REG(1, 1, 1);
-        case 3 * 100 + 22: DL_REG(1, 1, 2);
-        default: break;
-    }
-#undef DL_REG
     switch (tile * 8 + stages) {
         case 0 * 8 + 2: DL_GO(2, 2, 2);
         case 0 * 8 + 3: DL_GO(2, 2, 3);
