@@ -755,20 +755,7 @@ class Trainer:
         return s, mode
 
     def _concurrent(self, a, b):
-        """Do kernels of stream `b` run while a long kernel occupies stream `a`?  (HIP maps streams onto a few hardware queues -- four by
-        default --, and two streams of one queue never overlap: measured, not assumed.)"""
-        from . import _ffi
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(a):
-            e0.record(a)
-            _ffi.check(_ffi.lib().cdetr_delay(600, _ffi.stream_ptr()), "cdetr_delay")
-        b.wait_event(e0)
-        with torch.cuda.stream(b):
-            _ffi.check(_ffi.lib().cdetr_delay(1, _ffi.stream_ptr()), "cdetr_delay")
-            e1.record(b)
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) < 0.3           # b's kernel was through while a's 0.6 ms were still running
+        return streams_overlap(a, b)
 
     def _side_streams(self):
         """pf: zero-fill + data-gradient weight images + the next batch's frozen stage; wg: weight gradients beside the data-gradient chain.
@@ -782,6 +769,7 @@ class Trainer:
                 except Exception:
                     prio = 0
             cands = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(8)]
+            warm_streams(cands)
             self.side_priority = prio
             ok = [c for c in cands if self._concurrent(main, c)]
             pf = ok[0] if ok else cands[0]
@@ -1167,26 +1155,41 @@ def count_from_logits(pred_logits, threshold=0.5):
     return keep.sum(-1), keep, prob
 
 
-def probe_side_stream(main, device, n=8):
-    """A stream whose kernels really run beside `main`'s (HIP maps streams onto a few hardware queues; two streams of one queue never
-    overlap): candidates are probed with a long idle kernel on `main` and a short one on the candidate."""
+def warm_streams(streams):
+    """One trivial kernel per stream, then a device sync.  The FIRST launch on a fresh stream takes 0.2-40 ms (the runtime creates / binds its
+    hardware queue then: `tools/probe_streams.py`) -- probed cold, a concurrent stream looks serialised."""
     from . import _ffi
-
-    def concurrent(a, b):
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        with torch.cuda.stream(a):
-            e0.record(a)
-            _ffi.check(_ffi.lib().cdetr_delay(600, _ffi.stream_ptr()), "cdetr_delay")
-        b.wait_event(e0)
-        with torch.cuda.stream(b):
+    for c in streams:
+        with torch.cuda.stream(c):
             _ffi.check(_ffi.lib().cdetr_delay(1, _ffi.stream_ptr()), "cdetr_delay")
-            e1.record(b)
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) < 0.3
+    torch.cuda.synchronize()
+
+
+def streams_overlap(a, b):
+    """Do kernels of stream `b` run while a long kernel occupies stream `a`?  (HIP maps streams onto a few hardware queues -- four by
+    default --, and two streams of one queue never overlap: measured, not assumed.)  A 0.6 ms idle kernel on `a`, a 1 us kernel on `b` behind
+    an event recorded on `a` BEFORE the idle kernel: 0.02 ms from that event to the end of b's kernel when they overlap, 0.61 when they
+    do not (both streams warm, see warm_streams)."""
+    from . import _ffi
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(a):
+        e0.record(a)
+        _ffi.check(_ffi.lib().cdetr_delay(600, _ffi.stream_ptr()), "cdetr_delay")
+    b.wait_event(e0)
+    with torch.cuda.stream(b):
+        _ffi.check(_ffi.lib().cdetr_delay(1, _ffi.stream_ptr()), "cdetr_delay")
+        e1.record(b)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) < 0.3
+
+
+def probe_side_stream(main, device, n=8):
+    """A stream whose kernels really run beside `main`'s: candidates are warmed, then probed (streams_overlap)."""
     cands = [torch.cuda.Stream(device=device) for _ in range(n)]
+    warm_streams(cands)
     for c in cands:
-        if concurrent(main, c):
+        if streams_overlap(main, c):
             return c, True
     return cands[0], False
 

@@ -364,6 +364,10 @@ def test_graph_layouts_agree(monkeypatch):
             assert (e["segs"] is not None) == (seg == "1")
         else:
             assert len(e["S"]) == 3 and e["W"][0] is not None and e["W0"] is not None
+            # the side streams were PROBED concurrent with the main stream and with each other (warm candidates: a cold stream's first
+            # launch takes 0.2-40 ms and looks serialised): most of 8 candidates sit on another hardware queue than the main stream
+            pr = tr.side_stream_probe
+            assert pr["overlap_main"] >= 2 and pr["wg_overlaps_pf"], pr
         outs = []
         for _ in range(3):
             outs.append({k: float(v) for k, v in tr.replay().items()})
