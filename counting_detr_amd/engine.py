@@ -784,10 +784,10 @@ class Trainer:
 
     def _capture_chain(self, st, world, warmup):
         """The step as a chain of LINEAR graphs (see _capture_entry) on the main stream: F forward + cost matrices | B Hungarian solve +
-        criterion + the backward down to the backbone | S12 layer4 + layer3 | S3 layer2 | O clip + AdamW (world_size > 1: S1 | S2 | S3).  Beside them: Z (zero-fill +
+        criterion + the backward down to the backbone | S1 layer4 | S2 layer3 | S3 layer2 | O clip + AdamW.  Beside them: Z (zero-fill +
         data-gradient weight images) on the prefetch stream, released by the previous step's O (it runs beside the encoder / decoder forward, behind the
         backbone-done signal kernel of F; B waits for it); the next batch's frozen stage on the same stream, released by F and the signal
-        kernel that opens B (beside the solve); W0 (every parameter gradient above the backbone) and W12 (layer4 + layer3's) on the
+        kernel that opens B (beside the solve); W0 (every parameter gradient above the backbone), W1 (layer4's) and W2 (layer3's) on the
         weight-gradient stream, each released by the main piece that produced its operands and running beside the pieces that follow
         (layer2's stay on the main stream: nothing is left to run beside them); O waits for them."""
         from . import ops
