@@ -22,7 +22,7 @@ for prec in (1, 0):
     tr.capture(images, rects, targets, warmup=1)
     trace = []
     for i in range(steps):
-        out = tr.replay()
+        out = tr.replay(pipelined=True)        # the benchmark's step: chain of linear graphs + the next step's frozen stage beside the solve
         if i % 50 == 0 or i == steps - 1:
             trace.append((i, round(float(out["loss"]), 4), round(float(out["loss_bbox"]), 4), round(float(out["loss_giou"]), 4)))
-    print(("bf16x3 fwd / bf16 bwd" if prec == 1 else "fp32 MFMA"), "non-finite steps:", tr.nonfinite_steps(), trace, flush=True)
+    print(("bf16x3 fwd / bf16 bwd" if prec == 1 else "fp32 MFMA"), "non-finite steps:", tr.nonfinite_steps(), "prefetch", dict(tr.prefetch_stats), trace, flush=True)
