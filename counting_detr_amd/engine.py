@@ -762,15 +762,10 @@ class Trainer:
         Both must overlap the stream the steps are replayed on (the current one at the first call) and each other: candidates are probed."""
         if self._pf_stream is None:
             main = torch.cuda.current_stream()
-            prio = 0
-            if os.environ.get("CDETR_SIDE_PRIORITY", "normal") == "low":      # A/B: side work yields to the main chain at dispatch
-                try:
-                    prio = max(torch.cuda.Stream.priority_range())
-                except Exception:
-                    prio = 0
-            cands = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(8)]
+            # (stream priorities on this stack: 0 = default ... -1 = high; there is nothing below the default to give the side work, and a
+            # HIGH-priority main stream was measured unstable: profiles/r4_ab_priority.txt)
+            cands = [torch.cuda.Stream(device=self.device) for _ in range(8)]
             warm_streams(cands)
-            self.side_priority = prio
             ok = [c for c in cands if self._concurrent(main, c)]
             pf = ok[0] if ok else cands[0]
             rest = [c for c in ok[1:] if self._concurrent(pf, c)]
