@@ -67,7 +67,7 @@ class MirrorItem(C.Structure):
 
 
 EXPORTS = ["cdetr_gemm", "cdetr_gemm_dl", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_layernorm_bwd_merge", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
-           "cdetr_hw_reduce", "cdetr_posadd2_hw_reduce", "cdetr_bcast_add2", "cdetr_bcast_add2_sum", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_maxpool3x3s2_split", "cdetr_weight_mirror", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
+           "cdetr_hw_reduce", "cdetr_posadd2_hw_reduce", "cdetr_bcast_add2", "cdetr_bcast_add2_sum", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_maxpool3x3s2_split", "cdetr_weight_mirror", "cdetr_weight_images", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_mask_prep", "cdetr_stem_pack", "cdetr_exemplar_fwd", "cdetr_exemplar_bwd", "cdetr_aggr_weight_fwd", "cdetr_aggr_weight_bwd",
            "cdetr_box_head_fwd", "cdetr_box_head_bwd", "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version", "cdetr_delay", "cdetr_flag_signal", "cdetr_flag_wait"]
 
@@ -141,6 +141,8 @@ def lib():
         L.cdetr_add2.argtypes = [_p] * 5 + [C.c_int64, _p]
         L.cdetr_grad_merge.restype = C.c_int
         L.cdetr_grad_merge.argtypes = [_p] * 6 + [C.c_int64, _p]
+        L.cdetr_weight_images.restype = C.c_int
+        L.cdetr_weight_images.argtypes = [_p, C.c_int32, C.c_int32, _p]
         L.cdetr_weight_mirror.restype = C.c_int
         L.cdetr_weight_mirror.argtypes = [_p, C.c_int32, C.c_int32, _p]
         L.cdetr_bcast_add2.restype = C.c_int

@@ -202,6 +202,50 @@ __global__ __launch_bounds__(256) void weight_mirror_kernel(const cdetr_mirror_i
         }
     }
 }
+// The FORWARD images alone (transpose = 0: W * scale pre-split into groups [hi 32 | lo 32], same row-major order as W): a pure stream -- every
+// thread turns 4 consecutive weights (16-byte load; C % 32 == 0, so they share a row and a group) into 4 hi + 4 lo values (two 8-byte stores).  The
+// tiled kernel above did this with 4-byte loads and 2-byte stores (90 us for the 38 M weights of the model, in the step's critical path); item.tile0
+// counts blocks of 4096 weights here.  Bit-identical images.
+constexpr int WIMG_BLOCK = 4096;
+__global__ __launch_bounds__(256) void weight_image_kernel(const cdetr_mirror_item* __restrict__ items, const int n_items) {
+    const int b = blockIdx.x;
+    int lo = 0, hi = n_items - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (items[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const cdetr_mirror_item it = items[lo];
+    const long K = (long)it.taps * it.C, total = (long)it.R * K;
+    const long e0 = (long)(b - it.tile0) * WIMG_BLOCK + threadIdx.x * 4;
+    __bf16* sp = reinterpret_cast<__bf16*>(it.dst_split);
+    const bool al = (reinterpret_cast<uintptr_t>(it.src) & 15) == 0;       // block-uniform
+    float4 v[4];
+    float sc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {                                // clamped, unconditional: the four loads (and scales) of a thread are in flight together
+        const long e = min(e0 + u * 1024, total - 4);
+        if (al) v[u] = *reinterpret_cast<const float4*>(it.src + e);
+        else v[u] = make_float4(it.src[e], it.src[e + 1], it.src[e + 2], it.src[e + 3]);      // (a parameter view at an odd offset of its arena)
+        sc[u] = it.scale ? it.scale[e / K] : 1.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const long e = e0 + u * 1024;
+        if (e >= total) continue;
+        const float x[4] = {it.scale ? v[u].x * sc[u] : v[u].x, it.scale ? v[u].y * sc[u] : v[u].y, it.scale ? v[u].z * sc[u] : v[u].z,
+                            it.scale ? v[u].w * sc[u] : v[u].w};
+        __bf16 h[4], l[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h[j] = (__bf16)x[j];
+            l[j] = (__bf16)(x[j] - (float)h[j]);
+        }
+        __bf16* g = sp + (e >> 5) * 64 + (e & 31);
+        *reinterpret_cast<uint2*>(g) = *reinterpret_cast<const uint2*>(h);
+        *reinterpret_cast<uint2*>(g + 32) = *reinterpret_cast<const uint2*>(l);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ GroupNorm on NHWC rows
 // nn.GroupNorm(G, C) of A2/models/anchor_detr.py:86-92 on the NHWC activation [B][P = h*w][C]: a group is CG = C / G consecutive
 // channels of every pixel of one image.  One workgroup per (image, group): pass 1 sums x and x^2 over its P x CG slab (16-byte loads
@@ -907,6 +951,12 @@ extern "C" int cdetr_weight_mirror(const cdetr_mirror_item* items_dev, int32_t n
     CDETR_CHECK_ARG(items_dev && n_items > 0 && total_tiles > 0, "cdetr_weight_mirror: bad args");
     hipLaunchKernelGGL(weight_mirror_kernel, dim3(total_tiles), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), items_dev, n_items);
     return cdetr_launch_status("cdetr_weight_mirror");
+}
+
+extern "C" int cdetr_weight_images(const cdetr_mirror_item* items_dev, int32_t n_items, int32_t total_blocks, void* stream) {
+    CDETR_CHECK_ARG(items_dev && n_items > 0 && total_blocks > 0, "cdetr_weight_images: bad args");
+    hipLaunchKernelGGL(weight_image_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), items_dev, n_items);
+    return cdetr_launch_status("cdetr_weight_images");
 }
 
 extern "C" int cdetr_add2(const float* T, const float* A, const float* B, float* O1, float* O2, int64_t n, void* stream) {

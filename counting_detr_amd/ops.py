@@ -426,7 +426,7 @@ class WeightMirror:
             it.R, it.C, it.taps, it.tile0, it.transpose = R, Cc, taps, tile0, 0
             self.f_entries.append((w.data_ptr(), w.numel() * 4, off, R, Cc, taps, sc.data_ptr() if sc is not None else 0, True))
             self._keep.append((w, sc))
-            tile0 += ((R + 31) // 32) * ((Cc + 31) // 32) * taps
+            tile0 += (w.numel() + 4095) // 4096          # cdetr_weight_images: blocks of 4096 weights
             off += w.numel()
         self.tilesF, self.nF = tile0, len(fwd_entries)
         raw = np.frombuffer(bytes(items), dtype=np.uint8).copy()
@@ -443,8 +443,8 @@ class WeightMirror:
         "bwd": the transposed data-gradient operands (needed only when the backward starts -- the trainer rewrites them on a side
         stream under the Hungarian solve); "all": both."""
         if part in ("all", "fwd") and self.nF:
-            check(lib().cdetr_weight_mirror(self.items_dev.data_ptr() + self.nT * self.item_bytes, self.nF, self.tilesF, stream_ptr()),
-                  "cdetr_weight_mirror")
+            check(lib().cdetr_weight_images(self.items_dev.data_ptr() + self.nT * self.item_bytes, self.nF, self.tilesF, stream_ptr()),
+                  "cdetr_weight_images")
         if part in ("all", "bwd") and self.nT:
             check(lib().cdetr_weight_mirror(self.items_dev.data_ptr(), self.nT, self.tilesT, stream_ptr()), "cdetr_weight_mirror")
 

@@ -261,6 +261,9 @@ typedef struct {
                           /* (cdetr_gemm_desc.B16: full cache lines of hi values, no interleaved lo halves)             */
 } cdetr_mirror_item;
 int cdetr_weight_mirror(const cdetr_mirror_item* items_dev, int32_t n_items, int32_t total_tiles, void* stream);
+/* the forward images only (every item transpose = 0, 16-byte aligned src / dst_split, C % 32 == 0): a streaming pass, 4 weights per thread;
+ * item.tile0 = first block of the item in units of 4096 weights (ceil(R * taps * C / 4096) blocks per item), total_blocks their sum.           */
+int cdetr_weight_images(const cdetr_mirror_item* items_dev, int32_t n_items, int32_t total_blocks, void* stream);
 
 /* 3x3 stride-2 pad-1 max pooling, NHWC (A2/models/resnet.py:206,265) */
 int cdetr_maxpool3x3s2(const float* X, float* Y, int32_t Nimg, int32_t H, int32_t W, int32_t C, void* stream);

@@ -1188,3 +1188,29 @@ def test_fused_pos_mlp_node_equals_per_layer_nodes():
     close(dx1, dx0, rtol=1e-5, msg="dx")
     for i, (a, b) in enumerate(zip(g0, g1)):
         close(b, a, rtol=1e-5, msg=f"param grad {i}")
+
+
+def test_forward_weight_images_streaming_kernel():
+    """cdetr_weight_images (the forward operands' pre-split images W * scale -> [hi 32 | lo 32] groups as one streaming pass): bit-exact against
+    torch for 16-byte aligned sources and for a parameter view at an odd offset of its arena (4-byte aligned only), with and without a row scale,
+    sizes that are not a multiple of the 4096-weight block."""
+    from counting_detr_amd import ops
+    torch.manual_seed(3)
+    arena = torch.randn(2 + 96 * 160 + 6 + 64 * 9 * 32, device=DEV)
+    wl = arena[2:2 + 96 * 160].view(96, 160)                                  # 8 bytes into the arena
+    w3 = arena[2 + 96 * 160 + 6:].view(64, 3, 3, 32).permute(0, 3, 1, 2)       # channels_last [64, 32, 3, 3], 32 bytes in
+    assert wl.data_ptr() % 16 == 8 and w3.is_contiguous(memory_format=torch.channels_last)
+    s3 = torch.rand(64, device=DEV) + 0.5
+    big = torch.randn(512, 9 * 512, device=DEV)[:, :9 * 512]
+    mir = ops.WeightMirror([], [(wl, None), (w3, s3), (big, None)])
+    mir.refresh("fwd")
+    torch.cuda.synchronize()
+
+    def unsplit(buf, rows, klen):
+        v = buf[:rows * klen].view(torch.bfloat16).view(rows, klen // 32, 2, 32).float()
+        return v[:, :, 0].reshape(rows, klen), v[:, :, 1].reshape(rows, klen)
+    for w, sc, rows, klen, ref in ((wl, None, 96, 160, wl), (w3, s3, 64, 288, (w3 * s3.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(64, 288)),
+                                   (big, None, 512, 4608, big)):
+        hi, lo = unsplit(mir.lookup_fwd(w, sc), rows, klen)
+        assert torch.equal(hi, ref.bfloat16().float()), "hi image"
+        assert torch.equal(lo, (ref - ref.bfloat16().float()).bfloat16().float()), "lo image"
