@@ -562,6 +562,11 @@ def main(argv=None):
     dense = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
     total_traffic = (tj or {}).get("total_bytes_per_step")
     roofline = {"bound": "mfma", "achieved": achieved, "peak": dense, "unit": "TFLOP/s",
+                "bound_note": "priced against the matrix pipe as the contract asks (dense contraction).  What the launches actually run into at these shapes "
+                              "(M = 5000-20000 rows: 1-2.5 tile workgroups per CU) is not the pipe: the long reductions (3x3, K >= 1024) move their operand "
+                              "lines L2 -> LDS at 50-75 GB/s per CU (k-steps of 16 / 24 / 32 KB in 0.38 / 0.54 / 0.73 us whatever the loader, ring depth or "
+                              "arithmetic), the short ones (K <= 512 into N >= 1024) stream 53-120 MB of epilogue operands at 2.3-2.7 TB/s -- DESIGN.md section 0, "
+                              "profiles/r4_dl_sweep_regstage*.txt, r4_stride_pad.txt, r4_ab_epilogue_touch.txt",
                 "frac": achieved / dense,
                 "frac_note": "ALGORITHMIC FLOPs (2*M*N*K*taps per launch) of the dominant kernel family / HIP-event time of its launches / the "
                              "dense MFMA peak of the arithmetic's input type (2500 TF bf16; 157.3 TF for --precision fp32).  The split-bf16 forward "
