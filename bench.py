@@ -158,6 +158,7 @@ def self_launch(n):
     torch.distributed.run, one per GPU, rendezvous on 127.0.0.1.  Output and exit code are the ranks'."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("GPU_MAX_HW_QUEUES", "8")      # main + prefetch + weight-gradient + exchange streams + RCCL's own: more than HIP's default 4 queues
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -382,6 +383,9 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        # (ranks started by an external launcher: the HIP runtime has not initialised yet -- nothing above touches the device)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Counting-DETR HIP path has no CPU fallback")
     if world != a.gpus:
@@ -600,6 +604,9 @@ def main(argv=None):
                       "final_loss": loss,
                       "frozen_stage_prefetch": bool(pipelined and mode != "eager")},
            "step_ms": percentiles(per_step),
+           # stream -> hardware-queue verdict of the probes (engine.Trainer._side_streams): how many candidate streams run beside the main one,
+           # whether the weight-gradient / exchange streams overlap it and each other, and the fail-safe taken when none does
+           "streams": getattr(trainer, "side_stream_probe", None),
            "per_rank_ms_per_step": per_rank_ms,
            "scaling_note": ("measured on %d ranks" % world) if world > 1 else
                            "single-GPU line; no N > 1 scaling curve has been measured for this repo yet (one-GPU leases only: the driver's "
@@ -657,7 +664,11 @@ def main(argv=None):
             # the shipped training script: --spatial_prior grid --num_query_position 600 -> 24 x 24 = 576 anchors (A2/scripts/var_wh_laplace_600.sh)
             extra_shape(dev, 800, 800, 600, "grid", Ts, a.batch, a.precision),
             # a typical FSC-147 image after the resize rule (A2/data/fsc147.py:75-77)
-            extra_shape(dev, 384, 576, 300, "learned", Ts, a.batch, a.precision)]
+            extra_shape(dev, 384, 576, 300, "learned", Ts, a.batch, a.precision),
+            # crowded images (FSC-147 holds up to 3731 objects per image, A2/data/fsc147.py:80-84): target-capacity classes 2048 and 3800, where the
+            # assignment is one LDS-resident workgroup per image (A2/models/matcher.py:229-247 calls scipy there: 17 ms at 900 x 3000)
+            extra_shape(dev, 384, 576, 300, "learned", (37, 2100), a.batch, a.precision),
+            extra_shape(dev, 384, 576, 300, "learned", (3000, 3731), a.batch, a.precision)]
     if world == 1 and not a.no_inference:
         res["inference"] = inference_leg(dev, [(800, 800), (384, 576), (800, 800, 8), (384, 576, 16)], a.batch, a.precision)
         res["stage1_pseudo_labels"] = stage1_leg(dev, a.precision)

@@ -40,7 +40,11 @@ class FlatGradExchange:
 
     def __init__(self, flat_g, seg_bounds):
         self.flat_g, self.seg_bounds = flat_g, list(seg_bounds)
+        # (a fresh stream may share a hardware queue with the compute stream -- two streams of one queue never overlap: the trainer replaces it by
+        # a PROBED one, Trainer._side_streams -> set_stream)
         self.stream = torch.cuda.Stream() if (flat_g.is_cuda and is_dist_avail_and_initialized()) else None
+        self.probed = None      # {"overlaps_main": bool, "overlaps_wgrad": bool, "overlaps_prefetch": bool} once the trainer has probed the stream
+        self.dummy_us = 0       # rehearsal / tests: an idle kernel of this many microseconds per bucket stands in for the collective (world 1)
         self.launched = []
         self.graphs = None      # capture_buckets(): the bucket all-reduces as captured graphs
         self.probe = None       # a list: finish() appends (compute-side event, comm-side event) per step -> exposed_ms()
@@ -66,11 +70,27 @@ class FlatGradExchange:
         self.graphs = graphs
         return True
 
+    def set_stream(self, stream, verdict=None):
+        """The exchange runs on `stream` from now on (a stream the trainer has probed to run beside its compute streams)."""
+        self.stream, self.probed = stream, verdict
+
+    def active(self):
+        return get_world_size() > 1 or (self.dummy_us > 0 and self.stream is not None)
+
     def segment_done(self, seg, also=None):
         """also: a second stream whose work so far (parameter gradients running beside the backward) the bucket depends on."""
         lo, hi = self.seg_bounds[seg], self.seg_bounds[seg + 1]
         self.launched.append(seg)
-        if hi <= lo or get_world_size() < 2:
+        if hi <= lo:
+            return
+        if get_world_size() < 2:
+            if self.dummy_us > 0 and self.stream is not None:       # same ordering as a real bucket, an idle kernel instead of the collective
+                from . import _ffi
+                self.stream.wait_stream(torch.cuda.current_stream())
+                if also is not None:
+                    self.stream.wait_stream(also)
+                with torch.cuda.stream(self.stream):
+                    _ffi.check(_ffi.lib().cdetr_delay(int(self.dummy_us), _ffi.stream_ptr()), "cdetr_delay")
             return
         buf = self.flat_g[lo:hi]
         if self.stream is not None:
@@ -222,12 +242,15 @@ class Trainer:
         self._pf_timeout_us = int(os.environ.get("CDETR_PF_TIMEOUT_US", getattr(args, "frozen_prefetch_timeout_us", 400)))   # flag wait (chain layout)
         self._captured_allreduce = os.environ.get("CDETR_CAPTURED_ALLREDUCE", "1" if getattr(args, "captured_allreduce", False) else "0") == "1"
         self._z_late = os.environ.get("CDETR_Z_LATE", "1") != "0"               # Z released by the backbone-forward-done signal instead of at step start
+        self._z_timeout_us = int(os.environ.get("CDETR_Z_TIMEOUT_US", 4000))    # its flag wait gives up after this long (a lost signal = a delay, never a hang)
         self._pf_post_us = int(os.environ.get("CDETR_PF_POST_US", 30))          # head start of the solve over the prefetched stage's workgroups
         self._pf_delay_us = int(os.environ.get("CDETR_PF_DELAY_US", 0))        # "single" layout only: fixed delay in front of the prefetched stage
         self._pf_eager = os.environ.get("CDETR_PF_EAGER", "0") == "1"
         self._tail_inline = float(os.environ.get("CDETR_TAIL_INLINE", getattr(args, "wgrad_tail_inline", 1.0)))   # share of layer2's weight gradients kept on the main stream
         self._frozen = {}                       # image shape -> frozen-stage buffers + graph (see "frozen-stage prefetch")
         self._pf_stream = self._pf_pool = self._wg_stream = None
+        self._serial = False                    # _side_streams(): no stream runs beside the main one -> no prefetch, no flag waits
+        self._inject = {}                       # tests: {"before_B": us, "before_Z": us, "before_W0": us} idle kernels at those points of a chain step
         self.prefetch_stats = {"hits": 0, "inline": 0}
         self._cache_on = bool(getattr(args, "graph_cache", True))
         self._cache_size = int(getattr(args, "graph_cache_size", 32))
@@ -237,6 +260,8 @@ class Trainer:
         owners = model.__dict__.setdefault("_graph_cache_owners", [])      # checkpoint.invalidate_caches -> clear_graph_cache
         owners.append(weakref.ref(self))
         self.exchange = FlatGradExchange(self.flat_g, self.seg_bounds)
+        if self.exchange.stream is not None:      # world_size > 1 on a GPU: the exchange stream is probed against the compute streams NOW, so that
+            self._side_streams()                  # the stream-ordered step's buckets (hook below) overlap the backward as well
         _bb.set_backward_hook(self._segment_done if get_world_size() > 1 else None)
         self.sync_replicas()
 
@@ -576,13 +601,40 @@ class Trainer:
         return bool(getattr(c, "fused", False)) and list(getattr(c, "losses", [])) == ["labels", "boxes", "cardinality", "vars"]
 
     def clear_graph_cache(self):
-        """Drop every captured step.  Captured graphs hold the ADDRESSES of value-derived device tables (FrozenBN folds, padded stem
-        images): anything that rebuilds them (checkpoint.invalidate_caches: checkpoint loads, replica broadcast) calls this."""
-        if self._cache or self._entry is not None:
+        """Drop every captured step AND every frozen-stage graph.  Captured graphs hold the ADDRESSES of value-derived device tables (FrozenBN
+        folds, padded stem images): anything that rebuilds them (checkpoint.invalidate_caches: checkpoint loads, replica broadcast, an
+        InferenceEngine built on the same model) calls this."""
+        if self._cache or self._entry is not None or self._frozen:
             if self.flat_g.is_cuda:
                 torch.cuda.synchronize()
             self._cache.clear()
             self._entry = None
+            self._frozen.clear()            # (the stem + layer1 graphs read the same folds / stem images: stale after an invalidation)
+
+    def _drop_lru(self):
+        """Evict the least recently used cached step (the caller has synchronised); its frozen-stage buffers + graph go with it when no other
+        captured step of that image shape is left."""
+        key = next(iter(self._cache))
+        e = self._cache.pop(key)
+        self._release_frozen(e)
+
+    def _release_frozen(self, e):
+        fs = e.get("fs") if e is not None else None
+        if fs is None:
+            return
+        live = [x for x in list(self._cache.values()) + [self._entry] if x is not None and x is not e and x.get("fs") is fs]
+        if not live:
+            for shape, f in list(self._frozen.items()):
+                if f is fs:
+                    del self._frozen[shape]
+
+    def _trim_frozen(self, limit=2):
+        """Frozen-stage graphs that no captured step uses (a batch was announced and never arrived): keep the newest `limit`."""
+        used = {id(x["fs"]) for x in list(self._cache.values()) + [self._entry] if x is not None and x.get("fs") is not None}
+        idle = [shape for shape, f in self._frozen.items() if id(f) not in used]
+        for shape in idle[:max(0, len(idle) - limit)]:
+            torch.cuda.synchronize()
+            del self._frozen[shape]
 
     # ------------------------------------------------------------------ frozen-stage prefetch
     # The stem + layer1 (A2/models/backbone.py:93-95: frozen, and the images need no gradient) of batch i+1 depends on nothing step i
@@ -594,9 +646,17 @@ class Trainer:
     # with it; the backward reads the bf16 twin only), the twin into a staging copy that the next step moves over (41 MB, ~15 us).
     # A batch that was not announced (first step, another object than the announced one) runs its frozen stage in line, as before.
     def _prefetch_ok(self):
+        """The next batch's frozen stage may run beside this step only if (a) a side stream really runs beside the main one (probed), and
+        (b) the backward of this step reads layer1's output through its bf16 TWIN only -- the prefetch overwrites the fp32 tensor while the
+        backward is still running, and the weight gradients of layer2[0] (conv1, downsample) read X = that tensor: with CDETR_WGRAD_TWINS=0
+        (or a backward arithmetic that does not feed on twins) they would read it as fp32."""
         from . import ops
+        if not (self._prefetch_on and self.flat_g.is_cuda):
+            return False
+        self._side_streams()                # (probe: sets self._serial)
         body = self.model.backbone.body
-        return self._prefetch_on and self.flat_g.is_cuda and body.frozen_stage_is_frozen() and ops.bf16_twins()
+        return (not self._serial and body.frozen_stage_is_frozen() and ops.bf16_twins()
+                and os.environ.get("CDETR_WGRAD_TWINS", "1") != "0")
 
     def _frozen_for(self, shape):
         """Static buffers + captured graph of the frozen stage for one padded image shape."""
@@ -616,14 +676,10 @@ class Trainer:
         # with such a queue alive EVERY launch of the process slowed down, 9.3 -> 19 ms per step, in-line replays included:
         # profiles/r4_prefetch_ab_cumask.txt; an ordinary stream it is)
         ps, _ = self._side_streams()
-        prev = ops.MIRROR
-        ops.MIRROR = self.mirror
-        beside = ops.BRANCH_BESIDE
-        try:
+        with ops.scope(MIRROR=self.mirror, BRANCH_BESIDE=0):      # a LINEAR graph: every node runs on the stream it is launched on
             if self.mirror is not None:
                 self.mirror.refresh("fwd")                      # the frozen layers' pre-split images (rewritten, unchanged, by every step)
             ps.wait_stream(torch.cuda.current_stream())
-            beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0    # a LINEAR graph: every node runs on the (CU-masked) stream it is launched on
             with torch.cuda.stream(ps):
                 body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))       # lazily cached tables exist before the capture
             torch.cuda.current_stream().wait_stream(ps)
@@ -632,11 +688,9 @@ class Trainer:
             mode = {"capture_error_mode": "thread_local"} if get_world_size() > 1 else {}
             with torch.cuda.graph(g, pool=self._pf_pool, stream=ps, **mode):
                 body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))
-        finally:
-            ops.MIRROR = prev
-            ops.BRANCH_BESIDE = beside
         fs["graph"] = g
         self._frozen[shape] = fs
+        self._trim_frozen()
         return fs
 
     @staticmethod
@@ -654,7 +708,7 @@ class Trainer:
         fs = e["fs"]
         main = torch.cuda.current_stream()
         main.wait_stream(self._pf_stream)                       # whatever was prefetched has landed
-        if token is None or fs["token"] != token:               # not announced: in line
+        if token is None or fs["token"] != token:               # not announced (or another batch than the announced one): in line
             fs["images"].copy_(e["st"]["images"])
             fs["graph"].replay()
             self.prefetch_stats["inline"] += 1
@@ -666,7 +720,9 @@ class Trainer:
     def _prefetch(self, images, token, keep, ordered=False):
         """Release the frozen stage of the announced next batch behind everything issued so far on the current stream (`ordered`: the
         prefetch stream is already ordered behind it and has idled its delay)."""
-        fs = self._frozen_for(images.shape)
+        fs = self._frozen.get(tuple(images.shape))
+        if fs is None:                      # (resolved before the step's first launch by _replay_entry; a shape met here for the first time is
+            return                          # not worth a capture in the middle of a step: that batch runs its frozen stage in line)
         ps = self._pf_stream
         if not ordered:
             ev = torch.cuda.Event()
@@ -679,12 +735,8 @@ class Trainer:
                 _ffi.check(_ffi.lib().cdetr_delay(self._pf_delay_us, _ffi.stream_ptr()), "cdetr_delay")
             if self._pf_eager:                 # stream-ordered launches instead of the graph (A/B: CDETR_PF_EAGER)
                 from . import ops
-                prev, ops.MIRROR = ops.MIRROR, self.mirror
-                beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0
-                try:
+                with ops.scope(MIRROR=self.mirror, BRANCH_BESIDE=0):
                     self.model.backbone.body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))
-                finally:
-                    ops.MIRROR, ops.BRANCH_BESIDE = prev, beside
             else:
                 fs["graph"].replay()
         fs["token"], fs["keep"] = token, keep                   # (`keep`: the announced object stays alive, so its id cannot be re-used)
@@ -710,10 +762,13 @@ class Trainer:
         fs = self._frozen_for(images.shape) if self._prefetch_ok() else None
         try:
             if fs is not None:                     # the captured forward reads the frozen stage's output from fixed buffers
+                # (a prefetch of this very fs -- announced by the previous step, whose key differed only in capacity class / exemplar shape --
+                # may still be running on the prefetch stream: the same graph must not replay on two streams at once)
+                torch.cuda.current_stream().wait_stream(self._pf_stream)
                 fs["images"].copy_(st["images"])
                 fs["graph"].replay()
                 fs["x16"].copy_(fs["x16s"])
-                fs["token"] = None
+                fs["token"] = fs["keep"] = None
                 body.frozen_input = (fs["x"], fs["x16"])
             if layout == "chain":
                 e = self._capture_chain(st, world, warmup)
@@ -758,20 +813,52 @@ class Trainer:
         return streams_overlap(a, b)
 
     def _side_streams(self):
-        """pf: zero-fill + data-gradient weight images + the next batch's frozen stage; wg: weight gradients beside the data-gradient chain.
-        Both must overlap the stream the steps are replayed on (the current one at the first call) and each other: candidates are probed."""
+        """pf: zero-fill + data-gradient weight images + the next batch's frozen stage; wg: weight gradients beside the data-gradient chain;
+        (world_size > 1) ex: the gradient buckets' all-reduces.  Each must overlap the stream the steps are replayed on (the current one at
+        the first call) and the others: HIP maps streams onto a few hardware queues and two streams of one queue never overlap, so candidates
+        are warmed and PROBED (streams_overlap), never assumed.
+        Fail-safe: when NO candidate runs beside the main stream (`self._serial`), everything that only pays off with real concurrency is
+        switched off -- the frozen-stage prefetch (_prefetch_ok) and the device-side flag waits (`_z_late`): on one hardware queue a flag wait
+        sits IN FRONT of the graph that carries its signal and would idle its whole timeout (4 ms per step).  The side work then runs in
+        stream order behind events, as in round 3; `side_stream_probe` (printed in bench.py's line) says so."""
         if self._pf_stream is None:
             main = torch.cuda.current_stream()
             # (stream priorities on this stack: 0 = default ... -1 = high; there is nothing below the default to give the side work, and a
             # HIGH-priority main stream was measured unstable: profiles/r4_ab_priority.txt)
-            cands = [torch.cuda.Stream(device=self.device) for _ in range(8)]
+            want_ex = self.exchange.stream is not None or bool(int(os.environ.get("CDETR_PROBE_EXCHANGE", "0")))
+            cands = [torch.cuda.Stream(device=self.device) for _ in range(12 if want_ex else 8)]
             warm_streams(cands)
             ok = [c for c in cands if self._concurrent(main, c)]
             pf = ok[0] if ok else cands[0]
             rest = [c for c in ok[1:] if self._concurrent(pf, c)]
             wg = rest[0] if rest else next(c for c in cands if c is not pf)
             self._pf_stream, self._wg_stream = pf, wg
-            self.side_stream_probe = {"overlap_main": len(ok), "of": len(cands), "wg_overlaps_pf": bool(rest)}
+            self._serial = not ok
+            if self._serial:
+                self._z_late = False
+            self.side_stream_probe = {"overlap_main": len(ok), "of": len(cands), "wg_overlaps_pf": bool(rest),
+                                      "max_hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"),
+                                      "fallback": ("no candidate stream runs beside the main one: frozen-stage prefetch and flag-released side work are OFF, "
+                                                   "side streams are ordered by events only") if self._serial else None}
+            if want_ex:
+                # the exchange stream: beside the main chain (S1-S3) AND beside the weight gradients (a segment's bucket ships while the next
+                # segment's data and weight gradients run); beside the prefetch stream if the queues allow (its work sits under the solve, before the
+                # first bucket leaves).  Best candidate by (overlaps wg, overlaps pf) among those that overlap main.
+                best, score = None, (-1, -1)
+                for c in ok:
+                    if c is pf or c is wg:
+                        continue
+                    sc = (int(self._concurrent(wg, c)), int(self._concurrent(pf, c)))
+                    if sc > score:
+                        best, score = c, sc
+                    if sc == (1, 1):
+                        break
+                if best is None:            # nothing runs beside the main stream: keep a stream of its own, ordered by events (correct, serial)
+                    best = self.exchange.stream or next(c for c in cands if c is not pf and c is not wg)
+                    score = (int(self._concurrent(wg, best)), int(self._concurrent(pf, best)))
+                verdict = {"overlaps_main": bool(ok) and best in ok, "overlaps_wgrad": bool(score[0]), "overlaps_prefetch": bool(score[1])}
+                self.exchange.set_stream(best, verdict)
+                self.side_stream_probe["exchange"] = verdict
             self._pf_pool = torch.cuda.graph_pool_handle()      # NOT the steps' pool: the frozen-stage graph runs beside a step's backward
             # [solve-is-next counter, consumed | backbone-forward-done counter, consumed]   (cdetr_flag_signal / cdetr_flag_wait)
             self._sig = torch.zeros(4, dtype=torch.int32, device=self.device)
@@ -786,94 +873,86 @@ class Trainer:
         weight-gradient stream, each released by the main piece that produced its operands and running beside the pieces that follow
         (layer2's stay on the main stream: nothing is left to run beside them); O waits for them."""
         from . import ops
+        try:
+            with ops.scope(BRANCH_BESIDE=0, WGRAD_EVERY=0):      # no fork inside a capture: every graph is one chain
+                return self._capture_chain_pieces(st, world, warmup)
+        finally:
+            ops.MIRROR = None                                    # (armed by _forward; a failed capture must not leave it armed)
+            self._trunk_pending = None
+
+    def _capture_chain_pieces(self, st, world, warmup):
+        from . import _ffi, ops
         s, mode = self._capture_warmup(st, world, warmup)
         pf, wg = self._side_streams()
         G = torch.cuda.CUDAGraph
-        keep_beside, keep_every = ops.BRANCH_BESIDE, ops.WGRAD_EVERY
-        ops.BRANCH_BESIDE, ops.WGRAD_EVERY = 0, 0          # no fork inside a capture: every graph is one chain
-        e = {}
-        try:
-            e["F"] = G()
-            from . import _ffi
-            sig2 = self._sig.data_ptr() + 8                  # "the backbone's forward is done": releases Z under the encoder / decoder
-            ops.AFTER_BACKBONE = (lambda: _ffi.check(_ffi.lib().cdetr_flag_signal(sig2, _ffi.stream_ptr()), "cdetr_flag_signal")) if self._z_late else None
-            try:
-                with torch.cuda.graph(e["F"], stream=s, **mode):
-                    outputs = self._forward(st["images"], st["mask"], st["rects"])
-                    if hasattr(self.criterion, "pre_match"):    # the cost matrices close the forward piece: the next piece STARTS with the solve
-                        self.criterion.pre_match(outputs, st["targets"])
-            finally:
-                ops.AFTER_BACKBONE = None
-            e["Z"] = G()
-            with torch.cuda.graph(e["Z"], stream=pf, **mode):
-                self._zero_and_mirror()
-            # every parameter gradient above the backbone (heads, decoder, encoder, projection) is collected instead of submitted inside B:
-            # they become W0 on the weight-gradient stream, beside the backbone's data-gradient chain
-            held = []                                       # operands of the side-stream weight gradients: alive until every main piece that may
-            outer = ops.wgrad_queue()                       # run beside them has been captured (its tensors must not take their memory)
-            outer.__enter__()
-            ops.WG_DEFER_NESTED = True
-            try:
-                e["B"] = G()                                # solve + criterion + the backward down to the backbone
-                with torch.cuda.graph(e["B"], stream=s, **mode):
-                    from . import _ffi                      # "the solve is next": releases the prefetch stream (cdetr_flag_wait)
-                    _ffi.check(_ffi.lib().cdetr_flag_signal(self._sig.data_ptr(), _ffi.stream_ptr()), "cdetr_flag_signal")
-                    loss_dict, losses = self._criterion_forward(outputs, st["targets"], st["num_boxes"])
-                    self._backward(losses, defer_trunk=True)
-                e["W0"] = None
-                if ops._WG_QUEUE:
-                    held.append([x[2] for x in ops._WG_QUEUE])
-                    e["W0"] = G()
+        e = {"F": G()}
+        sig2 = self._sig.data_ptr() + 8                  # "the backbone's forward is done": releases Z under the encoder / decoder
+        after = (lambda: _ffi.check(_ffi.lib().cdetr_flag_signal(sig2, _ffi.stream_ptr()), "cdetr_flag_signal")) if self._z_late else None
+        with ops.scope(AFTER_BACKBONE=after):
+            with torch.cuda.graph(e["F"], stream=s, **mode):
+                outputs = self._forward(st["images"], st["mask"], st["rects"])
+                if hasattr(self.criterion, "pre_match"):    # the cost matrices close the forward piece: the next piece STARTS with the solve
+                    self.criterion.pre_match(outputs, st["targets"])
+        e["Z"] = G()
+        with torch.cuda.graph(e["Z"], stream=pf, **mode):
+            self._zero_and_mirror()
+        # every parameter gradient above the backbone (heads, decoder, encoder, projection) is collected instead of submitted inside B:
+        # they become W0 on the weight-gradient stream, beside the backbone's data-gradient chain
+        held = []                                       # operands of the side-stream weight gradients: alive until every main piece that may
+        #                                                 run beside them has been captured (its tensors must not take their memory)
+        with ops.wgrad_queue(), ops.scope(WG_DEFER_NESTED=True):
+            e["B"] = G()                                # solve + criterion + the backward down to the backbone
+            with torch.cuda.graph(e["B"], stream=s, **mode):
+                # "the solve is next": releases the prefetch stream (cdetr_flag_wait)
+                _ffi.check(_ffi.lib().cdetr_flag_signal(self._sig.data_ptr(), _ffi.stream_ptr()), "cdetr_flag_signal")
+                loss_dict, losses = self._criterion_forward(outputs, st["targets"], st["num_boxes"])
+                self._backward(losses, defer_trunk=True)
+            e["W0"] = None
+            if ops._WG_QUEUE:
+                held.append([x[2] for x in ops._WG_QUEUE])
+                e["W0"] = G()
+                with ops.scope(WG_DEFER_NESTED=False):      # (this flush SUBMITS: the outer queue closes empty)
                     with torch.cuda.graph(e["W0"], stream=wg, **mode):
                         ops.wgrad_flush()
-            finally:
-                ops.WG_DEFER_NESTED = False
-                outer.__exit__(None, None, None)
-            out = {k: v.detach() for k, v in loss_dict.items()}
-            out["loss"] = losses.detach()
-            e["S"], e["W"] = [], []
-            # main-stream pieces of the backbone's backward: layer4 | layer3 | layer2, one per gradient bucket (world_size > 1: the all-reduces
-            # are issued at the boundaries).  Merging the first two ([layer4 + layer3] | [layer2], CDETR_S_PIECES=2: one boundary fewer) is
-            # SLOWER by 0.10 ms in three same-lease pairs (profiles/r4_ab_launches.txt): layer4's weight gradients then start a piece later.
-            pieces = ((1, 2), (3,)) if (world == 1 and os.environ.get("CDETR_S_PIECES") == "2") else ((1,), (2,), (3,))
-            e["pieces"] = pieces
-            for segs in pieces:
-                q = ops.wgrad_queue()
-                q.__enter__()
-                try:
-                    g = G()
-                    with torch.cuda.graph(g, stream=s, **mode):
-                        for seg in segs:
-                            if self._trunk_pending is not None:
-                                self._trunk_pending.run(seg)
-                        if segs[-1] == 3 and ops._WG_QUEUE and self._tail_inline > 0:
-                            # the LAST segment's weight gradients have nothing left to run beside: the main stream would idle while the
-                            # weight-gradient stream works off its backlog -- the problems whose operands came last stay on the main stream
-                            q_all = list(ops._WG_QUEUE)
-                            k = int(round(len(q_all) * (1.0 - self._tail_inline)))
-                            ops._WG_QUEUE[:] = q_all[k:]
-                            ops.wgrad_flush()
-                            ops._WG_QUEUE[:] = q_all[:k]
-                    gw = None
-                    if ops._WG_QUEUE:
-                        held.append([x[2] for x in ops._WG_QUEUE])
-                        gw = G()
-                        with torch.cuda.graph(gw, stream=wg, **mode):
-                            ops.wgrad_flush()
-                finally:
-                    q.__exit__(None, None, None)
-                e["S"].append(g)
-                e["W"].append(gw)
-            ops.MIRROR = None
-            self._trunk_pending = None
-            e["O"] = G()
-            with torch.cuda.graph(e["O"], stream=s, **mode):
-                out["grad_norm"] = self._optimizer_step()
-            del held, outputs, losses, loss_dict
-        finally:
-            ops.BRANCH_BESIDE, ops.WGRAD_EVERY = keep_beside, keep_every
-            ops.MIRROR = None
+        out = {k: v.detach() for k, v in loss_dict.items()}
+        out["loss"] = losses.detach()
+        e["S"], e["W"] = [], []
+        # main-stream pieces of the backbone's backward: layer4 | layer3 | layer2, one per gradient bucket (world_size > 1: the all-reduces
+        # are issued at the boundaries).  Merging the first two ([layer4 + layer3] | [layer2], CDETR_S_PIECES=2: one boundary fewer) is
+        # SLOWER by 0.10 ms in three same-lease pairs (profiles/r4_ab_launches.txt): layer4's weight gradients then start a piece later.
+        pieces = ((1, 2), (3,)) if (world == 1 and os.environ.get("CDETR_S_PIECES") == "2") else ((1,), (2,), (3,))
+        e["pieces"] = pieces
+        for segs in pieces:
+            with ops.wgrad_queue():
+                g = G()
+                with torch.cuda.graph(g, stream=s, **mode):
+                    for seg in segs:
+                        if self._trunk_pending is not None:
+                            self._trunk_pending.run(seg)
+                    if segs[-1] == 3 and ops._WG_QUEUE and self._tail_inline > 0:
+                        # the LAST segment's weight gradients have nothing left to run beside: the main stream would idle while the
+                        # weight-gradient stream works off its backlog -- the problems whose operands came last stay on the main stream
+                        q_all = list(ops._WG_QUEUE)
+                        k = int(round(len(q_all) * (1.0 - self._tail_inline)))
+                        ops._WG_QUEUE[:] = q_all[k:]
+                        ops.wgrad_flush()
+                        ops._WG_QUEUE[:] = q_all[:k]
+                gw = None
+                if ops._WG_QUEUE:
+                    held.append([x[2] for x in ops._WG_QUEUE])
+                    gw = G()
+                    with torch.cuda.graph(gw, stream=wg, **mode):
+                        ops.wgrad_flush()
+            e["S"].append(g)
+            e["W"].append(gw)
+        ops.MIRROR = None
+        self._trunk_pending = None
+        e["O"] = G()
+        with torch.cuda.graph(e["O"], stream=s, **mode):
+            out["grad_norm"] = self._optimizer_step()
+        del held, outputs, losses, loss_dict
         e["out"] = out
+        e["z_late"] = bool(self._z_late)               # (F carries the signal kernel: Z's flag wait belongs to this entry, not to the trainer's current setting)
         if world > 1 and self.exchange.graphs is None and self._captured_allreduce:
             self.exchange.capture_buckets()
         return e
@@ -934,19 +1013,27 @@ class Trainer:
         """token: identity of the batch now in the entry's static buffers (None: unknown -> the frozen stage runs in line).
         next_samples: the batch the caller will hand to the NEXT step (the same object), or None."""
         e["replays"] += 1
-        if e["fs"] is not None:
-            self._frozen_ready(e, token)
         announce = None
         if e["fs"] is not None and next_samples is not None:
             tok = self._token(next_samples)
             if tok is not None:
                 announce = (next_samples.tensors if hasattr(next_samples, "tensors") else next_samples, tok)
+                # a shape announced for the first time: its frozen-stage graph is captured HERE, before anything of this step is launched
+                # (the capture synchronises the device and runs an eager frozen stage -- never between two pieces of a step)
+                self._frozen_for(announce[0].shape)
+        if e["fs"] is not None:
+            self._frozen_ready(e, token)
         return self._run_entry(e, announce)
 
     def _run_entry(self, e, announce):
         """announce = (image tensor of the next batch, its token) or None."""
         from . import _ffi
-        dp = get_world_size() > 1
+        dp = self.exchange.active()
+        inj = self._inject
+
+        def idle(where):                               # (tests: stretch one stream at a named point -- the flags / events must still order the step)
+            if inj.get(where):
+                _ffi.check(_ffi.lib().cdetr_delay(int(inj[where]), _ffi.stream_ptr()), "cdetr_delay")
         if e["layout"] != "chain":
             e["g_f"].replay()
             if e["g_p"] is not None:
@@ -969,8 +1056,9 @@ class Trainer:
         ev0.record(main)
         pf.wait_event(ev0)
         with torch.cuda.stream(pf):
-            if self._z_late:                           # (zero-fill + weight images are floods: beside the latency-bound encoder / decoder, not the backbone)
-                _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr() + 8, self._sig.data_ptr() + 12, 4000, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
+            idle("before_Z")
+            if e.get("z_late"):                        # (zero-fill + weight images are floods: beside the latency-bound encoder / decoder, not the backbone)
+                _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr() + 8, self._sig.data_ptr() + 12, self._z_timeout_us, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
             e["Z"].replay()
             evz = torch.cuda.Event()
             evz.record(pf)
@@ -986,12 +1074,14 @@ class Trainer:
                            "cdetr_flag_wait")
             self._prefetch(announce[0], announce[1], announce[0], ordered=True)
         main.wait_event(evz)
+        idle("before_B")
         e["B"].replay()
         if e["W0"] is not None:                        # the parameter gradients above the backbone: beside the backbone's data-gradient chain
             evb = torch.cuda.Event()
             evb.record(main)
             wg.wait_event(evb)
             with torch.cuda.stream(wg):
+                idle("before_W0")
                 e["W0"].replay()
         if dp:
             self.exchange.segment_done(0, also=wg if e["W0"] is not None else None)      # first bucket: everything above the backbone
@@ -1059,22 +1149,21 @@ class Trainer:
         if e is None:
             while len(self._cache) >= max(self._cache_size, 1):
                 torch.cuda.synchronize()           # nothing of the entry being dropped is still running
-                self._cache.pop(next(iter(self._cache)))
-            fs0 = self._frozen.get(tuple(images.shape))
-            pre = fs0 is not None and fs0["token"] == token
+                self._drop_lru()
             while True:
                 try:
                     e = self._capture_entry(images, mask, rects, targets)
                     break
                 except torch.OutOfMemoryError:     # a new shape does not fit beside the cached ones: drop the least recently used, retry
-                    if not self._cache:
+                    if not self._cache and not self._frozen:
                         raise
                     torch.cuda.synchronize()
-                    self._cache.pop(next(iter(self._cache)))
+                    if self._cache:
+                        self._drop_lru()
+                    self._trim_frozen(limit=0)     # frozen-stage buffers nobody's captured step reads (announced batches that never came)
                     torch.cuda.empty_cache()
             self.cache_stats["captures"] += 1
             token = None                           # (the capture recomputed the frozen stage itself; whatever was prefetched is spent)
-            del pre
         else:
             self._load_entry(e, images, mask, rects, targets)
         self._cache[key] = e                       # most recently used last
@@ -1241,12 +1330,8 @@ class InferenceEngine:
     @torch.no_grad()
     def _run(self, images, mask, rects):
         from . import ops
-        prev = ops.MIRROR
-        ops.MIRROR = self.mirror
-        try:
+        with ops.scope(MIRROR=self.mirror):
             outputs, ref = self.model(NestedTensor(images, mask), rects=rects)
-        finally:
-            ops.MIRROR = prev
         counts, keep, prob = count_from_logits(outputs["pred_logits"], self.threshold)
         return counts, keep, outputs, ref, prob
 
@@ -1267,9 +1352,7 @@ class InferenceEngine:
         ps = self._pf_stream
         fs = {"images": torch.zeros(shape, device=self.device), "x": torch.empty((B, h, w, 256), device=self.device),
               "xs": torch.empty((B, h, w, 256), device=self.device), "token": None, "keep": None}
-        prev, ops.MIRROR = ops.MIRROR, self.mirror
-        beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0
-        try:
+        with ops.scope(MIRROR=self.mirror, BRANCH_BESIDE=0):
             ps.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(ps):
                 body.frozen_stage(fs["images"], False, out_to=(fs["xs"], None))
@@ -1278,8 +1361,6 @@ class InferenceEngine:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, pool=self._pf_pool, stream=ps):
                 body.frozen_stage(fs["images"], False, out_to=(fs["xs"], None))
-        finally:
-            ops.MIRROR, ops.BRANCH_BESIDE = prev, beside
         fs["graph"] = g
         self._frozen[shape] = fs
         return fs
@@ -1304,7 +1385,7 @@ class InferenceEngine:
             st = (images.clone(), mask.clone(), rects.clone())
             if self._stream is None:
                 self._stream = torch.cuda.Stream(device=self.device)
-            beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0      # a LINEAR graph: hipGraphLaunch enqueues it in ~0.1 ms of host time (2.7 ms with forks)
+            after = None
             try:
                 if fs is not None:                     # the captured forward reads the frozen stage's output from a fixed buffer
                     fs["images"].copy_(st[0])
@@ -1313,20 +1394,20 @@ class InferenceEngine:
                     fs["token"] = None
                     body.frozen_input = (fs["x"], None)
                     sig = self._sig
-                    ops.AFTER_BACKBONE = lambda: _ffi.check(_ffi.lib().cdetr_flag_signal(sig.data_ptr(), _ffi.stream_ptr()), "cdetr_flag_signal")
-                self._run(*st)                         # lazily cached tables of this shape exist before the capture
-                self._stream.wait_stream(torch.cuda.current_stream())
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                if self._pool is None:
-                    self._pool = torch.cuda.graph_pool_handle()
-                with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
-                    out = self._run(*st)
+                    after = lambda: _ffi.check(_ffi.lib().cdetr_flag_signal(sig.data_ptr(), _ffi.stream_ptr()), "cdetr_flag_signal")      # noqa: E731
+                # a LINEAR graph (no in-graph forks): hipGraphLaunch enqueues it in ~0.1 ms of host time (2.7 ms with forks)
+                with ops.scope(BRANCH_BESIDE=0, AFTER_BACKBONE=after):
+                    self._run(*st)                     # lazily cached tables of this shape exist before the capture
+                    self._stream.wait_stream(torch.cuda.current_stream())
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    if self._pool is None:
+                        self._pool = torch.cuda.graph_pool_handle()
+                    with torch.cuda.graph(g, pool=self._pool, stream=self._stream):
+                        out = self._run(*st)
             finally:
-                ops.BRANCH_BESIDE = beside
                 if fs is not None:
                     body.frozen_input = None
-                    ops.AFTER_BACKBONE = None
             e = (g, st, out)
             self.stats["captures"] += 1
             token = None

@@ -58,6 +58,29 @@ class arithmetic:
         return False
 
 
+class scope:
+    """`with ops.scope(MIRROR=m, BRANCH_BESIDE=0, WGRAD_EVERY=0, AFTER_BACKBONE=fn, WG_DEFER_NESTED=True):` -- the launch-shaping switches an
+    ENGINE owns while it captures or runs a piece of a step (which weight images the GEMMs read, whether shortcut convolutions / weight
+    gradients fork to side streams, the release signal behind the backbone), set for the block and restored on exit whatever happens inside.
+    The same contract as `arithmetic`: engines never leave a module-level switch changed behind their back; the module values stay the
+    defaults of code that runs outside any engine.  Scopes nest."""
+    _KEYS = ("MIRROR", "BRANCH_BESIDE", "WGRAD_EVERY", "AFTER_BACKBONE", "WG_DEFER_NESTED")
+
+    def __init__(self, **kw):
+        assert all(k in self._KEYS for k in kw), kw
+        self.want = kw
+
+    def __enter__(self):
+        g = globals()
+        self.saved = {k: g[k] for k in self.want}
+        g.update(self.want)
+        return self
+
+    def __exit__(self, *exc):
+        globals().update(self.saved)
+        return False
+
+
 class _Timed:
     def __init__(self, family, flops, tag=None, nbytes=0.0, issued=None):
         self.family, self.flops, self.tag, self.nbytes = family, flops, tag, nbytes     # nbytes: compulsory (algorithmic) HBM bytes of the launch

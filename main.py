@@ -16,6 +16,11 @@ import os
 import time
 from pathlib import Path
 
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    # data-parallel run: the step uses main + prefetch + weight-gradient + exchange streams and RCCL adds its own -- more than HIP's default
+    # four hardware queues (two streams of one queue never overlap).  Must be in the environment before the HIP runtime initialises.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 import counting_detr_amd

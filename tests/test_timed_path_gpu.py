@@ -1,0 +1,242 @@
+"""Parity of the TIMED code path at the timed size.
+
+bench.py times `Trainer.replay(pipelined=True)` on the "chain" layout: 13 linear HIP graphs on three probed streams, ordered by events
+and refined by device-side flags, with the next batch's frozen stage (stem + layer1) running beside the Hungarian solve.  The full-size
+goldens (tests/golden/g10_full.npz: outputs of the REAL reference, A2/engine.py:28-57 on A2/models/anchor_detr.py's model) were so far
+compared with the stream-ordered step only.  Here the captured chain itself is held to them -- losses, gradient norm and the parameters
+after clip + AdamW -- on BASELINE config 2 (B=2, 800x800, Q=300, T=(37,120): bench.py's batch) and on the shipped script's grid-576 shape,
+once with the frozen stage in line (first replay) and once prefetched (second replay), and again under stress: flag waits that give up at
+once, idle kernels injected in front of B / Z / W0 so that every cross-stream dependency is exercised with the "wrong" timing.  The flags
+only refine WHEN side work starts; the events carry the dependencies -- so every variant must produce the same step.
+
+Also here: the fail-safe of the side-stream probe (no concurrent stream -> no flag waits, no prefetch), the exchange stream's overlap with the
+backbone's backward (a dummy collective of idle kernels), and the staleness of frozen-stage graphs after checkpoint.invalidate_caches
+(ADVICE r4)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from fullsize import case_inputs
+from test_full_size_gpu import build, to_dev
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _reset(tr, p0):
+    tr.flat_p.copy_(p0)
+    tr.exp_avg.zero_()
+    tr.exp_avg_sq.zero_()
+    tr.opt_state.copy_(torch.tensor([0.0, 1.0, 0.0, 0.0], device=tr.opt_state.device))
+
+
+def _check_step(z, name, out, model):
+    np.testing.assert_allclose(float(out["grad_norm"]), z[f"{name}/grad_total_norm"], rtol=2e-3, err_msg="gradient norm")
+    np.testing.assert_allclose(float(out["loss"]), z[f"{name}/loss_total"], rtol=1e-3, err_msg="weighted total")
+    for k in ("loss_ce", "loss_bbox", "loss_giou", "loss_variance"):
+        np.testing.assert_allclose(float(out[k]), z[f"{name}/L_{k}"], rtol=1e-3, atol=1e-5, err_msg=k)
+    params = dict(model.named_parameters())
+    for n, s in zip([str(x) for x in z[f"{name}/param_names"]], z[f"{name}/param_sums_after_step"]):
+        p = params[n]
+        lr = 1e-5 if "backbone" in n else 1e-4          # a step moves an element by <= lr: the sum's CHANGE budget, not the sum itself
+        assert abs(p.detach().double().sum().item() - s) <= 0.02 * lr * p.numel() + 1e-4 * abs(s) + 1e-6, n
+
+
+@pytest.mark.parametrize("stress", [False, True], ids=["as-timed", "stress"])
+@pytest.mark.parametrize("name", ["cfg2", "shipped576"])
+def test_pipelined_chain_replay_matches_the_reference_step(golden, name, stress):
+    from counting_detr_amd import ops
+    from counting_detr_amd.engine import Trainer
+    old = ops.PRECISION
+    ops.PRECISION = 1                                    # the arithmetic bench.py times (split-bf16 forward, plain-bf16 backward)
+    try:
+        z = golden("g10_full.npz")
+        c = case_inputs(z, name)
+        model, crit, args = build(c)
+        imgs, rects, tg = to_dev(c)
+        tr = Trainer(model, crit, args, device=DEV)
+        p0 = tr.flat_p.clone()
+        tr.capture(imgs, rects, tg)
+        e = tr._entry
+        assert e["layout"] == "chain"
+        if stress:
+            tr._pf_timeout_us = 0                        # the frozen stage's flag wait gives up at once: it floods the chip BEFORE the solve
+            tr._z_timeout_us = 0                         # so does Z's (zero-fill + weight images under the backbone instead of the encoder)
+        outs = []
+        plans = [{}, {}] if not stress else [{"before_B": 700}, {"before_Z": 3000}, {"before_W0": 1500, "before_B": 50}, {}]
+        for inj in plans:
+            _reset(tr, p0)
+            tr._inject = inj
+            out = tr.replay(pipelined=True)
+            torch.cuda.synchronize()
+            out = {k: v.clone() for k, v in out.items()}
+            _check_step(z, name, out, model)
+            outs.append(out)
+        tr._inject = {}
+        if e["fs"] is not None:                          # (None: the probe found no concurrent stream -- in-line everywhere, nothing to hit)
+            assert tr.prefetch_stats["hits"] >= len(plans) - 1, tr.prefetch_stats
+        # in line vs prefetched vs stressed: the same step (the RCDA key / value gradients and the weight gradients accumulate with fp32
+        # atomics whose order changes from run to run: measured 2e-5 on the norm between two identical replays -- not bitwise)
+        for o in outs[1:]:
+            for k in ("loss", "loss_ce", "loss_bbox", "loss_giou", "loss_variance"):
+                assert float(o[k]) == float(outs[0][k]), (k, float(o[k]), float(outs[0][k]))      # the forward + criterion ARE bitwise
+            np.testing.assert_allclose(float(o["grad_norm"]), float(outs[0]["grad_norm"]), rtol=2e-4)
+        print(name, "stress" if stress else "as timed", {k: float(v) for k, v in outs[-1].items()}, getattr(tr, "side_stream_probe", None))
+    finally:
+        ops.PRECISION = old
+
+
+def _small(Q=100):
+    import counting_detr_amd
+    from counting_detr_amd.args import default_args
+    from counting_detr_amd.init import seeded_init_
+    args = default_args(device=DEV, num_query_position=Q)
+    model, crit, _ = counting_detr_amd.build_model(args)
+    seeded_init_(model)
+    return model.to(DEV).train(), crit.train(), args
+
+
+def _batch(B, H, W, Ts, seed):
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    rects = torch.tensor([[.10, .10, .20, .20], [.40, .40, .50, .55], [.70, .20, .80, .30]])[None].repeat(B, 1, 1).to(DEV)
+    tg = []
+    for b in range(B):
+        box = torch.cat([torch.rand(Ts[b], 2, generator=g) * 0.8 + 0.1, torch.rand(Ts[b], 2, generator=g) * 0.10 + 0.02], 1)
+        tg.append({"boxes": box.to(DEV), "labels": torch.zeros(Ts[b], dtype=torch.int64, device=DEV)})
+    return images, rects, tg
+
+
+def test_probe_failure_switches_flags_and_prefetch_off(monkeypatch):
+    """No stream runs beside the main one (every probe says "serial"): the trainer must not enqueue a flag wait in front of the graph
+    that carries its signal (a 4 ms stall per step) -- flags and the prefetch are off, the step is the same step."""
+    from counting_detr_amd.engine import Trainer
+    model, crit, args = _small()
+    ref_model = copy.deepcopy(model)
+    b0, b1 = _batch(2, 64, 96, (5, 9), 1), _batch(2, 64, 96, (3, 11), 2)
+    tr = Trainer(model, crit, args, device=DEV)
+    monkeypatch.setattr(tr, "_concurrent", lambda a, b: False)
+    o0 = {k: float(v) for k, v in tr.step(b0[0], b0[1], b0[2], next_samples=b1[0]).items()}
+    o1 = {k: float(v) for k, v in tr.step(b1[0], b1[1], b1[2]).items()}
+    assert tr._serial and not tr._z_late and tr.side_stream_probe["fallback"]
+    e = next(iter(tr._cache.values()))
+    assert e["fs"] is None and not e["z_late"] and tr.prefetch_stats == {"hits": 0, "inline": 0}
+    # timing: a step of this size takes ~3 ms; a flag wait in front of its own signal would add 4 ms to every step
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    ev[0].record()
+    for _ in range(5):
+        tr.step(b1[0], b1[1], b1[2])
+    ev[1].record()
+    torch.cuda.synchronize()
+    per_step = ev[0].elapsed_time(ev[1]) / 5
+    # reference: the stream-ordered step on a copy of the same weights
+    crit2 = copy.deepcopy(crit)
+    tr2 = Trainer(ref_model, crit2, args, device=DEV)
+    r0 = {k: float(v) for k, v in tr2.train_step(b0[0], b0[1], b0[2]).items()}
+    r1 = {k: float(v) for k, v in tr2.train_step(b1[0], b1[1], b1[2]).items()}
+    for o, r in ((o0, r0), (o1, r1)):
+        for k in ("loss", "grad_norm"):
+            np.testing.assert_allclose(o[k], r[k], rtol=2e-4, err_msg=k)
+    tr2.capture(b1[0], b1[1], b1[2])
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for _ in range(2):
+        tr2.replay()
+    ev[0].record()
+    for _ in range(5):
+        tr2.replay()
+    ev[1].record()
+    torch.cuda.synchronize()
+    normal = ev[0].elapsed_time(ev[1]) / 5
+    assert per_step < normal + 2.0, f"serial fallback {per_step:.2f} ms per step vs {normal:.2f} with probed streams: a flag wait is stalling the step"
+
+
+def test_exchange_stream_runs_beside_the_backbone_backward():
+    """The gradient buckets' all-reduces (A1/main.py:206-208: DDP's overlap of communication with the backward) are issued on a PROBED
+    stream between the pieces of the chain.  With a dummy collective -- an idle kernel per bucket on the exchange stream, same ordering as
+    the real one -- a step must cost (almost) nothing more than without: the buckets run beside S1-S3 / W1-W2, only the last one is exposed."""
+    import os
+    from counting_detr_amd.engine import Trainer
+    model, crit, args = _small()
+    b = _batch(2, 128, 160, (5, 9), 1)
+    os.environ["CDETR_PROBE_EXCHANGE"] = "1"
+    try:
+        tr = Trainer(model, crit, args, device=DEV)
+        tr.capture(b[0], b[1], b[2])
+    finally:
+        del os.environ["CDETR_PROBE_EXCHANGE"]
+    v = tr.side_stream_probe.get("exchange")
+    assert v is not None and tr.exchange.stream is not None, tr.side_stream_probe
+    if tr._serial or not v["overlaps_main"]:
+        pytest.skip(f"no concurrent hardware queue on this box: {tr.side_stream_probe}")
+
+    def time_steps(n=10):
+        for _ in range(3):
+            tr.replay(pipelined=True)
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        ev[0].record()
+        for _ in range(n):
+            tr.replay(pipelined=True)
+        ev[1].record()
+        torch.cuda.synchronize()
+        return ev[0].elapsed_time(ev[1]) / n
+    t0 = time_steps()
+    us = 300
+    tr.exchange.dummy_us = us
+    t1 = time_steps()
+    tr.exchange.dummy_us = 0
+    nb = sum(1 for i in range(4) if tr.seg_bounds[i + 1] > tr.seg_bounds[i])
+    # serial execution would add nb * us; overlapped, at most the last bucket (+ launch slack) is exposed
+    assert t1 - t0 < (nb - 2) * us * 1e-3, f"{nb} dummy buckets of {us} us cost {t1 - t0:.3f} ms per step: the exchange stream does not overlap ({tr.side_stream_probe})"
+    print(f"step {t0:.3f} ms -> {t1:.3f} ms with {nb} x {us} us on the exchange stream; probe {tr.side_stream_probe}")
+
+
+def test_invalidate_caches_drops_the_frozen_stage_graphs():
+    """the frozen-stage graphs hold the addresses of the FrozenBN folds / stem images that
+    checkpoint.invalidate_caches frees; after an invalidation the trainer must re-capture them (Trainer.clear_graph_cache)."""
+    from counting_detr_amd.checkpoint import invalidate_caches
+    from counting_detr_amd.engine import Trainer
+    model, crit, args = _small()
+    b0, b1 = _batch(2, 64, 96, (5, 9), 1), _batch(2, 64, 96, (3, 11), 2)
+    tr = Trainer(model, crit, args, device=DEV)
+    tr.step(b0[0], b0[1], b0[2], next_samples=b1[0])
+    torch.cuda.synchronize()
+    assert tr._frozen or tr._serial
+    with torch.no_grad():                                # what a checkpoint load does to the frozen stage: new statistics in layer1 + stem
+        bn = model.backbone.body.layer1[0].bn1
+        bn.weight.mul_(1.7)
+        bn.running_mean.add_(0.3)
+        model.backbone.body.bn1.bias.add_(0.2)
+    invalidate_caches(model)
+    assert not tr._frozen and not tr._cache and tr._entry is None
+    junk = [torch.full((1 << 20,), 7.0, device=DEV) for _ in range(8)]        # the freed tables' memory is taken by something else
+    ref_model, crit2 = copy.deepcopy(model), copy.deepcopy(crit)
+    got = {k: float(v) for k, v in tr.step(b1[0], b1[1], b1[2]).items()}
+    tr2 = Trainer(ref_model, crit2, args, device=DEV)
+    want = {k: float(v) for k, v in tr2.train_step(b1[0], b1[1], b1[2]).items()}
+    del junk
+    for k in ("loss", "loss_ce", "loss_bbox", "grad_norm"):
+        np.testing.assert_allclose(got[k], want[k], rtol=2e-4, err_msg=k)
+
+
+def test_announced_shapes_that_never_arrive_do_not_pile_up():
+    """a batch that was announced and never came keeps its frozen-stage buffers only while it is among the newest two."""
+    from counting_detr_amd.engine import Trainer
+    model, crit, args = _small()
+    tr = Trainer(model, crit, args, device=DEV)
+    b0 = _batch(2, 64, 96, (5, 9), 1)
+    if not tr._prefetch_ok():
+        pytest.skip("no concurrent side stream")
+    for i, (H, W) in enumerate([(64, 128), (96, 96), (96, 128), (64, 160)]):
+        ghost = torch.randn(2, 3, H, W, device=DEV)
+        tr.step(b0[0], b0[1], b0[2], next_samples=ghost)
+    torch.cuda.synchronize()
+    shapes = set(tr._frozen)
+    assert (2, 3, 64, 96) in shapes and len(shapes) <= 3, shapes
+    while tr._cache:                                     # the last captured step of a shape takes its frozen-stage graph along
+        torch.cuda.synchronize()
+        tr._drop_lru()
+    assert (2, 3, 64, 96) not in tr._frozen
