@@ -534,6 +534,246 @@ __global__ __launch_bounds__(64) void lsap_wave_kernel(const float* __restrict__
     if (lane == 0) status[b] = 0;
 }
 
+// ------------------------------------------------------------------------------------------------ multi-wave solver (crowded images)
+// More than 1024 columns (FSC-147 holds up to 3731 objects per image, A2/data/fsc147.py:80-84; the reference hands these matrices to scipy,
+// A2/models/matcher.py:243-247): the single wave's register budget is exhausted and the cost matrix (Q x T fp32: 2.5-4.5 MB) no longer fits
+// the LDS.  lsap_kernel<256> (indirect `remaining` reads, f64 state in LDS, four barriers and a one-thread section per scan step) took
+// 5.2 / 6.9 ms at T = (37, 2100) / (3000, 3731) -- as long as the rest of the step.  This kernel is lsap_wave_kernel spread over the 16 waves of
+// ONE workgroup: thread t owns columns t, t + 1024, ... (CPL per thread) with their dual, shortest-path value, predecessor, row4col mirror
+// and tie key in REGISTERS; a scan step is CPL fused updates per thread, the DPP arg-min inside each wave, ONE barrier, and a 16-slot
+// LDS arg-min that every thread evaluates for itself (double-buffered slots: no second barrier).  Same arithmetic (f64 expression order),
+// same tie key (scipy's sequential rule folded into one integer) -> the same assignment, bit for bit.  The cost row of the step comes
+// from L2 / HBM: that round trip is what a step costs now.
+struct WgSlot { double val; unsigned key; int jstar; int rnext; int pad_; };
+
+template <int CPL>
+__global__ __launch_bounds__(1024) void lsap_wg_kernel(const float* __restrict__ cost_all, const int64_t* __restrict__ cost_off,
+                                                       const int* __restrict__ tgt_off, int Q, int Mmax, int64_t* __restrict__ idx_i,
+                                                       int64_t* __restrict__ idx_j, int* __restrict__ status) {
+    constexpr int NT = 1024, NW = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    __builtin_amdgcn_s_setprio(3);
+    const int b = blockIdx.x;
+    const int T = tgt_off[b + 1] - tgt_off[b];
+    const bool transpose = T < Q;
+    const int nr = transpose ? T : Q;
+    const int nc = transpose ? Q : T;
+    const float* __restrict__ cost = cost_all + cost_off[b];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int64_t* oi = idx_i + (long)b * Mmax;
+    int64_t* oj = idx_j + (long)b * Mmax;
+    for (int i = tid; i < Mmax; i += NT) { oi[i] = 0; oj[i] = 0; }
+    if (nr == 0) { if (tid == 0) status[b] = 0; return; }
+
+    // LDS carve: slots[2][16] | u[nr] f64 | col4row[nr] | row4col[nc] | remaining[nc] | path[nc]
+    WgSlot* slots = reinterpret_cast<WgSlot*>(lds);
+    double* u = reinterpret_cast<double*>(slots + 2 * NW);
+    int* col4row = reinterpret_cast<int*>(u + nr);
+    int* row4col = col4row + nr;
+    int* remaining = row4col + nc;
+    int* pathl = remaining + nc;
+    __shared__ int s_bad;
+    if (tid == 0) s_bad = 0;
+    for (int i = tid; i < nr; i += NT) { u[i] = 0.0; col4row[i] = -1; }
+    for (int j = tid; j < nc; j += NT) row4col[j] = -1;
+    __syncthreads();
+    {       // validity scan (scipy raises ValueError on NaN / -inf entries); 8 loads in flight per thread
+        int bad = 0;
+        const long ntot = (long)nr * nc;
+        for (long k0 = 0; k0 < ntot; k0 += (long)NT * 8) {
+            float t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = cost[min(k0 + tid + (long)NT * q, ntot - 1)];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bad |= (t[q] != t[q] || t[q] == -INFINITY) ? 1 : 0;
+        }
+        if (bad) atomicOr(&s_bad, 1);
+    }
+    __syncthreads();
+    if (s_bad) { if (tid == 0) status[b] = 2; return; }
+
+    double v[CPL], spc[CPL];
+    int path[CPL], r4c[CPL];
+    unsigned key[CPL];
+    unsigned valid = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; ++c) { v[c] = 0.0; spc[c] = INFINITY; path[c] = -1; r4c[c] = -1; key[c] = 0xffffffffu; if (tid + NT * c < nc) valid |= 1u << c; }
+    int parity = 0;
+
+    // workgroup-wide lexicographic arg-min of the per-thread candidates (bval, bkey; best_c = the owning column slot).  Returns the winner's
+    // value / key in (bval, bkey), its column in jstar and row4col[jstar] in rnext; `mine` = this thread owns the winning column.
+    auto wg_lexmin = [&](double& bval, unsigned& bkey, int best_c, int& jstar, int& rnext, bool& mine) __attribute__((always_inline)) {
+        const double my_val = bval;
+        const unsigned my_key = bkey;
+        wave_lexmin<true>(bval, bkey);
+        const bool wmine = (my_key == bkey) && (my_val == bval) && (bkey != 0xffffffffu);
+        const unsigned long long bal = __ballot(wmine);
+        const int wl = bal ? __builtin_ctzll(bal) : 0;
+        int my_r = r4c[0];
+#pragma unroll
+        for (int c = 1; c < CPL; ++c) my_r = (best_c == c) ? r4c[c] : my_r;
+        const int wj = __builtin_amdgcn_readlane(tid + NT * best_c, wl);
+        const int wr = __builtin_amdgcn_readlane(my_r, wl);
+        WgSlot* sl = slots + parity * NW;
+        if (lane == 0) { sl[wv].val = bval; sl[wv].key = bkey; sl[wv].jstar = wj; sl[wv].rnext = wr; }
+        __syncthreads();
+        double gv = sl[0].val;
+        unsigned gk = sl[0].key;
+        int gj = sl[0].jstar, gr = sl[0].rnext;
+#pragma unroll
+        for (int w2 = 1; w2 < NW; ++w2) {
+            const double ov = sl[w2].val;
+            const unsigned ok = sl[w2].key;
+            const bool take = (ov < gv) | ((ov == gv) & (ok < gk));
+            gv = take ? ov : gv;
+            gk = take ? ok : gk;
+            gj = take ? sl[w2].jstar : gj;
+            gr = take ? sl[w2].rnext : gr;
+        }
+        parity ^= 1;
+        mine = wmine && (my_key == gk) && (my_val == gv);
+        bval = gv; bkey = gk; jstar = gj; rnext = gr;
+    };
+
+    for (int cur = 0; cur < nr; ++cur) {
+        // ---- fast path (as lsap_wave_kernel): the first scan step of the row already ends on an unassigned column -> the augmenting path
+        // is the single edge (cur, j*), u[cur] += min, no column dual moves, no search state is set up
+        {
+            const float* crow0 = cost + (long)cur * nc;
+            const double ui0 = u[cur];
+            double bval = INFINITY;
+            unsigned bkey = 0xffffffffu;
+            int best_c = 0;
+            float cv[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cv[c] = crow0[((valid >> c) & 1u) ? tid + NT * c : 0];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const bool a = (valid >> c) & 1u;
+                const double r = ((0.0 + (double)cv[c]) - ui0) - v[c];
+                const double s = (a & (r < INFINITY)) ? r : INFINITY;
+                const unsigned p0 = (unsigned)(nc - 1 - (tid + NT * c));
+                const unsigned k = (r4c[c] == -1) ? (0x7fffffffu - p0) : (0x80000000u + p0);
+                const bool better = a & ((s < bval) | ((s == bval) & (k < bkey)));
+                bval = better ? s : bval;
+                bkey = better ? k : bkey;
+                best_c = better ? c : best_c;
+            }
+            int jstar, rnext;
+            bool mine;
+            wg_lexmin(bval, bkey, best_c, jstar, rnext, mine);
+            if (bkey != 0xffffffffu && bval != INFINITY && (bkey & 0x80000000u) == 0u) {
+                if (tid == 0) {
+                    u[cur] = ui0 + bval;
+                    row4col[jstar] = cur;
+                    col4row[cur] = jstar;
+                }
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) r4c[c] = (mine && best_c == c) ? cur : r4c[c];
+                continue;
+            }
+        }
+        unsigned sc = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            spc[c] = INFINITY;
+            const unsigned p0 = (unsigned)(nc - 1 - (tid + NT * c));
+            key[c] = (r4c[c] == -1) ? (0x7fffffffu - p0) : (0x80000000u + p0);
+        }
+        for (int it = tid; it < nc; it += NT) remaining[it] = nc - 1 - it;      // (first read: behind the first step's barrier)
+        int i = cur, num_remaining = nc, sink = -1;
+        double min_val = 0.0;
+        while (true) {
+            const int last = num_remaining - 1;
+            const float* crow = cost + (long)i * nc;
+            const double ui = u[i];
+            double bval = INFINITY;
+            unsigned bkey = 0xffffffffu;
+            int best_c = 0;
+            const unsigned act = valid & ~sc;
+            float cv[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) cv[c] = crow[((valid >> c) & 1u) ? tid + NT * c : 0];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const bool a = (act >> c) & 1u;
+                const double r = ((min_val + (double)cv[c]) - ui) - v[c];
+                const bool upd = a & (r < spc[c]);
+                spc[c] = upd ? r : spc[c];
+                path[c] = upd ? i : path[c];
+                const bool better = a & ((spc[c] < bval) | ((spc[c] == bval) & (key[c] < bkey)));
+                bval = better ? spc[c] : bval;
+                bkey = better ? key[c] : bkey;
+                best_c = better ? c : best_c;
+            }
+            int jstar, inext;
+            bool mine;
+            wg_lexmin(bval, bkey, best_c, jstar, inext, mine);
+            if (bkey == 0xffffffffu || bval == INFINITY) { sink = -2; break; }
+            min_val = bval;
+            const bool j_unassigned = (bkey & 0x80000000u) == 0u;
+            const int best_it = j_unassigned ? (int)(0x7fffffffu - bkey) : (int)(bkey - 0x80000000u);
+            sc |= mine ? (1u << best_c) : 0u;
+            // swap-removal from `remaining` (position best_it): the column that sat last moves there.  Every write of earlier steps is ordered
+            // before this read by the barrier inside wg_lexmin; this step's write (thread 0) hits position `last` only with the value it holds
+            const int jlast = remaining[last];
+            if (tid == 0) remaining[best_it] = jlast;
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) {
+                const unsigned nk = (r4c[c] == -1) ? (0x7fffffffu - (unsigned)best_it) : (0x80000000u + (unsigned)best_it);
+                key[c] = (tid + NT * c == jlast) ? nk : key[c];
+            }
+            num_remaining = last;
+            if (j_unassigned) { sink = jstar; break; }
+            i = inext;
+        }
+        if (sink == -2) { if (tid == 0) status[b] = 1; return; }
+        // ---- dual update (visited rows other than cur = row4col[j] of the visited non-sink columns: distinct rows, no conflicts)
+        if (tid == 0) u[cur] += min_val;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int j = tid + NT * c;
+            if ((sc >> c) & 1u) {
+                const double delta = min_val - spc[c];
+                v[c] -= delta;
+                if (j != sink) u[r4c[c]] += delta;
+            }
+            if (j < nc) pathl[j] = path[c];
+        }
+        __syncthreads();
+        if (tid == 0) {      // augment (short sequential walk)
+            int j = sink;
+            while (true) {
+                const int ii = pathl[j];
+                row4col[j] = ii;
+                const int t = col4row[ii];
+                col4row[ii] = j;
+                j = t;
+                if (ii == cur) break;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPL; ++c)
+            if ((valid >> c) & 1u) r4c[c] = row4col[tid + NT * c];
+    }
+    __syncthreads();
+    if (!transpose) {
+        for (int i = tid; i < nr; i += NT) { oi[i] = i; oj[i] = col4row[i]; }
+    } else {
+        for (int j = tid; j < nc; j += NT) remaining[j] = (row4col[j] != -1) ? 1 : 0;
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int j = 0; j < nc; ++j) { const int f = remaining[j]; remaining[j] = run; run += f; }
+        }
+        __syncthreads();
+        for (int j = tid; j < nc; j += NT)
+            if (row4col[j] != -1) { oi[remaining[j]] = j; oj[remaining[j]] = row4col[j]; }
+    }
+    if (tid == 0) status[b] = 0;
+}
+
 inline size_t lds_bytes(int nc_cap) { return (size_t)nc_cap * (3 * 8 + 4 * 4 + 2) + 16; }
 inline int round_cap(int nc) { return (nc + 15) & ~15; }
 
@@ -587,6 +827,11 @@ extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int3
     if (nc_max <= 1024) {
         if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         hipLaunchKernelGGL(lsap_kernel<64>, dim3(B), dim3(64), bytes, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status, cap);
+    } else if (nc_max <= 4096 && cdetr_tune_env("CDETR_LSAP_GENERIC") == nullptr) {
+        // crowded images: the register-resident solver over the 16 waves of one workgroup (rows <= Mmax, columns <= nc_max)
+        const size_t wb = 2 * 16 * sizeof(WgSlot) + (size_t)Mmax * 12 + (size_t)nc_max * 12 + 64;
+        if (nc_max <= 2048) hipLaunchKernelGGL(lsap_wg_kernel<2>, dim3(B), dim3(1024), wb, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status);
+        else hipLaunchKernelGGL(lsap_wg_kernel<4>, dim3(B), dim3(1024), wb, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status);
     } else {
         if (bytes > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lsap_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         hipLaunchKernelGGL(lsap_kernel<256>, dim3(B), dim3(256), bytes, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status, cap);

@@ -114,7 +114,7 @@ def test_probe_failure_switches_flags_and_prefetch_off(monkeypatch):
     that carries its signal (a 4 ms stall per step) -- flags and the prefetch are off, the step is the same step."""
     from counting_detr_amd.engine import Trainer
     model, crit, args = _small()
-    ref_model = copy.deepcopy(model)
+    ref_model, crit2 = copy.deepcopy(model), copy.deepcopy(crit)
     b0, b1 = _batch(2, 64, 96, (5, 9), 1), _batch(2, 64, 96, (3, 11), 2)
     tr = Trainer(model, crit, args, device=DEV)
     monkeypatch.setattr(tr, "_concurrent", lambda a, b: False)
@@ -133,7 +133,6 @@ def test_probe_failure_switches_flags_and_prefetch_off(monkeypatch):
     torch.cuda.synchronize()
     per_step = ev[0].elapsed_time(ev[1]) / 5
     # reference: the stream-ordered step on a copy of the same weights
-    crit2 = copy.deepcopy(crit)
     tr2 = Trainer(ref_model, crit2, args, device=DEV)
     r0 = {k: float(v) for k, v in tr2.train_step(b0[0], b0[1], b0[2]).items()}
     r1 = {k: float(v) for k, v in tr2.train_step(b1[0], b1[1], b1[2]).items()}
@@ -200,6 +199,7 @@ def test_invalidate_caches_drops_the_frozen_stage_graphs():
     from counting_detr_amd.checkpoint import invalidate_caches
     from counting_detr_amd.engine import Trainer
     model, crit, args = _small()
+    crit2 = copy.deepcopy(crit)
     b0, b1 = _batch(2, 64, 96, (5, 9), 1), _batch(2, 64, 96, (3, 11), 2)
     tr = Trainer(model, crit, args, device=DEV)
     tr.step(b0[0], b0[1], b0[2], next_samples=b1[0])
@@ -213,7 +213,7 @@ def test_invalidate_caches_drops_the_frozen_stage_graphs():
     invalidate_caches(model)
     assert not tr._frozen and not tr._cache and tr._entry is None
     junk = [torch.full((1 << 20,), 7.0, device=DEV) for _ in range(8)]        # the freed tables' memory is taken by something else
-    ref_model, crit2 = copy.deepcopy(model), copy.deepcopy(crit)
+    ref_model = copy.deepcopy(model)
     got = {k: float(v) for k, v in tr.step(b1[0], b1[1], b1[2]).items()}
     tr2 = Trainer(ref_model, crit2, args, device=DEV)
     want = {k: float(v) for k, v in tr2.train_step(b1[0], b1[1], b1[2]).items()}
