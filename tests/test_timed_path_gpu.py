@@ -159,7 +159,7 @@ def test_exchange_stream_runs_beside_the_backbone_backward():
     import os
     from counting_detr_amd.engine import Trainer
     model, crit, args = _small()
-    b = _batch(2, 128, 160, (5, 9), 1)
+    b = _batch(2, 192, 256, (5, 9), 1)
     os.environ["CDETR_PROBE_EXCHANGE"] = "1"
     try:
         tr = Trainer(model, crit, args, device=DEV)
@@ -183,7 +183,9 @@ def test_exchange_stream_runs_beside_the_backbone_backward():
         torch.cuda.synchronize()
         return ev[0].elapsed_time(ev[1]) / n
     t0 = time_steps()
-    us = 300
+    # the exchange stream runs its buckets one after the other: they hide while their backlog (3 buckets) is shorter than the backbone's
+    # backward -- ~0.4 ms on this small model (first run of this test: 4 x 300 us cost 0.81 ms = 1.2 ms - the backward) -> 100 us buckets
+    us = 100
     tr.exchange.dummy_us = us
     t1 = time_steps()
     tr.exchange.dummy_us = 0
