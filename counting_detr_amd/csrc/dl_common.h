@@ -14,10 +14,13 @@ typedef const __attribute__((address_space(1))) void* gbl_vp;
 __device__ __forceinline__ void wait_vm(int n) {              // counted wait: at most n of this wave's loads still in flight
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
         case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;

@@ -43,9 +43,21 @@ struct DlCfg {
 // EARLY: the epilogue's operands (bias, residual rows, gate rows -- nothing the k-loop computes) are requested BEFORE the first operand
 // tile, so their HBM round trip (2.9 of a 64 x 64 / K = 256 workgroup's 11.7 us in the phase probe, profiles/r3_dl_probe_v1.txt) runs under
 // the k-loop; loads complete in issue order, so the counted vmcnt waits of the ring stay valid (the older loads have landed by then).
-template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true>
-__global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN) {
+//
+// NHS > 0: the HALO-RESIDENT form for 3x3 convolutions of stride 1 (forward rows and data-gradient rows; any dilation, pad == dil).  The
+// classic form fetches the pixel operand once per filter tap: 9 x BM rows per channel chunk, although the nine taps of a tile of BM
+// CONSECUTIVE flattened pixels only touch the BM + 2 dil (W + 1) consecutive rows around it.  Here that row range (the "halo") is DMA'd
+// once per channel chunk -- double-buffered, its pieces riding in the per-step load batches of the previous chunk -- and the nine taps are
+// nine fragment reads at a row offset (y-tap * W + x-tap) * dil; taps that leave the image (or the row range of the tensor) read a zero row
+// of LDS instead (per-lane address select, no masking VALU).  The weights stream through the 3-deep ring as before, one (chunk, tap)
+// tile per step.  Operand bytes per step of a 64 x 64 tile: 8 KB + halo / 9 (2.4-3.8 KB) instead of 16 KB; the row swizzle stays
+// conflict-free for any row offset (16 consecutive rows x one logical chunk = 16 distinct (row parity, slot) pairs).
+// halo_R = dil (W + 1) rows in front of / behind the tile, nah = 32-row passes of the halo (<= 7 NHS: its pieces ride in taps 2..8).
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true, int NHS = 0>
+__global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN, const int halo_R, const int nah) {
     using Cf = DlCfg<FM, FN, TERMS, STAGES>;
+    constexpr bool HALO = NHS > 0;
+    static_assert(!HALO || STAGES == 3, "the halo form runs the weight ring three deep");
     unsigned long long* probe = PROBE ? reinterpret_cast<unsigned long long*>(d.splitk_ws) + (long)blockIdx.x * 8 : nullptr;
     auto stamp = [&](int slot) __attribute__((always_inline)) {
         if constexpr (PROBE) {
@@ -119,10 +131,12 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     const long a_ld = a_il ? 2 * d.lda : d.lda;                  // row stride in bf16 elements
     const int a_kb = a_il ? 4 : 2;                              // bytes along k per k-value
     RowCoord arow[NA];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) arow[j] = decode_row(d.g, m0 + j * 32 + prow, d.M);
     const unsigned char* ap[NA];
     unsigned amask = 0;
+    if constexpr (!HALO) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) arow[j] = decode_row(d.g, m0 + j * 32 + prow, d.M);
+    }
     auto set_tap = [&](int tap) {
         amask = 0;
 #pragma unroll
@@ -131,6 +145,26 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
             ap[j] = row >= 0 ? reinterpret_cast<const unsigned char*>(Apl + row * a_ld + a_kk) : zero;
             amask |= (row >= 0 ? 1u : 0u) << j;
         }
+    };
+    // halo form: piece q of the halo = rows 32 q + prow of [m0 - halo_R, m0 + BM + halo_R); rows outside the tensor come from the zero page
+    const int HB = nah * 4096;                                  // bytes of one halo buffer
+    const int offB = HALO ? 2 * HB : STAGES * A_STAGE;          // the weight ring behind the pixel operand's buffers
+    const int offZ = offB + STAGES * B_STAGE;                   // halo form: 128 zero bytes (the row of every out-of-image tap), then a 4 KB dump
+    const unsigned char* hsrc = nullptr;
+    unsigned hmask = 0;
+    if constexpr (HALO) {
+        const long r0 = (long)m0 - halo_R + prow;
+        hsrc = reinterpret_cast<const unsigned char*>(Apl) + (r0 * a_ld + a_kk) * 2;
+        const int HR = BM + 2 * halo_R;
+        for (int q = 0; q < nah; ++q) {
+            const long r = r0 + 32 * q;
+            hmask |= ((32 * q + prow < HR && r >= 0 && r < d.M) ? 1u : 0u) << q;
+        }
+        if (tid < 32) *reinterpret_cast<unsigned*>(smem + offZ + tid * 4) = 0u;      // (ordered before its first use by the first barrier)
+    }
+    auto issue_halo = [&](int q, int buf, int kc) __attribute__((always_inline)) {      // q < nah
+        const unsigned char* src = ((hmask >> q) & 1u) ? hsrc + ((long)q * 32 * a_ld) * 2 + kc * a_kb : zero;
+        __builtin_amdgcn_global_load_lds((gbl_vp)src, (lds_vp)(smem + buf * HB + q * 4096 + w * 1024), 16, 0, 0);
     };
     const unsigned char* bp[NB];
 #pragma unroll
@@ -147,10 +181,12 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
         const int koa = kc * a_kb;                              // bytes along k of the A planes / groups
         const long kob = ((long)tap * K + kc) << bshift;        // bytes along (tap, k) of the weight image
         unsigned char* la = smem + stage * A_STAGE + w * 1024;
-        unsigned char* lb = smem + STAGES * A_STAGE + stage * B_STAGE + w * 1024;
+        unsigned char* lb = smem + offB + stage * B_STAGE + w * 1024;
+        if constexpr (!HALO) {
 #pragma unroll
-        for (int j = 0; j < NA; ++j)
-            __builtin_amdgcn_global_load_lds((gbl_vp)(ap[j] + (((amask >> j) & 1u) ? koa : 0)), (lds_vp)(la + j * 4096), 16, 0, 0);
+            for (int j = 0; j < NA; ++j)
+                __builtin_amdgcn_global_load_lds((gbl_vp)(ap[j] + (((amask >> j) & 1u) ? koa : 0)), (lds_vp)(la + j * 4096), 16, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j)
             __builtin_amdgcn_global_load_lds((gbl_vp)(bp[j] + kob), (lds_vp)(lb + j * 4096), 16, 0, 0);
@@ -163,7 +199,25 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     for (int j = 0; j < 4; ++j) {
         const int s16 = ((2 * j + g) ^ fx) << 4;
         xo[j] = (wm * 32 * FM + i32) * 128 + s16;
-        wo[j] = STAGES * A_STAGE + (wn * 32 * FN + i32) * 128 + s16;
+        wo[j] = offB + (wn * 32 * FN + i32) * 128 + s16;
+    }
+    // halo form: per fragment row its pixel coordinates -> 9 validity bits; the row of tap (ty, tx) sits (ty W + tx) dil rows further
+    unsigned vmask[FM];
+    const int hsgn = d.g.mode == CDETR_ROWS_CONV_FWD ? d.g.dil : -d.g.dil;      // forward rows read pixel + (k - 1) dil, data-gradient rows pixel - (k - 1) dil
+    if constexpr (HALO) {
+#pragma unroll
+        for (int a = 0; a < FM; ++a) {
+            const int m = m0 + wm * 32 * FM + a * 32 + i32;
+            const int hw = d.g.Hc * d.g.Wc;
+            const int rem = m % hw;
+            const int y = rem / d.g.Wc, x = rem - y * d.g.Wc;
+            vmask[a] = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + (t / 3 - 1) * hsgn, xx = x + (t % 3 - 1) * hsgn;
+                vmask[a] |= ((m < d.M && yy >= 0 && yy < d.g.Hc && xx >= 0 && xx < d.g.Wc) ? 1u : 0u) << t;
+            }
+        }
     }
     f32x16 acc[FN][FM];
 #pragma unroll
@@ -173,16 +227,35 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[b][a][r] = 0.f;
 
-    auto compute = [&](int stage) __attribute__((always_inline)) {
-        const unsigned char* xs = smem + stage * A_STAGE;
+    auto compute = [&](int stage, int hbuf = 0, int tap = 0) __attribute__((always_inline)) {
+        const unsigned char* xs = smem + (HALO ? hbuf * HB : stage * A_STAGE);
         const unsigned char* ws = smem + stage * B_STAGE;
+        int xh_o[FM][4];
+        if constexpr (HALO) {
+            const int ty = tap / 3, tx = tap - 3 * ty;
+            const int delta = ((ty - 1) * d.g.Wc + (tx - 1)) * hsgn;
+#pragma unroll
+            for (int a = 0; a < FM; ++a) {
+                const int h = wm * 32 * FM + a * 32 + i32 + halo_R + delta;
+                const bool ok = (vmask[a] >> tap) & 1u;
+                const int rb = ok ? h * 128 : offZ - hbuf * HB;
+                const int hx = ok ? (h >> 1) & 7 : 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) xh_o[a][j] = rb + (((2 * j + g) ^ hx) << 4);
+            }
+        }
 #pragma unroll
         for (int hp = 0; hp < KT / 16; ++hp) {
             bf16x8 xh[FM], xl[FM], wh[FN], wl[FN];
 #pragma unroll
             for (int a = 0; a < FM; ++a) {
-                xh[a] = *reinterpret_cast<const bf16x8*>(xs + xo[hp] + a * 4096);
-                if constexpr (TERMS == 3) xl[a] = *reinterpret_cast<const bf16x8*>(xs + xo[2 + hp] + a * 4096);
+                if constexpr (HALO) {
+                    xh[a] = *reinterpret_cast<const bf16x8*>(xs + xh_o[a][hp]);
+                    if constexpr (TERMS == 3) xl[a] = *reinterpret_cast<const bf16x8*>(xs + xh_o[a][2 + hp]);
+                } else {
+                    xh[a] = *reinterpret_cast<const bf16x8*>(xs + xo[hp] + a * 4096);
+                    if constexpr (TERMS == 3) xl[a] = *reinterpret_cast<const bf16x8*>(xs + xo[2 + hp] + a * 4096);
+                }
             }
 #pragma unroll
             for (int b = 0; b < FN; ++b) {
@@ -208,13 +281,55 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
             if (f_tap < taps) set_tap(f_tap);
         }
     };
-    set_tap(0);
+    if constexpr (HALO) {
+        // step s = (channel chunk c = s / 9, tap t = s % 9).  Batch b = the weight tile of step b (NB loads per thread) + for t >= 2, while a
+        // next chunk exists, NHS pieces of ITS halo (the other halo buffer was last read in step 9 c - 1; batch b is issued behind the
+        // barrier of step b - 2, so batches t = 0, 1 must not touch it).  Loads complete in order: at the top of step s everything up to
+        // batch s has landed once at most size(batch s + 1) loads are outstanding.
+        const int nchunks = nkt_tap, nsteps = nkt;
+        auto batch_size = [&](int t, int c) { return NB + ((t >= 2 && c + 1 < nchunks) ? NHS : 0); };
+        int bt = 0, bc = 0, bidx = 0;                            // (tap, chunk, index) of the next batch to issue
+        auto issue_batch = [&](int stage) __attribute__((always_inline)) {
+            issue(stage, bt, bc * KT);
+            if (bt >= 2 && bc + 1 < nchunks) {
+#pragma unroll
+                for (int i = 0; i < NHS; ++i) {
+                    const int q = (bt - 2) * NHS + i;
+                    if (q < nah) issue_halo(q, (bc + 1) & 1, (bc + 1) * KT);
+                    else __builtin_amdgcn_global_load_lds((gbl_vp)zero, (lds_vp)(smem + offZ + 256 + w * 1024), 16, 0, 0);
+                }
+            }
+            ++bidx;
+            if (++bt == 9) { bt = 0; ++bc; }
+        };
+        for (int q = 0; q < nah; ++q) issue_halo(q, 0, 0);
+        issue_batch(0);
+        if (nsteps > 1) issue_batch(1);
+        stamp(1);
+        int st = 0, sn = 2, t = 0, c = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            int tn = t + 1, cn = c;
+            if (tn == 9) { tn = 0; ++cn; }
+            wait_vm(s + 1 < nsteps ? batch_size(tn, cn) : 0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PROBE) { if (s == 0) stamp(2); }
+            if (bidx < nsteps) issue_batch(sn);
+            compute(st, c & 1, t);
+            __builtin_amdgcn_sched_barrier(0);
+            st = (st + 1 == 3) ? 0 : st + 1;
+            sn = (sn + 1 == 3) ? 0 : sn + 1;
+            t = tn;
+            c = cn;
+        }
+    }
+    if constexpr (!HALO) set_tap(0);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nkt) issue_next(s);
-    stamp(1);
+        if (!HALO && s < nkt) issue_next(s);
+    if constexpr (!HALO) stamp(1);
     int st = 0, sn = STAGES - 1;                                 // stage of the tile being computed / of the tile being issued
-    for (int kt = 0; kt < nkt; ++kt) {
+    for (int kt = 0; !HALO && kt < nkt; ++kt) {
         // tiles kt .. min(kt + STAGES - 2, nkt - 1) are in flight; tile kt must have landed (this wave's pieces), the others may fly on
         const int fly = min(STAGES - 2, nkt - 1 - kt);
         if (fly >= 2) wait_vm(2 * NI);
@@ -339,7 +454,29 @@ int launch_dl(const cdetr_gemm_desc& d, hipStream_t st) {
         }
     }
     dim3 grid(8 * ((tilesM + 7) / 8) * tilesN), block(256);
-    hipLaunchKernelGGL(kern, grid, block, Cf::LDS, st, d, tilesM, tilesN);
+    hipLaunchKernelGGL(kern, grid, block, Cf::LDS, st, d, tilesM, tilesN, 0, 0);
+    return cdetr_launch_status("cdetr_gemm");
+}
+
+// halo-resident 3x3 form: LDS = two halo buffers of nah 32-row passes + the 3-deep weight ring + zero row + dump
+template <int FM, int FN, int TERMS, int NHS>
+int launch_dl_halo(const cdetr_gemm_desc& d, int halo_R, int nah, hipStream_t st) {
+    using Cf = DlCfg<FM, FN, TERMS, 3>;
+    const int tilesM = (d.M + Cf::BM - 1) / Cf::BM, tilesN = (d.N + Cf::BN - 1) / Cf::BN;
+    auto kern = igemm_dl_kernel<FM, FN, TERMS, 3, false, true, NHS>;
+    int lds = 2 * nah * 4096 + 3 * Cf::B_STAGE + 256 + 4096;
+    if (lds < Cf::STAGING) lds = Cf::STAGING;
+    static int raised = 64 * 1024;                              // per instantiation
+    if (lds > raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            cdetr_set_error("cdetr_gemm (direct-to-LDS, halo): hipFuncSetAttribute(%d): %s", lds, hipGetErrorString(e));
+            return CDETR_ERR_LAUNCH;
+        }
+        raised = lds;
+    }
+    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, d, tilesM, tilesN, halo_R, nah);
     return cdetr_launch_status("cdetr_gemm");
 }
 
@@ -370,9 +507,41 @@ bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d) {
     return true;
 }
 
-// tile: 0 = 128x128, 1 = 128x64 (rows x channels), 2 = 64x128, 3 = 64x64; stages 2..4
+// Whether the halo-resident 3x3 form can run this (direct-to-LDS-eligible) problem on `tile`: stride-1 3x3 rows over a same-size map with
+// pad == dil, the halo's pieces fit the seven batches per chunk that may carry them, everything fits the LDS.
+bool cdetr_gemm_dl_halo_plan(const cdetr_gemm_desc& d, int tile, int& halo_R, int& nah, int& nhs) {
+    const cdetr_conv_geom& g = d.g;
+    if (g.mode != CDETR_ROWS_CONV_FWD && g.mode != CDETR_ROWS_CONV_DGRAD) return false;
+    if (g.kh != 3 || g.kw != 3 || d.taps != 9 || g.stride != 1 || g.pad != g.dil || g.Ha != g.Hc || g.Wa != g.Wc) return false;
+    if (d.flags & CDETR_GEMM_A_GROUPS) return false;
+    const int BM = (tile == 0 || tile == 1) ? 128 : 64, BN = (tile == 0 || tile == 2) ? 128 : 64;
+    halo_R = g.dil * (g.Wc + 1);
+    nah = (BM + 2 * halo_R + 31) / 32;
+    nhs = (nah + 6) / 7;
+    if (nhs > 2) return false;
+    return 2 * nah * 4096 + 3 * BN * 128 + 256 + 4096 <= 160 * 1024;
+}
+
+// tile: 0 = 128x128, 1 = 128x64 (rows x channels), 2 = 64x128, 3 = 64x64; stages 2..4; stages 13 = the halo-resident 3x3 form (3-deep weight ring)
 int cdetr_gemm_dl_launch(const cdetr_gemm_desc& d, int tile, int stages, hipStream_t st) {
     const bool x3 = d.precision == 1;
+    if (stages == 13) {
+        int R = 0, nah = 0, nhs = 0;
+        if (!cdetr_gemm_dl_halo_plan(d, tile, R, nah, nhs)) {
+            cdetr_set_error("cdetr_gemm (direct-to-LDS, halo): needs 3x3 stride-1 rows with pad == dil over a same-size map, halo <= 448 rows, <= 160 KB of LDS");
+            return CDETR_ERR_UNSUPPORTED;
+        }
+#define DL_HALO(FM, FN)                                                                                                              \
+    return x3 ? (nhs == 1 ? launch_dl_halo<FM, FN, 3, 1>(d, R, nah, st) : launch_dl_halo<FM, FN, 3, 2>(d, R, nah, st))               \
+              : (nhs == 1 ? launch_dl_halo<FM, FN, 1, 1>(d, R, nah, st) : launch_dl_halo<FM, FN, 1, 2>(d, R, nah, st))
+        switch (tile) {
+            case 0: DL_HALO(2, 2);
+            case 1: DL_HALO(2, 1);
+            case 2: DL_HALO(1, 2);
+            default: DL_HALO(1, 1);
+        }
+#undef DL_HALO
+    }
     static const bool late = getenv("CDETR_DL_LATE_EPILOGUE") != nullptr;       // A/B: epilogue operands fetched after the k-loop (round 3)
     if (stages >= 100) {                                        // phase probe (tools/dl_probe.py): splitk_ws receives the time stamps
         if (!d.splitk_ws) { cdetr_set_error("cdetr_gemm_dl: the phase probe writes into splitk_ws"); return CDETR_ERR_ARG; }

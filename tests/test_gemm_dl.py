@@ -141,6 +141,82 @@ def test_dl_conv_dgrad_rows(precision):
         assert torch.equal(dx16, dx.bfloat16())
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3], ids=["128x128", "128x64", "64x128", "64x64"])
+@pytest.mark.parametrize("precision", [1, 3], ids=["bf16x3", "bf16"])
+@pytest.mark.parametrize("case", [(2, 19, 23, 192, 132, 1), (2, 19, 23, 64, 64, 2), (1, 50, 50, 128, 128, 2), (3, 9, 100, 128, 64, 1), (2, 7, 5, 64, 68, 1)],
+                         ids=["19x23", "19x23d2", "50x50d2", "9x100", "7x5"])
+def test_dl_halo_conv_forward(tile, precision, case):
+    """The halo-resident 3x3 form (stages code 13; math: A2/models/resnet.py:146-148 conv2 + FrozenBN + ReLU, dilation as A2/models/backbone.py:153-155):
+    the pixel rows around a tile are staged once per channel chunk, the nine taps read them at row offsets.  Borders in both directions, tiles
+    that straddle image rows and images, M not a multiple of the tile, 1..6 channel chunks (halo double buffer reused), halo of one or two
+    pieces per batch (W = 100, dilation 2), maps smaller than a tile."""
+    from counting_detr_amd import ops
+    Nb, H, W, Cin, Cout, dil = case
+    x = torch.randn(Nb, H, W, Cin, generator=g(1)).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(2)) / (Cin * 9) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    sc = (1 + 0.2 * torch.randn(Cout, generator=g(3))).to(DEV)
+    bias = torch.randn(Cout, generator=g(4)).to(DEV)
+    geo, Ho, Wo = ops.conv_geom_fwd(H, W, 3, 3, 1, dil, dil)
+    assert (Ho, Wo) == (H, W)
+    resid = torch.randn(Nb, H, W, Cout, generator=g(5)).to(DEV)
+    mir, sp = _mirror(w, sc)
+    xh, xl = ops.split_planes(x)
+    y = torch.empty(Nb, H, W, Cout, device=DEV)
+    y16 = torch.empty(Nb, H, W, Cout, device=DEV, dtype=torch.bfloat16)
+    y16lo = torch.empty_like(y16)
+    ops.gemm_raw(x, Cin, w, 9 * Cin, y, Cout, Nb * H * W, Cout, Cin, taps=9, w_scale=sc, bias=bias, relu=True, resid=resid,
+                 ldr=Cout, geom=geo, B_split=sp, precision=precision, A16=xh, A16lo=xl, C16=y16, C16lo=y16lo, dl=(tile, 13))
+    ws = w * sc.view(-1, 1, 1, 1)
+    wh, wl = _split_ref(ws)
+    conv = lambda a, b: F.conv2d(a.double().permute(0, 3, 1, 2).cpu(), b.double().cpu(), padding=dil, dilation=dil).permute(0, 2, 3, 1)   # noqa: E731
+    ref = (conv(xh.double() + xl.double(), wh.double() + wl.double()) - conv(xl, wl)) if precision == 1 else conv(xh, wh)
+    ref = (ref + bias.double().cpu() + resid.double().cpu()).clamp(min=0)
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 3e-5 * (ref.abs().max().item() + 1.0), f"{err:.3e}"
+    _check_planes(y, y16, y16lo)
+    # and against the classic (tap-by-tap gather) form of the same kernel: same products, another summation order
+    y2 = torch.empty_like(y)
+    ops.gemm_raw(x, Cin, w, 9 * Cin, y2, Cout, Nb * H * W, Cout, Cin, taps=9, w_scale=sc, bias=bias, relu=True, resid=resid,
+                 ldr=Cout, geom=geo, B_split=sp, precision=precision, A16=xh, A16lo=xl, C16=y16, C16lo=y16lo, dl=(3, 3))
+    assert (y - y2).abs().max().item() <= 2e-5 * (ref.abs().max().item() + 1.0)
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2, 3], ids=["128x128", "128x64", "64x128", "64x64"])
+@pytest.mark.parametrize("precision", [1, 3], ids=["bf16x3", "bf16"])
+@pytest.mark.parametrize("dil", [1, 2])
+def test_dl_halo_conv_dgrad_rows(tile, precision, dil):
+    """Data-gradient rows of a stride-1 3x3 through the halo form (the taps mirror: pixel - (k - 1) dil), ReLU gate from the bf16 twin,
+    twin-only output (C == NULL) as the backbone's inner gradients use it."""
+    from counting_detr_amd import ops, _ffi
+    Nb, H, W, Cin, Cout = 2, 21, 17, 128, 192
+    dz = torch.randn(Nb, H, W, Cout, generator=g(1)).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(2)) / (Cout * 9) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    sc = (1 + 0.2 * torch.randn(Cout, generator=g(3))).to(DEV)
+    gate = torch.randn(Nb, H, W, Cin, generator=g(4)).to(DEV)
+    mir = ops.WeightMirror([(w, sc)], [])
+    mir.refresh("bwd")
+    m = mir.lookup(w, sc)
+    geo = ops._geom(_ffi.ROWS_CONV_DGRAD, H, W, H, W, 3, 3, 1, dil, dil)
+    dh, dl_ = ops.split_planes(dz)
+    dx = torch.empty(Nb, H, W, Cin, device=DEV)
+    dx16 = torch.empty(Nb, H, W, Cin, device=DEV, dtype=torch.bfloat16)
+    ops.gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * H * W, Cin, Cout, taps=9, gate=gate, ldg=Cin, geom=geo, B_split=m[2], B16=m[3],
+                 gate16=gate.bfloat16(), precision=precision, A16=dh, A16lo=dl_, C16=dx16, dl=(tile, 13))
+    ws = (w * sc.view(-1, 1, 1, 1))
+    wh, wl = _split_ref(ws)
+    ct = lambda a, b: F.conv_transpose2d(a.double().permute(0, 3, 1, 2).cpu(), b.double().cpu(), padding=dil, dilation=dil).permute(0, 2, 3, 1)   # noqa: E731
+    ref = (ct(dh.double() + dl_.double(), wh.double() + wl.double()) - ct(dl_, wl)) if precision == 1 else ct(dh, wh)
+    ref = torch.where(gate.double().cpu() > 0, ref, torch.zeros_like(ref))
+    err = (dx.double().cpu() - ref).abs().max().item()
+    assert err <= 3e-5 * (ref.abs().max().item() + 1.0), f"{err:.3e}"
+    assert torch.equal(dx16, dx.bfloat16())
+    if precision == 3:
+        dx16b = torch.empty_like(dx16)
+        ops.gemm_raw(None, Cout, m[0], m[1], None, Cin, Nb * H * W, Cin, Cout, taps=9, gate=gate, ldg=Cin, geom=geo, B_split=m[2], B16=m[3],
+                     gate16=gate.bfloat16(), precision=3, A16=dh, C16=dx16b, dl=(tile, 13))
+        assert torch.equal(dx16b, dx16)
+
+
 def test_dl_is_what_cdetr_gemm_picks_for_presplit_operands():
     """cdetr_gemm itself routes a large-enough problem with A16 + A16lo + B_split to the direct-to-LDS kernel: same result as the
     forced configuration, and within the split-product error of the register-staged kernel fed the fp32 operand."""
