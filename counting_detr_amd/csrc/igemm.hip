@@ -1374,14 +1374,17 @@ __device__ __forceinline__ void wgrad_tr_body(const cdetr_wgrad_desc& d, const i
 // [32-channel block][pixel][32] plane with one ds_write_b128), hi planes only.  Plain bf16 products (TERMS 1) by construction.
 
 
-template <int BI, int BJ>
+// KP: 32-pixel blocks per staged k-tile (round 5).  A workgroup's slice is only 10-50 blocks long and a block is two MFMAs per fragment pair: with
+// KP = 1 the loop is a barrier + a load round trip every 2 (64x64) to 8 (128x128) MFMAs per wave.  KP = 2 / 4 stages 64 / 128 pixels per
+// barrier (KP x the loads in flight per thread, KP x the MFMAs between two barriers); the host keeps counting slices in 32-pixel blocks.
+template <int BI, int BJ, int KP = 1>
 __device__ __forceinline__ void wgrad_tr16_body(const cdetr_wgrad_desc& d, const int tilesI, const int tilesJ, const int kt_per_slice,
                                                 const int bx, const int by, const int bz, const bool single) {
-    constexpr int BKF = 32;
+    constexpr int BKF = 32 * KP;
     constexpr int FM = BI / 64, FN = BJ / 64;
     constexpr int A_BLK = BI / 32, B_BLK = BJ / 32;               // 32-channel blocks per operand tile
     constexpr int A_SLOTS = BI / 64, B_SLOTS = BJ / 64;            // 256 threads = 32 pixels x 8 chunks of 8 channels (128 contiguous bytes per pixel row) per pass
-    constexpr int BLK = 32 * 32 + 32;                             // bf16 per [32 pixels][32 channels] block + 64 B: the two blocks a pixel row's
+    constexpr int BLK = BKF * 32 + 32;                            // bf16 per [BKF pixels][32 channels] block + 64 B: the two blocks a pixel row's
                                                                   // 8 lanes write to land on different banks
     constexpr int PLANE_A = A_BLK * BLK, PLANE_B = B_BLK * BLK;
     constexpr int BUF = PLANE_A + PLANE_B;                        // per buffer: dY | X (hi planes only)
@@ -1401,15 +1404,16 @@ __device__ __forceinline__ void wgrad_tr16_body(const cdetr_wgrad_desc& d, const
     const __bf16* __restrict__ dY = reinterpret_cast<const __bf16*>(d.dY16) + batch_off(z, d.batch_inner, d.sY, d.sY2);
     const __bf16* __restrict__ X = reinterpret_cast<const __bf16*>(d.X16) + batch_off(z, d.batch_inner, d.sX, d.sX2);
     float* __restrict__ dW = d.dW + batch_off(z, d.batch_inner, d.sW, d.sW2);
-    const int nkt_all = (d.P + BKF - 1) / BKF;
+    const int nkt_all = (d.P + 31) / 32;
     const int kt_begin = by * kt_per_slice;
     const int kt_end = min(nkt_all, kt_begin + kt_per_slice);
     if (kt_begin >= kt_end) return;
+    const int p_end = min(d.P, kt_end * 32);                      // this slice: pixels [32 kt_begin, p_end)
 
     const int kr = tid >> 3, c8 = (tid & 7) * 8;
     const bool dense = d.g.mode == CDETR_ROWS_DENSE;
     const int ky = dense ? 0 : tap / d.g.kw, kx = dense ? 0 : tap - (tap / d.g.kw) * d.g.kw;
-    int p = kt_begin * BKF + kr;
+    int p = kt_begin * 32 + kr;
     int pn = 0, py = 0, px = 0;
     if (!dense) {
         const int hw = d.g.Hc * d.g.Wc;
@@ -1419,48 +1423,55 @@ __device__ __forceinline__ void wgrad_tr16_body(const cdetr_wgrad_desc& d, const
         px = rem - py * d.g.Wc;
     }
     // two register sets = two pixel tiles in flight; unconditional clamped loads + validity bits
-    u32x4 ra[2][A_SLOTS], rb[2][B_SLOTS];
+    u32x4 ra[2][KP][A_SLOTS], rb[2][KP][B_SLOTS];
     unsigned rf[2] = {0, 0};
     int acol[A_SLOTS], bcol[B_SLOTS];
-    const int nk = kt_end - kt_begin;
-    int ft = 0;
+    const int nk = (kt_end - kt_begin + KP - 1) / KP;
 #pragma unroll
     for (int s = 0; s < A_SLOTS; ++s) acol[s] = min(i0 + 64 * s + c8, d.Nout - 8);
 #pragma unroll
     for (int s = 0; s < B_SLOTS; ++s) bcol[s] = min(c0 + 64 * s + c8, d.Cin - 8);
-    auto fetch = [&](u32x4 (&qa)[A_SLOTS], u32x4 (&qb)[B_SLOTS], unsigned& qf) __attribute__((always_inline)) {
-        const bool pv = p < d.P;
-        const __bf16* yp = dY + (long)(pv ? p : d.P - 1) * d.ldy;
+    auto fetch = [&](u32x4 (&qa)[KP][A_SLOTS], u32x4 (&qb)[KP][B_SLOTS], unsigned& qf) __attribute__((always_inline)) {
+        qf = 0;
 #pragma unroll
-        for (int s = 0; s < A_SLOTS; ++s) qa[s] = ld16(yp + acol[s]);
-        long row = -1;
-        if (pv) {
-            if (dense) row = p;
-            else {
-                const int iy = py * d.g.stride - d.g.pad + ky * d.g.dil;
-                const int ix = px * d.g.stride - d.g.pad + kx * d.g.dil;
-                if (iy >= 0 && iy < d.g.Ha && ix >= 0 && ix < d.g.Wa) row = ((long)pn * d.g.Ha + iy) * d.g.Wa + ix;
+        for (int kp = 0; kp < KP; ++kp) {
+            const bool pv = p < p_end;
+            const __bf16* yp = dY + (long)(pv ? p : d.P - 1) * d.ldy;
+#pragma unroll
+            for (int s = 0; s < A_SLOTS; ++s) qa[kp][s] = ld16(yp + acol[s]);
+            long row = -1;
+            if (pv) {
+                if (dense) row = p;
+                else {
+                    const int iy = py * d.g.stride - d.g.pad + ky * d.g.dil;
+                    const int ix = px * d.g.stride - d.g.pad + kx * d.g.dil;
+                    if (iy >= 0 && iy < d.g.Ha && ix >= 0 && ix < d.g.Wa) row = ((long)pn * d.g.Ha + iy) * d.g.Wa + ix;
+                }
             }
-        }
-        qf = ((pv && ft < nk) ? 1u : 0u) | (row >= 0 ? 2u : 0u);
-        ++ft;
-        const __bf16* xp = X + (row >= 0 ? row : 0) * d.ldx;
+            qf |= ((pv ? 1u : 0u) | (row >= 0 ? 2u : 0u)) << (2 * kp);
+            const __bf16* xp = X + (row >= 0 ? row : 0) * d.ldx;
 #pragma unroll
-        for (int s = 0; s < B_SLOTS; ++s) qb[s] = ld16(xp + bcol[s]);
-        p += BKF;
-        if (!dense) {
-            px += BKF;
-            while (px >= d.g.Wc) { px -= d.g.Wc; ++py; }
-            while (py >= d.g.Hc) { py -= d.g.Hc; ++pn; }
+            for (int s = 0; s < B_SLOTS; ++s) qb[kp][s] = ld16(xp + bcol[s]);
+            p += 32;
+            if (!dense) {
+                px += 32;
+                while (px >= d.g.Wc) { px -= d.g.Wc; ++py; }
+                while (py >= d.g.Hc) { py -= d.g.Hc; ++pn; }
+            }
         }
     };
     __bf16* const wbase = Zs + (c8 >> 5) * BLK + kr * 32 + (c8 & 31);
     const u32x4 z4 = {0u, 0u, 0u, 0u};
-    auto stash = [&](const u32x4 (&qa)[A_SLOTS], const u32x4 (&qb)[B_SLOTS], unsigned qf, int buf) __attribute__((always_inline)) {
+    auto stash = [&](const u32x4 (&qa)[KP][A_SLOTS], const u32x4 (&qb)[KP][B_SLOTS], unsigned qf, int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < A_SLOTS; ++s) *reinterpret_cast<u32x4*>(wbase + buf * BUF + 2 * s * BLK) = (qf & 1u) ? qa[s] : z4;
+        for (int kp = 0; kp < KP; ++kp) {
 #pragma unroll
-        for (int s = 0; s < B_SLOTS; ++s) *reinterpret_cast<u32x4*>(wbase + buf * BUF + PLANE_A + 2 * s * BLK) = (qf & 2u) ? qb[s] : z4;
+            for (int s = 0; s < A_SLOTS; ++s)
+                *reinterpret_cast<u32x4*>(wbase + buf * BUF + 2 * s * BLK + kp * 1024) = ((qf >> (2 * kp)) & 1u) ? qa[kp][s] : z4;
+#pragma unroll
+            for (int s = 0; s < B_SLOTS; ++s)
+                *reinterpret_cast<u32x4*>(wbase + buf * BUF + PLANE_A + 2 * s * BLK + kp * 1024) = ((qf >> (2 * kp)) & 2u) ? qb[kp][s] : z4;
+        }
     };
 
     f32x16 acc[FM][FN];
@@ -1479,7 +1490,7 @@ __device__ __forceinline__ void wgrad_tr16_body(const cdetr_wgrad_desc& d, const
         const __bf16* as = abase + buf * BUF;
         const __bf16* bs = bbase + buf * BUF;
 #pragma unroll
-        for (int hp = 0; hp < 2; ++hp) {
+        for (int hp = 0; hp < 2 * KP; ++hp) {
             bf16x8 ah[FM], bh[FN];
 #pragma unroll
             for (int a = 0; a < FM; ++a) ah[a] = lds_tr8(as + a * BLK + hp * 512, as + a * BLK + hp * 512 + 128);
@@ -1547,16 +1558,16 @@ __device__ __forceinline__ void wgrad_xcd_slice(int lid, int nx, int& bx, int& b
     by = (j / nx) * 8 + xcd;
 }
 
-template <int BI, int BJ>
+template <int BI, int BJ, int KP = 1>
 __global__ __launch_bounds__(256) void wgrad_tr16_kernel(const cdetr_wgrad_desc d, const int tilesI, const int tilesJ, const int kt_per_slice,
                                                          const int nx_xcd) {
     if (nx_xcd > 0) {      // 1-D grid, XCD-aware slices (never a single slice: ny is a multiple of 8; empty trailing slices exit at once)
         int bx, by;
         wgrad_xcd_slice(blockIdx.x, nx_xcd, bx, by);
-        wgrad_tr16_body<BI, BJ>(d, tilesI, tilesJ, kt_per_slice, bx, by, 0, false);
+        wgrad_tr16_body<BI, BJ, KP>(d, tilesI, tilesJ, kt_per_slice, bx, by, 0, false);
         return;
     }
-    wgrad_tr16_body<BI, BJ>(d, tilesI, tilesJ, kt_per_slice, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
+    wgrad_tr16_body<BI, BJ, KP>(d, tilesI, tilesJ, kt_per_slice, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y == 1);
 }
 
 template <int BI, int BJ, int TERMS = 3>
@@ -1586,7 +1597,7 @@ __global__ __launch_bounds__(256) void wgrad_tr_group_kernel(const WgradGroupArg
     wgrad_tr_body<BI, BJ, TERMS>(it.d, it.tilesI, it.tilesJ, it.per, it.d.dbias, l % it.nx, l / it.nx, z, false);
 }
 
-template <int BI, int BJ>
+template <int BI, int BJ, int KP = 1>
 __global__ __launch_bounds__(256) void wgrad_tr16_group_kernel(const WgradGroupArgs g) {
     int p = 0;
     while (p + 1 < g.n && (int)blockIdx.x >= g.blk0[p + 1]) ++p;
@@ -1598,7 +1609,7 @@ __global__ __launch_bounds__(256) void wgrad_tr16_group_kernel(const WgradGroupA
     int bx, by;
     if (it.pad_) wgrad_xcd_slice(l, it.nx, bx, by);    // (host: ny % 8 == 0, batch 1; blk0 is a multiple of 8: l % 8 == blockIdx.x % 8 == the XCD)
     else { bx = l % it.nx; by = l / it.nx; }
-    wgrad_tr16_body<BI, BJ>(it.d, it.tilesI, it.tilesJ, it.per, bx, by, z, false);
+    wgrad_tr16_body<BI, BJ, KP>(it.d, it.tilesI, it.tilesJ, it.per, bx, by, z, false);
 }
 
 // ------------------------------------------------------------------------------------------------ direct small GEMMs
@@ -2315,6 +2326,13 @@ bool wgrad_has_twins(const cdetr_wgrad_desc& d) {
     return on && d.precision == 3 && d.dY16 && d.X16 && !d.dbias && (d.Nout & 7) == 0 && (d.Cin & 7) == 0 && (d.ldy & 7) == 0 && (d.ldx & 7) == 0 &&
            (d.sY & 7) == 0 && (d.sX & 7) == 0 && (d.sY2 & 7) == 0 && (d.sX2 & 7) == 0 && aligned16(d.dY16) && aligned16(d.X16) && d.Nout >= 8 && d.Cin >= 8;
 }
+// 32-pixel blocks per staged k-tile of the twin-fed kernels (wgrad_tr16_body's KP): CDETR_WGRAD_KP = 1 / 2 / 4 (A/B knob, read per call by the tools)
+int wgrad_kp() {
+    static const int kp_env = getenv("CDETR_WGRAD_KP") ? atoi(getenv("CDETR_WGRAD_KP")) : 1;
+    const char* e = cdetr_tune_env("CDETR_WGRAD_KP");
+    const int kp = e ? atoi(e) : kp_env;      // (default 1: see profiles/r5_ab_wgrad_kp.txt)
+    return kp >= 4 ? 4 : kp >= 2 ? 2 : 1;
+}
 bool wgrad_is_fast(const cdetr_wgrad_desc& d) { return (d.ldy & 3) == 0 && (d.ldx & 3) == 0 && (d.Nout & 3) == 0 && (d.Cin & 3) == 0; }
 }  // namespace
 
@@ -2343,7 +2361,8 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             static const long target_env = getenv("CDETR_WGRAD_TARGET") ? atol(getenv("CDETR_WGRAD_TARGET")) : 0;
             // ~3 workgroups per CU; weights of <= 16 tiles pay slices x (atomic epilogue + pipeline fill) for little parallelism
             // gained: half as many slices measured 10-15 % faster there (5000x256x256, 20000x512x128)
-            const long target = target_env ? target_env : (base <= 16 ? 384 : 768);
+            // (round 5: 384 for every problem -- beside the data-gradient chain fewer, longer workgroups disturb it less: profiles/r5_ab_wgrad.txt)
+            const long target = target_env ? target_env : 384;
             long slices = (target + base - 1) / base;
             const long max_slices = (nktf + 3) / 4;                 // >= 4 k-tiles (128 pixels) per slice
             if (slices > max_slices) slices = max_slices;
@@ -2355,17 +2374,24 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             dim3 grid(tilesI * tilesJ * d.taps, (unsigned)slices, d.batch), block(256);
             // split-bf16: the LDS transpose-read kernel (wgrad_tr_kernel); fp32 MFMA: wgrad_fast_kernel
             if (wgrad_has_twins(d)) {
-                const int tbytes = 2 * ((BI + BJ) / 32) * (32 * 32 + 32) * 2;   // two buffers of hi planes (padded blocks)
-                if ((rcf = raise_lds(wgrad_tr16_kernel<BI, BJ>, tbytes, "cdetr_wgrad"))) return;
-                static const int xcd16 = getenv("CDETR_WGRAD_XCD16") ? atoi(getenv("CDETR_WGRAD_XCD16")) : 1;
-                if (xcd16 && d.batch == 1 && slices >= 8 && max_slices >= 8) {      // XCD-aware slices: a multiple of 8 of them, 1-D grid
-                    long s8 = std::min<long>((slices + 7) / 8 * 8, max_slices / 8 * 8);
-                    if (s8 < 8) s8 = 8;
-                    const int per8 = (int)((nktf + s8 - 1) / s8);
-                    const int nx = tilesI * tilesJ * d.taps;
-                    hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ>), dim3((unsigned)(nx * s8)), block, tbytes, st, d, tilesI, tilesJ, per8, nx);
-                } else
-                    hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ>), grid, block, tbytes, st, d, tilesI, tilesJ, per, 0);
+                auto go16 = [&](auto kp_c) {
+                    constexpr int KP = decltype(kp_c)::value;
+                    const int tbytes = 2 * ((BI + BJ) / 32) * (KP * 32 * 32 + 32) * 2;   // two buffers of hi planes (padded blocks)
+                    if ((rcf = raise_lds(wgrad_tr16_kernel<BI, BJ, KP>, tbytes, "cdetr_wgrad"))) return;
+                    static const int xcd16 = getenv("CDETR_WGRAD_XCD16") ? atoi(getenv("CDETR_WGRAD_XCD16")) : 1;
+                    if (xcd16 && d.batch == 1 && slices >= 8 && max_slices >= 8) {      // XCD-aware slices: a multiple of 8 of them, 1-D grid
+                        long s8 = std::min<long>((slices + 7) / 8 * 8, max_slices / 8 * 8);
+                        if (s8 < 8) s8 = 8;
+                        const int per8 = (int)((nktf + s8 - 1) / s8);
+                        const int nx = tilesI * tilesJ * d.taps;
+                        hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ, KP>), dim3((unsigned)(nx * s8)), block, tbytes, st, d, tilesI, tilesJ, per8, nx);
+                    } else
+                        hipLaunchKernelGGL((wgrad_tr16_kernel<BI, BJ, KP>), grid, block, tbytes, st, d, tilesI, tilesJ, per, 0);
+                };
+                const int kp = wgrad_kp();
+                if (kp == 4 && BI + BJ <= 192) go16(std::integral_constant<int, 4>{});
+                else if (kp >= 2) go16(std::integral_constant<int, 2>{});
+                else go16(std::integral_constant<int, 1>{});
             } else if (d.precision >= 1) {
                 const int tbytes = 2 * 2 * (BI + BJ) * 32 * 2;
                 if (d.precision == 2) {
@@ -2491,7 +2517,7 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             const cdetr_wgrad_desc& d = descs[tr64[c0 + k]];
             work += (long)((d.Nout + 63) / 64) * ((d.Cin + 63) / 64) * d.taps * d.batch * ((d.P + 31) / 32);
         }
-        static const long gtarget = getenv("CDETR_WGRAD_GROUP_TARGET") ? atol(getenv("CDETR_WGRAD_GROUP_TARGET")) : 768;
+        static const long gtarget = getenv("CDETR_WGRAD_GROUP_TARGET") ? atol(getenv("CDETR_WGRAD_GROUP_TARGET")) : 384;      // (round 5: was 768, profiles/r5_ab_wgrad.txt)
         long per_all = (work + gtarget - 1) / gtarget;
         if (per_all < 4) per_all = 4;
         for (int k = 0; k < m; ++k) {
@@ -2511,7 +2537,14 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
         }
         // one precision per grouped launch: the group's members come from one backward pass, the first member decides
         const int gprec = g.it[0].d.precision;
-        if (twins) hipLaunchKernelGGL((wgrad_tr16_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 4 * (32 * 32 + 32) * 2, st, g);
+        if (twins) {
+            const int kp = wgrad_kp();
+            if (kp == 4) {
+                if (int rcl = raise_lds(wgrad_tr16_group_kernel<64, 64, 4>, 2 * 4 * (4 * 32 * 32 + 32) * 2, "cdetr_wgrad_group")) return rcl;
+                hipLaunchKernelGGL((wgrad_tr16_group_kernel<64, 64, 4>), dim3(g.blk0[m]), dim3(256), 2 * 4 * (4 * 32 * 32 + 32) * 2, st, g);
+            } else if (kp == 2) hipLaunchKernelGGL((wgrad_tr16_group_kernel<64, 64, 2>), dim3(g.blk0[m]), dim3(256), 2 * 4 * (2 * 32 * 32 + 32) * 2, st, g);
+            else hipLaunchKernelGGL((wgrad_tr16_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 4 * (32 * 32 + 32) * 2, st, g);
+        }
         else if (gprec == 2) hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64, 2>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
         else if (gprec == 3) hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64, 1>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);
         else hipLaunchKernelGGL((wgrad_tr_group_kernel<64, 64>), dim3(g.blk0[m]), dim3(256), 2 * 2 * (64 + 64) * 32 * 2, st, g);

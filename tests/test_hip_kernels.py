@@ -904,6 +904,43 @@ def test_reduced_term_backward_kernels(Cin, Cout, k, stride, pad, dil, H, W, bwd
         ops.PRECISION = old
 
 
+@pytest.mark.parametrize("kp", [1, 2, 4])
+@pytest.mark.parametrize("Cin,Cout,k,stride,pad,dil,H,W", [(256, 256, 3, 1, 1, 1, 50, 50), (512, 2048, 1, 1, 0, 1, 50, 50), (128, 128, 3, 2, 1, 1, 100, 100),
+                                                        (512, 512, 3, 1, 2, 2, 50, 50), (72, 40, 3, 1, 1, 1, 21, 19), (64, 256, 1, 1, 0, 1, 37, 41)])
+def test_twin_fed_weight_gradient_pixel_blocks(Cin, Cout, k, stride, pad, dil, H, W, kp, monkeypatch):
+    """The twin-fed weight-gradient kernels stage KP 32-pixel blocks per barrier (csrc/igemm.hip wgrad_tr16_body, CDETR_WGRAD_KP): every KP
+    must give the fp64 result of the SAME bf16 operands (gradient of A2/models/resnet.py:140-160's convolutions), single launch and grouped
+    launch, slices that end inside a staged tile, pixel counts that are no multiple of 32 KP."""
+    from counting_detr_amd import ops
+    monkeypatch.setenv("CDETR_WGRAD_KP", str(kp))
+    ops.PRECISION, old = 1, ops.PRECISION
+    ops.PRECISION_BWD = 3
+    try:
+        B = 2
+        Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        x = torch.randn(B, H, W, Cin, generator=g(21)).to(DEV)
+        gy = torch.randn(B, Ho, Wo, Cout, generator=g(22)).to(DEV)
+        sc = (torch.rand(Cout, generator=g(23)) + 0.5).to(DEV)
+        x16, gy16 = x.bfloat16(), gy.bfloat16()
+        ws = [torch.nn.Parameter(torch.zeros(Cout, Cin, k, k, device=DEV).contiguous(memory_format=torch.channels_last)) for _ in range(3)]
+        for w in ws:
+            w.grad = torch.zeros_like(w)
+        ops.conv_wgrad_(gy, x, ws[0], sc, stride=stride, pad=pad, dil=dil, dz16=gy16, x16=x16)
+        with ops.wgrad_queue():                        # the grouped launch (two problems of the 64x64 class ride together when eligible)
+            ops.conv_wgrad_(gy, x, ws[1], sc, stride=stride, pad=pad, dil=dil, dz16=gy16, x16=x16)
+            ops.conv_wgrad_(gy, x, ws[2], sc, stride=stride, pad=pad, dil=dil, dz16=gy16, x16=x16)
+        x64 = x16.double().cpu().permute(0, 3, 1, 2)
+        w64 = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, requires_grad=True)
+        y64 = F.conv2d(x64, w64 * sc.double().cpu().view(-1, 1, 1, 1), None, stride, pad, dil)
+        y64.backward(gy16.double().cpu().permute(0, 3, 1, 2))
+        scale = w64.grad.abs().max().item()
+        for i, w in enumerate(ws):          # exact bf16 products, fp32 accumulation over <= 20000 pixels (+ fp32 atomics across the slices)
+            err = (w.grad.double().cpu() - w64.grad).abs().max().item()
+            assert err <= 3e-5 * scale, f"dW kp={kp} launch {i}: {err:.3e} vs scale {scale:.3e}"
+    finally:
+        ops.PRECISION = old
+
+
 # ----------------------------------------------------------------------------------------------------- glue kernels (csrc/glue.hip)
 @pytest.mark.parametrize("B,H,W,h,w", [(2, 800, 800, 50, 50), (3, 128, 160, 8, 10), (2, 96, 75, 6, 5), (1, 37, 53, 3, 4)])
 def test_mask_prep_matches_the_tensor_composition(B, H, W, h, w):

@@ -12,6 +12,10 @@ from counting_detr_amd import ops, _ffi
 DEV = "cuda"
 GROUPS = os.environ.get("DL_SWEEP_GROUPS", "0") == "1"      # also time the interleaved-groups operand format (forward only)
 CONFIGS = [(0, 2), (0, 3), (1, 2), (1, 3), (1, 4), (2, 3), (3, 3), (3, 4)]
+if os.environ.get("DL_SWEEP_SHALLOW") == "1":      # round 5: 2-deep rings on the small tiles (32 KB of LDS: 5 workgroups per CU instead of 3)
+    CONFIGS = [(1, 2), (1, 3), (2, 2), (2, 3), (3, 2), (3, 3)]
+if os.environ.get("DL_SWEEP_ONLY"):                # comma-separated indices into FWD
+    _only = [int(x) for x in os.environ["DL_SWEEP_ONLY"].split(",")]
 # (M rows, N, K, taps, conv geometry (H, W, stride, pad, dil) or None, epilogue with residual)
 FWD = [(80000, 64, 64, 1, None, False), (80000, 64, 64, 9, (200, 200, 1, 1, 1), False), (80000, 256, 64, 1, None, True),
        (80000, 64, 256, 1, None, False), (20000, 128, 256, 1, None, False), (20000, 128, 128, 9, (100, 100, 1, 1, 1), False),
@@ -96,7 +100,9 @@ if __name__ == "__main__":
         print(f"== {tag}: precision {precision} ({'bf16x3' if precision == 1 else 'bf16'}), M x{mult}; us per launch (TF algorithmic)")
         print("%-34s %14s | " % ("M N K taps", "reg-staged") + " ".join("%13s" % f"{names[t]}/{s}" for t, s in CONFIGS))
         tot_old = tot_best = tot_g = tot_gonly = 0.0
-        for sh in FWD:
+        for si, sh in enumerate(FWD):
+            if os.environ.get("DL_SWEEP_ONLY") and si not in _only:
+                continue
             row, fl = run(sh, precision, mult)
             best = min((v, k) for k, v in row.items() if k != "old" and k[0] != "g")
             tot_old += row["old"]
