@@ -70,11 +70,14 @@ class Bottleneck(nn.Module):
         self.downsample = nn.Sequential(ConvW(inplanes, planes * 4, 1), FrozenBatchNorm2d(planes * 4)) if has_down else None
         self.stride, self.dilation = stride, dilation
 
-    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False, out_to=None):
+    def forward_fused(self, x, save=None, x16=None, twins=False, twin_out=False, out_to=None, out_groups=False):
         """twins: every activation a weight gradient of this block will read (a1, a2) and the block's output (the next block's x) also
         leave their producing epilogue as a bf16 copy (ops.bf16_twins); x16 = the twin of x, from the previous block.
         twin_out: only the output gets a twin (the last frozen block in front of the trainable ones).
-        out_to = (y, y16): caller-owned buffers the block's output (and its twin) are written to (fixed addresses: ResNetBody.frozen_stage)."""
+        out_to = (y, y16): caller-owned buffers the block's output (and its twin) are written to (fixed addresses: ResNetBody.frozen_stage).
+        out_groups: the output leaves conv3's epilogue as interleaved split-bf16 groups (ops.Groups, 4 bytes per element, no fp32 tensor):
+        the next block's conv1 streams it in full lines on the direct-to-LDS kernel, its conv3 adds hi + lo as the residual; the twin still
+        serves the backward (weight-gradient operand, ReLU mask).  `x` may itself be such a tensor."""
         twin_out = twin_out or twins
         s1, b1 = self.bn1.affine()
         s2, b2 = self.bn2.affine()
@@ -104,7 +107,7 @@ class Bottleneck(nn.Module):
         if br is not None:
             br.join()
         out = ops.conv_fwd(a2, self.conv3.weight, s3, b3, relu=True, resid=idn, twin=twin_out, xs=(a2_16, a2l) if a2l is not None else None,
-                           out=out_to[0] if out_to is not None else None, out16=out_to[1] if out_to is not None else None)
+                           out=out_to[0] if out_to is not None else None, out16=out_to[1] if out_to is not None else None, out_groups=out_groups)
         out, out16 = out if twin_out else (out, None)
         if not twins:
             a2_16 = None
@@ -155,6 +158,24 @@ class Bottleneck(nn.Module):
             br.join()
         # x = relu(previous pre-activation): the gate applies the previous block's ReLU mask in the same epilogue
         return ops.conv_dgrad(dz1, w1, s1, x.shape[1:3], gate=x, resid=d_idn, twin=tw, dz16=dz1_16, gate16=x16 if tw else None)
+
+
+GROUPS_PLANES = tuple(64 << (int(c) - 1) for c in __import__("os").environ.get("CDETR_GROUPS_LAYERS", "2,3,4").split(",") if c.strip())
+
+
+def groups_between(blocks, i, x):
+    """Whether block i's output goes to block i + 1 as interleaved groups (ops.Groups) instead of an fp32 tensor: inside one backbone stage only
+    (the stage's last block feeds a strided / long-reduction shortcut convolution and, at the trunk's end, the projection: fp32), stride-1 block,
+    and ops.use_groups (split-bf16 forward with weight images, >= 4096 pixel rows).  Measured per shape: profiles/r4_fwd_split_groups.txt."""
+    if i + 1 >= len(blocks) or blocks[i + 1].downsample is not None:
+        return False
+    blk = blocks[i]
+    planes = blk.conv3.weight.shape[1]
+    if planes not in GROUPS_PLANES or not x.is_cuda:
+        return False
+    Nb, H, W, _ = x.shape
+    Ho, Wo = (H - 1) // blk.stride + 1, (W - 1) // blk.stride + 1
+    return ops.use_groups(Nb * Ho * Wo, 4 * planes)
 
 
 _BACKWARD_HOOK = None
@@ -213,9 +234,10 @@ class _TrunkFn(torch.autograd.Function):
         saved = []
         twins = x16 is not None
         with torch.no_grad():
-            for blk in blocks:
+            for i, blk in enumerate(blocks):
+                og = twins and groups_between(blocks, i, x)
                 if twins:
-                    x, x16 = blk.forward_fused(x, saved, x16=x16, twins=True)
+                    x, x16 = blk.forward_fused(x, saved, x16=x16, twins=True, out_groups=og)
                 else:
                     x = blk.forward_fused(x, saved)
         ctx.blocks, ctx.saved_acts = blocks, saved
@@ -360,8 +382,8 @@ class ResNetBody(nn.Module):
         if train:
             return _TrunkFn.apply(x, anchor, blocks, x16)
         with torch.no_grad():
-            for blk in blocks:
-                x = blk.forward_fused(x)
+            for i, blk in enumerate(blocks):
+                x = blk.forward_fused(x, out_groups=groups_between(blocks, i, x))
         return x
 
 

@@ -2038,7 +2038,7 @@ int check_gemm_desc(const cdetr_gemm_desc& d) {
     // C == nullptr: the fp32 output is not wanted (an inner gradient of a bottleneck that only the next bf16 contraction reads): only the
     // direct-to-LDS kernel writes the bf16 twin alone -- the problem must be eligible for it (cdetr_gemm_dl_eligible)
     // (likewise A == NULL: the operand exists as its twin A16 only)
-    CDETR_CHECK_ARG((d.C && d.A && !(d.flags & (CDETR_GEMM_A_GROUPS | CDETR_GEMM_C_GROUPS))) || cdetr_gemm_dl_eligible(d), "cdetr_gemm: A == NULL / C == NULL need A16 / C16 and direct-to-LDS-eligible operands (A16, B16 / B_split, K %% 64 == 0)");
+    CDETR_CHECK_ARG((d.C && d.A && !(d.flags & (CDETR_GEMM_A_GROUPS | CDETR_GEMM_C_GROUPS | CDETR_GEMM_RESID_GROUPS | CDETR_GEMM_GATE16_ONLY))) || cdetr_gemm_dl_eligible(d), "cdetr_gemm: A == NULL / C == NULL need A16 / C16 and direct-to-LDS-eligible operands (A16, B16 / B_split, K %% 64 == 0)");
     CDETR_CHECK_ARG(d.b_layout == 0 || d.b_layout == 1, "cdetr_gemm: b_layout %d", d.b_layout);
     if (d.g.mode == CDETR_ROWS_DENSE) {
         CDETR_CHECK_ARG(d.taps == 1, "cdetr_gemm: dense rows need taps == 1");
@@ -2113,7 +2113,7 @@ extern "C" int cdetr_gemm(const cdetr_gemm_desc* dp, void* stream) {
     const char* force_s = cdetr_tune_env("CDETR_GEMM_VARIANT");
     const int force = force_s ? atoi(force_s) : 0;
     const bool fast_ok = vecA && vecB && (d.K % 32) == 0;
-    if (!d.C || !d.A || (d.flags & (CDETR_GEMM_A_GROUPS | CDETR_GEMM_C_GROUPS))) { // grouped operands, twin-only output / operand: the direct-to-LDS kernel is the only one that handles it (check_gemm_desc made sure it can)
+    if (!d.C || !d.A || (d.flags & (CDETR_GEMM_A_GROUPS | CDETR_GEMM_C_GROUPS | CDETR_GEMM_RESID_GROUPS | CDETR_GEMM_GATE16_ONLY))) { // grouped operands, twin-only output / operand: the direct-to-LDS kernel is the only one that handles it (check_gemm_desc made sure it can)
         int stages = 3;
         const int tile = gemm_dl_choice(d, stages);
         return cdetr_gemm_dl_launch(d, tile >= 0 ? tile : 3, stages, st);
@@ -2291,10 +2291,11 @@ bool wgrad_is_direct(const cdetr_wgrad_desc& d);
 bool wgrad_is_fast(const cdetr_wgrad_desc& d);
 int check_wgrad_desc(const cdetr_wgrad_desc& d) {
     CDETR_CHECK_ARG(d.P >= 0 && d.Nout > 0 && d.Cin > 0 && d.taps > 0 && d.batch > 0, "cdetr_wgrad: bad sizes");
-    CDETR_CHECK_ARG((d.dY || d.dY16) && d.X && d.dW, "cdetr_wgrad: null pointer");
+    CDETR_CHECK_ARG((d.dY || d.dY16) && (d.X || d.X16) && d.dW, "cdetr_wgrad: null pointer");
     // dY == NULL: the gradient exists as its bf16 twin only (cdetr_gemm_desc.C == NULL upstream): the twin-fed tile kernel must be the one that runs
-    CDETR_CHECK_ARG(d.dY || (wgrad_has_twins(d) && wgrad_is_fast(d) && !wgrad_is_direct(d)),
-                    "cdetr_wgrad: dY == NULL needs dY16 + X16, plain-bf16 products and a problem of the tile-kernel class");
+    // (X == NULL likewise: the activation exists as interleaved groups + its twin, there is no fp32 tensor to read)
+    CDETR_CHECK_ARG((d.dY && d.X) || (wgrad_has_twins(d) && wgrad_is_fast(d) && !wgrad_is_direct(d)),
+                    "cdetr_wgrad: dY == NULL / X == NULL need dY16 + X16, plain-bf16 products and a problem of the tile-kernel class");
     CDETR_CHECK_ARG(aligned16(d.dY) && aligned16(d.X) && (d.sY & 3) == 0 && (d.sX & 3) == 0 && (d.sY2 & 3) == 0 && (d.sX2 & 3) == 0, "cdetr_wgrad: dY/X must be 16-byte aligned");
     if (d.g.mode == CDETR_ROWS_DENSE) {
         CDETR_CHECK_ARG(d.taps == 1, "cdetr_wgrad: dense rows need taps == 1");

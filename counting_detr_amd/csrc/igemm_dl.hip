@@ -104,6 +104,10 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     const __bf16* __restrict__ g16 = d.gate ? reinterpret_cast<const __bf16*>(d.gate16) : nullptr;      // bf16 twin of the gate: same sign, half the bytes
     float4 bia[2], res[NPASS][2];
     uint2 gat16[NPASS][2];
+    // CDETR_GEMM_RESID_GROUPS: the residual is stored as interleaved groups [hi 32 | lo 32] (a block output written by CDETR_GEMM_C_GROUPS):
+    // 16 bytes of hi + 16 bytes of lo per lane and pass instead of two float4 -- same registers, decoded (hi + lo) in the epilogue
+    const bool r_il = d.resid && (d.flags & CDETR_GEMM_RESID_GROUPS);
+    const int ng = min(n, d.N - 8);
     // residual / gate-twin rows of every pass: ONE batch of unconditional loads (clamped row / channel, masked use).  An fp32 gate without
     // a twin (not a product configuration: the kernel's operands ARE twins) is fetched in the epilogue: twice the registers for the k-loop
     auto load_epilogue_operands = [&]() __attribute__((always_inline)) {
@@ -112,8 +116,14 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
 #pragma unroll
         for (int p = 0; p < NPASS; ++p) {
             const long mrow = min(mw + p * RPP + rr, d.M - 1);
-            res[p][0] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
-            res[p][1] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r_il) {
+                const unsigned char* rp = reinterpret_cast<const unsigned char*>(d.resid) + (mrow * d.ldr + (ng & ~31)) * 4 + (ng & 31) * 2;
+                res[p][0] = *reinterpret_cast<const float4*>(rp);
+                res[p][1] = *reinterpret_cast<const float4*>(rp + 64);
+            } else {
+                res[p][0] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                res[p][1] = d.resid ? *reinterpret_cast<const float4*>(d.resid + mrow * d.ldr + nl1) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             gat16[p][0] = g16 ? *reinterpret_cast<const uint2*>(g16 + mrow * d.ldg + nl0) : make_uint2(0x3f803f80u, 0x3f803f80u);
             gat16[p][1] = g16 ? *reinterpret_cast<const uint2*>(g16 + mrow * d.ldg + nl1) : make_uint2(0x3f803f80u, 0x3f803f80u);
         }
@@ -387,7 +397,16 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
         const float4 s0 = *reinterpret_cast<const float4*>(stg + row * LDW + cc);
         const float4 s1 = *reinterpret_cast<const float4*>(stg + row * LDW + cc + 4);
         const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float re[8] = {res[p][0].x, res[p][0].y, res[p][0].z, res[p][0].w, res[p][1].x, res[p][1].y, res[p][1].z, res[p][1].w};
+        float re[8] = {res[p][0].x, res[p][0].y, res[p][0].z, res[p][0].w, res[p][1].x, res[p][1].y, res[p][1].z, res[p][1].w};
+        if (r_il) {
+            const unsigned hq[4] = {__float_as_uint(res[p][0].x), __float_as_uint(res[p][0].y), __float_as_uint(res[p][0].z), __float_as_uint(res[p][0].w)};
+            const unsigned lq[4] = {__float_as_uint(res[p][1].x), __float_as_uint(res[p][1].y), __float_as_uint(res[p][1].z), __float_as_uint(res[p][1].w)};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                re[2 * q] = __uint_as_float(hq[q] << 16) + __uint_as_float(lq[q] << 16);
+                re[2 * q + 1] = __uint_as_float(hq[q] & 0xffff0000u) + __uint_as_float(lq[q] & 0xffff0000u);
+            }
+        }
         float ga[8] = {__uint_as_float(gat16[p][0].x << 16), __uint_as_float(gat16[p][0].x & 0xffff0000u), __uint_as_float(gat16[p][0].y << 16),
                        __uint_as_float(gat16[p][0].y & 0xffff0000u), __uint_as_float(gat16[p][1].x << 16), __uint_as_float(gat16[p][1].x & 0xffff0000u),
                        __uint_as_float(gat16[p][1].y << 16), __uint_as_float(gat16[p][1].y & 0xffff0000u)};
@@ -499,8 +518,10 @@ bool cdetr_gemm_dl_eligible(const cdetr_gemm_desc& d) {
     if ((reinterpret_cast<uintptr_t>(d.A16) & 15) || (reinterpret_cast<uintptr_t>(d.A16lo) & 15) || (reinterpret_cast<uintptr_t>(d.B_split) & 15)) return false;
     if ((reinterpret_cast<uintptr_t>(d.C) & 15) || (reinterpret_cast<uintptr_t>(d.C16) & 7) || (reinterpret_cast<uintptr_t>(d.C16lo) & 7)) return false;
     if (d.resid && ((reinterpret_cast<uintptr_t>(d.resid) & 15) || (d.ldr & 3))) return false;
+    if (d.resid && (d.flags & CDETR_GEMM_RESID_GROUPS) && ((d.ldr & 31) || (d.N & 31))) return false;
     if (d.gate && ((reinterpret_cast<uintptr_t>(d.gate) & 15) || (d.ldg & 3))) return false;
     if (d.gate16 && (reinterpret_cast<uintptr_t>(d.gate16) & 7)) return false;
+    if ((d.flags & CDETR_GEMM_GATE16_ONLY) && !(d.gate && d.gate16)) return false;
     if (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15)) return false;
     if (!d.C && !d.C16 && !c_groups) return false;
     if (d.C16lo && !d.C16 && !c_groups) return false;

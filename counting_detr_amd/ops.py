@@ -126,7 +126,7 @@ def splitk_ws():
 def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, w_scale=None, resid=None, ldr=0,
              gate=None, ldg=0, relu=False, out_scale=1.0, geom=None, batch=1, sA=0, sB=0, sC=0, B_split=None,
              batch_inner=0, sA2=0, sB2=0, sC2=0, precision=None, C16=None, A16=None, A16lo=None, C16lo=None, dl=None, probe_ws=None, B16=None, gate16=None,
-             A_split=None, C_split=None, prio=False):
+             A_split=None, C_split=None, prio=False, resid_groups=False, gate16_only=False):
     """dl = (tile, stages): run the direct-to-LDS tile kernel with that configuration (cdetr_gemm_dl; tests / sweeps)."""
     d = GemmDesc()
     d.C16, d.A16, d.A16lo, d.C16lo, d.B16, d.gate16 = ptr(C16), ptr(A16), ptr(A16lo), ptr(C16lo), ptr(B16), ptr(gate16)
@@ -136,6 +136,10 @@ def gemm_raw(A, lda, B, ldb, Cout, ldc, M, N, K, taps=1, b_layout=0, bias=None, 
         d.C16lo, d.flags = ptr(C_split), d.flags | 2
     if prio:
         d.flags |= 4                # CDETR_GEMM_PRIO
+    if resid_groups:
+        d.flags |= 8                # CDETR_GEMM_RESID_GROUPS: `resid` is an interleaved-groups tensor
+    if gate16_only:
+        d.flags |= 16               # CDETR_GEMM_GATE16_ONLY: `gate` is no fp32 tensor, only its twin may be read
     d.batch_inner, d.sA2, d.sB2, d.sC2 = batch_inner, sA2, sB2, sC2
     d.M, d.N, d.K, d.taps, d.batch, d.b_layout, d.relu, d.out_scale = M, N, K, taps, batch, b_layout, int(relu), out_scale
     d.precision = PRECISION if precision is None else precision
@@ -366,6 +370,50 @@ def split_groups(x):
     lo = (x - hi.float()).bfloat16()
     sh = x.shape[:-1] + (x.shape[-1] // 32, 32)
     return torch.cat([hi.view(sh), lo.view(sh)], dim=-1).contiguous()
+
+
+class Groups:
+    """An NHWC activation kept ONCE as interleaved split-bf16 groups -- per 32 channels [hi 32 | lo 32] bf16, 4 bytes per element, the byte layout
+    of cdetr_gemm_desc.B_split -- instead of an fp32 tensor: the direct-to-LDS tile kernel reads it as its A operand in full 128-byte lines
+    (CDETR_GEMM_A_GROUPS), the epilogue that produces it writes it in place of the fp32 output (CDETR_GEMM_C_GROUPS), a later residual add reads
+    hi + lo (CDETR_GEMM_RESID_GROUPS).  hi + lo carries 16 mantissa bits of the fp32 value (the split-bf16 x3 product reads no more of it).
+    `.t` = the bf16 buffer [N, H, W, C / 32, 64]; `.shape` = the logical (N, H, W, C)."""
+    __slots__ = ("t", "shape")
+
+    def __init__(self, t, shape):
+        self.t, self.shape = t, tuple(shape)
+
+    @classmethod
+    def empty(cls, shape, device):
+        assert shape[-1] % 32 == 0
+        return cls(torch.empty(tuple(shape[:-1]) + (shape[-1] // 32, 64), device=device, dtype=torch.bfloat16), shape)
+
+    @classmethod
+    def of(cls, x):
+        return cls(split_groups(x), x.shape)
+
+    @property
+    def device(self):
+        return self.t.device
+
+    @property
+    def is_cuda(self):
+        return self.t.is_cuda
+
+    def float(self):
+        """fp32 value hi + lo (tests, fallbacks)."""
+        g = self.t.float()
+        return (g[..., :32] + g[..., 32:]).reshape(self.shape)
+
+
+GROUPS = os.environ.get("CDETR_GROUPS", "1") != "0"           # bottleneck outputs inside a backbone stage as interleaved groups (A/B knob)
+GROUPS_MIN_ROWS = 4096      # every consumer must run on the direct-to-LDS tile kernel: pixel rows from which cdetr_gemm's rules send it there
+
+
+def use_groups(rows, channels):
+    """Whether a bottleneck output of `rows` pixels x `channels` may leave its epilogue as interleaved groups only (split-bf16 forward with the
+    pre-split weight images at hand; big enough that the next 1x1 convolutions are direct-to-LDS problems)."""
+    return GROUPS and PRECISION == 1 and MIRROR is not None and rows >= GROUPS_MIN_ROWS and channels % 64 == 0
 
 
 def split_planes(x):
@@ -921,22 +969,33 @@ def expand_planes():
     return EXPAND_PLANES and PRECISION == 1 and MIRROR is not None
 
 
-def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False, xs=None, split=False, out=None, out16=None):
+def conv_fwd(x, weight, scale, bias, stride=1, pad=0, dil=1, relu=False, resid=None, twin=False, xs=None, split=False, out=None, out16=None,
+             out_groups=False):
     """x [N,H,W,Cin] NHWC -> [N,Ho,Wo,Cout]; weight logical [Cout,Cin,kh,kw] in channels_last memory.
     y = relu?( conv(x, W) * scale[c] + bias[c] + resid )   (A2/models/resnet.py:140-160 + backbone.py:50-60).
     twin: -> (y, bf16 copy of y written by the same epilogue).  split: -> (y, hi, lo) = y with its split-bf16 planes.
-    xs = (hi, lo) planes of x (from the producer's epilogue): the tile kernels read them instead of x."""
+    xs = (hi, lo) planes of x (from the producer's epilogue): the tile kernels read them instead of x.
+    x / resid may be `Groups` (interleaved split-bf16 form, no fp32 tensor); out_groups: y is returned as `Groups` (no fp32 output).  Any of
+    the three sends the problem to the direct-to-LDS tile kernel, which needs the pre-split weight image (ops.MIRROR)."""
     Nb, H, W, Cin = x.shape
     Cout, Cin_w, kh, kw = weight.shape
-    assert Cin_w == Cin and x.is_contiguous()
+    xg = x if isinstance(x, Groups) else None
+    rg = resid if isinstance(resid, Groups) else None
+    assert Cin_w == Cin and (xg is not None or x.is_contiguous())
     g, Ho, Wo = conv_geom_fwd(H, W, kh, kw, stride, pad, dil)
-    y = out if out is not None else torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    y16 = out16 if out16 is not None else (torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if (twin or split) else None)
-    ylo = torch.empty((Nb, Ho, Wo, Cout), device=x.device, dtype=torch.bfloat16) if split else None
+    dev = x.device
+    yg = Groups.empty((Nb, Ho, Wo, Cout), dev) if out_groups else None
+    y = None if out_groups else (out if out is not None else torch.empty((Nb, Ho, Wo, Cout), device=dev, dtype=torch.float32))
+    y16 = out16 if out16 is not None else (torch.empty((Nb, Ho, Wo, Cout), device=dev, dtype=torch.bfloat16) if (twin or split) else None)
+    ylo = torch.empty((Nb, Ho, Wo, Cout), device=dev, dtype=torch.bfloat16) if split else None
     sp = MIRROR.lookup_fwd(weight, scale) if MIRROR is not None else None
+    assert sp is not None or (xg is None and rg is None and not out_groups), "interleaved-group operands need the pre-split weight images (a trainer / inference engine around the model)"
     xh, xl = xs if xs is not None else (None, None)
-    gemm_raw(x, Cin, weight, kh * kw * Cin, y, Cout, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, bias=bias,
-             relu=relu, resid=resid, ldr=Cout, geom=g, B_split=sp, C16=y16, C16lo=ylo, A16=xh if xl is not None else None, A16lo=xl)
+    gemm_raw(None if xg is not None else x, Cin, weight, kh * kw * Cin, y, Cout, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, bias=bias,
+             relu=relu, resid=rg.t if rg is not None else resid, ldr=Cout, geom=g, B_split=sp, C16=y16, C16lo=ylo, A16=xh if xl is not None else None, A16lo=xl,
+             A_split=xg.t if xg is not None else None, C_split=yg.t if yg is not None else None, resid_groups=rg is not None)
+    if out_groups:
+        y = yg
     if split:
         return y, y16, ylo
     return (y, y16) if twin else y
@@ -959,6 +1018,12 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     dense = kh == 1 and kw == 1 and stride == 1 and pad == 0
     g = _geom() if dense else _geom(_ffi.ROWS_CONV_DGRAD, Ho, Wo, Hin, Win, kh, kw, stride, pad, dil)
     m = MIRROR.lookup(weight, scale) if MIRROR is not None else None
+    g16_only = False
+    if isinstance(gate, Groups):
+        # the activation exists as interleaved groups only: its ReLU mask comes from the bf16 twin (same signs), which only the direct-to-LDS
+        # kernel reads -- ops.use_groups made sure this problem is one of its (>= 4096 rows, twins, weight images); `gate` itself is just the flag
+        assert gate16 is not None and m is not None, "a grouped activation gates a data gradient through its bf16 twin (direct-to-LDS kernel)"
+        gate, g16_only = gate.t, True
     # (the consumers must be twin-fed too: the direct-to-LDS data gradient and the tile-class weight gradient -- more than 1024 rows,
     # 8-channel granularity: csrc/igemm.hip wgrad_has_twins / wgrad_is_direct; a few-row problem keeps its fp32 gradient)
     no_fp32 = (twin_only and twin and TWIN_ONLY and out is None and m is not None and m[3] is not None and dz16 is not None
@@ -970,7 +1035,7 @@ def conv_dgrad(dz, weight, scale, in_hw, stride=1, pad=0, dil=1, gate=None, resi
     if m is not None:     # FrozenBN scale is folded into the mirror
         gemm_raw(dz, Cout, m[0], m[1], dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=0,
                  gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, B_split=m[2], B16=m[3], precision=bwd_precision(), C16=dx16, A16=dz16,
-                 gate16=gate16 if gate is not None else None, prio=DGRAD_PRIO)
+                 gate16=gate16 if gate is not None else None, prio=DGRAD_PRIO, gate16_only=g16_only)
     else:
         gemm_raw(dz, Cout, weight, Cin, dx, Cin, Nb * Hin * Win, Cin, Cout, taps=kh * kw, b_layout=1, w_scale=scale,
                  gate=gate, ldg=Cin, resid=resid, ldr=Cin, geom=g, precision=bwd_precision(), C16=dx16)
@@ -984,6 +1049,10 @@ def conv_wgrad_(dz, x, weight, scale, stride=1, pad=0, dil=1, dz16=None, x16=Non
     kh, kw = weight.shape[2:]
     g, Ho2, Wo2 = conv_geom_fwd(H, W, kh, kw, stride, pad, dil)
     assert (Ho2, Wo2) == (Ho, Wo)
+    if isinstance(x, Groups):      # no fp32 tensor: only the twin-fed tile kernel can run it (csrc/igemm.hip wgrad_has_twins / wgrad_is_direct)
+        assert x16 is not None and dz16 is not None and bwd_precision() == 3 and Cout % 8 == 0 and Cin % 8 == 0 and Nb * Ho * Wo > 1024 \
+            and os.environ.get("CDETR_WGRAD_TWINS", "1") != "0", "a grouped activation feeds a weight gradient through its bf16 twin"
+        x = None                   # cdetr_wgrad_desc.X == NULL: the C side refuses any kernel class but the twin-fed one
     gw = grad_buffer(weight)
     assert gw.is_contiguous(memory_format=torch.channels_last) or (kh == 1 and kw == 1)
     wgrad_raw(dz, Cout, x, Cin, gw, kh * kw * Cin, Nb * Ho * Wo, Cout, Cin, taps=kh * kw, w_scale=scale, geom=g, may_defer=True,

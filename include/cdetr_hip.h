@@ -110,6 +110,13 @@ typedef struct {
 /* CDETR_GEMM_PRIO: the launch's waves run at raised instruction priority (s_setprio): for launches of a step's MAIN chain that share the
  *   chip with another stream's throughput work (the backbone's data gradients beside the weight gradients); results are unaffected.   */
 #define CDETR_GEMM_PRIO 4
+/* CDETR_GEMM_RESID_GROUPS: `resid` points to a tensor in the interleaved-group form (what CDETR_GEMM_C_GROUPS wrote: a bottleneck's output kept
+ *   ONCE as [hi 32 | lo 32] groups instead of fp32 + twin); ldr applies unchanged (4 bytes per element), ldr % 32 == 0, N % 32 == 0; the epilogue
+ *   adds hi + lo.  Direct-to-LDS kernel only, like the other two group flags.                                                          */
+#define CDETR_GEMM_RESID_GROUPS 8
+/* CDETR_GEMM_GATE16_ONLY: `gate` is NOT an fp32 tensor (the gating activation exists as interleaved groups + its twin): only gate16 may be read,
+ *   i.e. the problem must run on the direct-to-LDS kernel (CDETR_ERR_ARG otherwise); `gate` must still be non-NULL (it switches the gate on).  */
+#define CDETR_GEMM_GATE16_ONLY 16
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 /* The direct-to-LDS tile kernel (csrc/igemm_dl.hip) with an explicit configuration -- what cdetr_gemm picks by itself for problems
  * whose operands are given pre-split (A16 [+ A16lo] and B_split); for tests and tile sweeps.  tile: 0 = 128x128, 1 = 128x64,

@@ -217,6 +217,93 @@ def test_dl_halo_conv_dgrad_rows(tile, precision, dil):
         assert torch.equal(dx16b, dx16)
 
 
+def test_grouped_operands_through_conv_ops():
+    """ops.Groups (interleaved split-bf16 groups, include/cdetr_hip.h CDETR_GEMM_A_GROUPS / C_GROUPS / RESID_GROUPS) through ops.conv_fwd:
+    a 1x1 convolution reading grouped rows, adding a grouped residual and writing grouped output equals the fp32-tensor path on the same
+    hi + lo values (A2/models/resnet.py:140-160: conv + FrozenBN + residual + ReLU)."""
+    from counting_detr_amd import ops
+    ops.PRECISION, old = 1, ops.PRECISION
+    Nb, H, W, Cin, Cout = 2, 48, 50, 256, 128
+    try:
+        x = torch.randn(Nb, H, W, Cin, generator=g(1)).to(DEV)
+        r = torch.randn(Nb, H, W, Cout, generator=g(2)).to(DEV)
+        w = (torch.randn(Cout, Cin, 1, 1, generator=g(3)) / Cin ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+        sc = (1 + 0.2 * torch.randn(Cout, generator=g(4))).to(DEV)
+        bias = torch.randn(Cout, generator=g(5)).to(DEV)
+        ops.MIRROR = ops.WeightMirror([], [(w, sc)])
+        ops.MIRROR.refresh("fwd")
+        xg, rg = ops.Groups.of(x), ops.Groups.of(r)
+        assert torch.equal(xg.float(), (x.bfloat16().float() + (x - x.bfloat16().float()).bfloat16().float()))
+        yg, y16 = ops.conv_fwd(xg, w, sc, bias, relu=True, resid=rg, twin=True, out_groups=True)
+        assert isinstance(yg, ops.Groups) and yg.shape == (Nb, H, W, Cout)
+        # the same values as fp32 tensors through the ordinary path
+        y_ref = ops.conv_fwd(xg.float(), w, sc, bias, relu=True, resid=rg.float())
+        got = yg.float()
+        assert (got - y_ref).abs().max().item() <= 2e-5 * (y_ref.abs().max().item() + 1.0)
+        hi = y_ref.bfloat16()
+        assert (y16.float() - hi.float()).abs().max().item() <= 2 ** -7 * (y_ref.abs().max().item() + 1.0)      # twin = bf16 of the same value (ulp flips at ties)
+        # groups written by the epilogue ARE the split of its fp32 value: hi = bf16(v), lo = bf16(v - hi)
+        gt = yg.t.view(-1, Cout // 32, 64)
+        assert torch.equal(gt[..., :32].reshape(-1, Cout), y16.view(-1, Cout))
+    finally:
+        ops.MIRROR = None
+        ops.PRECISION = old
+
+
+@pytest.mark.parametrize("planes,H,W", [(64, 48, 48), (128, 50, 50)])
+def test_bottleneck_chain_with_grouped_block_outputs(planes, H, W):
+    """Two stride-1 bottlenecks (A2/models/resnet.py:105-160) in training mode, the first block's output handed over as ops.Groups (no fp32
+    tensor: conv1 of the second block streams it on the direct-to-LDS kernel, its conv3 adds hi + lo, the backward takes ReLU mask and
+    weight-gradient operand from the twin) against the same chain with an fp32 hand-over: outputs to 2e-5, input gradient and every weight
+    gradient to 1e-2 in norm (a few ReLU masks flip between two forwards that differ in the fifth digit)."""
+    from counting_detr_amd import ops
+    from counting_detr_amd.backbone import Bottleneck
+    ops.PRECISION, old = 1, ops.PRECISION
+    ops.PRECISION_BWD = 3
+    torch.manual_seed(0)
+    try:
+        blks = [Bottleneck(4 * planes, planes, 1, 1, False).to(DEV) for _ in range(2)]
+        for b in blks:
+            for bn in (b.bn1, b.bn2, b.bn3):
+                bn.weight.data.uniform_(0.5, 1.5)
+                bn.bias.data.normal_(0, 0.1)
+        ent = []
+        for b in blks:
+            ent += [(b.conv1.weight.data, b.bn1.affine()[0]), (b.conv2.weight.data, b.bn2.affine()[0]), (b.conv3.weight.data, b.bn3.affine()[0])]
+        ops.MIRROR = ops.WeightMirror(ent, ent)
+        ops.MIRROR.refresh()
+        x = torch.randn(2, H, W, 4 * planes, generator=g(7)).relu().to(DEV)
+        x16 = x.bfloat16()
+        dz = torch.randn(2, H, W, 4 * planes, generator=g(8)).to(DEV)
+        res = {}
+        for grouped in (False, True):
+            for b in blks:
+                for c in (b.conv1, b.conv2, b.conv3):
+                    c.weight.grad = torch.zeros_like(c.weight)
+            saved = []
+            with torch.no_grad():
+                h, h16 = blks[0].forward_fused(x, saved, x16=x16, twins=True, out_groups=grouped)
+                assert isinstance(h, ops.Groups) == grouped
+                out, out16 = blks[1].forward_fused(h, saved, x16=h16, twins=True)
+                d, d16 = ops.relu_mask(out, dz, twin=True)
+                d, d16 = blks[1].backward_fused(saved[1], d, need_dx=True, dz16=d16)
+                dx, _ = blks[0].backward_fused(saved[0], d, need_dx=True, dz16=d16)
+            torch.cuda.synchronize()
+            res[grouped] = (out.clone(), dx.clone(), [c.weight.grad.clone() for b in blks for c in (b.conv1, b.conv2, b.conv3)])
+        o0, dx0, g0 = res[False]
+        o1, dx1, g1 = res[True]
+        assert (o0 - o1).abs().max().item() <= 2e-5 * (o0.abs().max().item() + 1.0)
+        # the two forwards differ by ~1e-5 of the scale, so a handful of the 10^6 outputs sit on the other side of a ReLU: their mask flips and the
+        # gradient moves by a full element there (seen: max difference 5 % of the largest entry, one flip).  The norms say whether the paths agree.
+        rel = lambda a, b: ((a - b).double().norm() / a.double().norm()).item()      # noqa: E731
+        assert rel(dx0, dx1) <= 1e-2, rel(dx0, dx1)
+        for a, b in zip(g0, g1):
+            assert rel(a, b) <= 1e-2, rel(a, b)
+    finally:
+        ops.MIRROR = None
+        ops.PRECISION = old
+
+
 def test_dl_is_what_cdetr_gemm_picks_for_presplit_operands():
     """cdetr_gemm itself routes a large-enough problem with A16 + A16lo + B_split to the direct-to-LDS kernel: same result as the
     forced configuration, and within the split-product error of the register-staged kernel fed the fp32 operand."""
