@@ -386,6 +386,12 @@ def main(argv=None):
     if world > 1:
         # (ranks started by an external launcher: the HIP runtime has not initialised yet -- nothing above touches the device)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    else:
+        # one GPU: the step uses three streams (main | prefetch | weight gradients) and the two side streams are busy in different phases.  TWO
+        # hardware queues instead of HIP's default four are 0.07-0.11 ms per step faster in five same-lease pairs (8.75-8.79 vs 8.82-8.86 ms;
+        # 3 queues: -0.03; 1 queue: the serial fallback, 9.48 ms) -- fewer queues for the command processor to arbitrate between the ~450
+        # dependent launches of the main chain.  profiles/r5_ab_hw_queues.txt
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Counting-DETR HIP path has no CPU fallback")
     if world != a.gpus:

@@ -255,7 +255,7 @@ class Trainer:
         self._cache_on = bool(getattr(args, "graph_cache", True))
         self._cache_size = int(getattr(args, "graph_cache_size", 32))
         self.cache_stats = {"captures": 0, "steps": 0}
-        self.mirror = self._build_mirror(named)
+        self._named, self._mirror, self._mirror_stale = named, None, True      # built on first use (see the `mirror` property)
         import weakref
         owners = model.__dict__.setdefault("_graph_cache_owners", [])      # checkpoint.invalidate_caches -> clear_graph_cache
         owners.append(weakref.ref(self))
@@ -292,6 +292,17 @@ class Trainer:
 
     def _build_mirror(self, named):
         return build_weight_mirror(self.model, named)
+
+    @property
+    def mirror(self):
+        """The weight images (ops.WeightMirror).  Its tables hold the ADDRESSES of the FrozenBN folds (`bn.affine()`), and lookups are keyed on
+        them: checkpoint.invalidate_caches (checkpoint loads, sync_replicas, an InferenceEngine built on the same model) makes the model
+        compute new folds, so the mirror is rebuilt with them -- a stale one would answer every backbone lookup with None and the step would
+        silently run without pre-split weights (found in round 5 on the inference engine)."""
+        if self._mirror_stale:
+            self._mirror = self._build_mirror(self._named)
+            self._mirror_stale = False
+        return self._mirror
 
     @staticmethod
     def _view_like(chunk, p):
@@ -610,6 +621,7 @@ class Trainer:
             self._cache.clear()
             self._entry = None
             self._frozen.clear()            # (the stem + layer1 graphs read the same folds / stem images: stale after an invalidation)
+        self._mirror_stale = True           # the weight images are keyed on the folds' addresses (property `mirror`)
 
     def _drop_lru(self):
         """Evict the least recently used cached step (the caller has synchronised); its frozen-stage buffers + graph go with it when no other
@@ -665,6 +677,7 @@ class Trainer:
         fs = self._frozen.get(shape)
         if fs is not None:
             return fs
+        _ = self.mirror                            # (re)built outside the capture below
         body = self.model.backbone.body
         B, _, H, W = shape
         h, w = body.frozen_out_hw(H, W)
@@ -742,6 +755,7 @@ class Trainer:
         fs["token"], fs["keep"] = token, keep                   # (`keep`: the announced object stays alive, so its id cannot be re-used)
 
     def _capture_entry(self, images, mask, rects, targets, warmup=0):
+        _ = self.mirror                            # (re)built OUTSIDE any capture: its tables are uploaded with synchronous copies
         st = self._make_static(images, mask, rects, targets)
         st["sizes"] = tuple(len(t["boxes"]) for t in targets)
         world = get_world_size()
@@ -1299,7 +1313,7 @@ class InferenceEngine:
         self.device = torch.device(device) if device is not None else (p0.device if p0 is not None else torch.device("cpu"))
         self.model.eval()
         named = [(n, p) for n, p in model.named_parameters() if not n.startswith(UNUSED_PREFIXES)]
-        self.mirror = build_weight_mirror(model, named, dgrad=False) if (self.device.type == "cuda" and p0 is not None) else None
+        self._named, self._mirror, self._mirror_stale = named, None, True      # built by refresh_weights() below, AFTER the folds were invalidated
         self._cache = {}
         self._stream = None
         self._pool = None                # one graph memory pool for all shapes (graphs never run concurrently; outputs stay allocated)
@@ -1316,6 +1330,20 @@ class InferenceEngine:
                 torch.cuda.synchronize()
             self._cache.clear()
             self._frozen.clear()
+        self._mirror_stale = True
+
+    @property
+    def mirror(self):
+        """Forward weight images, rebuilt after every invalidation of the FrozenBN folds (see Trainer.mirror: lookups are keyed on the folds'
+        addresses).  Until round 5 this engine built its images BEFORE refresh_weights() invalidated the folds: every backbone lookup missed and
+        the forward ran on the fp32 weights + scale vectors -- correct, slower."""
+        if self._mirror_stale:
+            has = self.device.type == "cuda" and next(self.model.parameters(), None) is not None
+            self._mirror = build_weight_mirror(self.model, self._named, dgrad=False) if has else None
+            if self._mirror is not None:
+                self._mirror.refresh("fwd")
+            self._mirror_stale = False
+        return self._mirror
 
     @_scoped
     def refresh_weights(self):
@@ -1342,6 +1370,7 @@ class InferenceEngine:
         fs = self._frozen.get(shape)
         if fs is not None:
             return fs
+        _ = self.mirror                            # (re)built outside the capture below
         body = self.model.backbone.body
         B, _, H, W = shape
         h, w = body.frozen_out_hw(H, W)

@@ -406,7 +406,10 @@ class Groups:
         return (g[..., :32] + g[..., 32:]).reshape(self.shape)
 
 
-GROUPS = os.environ.get("CDETR_GROUPS", "1") != "0"           # bottleneck outputs inside a backbone stage as interleaved groups (A/B knob)
+# Bottleneck outputs inside a backbone stage as interleaved groups.  Built and parity-green in round 5 (g10 goldens, timed-path tests, the chain test in
+# tests/test_gemm_dl.py), and NEUTRAL in the step: 8.88-8.91 ms against 8.91-8.93 ms without (two same-lease pairs; under the tracer +0.05 ms) --
+# the cold-operand sweep's 1.12-1.29x on the 1x1 shapes does not appear when the operand was just written (profiles/r5_ab_groups.txt).  Off by default.
+GROUPS = os.environ.get("CDETR_GROUPS", "0") != "0"
 GROUPS_MIN_ROWS = 4096      # every consumer must run on the direct-to-LDS tile kernel: pixel rows from which cdetr_gemm's rules send it there
 
 

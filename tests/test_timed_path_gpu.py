@@ -242,3 +242,27 @@ def test_announced_shapes_that_never_arrive_do_not_pile_up():
         torch.cuda.synchronize()
         tr._drop_lru()
     assert (2, 3, 64, 96) not in tr._frozen
+
+
+def test_weight_images_survive_an_invalidation_of_the_folds():
+    """ops.WeightMirror answers lookups by (weight address, FrozenBN-fold address).  checkpoint.invalidate_caches makes the model compute NEW
+    folds, so a mirror built before it misses every backbone lookup and the step silently runs without pre-split weights (round 5: the
+    inference engine built its images before its own refresh_weights(); a trainer after sync_replicas / a checkpoint load was in the same
+    position).  Both engines now rebuild their mirror after an invalidation."""
+    from counting_detr_amd import checkpoint
+    from counting_detr_amd.engine import InferenceEngine, Trainer
+    model, crit, args = _small()
+    blk = model.backbone.body.layer3[1]
+    eng = InferenceEngine(model, device=DEV)
+    assert eng.mirror.lookup_fwd(blk.conv1.weight.data, blk.bn1.affine()[0]) is not None, "inference engine: backbone weight without its pre-split image"
+    model.train()
+    tr = Trainer(model, crit, args, device=DEV)
+    b = _batch(2, 128, 160, (5, 9), 1)
+    tr.train_step(*b)
+    assert tr.mirror.lookup_fwd(blk.conv1.weight.data, blk.bn1.affine()[0]) is not None
+    old = tr.mirror
+    checkpoint.invalidate_caches(model)
+    tr.train_step(*b)
+    assert tr.mirror is not old
+    assert tr.mirror.lookup_fwd(blk.conv1.weight.data, blk.bn1.affine()[0]) is not None, "trainer: stale mirror after invalidate_caches"
+    assert tr.mirror.lookup(blk.conv1.weight.data, blk.bn1.affine()[0]) is not None
