@@ -386,12 +386,6 @@ def main(argv=None):
     if world > 1:
         # (ranks started by an external launcher: the HIP runtime has not initialised yet -- nothing above touches the device)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    else:
-        # one GPU: the step uses three streams (main | prefetch | weight gradients) and the two side streams are busy in different phases.  TWO
-        # hardware queues instead of HIP's default four are 0.07-0.11 ms per step faster in five same-lease pairs (8.75-8.79 vs 8.82-8.86 ms;
-        # 3 queues: -0.03; 1 queue: the serial fallback, 9.48 ms) -- fewer queues for the command processor to arbitrate between the ~450
-        # dependent launches of the main chain.  profiles/r5_ab_hw_queues.txt
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Counting-DETR HIP path has no CPU fallback")
     if world != a.gpus:
@@ -437,7 +431,9 @@ def main(argv=None):
                 fn()
             barrier()
             return (time.perf_counter() - t) / n
-        te = timed(eager_step)
+        # the capture comes FIRST: the trainer probes its side streams at the first capture, and the streams the stream-ordered step creates
+        # (weight-gradient side stream, shortcut-branch forks) would otherwise take hardware-queue slots ahead of them -- with two hardware queues
+        # the replay then ran 0.6 ms slower (9.29 against 8.69 ms, two same-lease pairs: profiles/r5_ab_hw_queues.txt)
         ok = 1.0
         try:
             trainer.capture(images, rects, targets, warmup=1)
@@ -450,6 +446,7 @@ def main(argv=None):
             dist.all_reduce(okt, op=dist.ReduceOp.MIN)
             ok = float(okt[0])
         tg = timed(trainer.replay) if ok > 0 else float("inf")
+        te = timed(eager_step)
         tt = torch.tensor([te, tg], dtype=torch.float64, device=dev)
         if world > 1:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # every rank takes the same decision

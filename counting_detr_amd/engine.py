@@ -845,12 +845,23 @@ class Trainer:
             ok = [c for c in cands if self._concurrent(main, c)]
             pf = ok[0] if ok else cands[0]
             rest = [c for c in ok[1:] if self._concurrent(pf, c)]
-            wg = rest[0] if rest else next(c for c in cands if c is not pf)
+            # no candidate beside BOTH main and pf (two hardware queues): the weight gradients still belong beside the MAIN chain -- sharing pf's
+            # queue costs little (Z / the frozen stage are early in the step, the weight gradients late), sharing main's serialises them with the
+            # data-gradient chain (+0.3...0.6 ms; round 5 found the old fallback `first candidate that is not pf` doing exactly that)
+            wg = rest[0] if rest else (ok[1] if len(ok) > 1 else next(c for c in cands if c is not pf))
+            # ONE side stream by default (round 5): the prefetch stream's work (zero-fill + weight images, the next batch's frozen stage) sits in
+            # the first half of a step, the weight gradients in the second, so they lose nothing by queueing behind each other -- and with only TWO
+            # active hardware queues every shape of the bench runs ~0.1 ms faster (800x800: 8.75-8.79 against 8.81-8.88 ms; 384x576: 5.79-5.82
+            # against 5.95; the same gain appears with two side streams under GPU_MAX_HW_QUEUES=2, i.e. it is the queue count, not the order:
+            # profiles/r5_ab_hw_queues.txt).  CDETR_ONE_SIDE_STREAM=0 restores two side streams.
+            self._one_side = os.environ.get("CDETR_ONE_SIDE_STREAM", "1") != "0"
+            if self._one_side:
+                wg = pf
             self._pf_stream, self._wg_stream = pf, wg
             self._serial = not ok
             if self._serial:
                 self._z_late = False
-            self.side_stream_probe = {"overlap_main": len(ok), "of": len(cands), "wg_overlaps_pf": bool(rest),
+            self.side_stream_probe = {"overlap_main": len(ok), "of": len(cands), "wg_overlaps_pf": bool(rest), "one_side_stream": self._one_side,
                                       "max_hw_queues_env": os.environ.get("GPU_MAX_HW_QUEUES"),
                                       "fallback": ("no candidate stream runs beside the main one: frozen-stage prefetch and flag-released side work are OFF, "
                                                    "side streams are ordered by events only") if self._serial else None}

@@ -20,10 +20,6 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     # data-parallel run: the step uses main + prefetch + weight-gradient + exchange streams and RCCL adds its own -- more than HIP's default
     # four hardware queues (two streams of one queue never overlap).  Must be in the environment before the HIP runtime initialises.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-else:
-    # one GPU: main | prefetch | weight-gradient streams; two hardware queues are 0.07-0.11 ms per step faster than HIP's default four
-    # (profiles/r5_ab_hw_queues.txt); the trainer probes its side streams and falls back to a serial schedule if none runs beside the main one
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 
 import torch
 
