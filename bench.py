@@ -572,8 +572,11 @@ def main(argv=None):
                 "bound_note": "priced against the matrix pipe as the contract asks (dense contraction).  What the launches actually run into at these shapes "
                               "(M = 5000-20000 rows: 1-2.5 tile workgroups per CU) is not the pipe: the long reductions (3x3, K >= 1024) move their operand "
                               "lines L2 -> LDS at 50-75 GB/s per CU (k-steps of 16 / 24 / 32 KB in 0.38 / 0.54 / 0.73 us whatever the loader, ring depth or "
-                              "arithmetic), the short ones (K <= 512 into N >= 1024) stream 53-120 MB of epilogue operands at 2.3-2.7 TB/s -- DESIGN.md section 0, "
-                              "profiles/r4_dl_sweep_regstage*.txt, r4_stride_pad.txt, r4_ab_epilogue_touch.txt",
+                              "arithmetic), the short ones (K <= 512 into N >= 1024) stream 53-120 MB of epilogue operands at 2.3-2.7 TB/s -- HISTORY.md (round 4), "
+                              "profiles/r4_dl_sweep_regstage*.txt, r4_stride_pad.txt, r4_ab_epilogue_touch.txt.  Round 5: a third fewer operand bytes per "
+                              "k-step (3x3 halo resident in LDS), another operand format (interleaved groups), 2-4x the work per barrier and 5 instead of 3 "
+                              "resident workgroups per CU each left these launches where they were: at about one wave per SIMD a workgroup is a latency "
+                              "chain, not a byte stream -- DESIGN.md section 0, profiles/r5_ab_halo_3x3.txt, r5_ab_groups.txt, r5_ab_wgrad.txt",
                 "frac": achieved / dense,
                 "frac_note": "ALGORITHMIC FLOPs (2*M*N*K*taps per launch) of the dominant kernel family / HIP-event time of its launches / the "
                              "dense MFMA peak of the arithmetic's input type (2500 TF bf16; 157.3 TF for --precision fp32).  The split-bf16 forward "
