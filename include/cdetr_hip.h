@@ -120,7 +120,9 @@ typedef struct {
 int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
 /* The direct-to-LDS tile kernel (csrc/igemm_dl.hip) with an explicit configuration -- what cdetr_gemm picks by itself for problems
  * whose operands are given pre-split (A16 [+ A16lo] and B_split); for tests and tile sweeps.  tile: 0 = 128x128, 1 = 128x64,
- * 2 = 64x128, 3 = 64x64 (rows x channels per workgroup); stages: LDS ring depth 2..4 (3 for tile 0).  CDETR_ERR_UNSUPPORTED when the
+ * 2 = 64x128, 3 = 64x64 (rows x channels per workgroup); stages: LDS ring depth 2..4 (3 for tile 0), or 13 = the halo-resident form for
+ * stride-1 3x3 rows with pad == dil over a same-size map (forward or data-gradient rows; the pixel rows around a tile are staged once per
+ * channel chunk, the nine taps read them at row offsets; <= 448 halo rows, <= 160 KB of LDS).  CDETR_ERR_UNSUPPORTED when the
  * operand formats / alignment do not allow it (cdetr_last_error says why).                                                        */
 int cdetr_gemm_dl(const cdetr_gemm_desc* d, int32_t tile, int32_t stages, void* stream);
 /* n INDEPENDENT GEMMs submitted together (same results as n cdetr_gemm calls; no problem may read another's output).  Few-row
@@ -149,6 +151,10 @@ typedef struct {
     const void* dY16;  /* optional bf16 TWINS of dY / X (same shapes, leading dimensions and batch strides, in elements): with        */
     const void* X16;   /* precision 3 (plain bf16) the kernel reads these instead -- half the operand bytes, no conversion at staging. */
                        /* Needs both, Nout / Cin / ldy / ldx multiples of 8, 16-byte aligned bases, no dbias; otherwise dY / X are read. */
+                       /* dY and / or X may be NULL when the tensor exists as its twin only (an inner gradient written with cdetr_gemm_desc.C  */
+                       /* == NULL; an activation kept as interleaved groups + twin): the twin-fed tile kernel must then be the one that runs   */
+                       /* (more than 1024 pixels, the conditions above), CDETR_ERR_ARG otherwise -- never a silent read of a missing tensor.   */
+                       /* CDETR_WGRAD_KP (environment, A/B): 32-pixel blocks staged per barrier by the twin-fed kernels, 1 (default) / 2 / 4.  */
 } cdetr_wgrad_desc;
 int cdetr_wgrad(const cdetr_wgrad_desc* d, void* stream);
 /* n INDEPENDENT weight-gradient problems submitted together (same semantics as n cdetr_wgrad calls in any order; problems may
