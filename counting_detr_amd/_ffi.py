@@ -37,7 +37,7 @@ class WgradDesc(C.Structure):
                 ("dY", _p), ("ldy", C.c_int64), ("sY", C.c_int64),
                 ("X", _p), ("ldx", C.c_int64), ("sX", C.c_int64),
                 ("dW", _p), ("ldw", C.c_int64), ("sW", C.c_int64),
-                ("w_scale", _p), ("dbias", _p), ("g", ConvGeom), ("batch_inner", C.c_int32), ("pad_", C.c_int32),
+                ("w_scale", _p), ("dbias", _p), ("g", ConvGeom), ("batch_inner", C.c_int32), ("wg_target", C.c_int32),
                 ("sY2", C.c_int64), ("sX2", C.c_int64), ("sW2", C.c_int64), ("dY16", _p), ("X16", _p)]
 
 

@@ -41,6 +41,8 @@ static inline int cdetr_launch_status(const char* what) {
     return CDETR_OK;
 }
 
+constexpr int SPLITK_COUNTERS = 4096;      // int32 arrival counters at the head of cdetr_gemm_desc.splitk_ws (one per output tile; igemm.hip, igemm_dl.hip)
+
 // hipcc (ROCm 7.2) does not pad the MFMA -> accumulator-read hazard across a loop-exit edge: the register copies
 // (v_accvgpr_read) that follow a k-loop can issue before the last 16-pass MFMA has written its final rows (seen on
 // wgrad_fast_kernel<64,64>: accumulator row r = 15 stale).  Scheduling barriers / inline nops do not help (the copies are

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const cdetr_wgrad_desc d, co
 // split-plane LDS rows are groups of 32 k-values, [hi 32 | lo 32] each (= the byte layout of cdetr_gemm_desc.B_split): position
 // of k inside a row, in bf16 units; the lo plane of the same k sits 32 further.
 #define KPOS(k) ((((k) >> 5) << 6) + ((k) & 31))
-constexpr int SPLITK_COUNTERS = 4096;      // int32 arrival counters at the head of cdetr_gemm_desc.splitk_ws (one per output tile)
+// (SPLITK_COUNTERS: common.h -- the arrival counters at the head of cdetr_gemm_desc.splitk_ws, shared with igemm_dl.hip)
 // TERMS (split-bf16 staging modes only): bf16 MFMAs per algorithmic product -- 3 = hi*hi + hi*lo + lo*hi ("bf16x3", ~5e-6 relative),
 // 2 = hi*hi + lo*hi (the B operand rounded to bf16, A exact to 2^-17: "bf16x2"), 1 = hi*hi (both rounded: plain bf16).  Fewer terms
 // skip the MFMAs, the LDS reads of the unused lo planes and (TERMS 1) the lo half of the staging split of A.
@@ -2078,9 +2078,28 @@ int gemm_dl_choice(const cdetr_gemm_desc& d, int& stages) {
     }
     auto blocks = [&](int bm, int bn) { return (long)((d.M + bm - 1) / bm) * ((d.N + bn - 1) / bn); };
     stages = 3;
+    // split reduction (stages code 200 + 10 * slices + ring depth, igemm_dl.hip) -- CDETR_DL_SPLITK: 0 = never (default), 1 = this rule.
+    // In the step the rule is neutral (three same-lease pairs, profiles/r5_dl_splitk.txt: the backbone's backward is throughput-bound on
+    // two queues -- a shorter data-gradient launch gives its CUs to the weight gradients beside it, not to the chain): off.
+    // Cold-operand sweep of the data gradients (profiles/r5_dl_splitk.txt): three slices on 64x128 tiles win on the 3x3 convolutions of
+    // 50x50 maps (36-72 k-tiles per tile; 256 -> 256: 22.9 -> 19.5 us, 512 -> 512: 58.0 -> 45.5 us), the exchange (write-through partials,
+    // arrival count, late epilogue operands: ~6 us of round trips) costs more than it hides on every 1x1 shape (K <= 2048: 8-32 k-tiles)
+    auto split_3x3 = [&]() {
+        static const int sm = getenv("CDETR_DL_SPLITK") ? atoi(getenv("CDETR_DL_SPLITK")) : 0;
+        const long wgs = blocks(64, 128);
+        const int nkt_all = (int)((long)d.K / (d.precision == 1 ? 32 : 64) * d.taps);
+        return sm == 1 && d.taps == 9 && d.N % 128 == 0 && d.splitk_ws && wgs <= 384 && nkt_all >= 24 &&
+               (long)SPLITK_COUNTERS * 4 + wgs * 3 * 64 * 128 * 4 <= d.splitk_ws_bytes;
+    };
     if (!d.C) return blocks(64, 64) >= 512 && (long)d.K * d.taps >= 2048 && d.N % 128 == 0 ? 0 : 3;   // no fp32 output: only this kernel can run it
     if (blocks(64, 64) < 192) return -1;                                      // few tiles: the split-reduction forms of the register-staged kernels
-    if (d.precision == 3) return ((long)d.K * d.taps >= 2048 && d.N % 128 == 0 && blocks(128, 128) >= 128) ? 0 : 3;
+    if (d.precision == 3) {
+        if (split_3x3()) {
+            stages = 233;
+            return 2;
+        }
+        return ((long)d.K * d.taps >= 2048 && d.N % 128 == 0 && blocks(128, 128) >= 128) ? 0 : 3;
+    }
     // split-bf16 x3 with planes given: where the sweep has it ahead -- the expanding 1x1 convolutions (K = planes <= 512, N = 4 K), whose
     // epilogue dominates; 64x128 tiles for the widest one
     if ((long)d.K * d.taps <= 512 && d.N >= 2 * d.K) return d.N >= 2048 ? 2 : 3;
@@ -2363,7 +2382,7 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             // ~3 workgroups per CU; weights of <= 16 tiles pay slices x (atomic epilogue + pipeline fill) for little parallelism
             // gained: half as many slices measured 10-15 % faster there (5000x256x256, 20000x512x128)
             // (round 5: 384 for every problem -- beside the data-gradient chain fewer, longer workgroups disturb it less: profiles/r5_ab_wgrad.txt)
-            const long target = target_env ? target_env : 384;
+            const long target = d.wg_target > 0 ? d.wg_target : (target_env ? target_env : 384);      // (wg_target: the caller knows better -- a launch alone on the chip)
             long slices = (target + base - 1) / base;
             const long max_slices = (nktf + 3) / 4;                 // >= 4 k-tiles (128 pixels) per slice
             if (slices > max_slices) slices = max_slices;
@@ -2519,7 +2538,10 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             work += (long)((d.Nout + 63) / 64) * ((d.Cin + 63) / 64) * d.taps * d.batch * ((d.P + 31) / 32);
         }
         static const long gtarget = getenv("CDETR_WGRAD_GROUP_TARGET") ? atol(getenv("CDETR_WGRAD_GROUP_TARGET")) : 384;      // (round 5: was 768, profiles/r5_ab_wgrad.txt)
-        long per_all = (work + gtarget - 1) / gtarget;
+        long want = 0;                                    // cdetr_wgrad_desc.wg_target: the largest request of the members (a launch alone on the chip)
+        for (int k = 0; k < m; ++k) want = std::max<long>(want, descs[tr64[c0 + k]].wg_target);
+        const long gt = want > 0 ? want : gtarget;
+        long per_all = (work + gt - 1) / gt;
         if (per_all < 4) per_all = 4;
         for (int k = 0; k < m; ++k) {
             WgradGroupItem& it = g.it[k];

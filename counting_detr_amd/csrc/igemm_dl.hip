@@ -53,11 +53,19 @@ struct DlCfg {
 // tile per step.  Operand bytes per step of a 64 x 64 tile: 8 KB + halo / 9 (2.4-3.8 KB) instead of 16 KB; the row swizzle stays
 // conflict-free for any row offset (16 consecutive rows x one logical chunk = 16 distinct (row parity, slot) pairs).
 // halo_R = dil (W + 1) rows in front of / behind the tile, nah = 32-row passes of the halo (<= 7 NHS: its pieces ride in taps 2..8).
-template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true, int NHS = 0>
+//
+// SPLIT: the reduction of one output tile cut into gridDim.y slices (blockIdx.y = slice) -- the problems whose grid leaves the CUs with one
+// wave per SIMD (5000 x 256 outputs on 64 x 64 tiles: 316 workgroups; the k-step of a workgroup is a latency chain [wait, barrier, 8 LDS reads,
+// dependent MFMAs] that only OTHER resident workgroups can overlap).  Same exchange as igemm_fast_kernel's (igemm.hip): every slice parks
+// its partial accumulators in cdetr_gemm_desc.splitk_ws as device-scope write-through stores, counts itself in on the tile's arrival
+// counter, and the slice that arrives LAST adds the partials in slice order (a sum that does not depend on who is last), fetches the
+// epilogue's operands -- only now: the other slices never touch them -- and runs the fused epilogue.  No slice waits for another.
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true, int NHS = 0, bool SPLIT = false>
 __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, const int tilesM, const int tilesN, const int halo_R, const int nah) {
     using Cf = DlCfg<FM, FN, TERMS, STAGES>;
     constexpr bool HALO = NHS > 0;
     static_assert(!HALO || STAGES == 3, "the halo form runs the weight ring three deep");
+    static_assert(!SPLIT || (!HALO && !PROBE && !EARLY), "split reductions: classic form, epilogue operands fetched by the finishing slice");
     unsigned long long* probe = PROBE ? reinterpret_cast<unsigned long long*>(d.splitk_ws) + (long)blockIdx.x * 8 : nullptr;
     auto stamp = [&](int slot) __attribute__((always_inline)) {
         if constexpr (PROBE) {
@@ -87,7 +95,11 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     if (tm >= tilesM) return;
     const int m0 = tm * BM, n0 = tn * BN;
     const int K = d.K, taps = d.taps;
-    const int nkt_tap = K / KT, nkt = nkt_tap * taps;
+    const int nkt_tap = K / KT;
+    const int ksplit = SPLIT ? (int)gridDim.y : 1, kslice = SPLIT ? (int)blockIdx.y : 0;
+    // slice kslice owns k-tiles [kt0, kt0 + nkt) of the nkt_tap * taps tiles of the reduction (one slice: all of them)
+    const int kt0 = SPLIT ? (int)((long)nkt_tap * taps * kslice / ksplit) : 0;
+    const int nkt = SPLIT ? (int)((long)nkt_tap * taps * (kslice + 1) / ksplit) - kt0 : nkt_tap * taps;
 
     // ---------------------------------------------------------------- epilogue geometry + its operand loads
     // (the accumulators are transposed through LDS at the end so that LR = 4 FN lanes hold 8 consecutive channels each of ONE row)
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     };
 
     // ---------------------------------------------------------------- the pipeline
-    int f_tap = 0, f_kc = 0, f_idx = 0;                         // coordinates of the next tile to issue
+    int f_tap = kt0 / nkt_tap, f_kc = (kt0 - f_tap * nkt_tap) * KT, f_idx = 0;      // coordinates of the next tile to issue
     auto issue_next = [&](int stage) __attribute__((always_inline)) {
         issue(stage, f_tap, f_kc);
         ++f_idx;
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
             c = cn;
         }
     }
-    if constexpr (!HALO) set_tap(0);
+    if constexpr (!HALO) set_tap(f_tap);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (!HALO && s < nkt) issue_next(s);
@@ -364,6 +376,71 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     // in each of 32 rows.  Staging rows are padded by 16 bytes: the float4 writes of 8 consecutive lanes (8 rows, same column) and
     // the row-major float4 reads both spread over the banks.
     __builtin_amdgcn_s_barrier();                               // every wave has finished reading the ring
+    if constexpr (SPLIT) {
+        // Coherence across the 8 XCDs without fences (a device-scope fence writes back / invalidates a whole L2): the partials travel as
+        // relaxed device-scope atomic stores / loads (sc1), s_waitcnt orders them before the arrival count, a device-scope RMW.
+        constexpr int FR = FM * FN * 16;
+        int* cnt = reinterpret_cast<int*>(d.splitk_ws);
+        float* wsp = reinterpret_cast<float*>(cnt + SPLITK_COUNTERS);
+        const int tile = tm * tilesN + tn;
+        float* mine = wsp + ((long)tile * ksplit + kslice) * FR * 256 + tid;
+#pragma unroll
+        for (int b = 0; b < FN; ++b)
+#pragma unroll
+            for (int a = 0; a < FM; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    __hip_atomic_store(mine + ((b * FM + a) * 16 + r) * 256, acc[b][a][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0);       // the stores above have been acknowledged
+        __syncthreads();                     // ... by every wave
+        int* flag = reinterpret_cast<int*>(smem + Cf::LDS);      // 16 bytes behind the ring / staging tiles (launch_dl)
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old == ksplit - 1) ? 1 : 0;
+            if (last) __hip_atomic_store(cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // leave the counters zero for the next launch
+            *flag = last;
+        }
+        __syncthreads();
+        if (*flag == 0) return;
+        load_epilogue_operands();
+        if (ksplit == 2) {                   // two slices: a + b == b + a, in place
+            const float* other = wsp + ((long)tile * ksplit + (1 - kslice)) * FR * 256 + tid;
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+#pragma unroll
+                for (int a = 0; a < FM; ++a) {
+                    float t[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) t[r] = __hip_atomic_load(other + ((b * FM + a) * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[b][a][r] += t[r];
+                }
+        } else {                             // slice order: ((p0 + p1) + p2) + p3 whichever slice finishes
+            f32x16 sum[FN][FM];
+            for (int q = 0; q < ksplit; ++q) {
+                const float* other = wsp + ((long)tile * ksplit + q) * FR * 256 + tid;
+#pragma unroll
+                for (int b = 0; b < FN; ++b)
+#pragma unroll
+                    for (int a = 0; a < FM; ++a) {
+                        float t[16];
+                        if (q == kslice) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) t[r] = acc[b][a][r];
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) t[r] = __hip_atomic_load(other + ((b * FM + a) * 16 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sum[b][a][r] = (q == 0) ? t[r] : sum[b][a][r] + t[r];
+                    }
+            }
+#pragma unroll
+            for (int b = 0; b < FN; ++b)
+#pragma unroll
+                for (int a = 0; a < FM; ++a) acc[b][a] = sum[b][a];
+        }
+    }
     float* stg = reinterpret_cast<float*>(smem) + w * (32 * FM * LDW);
 #pragma unroll
     for (int a = 0; a < FM; ++a)
@@ -378,7 +455,7 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     const bool c_il = d.flags & CDETR_GEMM_C_GROUPS;
     __bf16* __restrict__ C16lo = c_il ? nullptr : reinterpret_cast<__bf16*>(d.C16lo);
     unsigned char* __restrict__ Cil = c_il ? reinterpret_cast<unsigned char*>(d.C16lo) : nullptr;       // (N % 32 == 0: a lane's 8 channels never straddle a group)
-    if constexpr (!EARLY) load_epilogue_operands();
+    if constexpr (!EARLY && !SPLIT) load_epilogue_operands();
     float4 gat32[NPASS][2];
     if (d.gate && !g16) {
 #pragma unroll
@@ -456,24 +533,34 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     if constexpr (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); stamp(6); }
 }
 
-template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true>
-int launch_dl(const cdetr_gemm_desc& d, hipStream_t st) {
+template <int FM, int FN, int TERMS, int STAGES, bool PROBE = false, bool EARLY = true, bool SPLIT = false>
+int launch_dl(const cdetr_gemm_desc& d, hipStream_t st, int ksplit = 1) {
     using Cf = DlCfg<FM, FN, TERMS, STAGES>;
     const int tilesM = (d.M + Cf::BM - 1) / Cf::BM, tilesN = (d.N + Cf::BN - 1) / Cf::BN;
-    auto kern = igemm_dl_kernel<FM, FN, TERMS, STAGES, PROBE, EARLY>;
-    if (Cf::LDS > 64 * 1024) {
+    auto kern = igemm_dl_kernel<FM, FN, TERMS, STAGES, PROBE, EARLY, 0, SPLIT>;
+    if (SPLIT) {
+        const long need = (long)SPLITK_COUNTERS * 4 + (long)tilesM * tilesN * ksplit * Cf::BM * Cf::BN * 4;
+        const int nkt_all = d.K / Cf::KT * d.taps;
+        if (!d.splitk_ws || d.splitk_ws_bytes < need || (long)tilesM * tilesN > SPLITK_COUNTERS || ksplit < 2 || ksplit > 8 || ksplit > nkt_all) {
+            cdetr_set_error("cdetr_gemm (direct-to-LDS, split reduction): %d slices of %d k-tiles need splitk_ws >= %ld bytes (have %ld) and <= %d output tiles",
+                            ksplit, nkt_all, need, (long)d.splitk_ws_bytes, SPLITK_COUNTERS);
+            return CDETR_ERR_ARG;
+        }
+    }
+    constexpr int lds = Cf::LDS + (SPLIT ? 16 : 0);           // split reductions: the arrival flag
+    if (lds > 64 * 1024) {
         static bool raised = false;                             // per instantiation
         if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             if (e != hipSuccess) {
-                cdetr_set_error("cdetr_gemm (direct-to-LDS): hipFuncSetAttribute(%d): %s", Cf::LDS, hipGetErrorString(e));
+                cdetr_set_error("cdetr_gemm (direct-to-LDS): hipFuncSetAttribute(%d): %s", lds, hipGetErrorString(e));
                 return CDETR_ERR_LAUNCH;
             }
             raised = true;
         }
     }
-    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN), block(256);
-    hipLaunchKernelGGL(kern, grid, block, Cf::LDS, st, d, tilesM, tilesN, 0, 0);
+    dim3 grid(8 * ((tilesM + 7) / 8) * tilesN, SPLIT ? ksplit : 1), block(256);
+    hipLaunchKernelGGL(kern, grid, block, lds, st, d, tilesM, tilesN, 0, 0);
     return cdetr_launch_status("cdetr_gemm");
 }
 
@@ -543,7 +630,8 @@ bool cdetr_gemm_dl_halo_plan(const cdetr_gemm_desc& d, int tile, int& halo_R, in
     return 2 * nah * 4096 + 3 * BN * 128 + 256 + 4096 <= 160 * 1024;
 }
 
-// tile: 0 = 128x128, 1 = 128x64 (rows x channels), 2 = 64x128, 3 = 64x64; stages 2..4; stages 13 = the halo-resident 3x3 form (3-deep weight ring)
+// tile: 0 = 128x128, 1 = 128x64 (rows x channels), 2 = 64x128, 3 = 64x64; stages 2..4; stages 13 = the halo-resident 3x3 form (3-deep weight ring);
+// stages 200 + 10 * slices + ring depth (2 | 3) = the reduction cut into 2..8 slices per output tile (needs cdetr_gemm_desc.splitk_ws)
 int cdetr_gemm_dl_launch(const cdetr_gemm_desc& d, int tile, int stages, hipStream_t st) {
     const bool x3 = d.precision == 1;
     if (stages == 13) {
@@ -562,6 +650,24 @@ int cdetr_gemm_dl_launch(const cdetr_gemm_desc& d, int tile, int stages, hipStre
             default: DL_HALO(1, 1);
         }
 #undef DL_HALO
+    }
+    if (stages >= 200) {                                        // split reduction: stages = 200 + 10 * slices + ring depth (2 or 3)
+        const int ks = (stages - 200) / 10, S = (stages - 200) % 10;
+#define DL_SPLIT(FM, FN)                                                                                                                     \
+    return S == 3 ? (x3 ? launch_dl<FM, FN, 3, 3, false, false, true>(d, st, ks) : launch_dl<FM, FN, 1, 3, false, false, true>(d, st, ks))    \
+                  : (x3 ? launch_dl<FM, FN, 3, 2, false, false, true>(d, st, ks) : launch_dl<FM, FN, 1, 2, false, false, true>(d, st, ks))
+        if (S == 2 || S == 3) {
+            switch (tile) {
+                case 0: DL_SPLIT(2, 2);
+                case 1: DL_SPLIT(2, 1);
+                case 2: DL_SPLIT(1, 2);
+                case 3: DL_SPLIT(1, 1);
+                default: break;
+            }
+        }
+#undef DL_SPLIT
+        cdetr_set_error("cdetr_gemm (direct-to-LDS, split reduction): no kernel for tile %d with stages code %d", tile, stages);
+        return CDETR_ERR_UNSUPPORTED;
     }
     static const bool late = getenv("CDETR_DL_LATE_EPILOGUE") != nullptr;       // A/B: epilogue operands fetched after the k-loop (round 3)
     if (stages >= 100) {                                        // phase probe (tools/dl_probe.py): splitk_ws receives the time stamps

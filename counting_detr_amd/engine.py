@@ -246,6 +246,9 @@ class Trainer:
         self._pf_post_us = int(os.environ.get("CDETR_PF_POST_US", 30))          # head start of the solve over the prefetched stage's workgroups
         self._pf_delay_us = int(os.environ.get("CDETR_PF_DELAY_US", 0))        # "single" layout only: fixed delay in front of the prefetched stage
         self._pf_eager = os.environ.get("CDETR_PF_EAGER", "0") == "1"
+        # workgroups of the in-line tail launch (0 = the library's default, 384): 8.82 / 8.73 / 8.70 / 8.67 ms at 384 / 768 / 2048 / 4096, flat to
+        # 8192, +0.04 at 16384 (profiles/r5_ab_tail_wgrad.txt)
+        self._tail_wg_target = int(os.environ.get("CDETR_TAIL_WG_TARGET", "6144"))
         self._tail_inline = float(os.environ.get("CDETR_TAIL_INLINE", getattr(args, "wgrad_tail_inline", 1.0)))   # share of layer2's weight gradients kept on the main stream
         self._frozen = {}                       # image shape -> frozen-stage buffers + graph (see "frozen-stage prefetch")
         self._pf_stream = self._pf_pool = self._wg_stream = None
@@ -960,6 +963,10 @@ class Trainer:
                         q_all = list(ops._WG_QUEUE)
                         k = int(round(len(q_all) * (1.0 - self._tail_inline)))
                         ops._WG_QUEUE[:] = q_all[k:]
+                        # ... and have the chip to themselves once the side stream has drained: many short pixel slices instead of the 1.5
+                        # workgroups per CU that suit a launch beside the data-gradient chain (cdetr_wgrad_desc.wg_target; profiles/r5_ab_tail_wgrad.txt)
+                        for item in ops._WG_QUEUE:
+                            item[0].wg_target = self._tail_wg_target
                         ops.wgrad_flush()
                         ops._WG_QUEUE[:] = q_all[:k]
                 gw = None

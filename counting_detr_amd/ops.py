@@ -206,9 +206,11 @@ class gemm_queue:
 
 
 def wgrad_raw(dY, ldy, X, ldx, dW, ldw, P, Nout, Cin, taps=1, w_scale=None, geom=None, batch=1, sY=0, sX=0, sW=0,
-              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False, dY16=None, X16=None, precision=None):
-    """dY16 / X16: optional bf16 twins of dY / X (same shape and strides in elements): the plain-bf16 kernel reads them instead."""
+              dbias=None, batch_inner=0, sY2=0, sX2=0, sW2=0, may_defer=False, dY16=None, X16=None, precision=None, wg_target=0):
+    """dY16 / X16: optional bf16 twins of dY / X (same shape and strides in elements): the plain-bf16 kernel reads them instead.
+    wg_target: cdetr_wgrad_desc.wg_target (0 = the library's default; a launch that has the chip to itself asks for more workgroups)."""
     d = WgradDesc()
+    d.wg_target = wg_target
     d.dY16, d.X16 = ptr(dY16), ptr(X16)
     d.batch_inner, d.sY2, d.sX2, d.sW2 = batch_inner, sY2, sX2, sW2
     d.P, d.Nout, d.Cin, d.taps, d.batch = P, Nout, Cin, taps, batch

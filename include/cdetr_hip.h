@@ -146,7 +146,10 @@ typedef struct {
     float* dbias;
     cdetr_conv_geom g; /* mode DENSE or CONV_FWD (p = output pixel) */
     int32_t batch_inner; /* two-level batch, as in cdetr_gemm_desc */
-    int32_t pad_;
+    int32_t wg_target;   /* 0 = default.  > 0: the number of workgroups the launch (for cdetr_wgrad_group: the grouped launch this problem   */
+                         /* becomes part of -- the largest request of its members) should spread its pixel slices over.  The default (384 =    */
+                         /* 1.5 per CU) suits a launch that runs BESIDE another stream's chain; a caller that knows the launch has the chip to  */
+                         /* itself (the last weight gradients of a step) asks for more.  Results do not depend on it beyond fp32 summation order. */
     int64_t sY2, sX2, sW2;
     const void* dY16;  /* optional bf16 TWINS of dY / X (same shapes, leading dimensions and batch strides, in elements): with        */
     const void* X16;   /* precision 3 (plain bf16) the kernel reads these instead -- half the operand bytes, no conversion at staging. */

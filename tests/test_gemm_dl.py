@@ -71,6 +71,79 @@ def test_dl_dense_rows(tile, stages, precision):
         _check_planes(y, y16, y16lo)
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3])
+@pytest.mark.parametrize("ring", [2, 3])
+@pytest.mark.parametrize("slices", [2, 3, 4])
+@pytest.mark.parametrize("precision", [1, 3], ids=["bf16x3", "bf16"])
+def test_dl_split_reduction(tile, ring, slices, precision):
+    """The reduction of an output tile cut into 2..4 slices (stages code 200 + 10 * slices + ring depth): dense rows with ragged M / N and a
+    3x3 convolution (slices that start inside a tap and cross tap boundaries), full epilogue.  The result must not depend on which slice
+    arrives last: two launches are bit-identical, and equal to fp64 math on the split operands within the accumulation tolerance; the
+    unsplit kernels that share the arrival counters still run right afterwards (the counters are left zero)."""
+    from counting_detr_amd import ops
+    code = 200 + 10 * slices + ring
+    for (M, N, K) in [(1000, 256, 512), (333, 132, 256), (5000, 256, 1024)]:
+        x = torch.randn(M, K, generator=g(M + K)).to(DEV)
+        w = (torch.randn(N, K, generator=g(N + K)) / K ** 0.5).to(DEV)
+        sc = (1 + 0.2 * torch.randn(N, generator=g(7))).to(DEV)
+        bias = torch.randn(N, generator=g(8)).to(DEV)
+        resid = torch.randn(M, N, generator=g(9)).to(DEV)
+        gate = torch.randn(M, N, generator=g(10)).to(DEV)
+        mir, sp = _mirror(w, sc)
+        xh, xl = ops.split_planes(x)
+        outs = []
+        for rep in range(2):
+            y = torch.empty(M, N, device=DEV)
+            y16 = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            y16lo = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            ops.gemm_raw(x, K, w, K, y, N, M, N, K, w_scale=sc, bias=bias, relu=True, resid=resid, ldr=N, gate=gate, ldg=N, B_split=sp,
+                         precision=precision, A16=xh, A16lo=xl, C16=y16, C16lo=y16lo, dl=(tile, code), out_scale=0.5,
+                         gate16=gate.bfloat16() if rep else None)
+            _check_planes(y, y16, y16lo)
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]), "the split sum depends on the arrival order"
+        ws = (w * sc[:, None])
+        wh, wl = _split_ref(ws)
+        if precision == 1:
+            ref = (xh.double() + xl.double()) @ (wh.double() + wl.double()).t() - xl.double() @ wl.double().t()
+        else:
+            ref = xh.double() @ wh.double().t()
+        ref = (ref + bias.double()) * 0.5 + resid.double()
+        ref = torch.where(gate.double() > 0, ref, torch.zeros_like(ref)).clamp(min=0)
+        err = (outs[0].double() - ref).abs().max().item()
+        assert err <= 3e-5 * (ref.abs().max().item() + 1.0), f"M={M} N={N} K={K}: {err:.3e}"
+        # whatever cdetr_gemm picks for this problem (the register-staged kernels' own split reductions share the arrival counters) still
+        # runs right on the same scratch afterwards
+        y2 = torch.empty(M, N, device=DEV)
+        ops.gemm_raw(x, K, w, K, y2, N, M, N, K, w_scale=sc, bias=bias, relu=True, resid=resid, ldr=N, gate=gate, ldg=N, B_split=sp, precision=1, out_scale=0.5)
+        ref1 = (xh.double() + xl.double()) @ (wh.double() + wl.double()).t() - xl.double() @ wl.double().t()
+        ref1 = (ref1 + bias.double()) * 0.5 + resid.double()
+        ref1 = torch.where(gate.double() > 0, ref1, torch.zeros_like(ref1)).clamp(min=0)
+        assert (y2.double() - ref1).abs().max().item() <= 3e-5 * (ref1.abs().max().item() + 1.0)
+    # 3x3, dilation 2: 9 taps x (Cin / KT) k-tiles
+    Nb, H, W, Cin, Cout = 2, 19, 23, 128, 132
+    x = torch.randn(Nb, H, W, Cin, generator=g(1)).to(DEV)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g(2)) / (Cin * 9) ** 0.5).to(DEV).contiguous(memory_format=torch.channels_last)
+    sc = (1 + 0.2 * torch.randn(Cout, generator=g(3))).to(DEV)
+    bias = torch.randn(Cout, generator=g(4)).to(DEV)
+    geo, Ho, Wo = ops.conv_geom_fwd(H, W, 3, 3, 1, 2, 2)
+    resid = torch.randn(Nb, Ho, Wo, Cout, generator=g(5)).to(DEV)
+    mir, sp = _mirror(w, sc)
+    xh, xl = ops.split_planes(x)
+    y = torch.empty(Nb, Ho, Wo, Cout, device=DEV)
+    y16 = torch.empty(Nb, Ho, Wo, Cout, device=DEV, dtype=torch.bfloat16)
+    y16lo = torch.empty_like(y16)
+    ops.gemm_raw(x, Cin, w, 9 * Cin, y, Cout, Nb * Ho * Wo, Cout, Cin, taps=9, w_scale=sc, bias=bias, relu=True, resid=resid,
+                 ldr=Cout, geom=geo, B_split=sp, precision=precision, A16=xh, A16lo=xl, C16=y16, C16lo=y16lo, dl=(tile, code))
+    wh, wl = _split_ref(w * sc.view(-1, 1, 1, 1))
+    conv = lambda a, b: F.conv2d(a.double().permute(0, 3, 1, 2).cpu(), b.double().cpu(), stride=1, padding=2, dilation=2).permute(0, 2, 3, 1)   # noqa: E731
+    ref = conv(xh.double() + xl.double(), wh.double() + wl.double()) - conv(xl, wl) if precision == 1 else conv(xh, wh)
+    ref = (ref + bias.double().cpu() + resid.double().cpu()).clamp(min=0)
+    err = (y.double().cpu() - ref).abs().max().item()
+    assert err <= 3e-5 * (ref.abs().max().item() + 1.0), f"3x3: {err:.3e}"
+    _check_planes(y, y16, y16lo)
+
+
 @pytest.mark.parametrize("tile,stages", [(0, 3), (1, 3), (2, 2), (3, 4)])
 @pytest.mark.parametrize("precision", [1, 3], ids=["bf16x3", "bf16"])
 @pytest.mark.parametrize("geom", [(3, 1, 1, 1), (3, 2, 1, 1), (3, 1, 2, 2), (1, 2, 0, 1)], ids=["3x3", "3x3s2", "3x3d2", "1x1s2"])

@@ -819,6 +819,41 @@ def test_wgrad_group_matches_individual_calls(precision):
         close(db, rb, msg=f"group dbias {P}x{Nout}x{Cin}", rtol=5e-4, atol_scale=6e-5)
 
 
+@pytest.mark.parametrize("target", [0, 1536, 6144, 50000])
+def test_wgrad_workgroup_target(target):
+    """cdetr_wgrad_desc.wg_target (the step's last weight-gradient launch asks for many short pixel slices: it has the chip to itself):
+    single launches and a grouped launch, fp32 operands and bf16 twins, 1x1 and 3x3 -- the same sums for every target (fp64 reference)."""
+    from counting_detr_amd import ops
+    cases = [(20000, 512, 128, 1), (20000, 128, 512, 1), (5000, 256, 1024, 1), (1500, 132, 68, 1), (3200, 128, 128, 9)]
+    for grouped in (False, True):
+        refs, outs, keep = [], [], []
+        with ops.wgrad_queue():
+            for k, (P, Nout, Cin, taps) in enumerate(cases):
+                geom = None
+                if taps == 9:
+                    geom, Ho, Wo = ops.conv_geom_fwd(40, 40, 3, 3, 1, 1, 1)
+                    x4 = torch.randn(2, 40, 40, Cin, generator=g(5 * k))
+                    dY = torch.randn(2 * Ho * Wo, Nout, generator=g(5 * k + 1))
+                    X = x4.reshape(-1, Cin)
+                    w = torch.zeros(Nout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+                    y = torch.nn.functional.conv2d(x4.bfloat16().double().permute(0, 3, 1, 2), w, padding=1)
+                    (y * dY.bfloat16().double().view(2, Ho, Wo, Nout).permute(0, 3, 1, 2)).sum().backward()
+                    ref = w.grad.permute(0, 2, 3, 1).reshape(Nout, 9 * Cin)
+                else:
+                    dY = torch.randn(P, Nout, generator=g(5 * k + 1))
+                    X = torch.randn(P, Cin, generator=g(5 * k))
+                    ref = dY.bfloat16().double().t() @ X.bfloat16().double()
+                dYd, Xd = dY.to(DEV), X.to(DEV)
+                dW = torch.zeros(Nout, taps * Cin, device=DEV)
+                tw = k % 2 == 0 and Nout % 8 == 0 and Cin % 8 == 0
+                d16, x16 = (dYd.bfloat16(), Xd.bfloat16()) if tw else (None, None)
+                ops.wgrad_raw(dYd, Nout, Xd, Cin, dW, taps * Cin, dYd.shape[0], Nout, Cin, taps=taps, geom=geom, may_defer=grouped, dY16=d16, X16=x16,
+                              precision=3, wg_target=target)
+                refs.append(ref); outs.append(dW); keep += [dYd, Xd, d16, x16]
+        for (P, Nout, Cin, taps), rw, dW in zip(cases, refs, outs):
+            close(dW, rw, msg=f"wg_target {target} grouped {grouped}: {P}x{Nout}x{Cin}x{taps}", rtol=5e-4, atol_scale=6e-5)
+
+
 def test_sine_embed_matches_reference_formula():
     """cdetr_sine_embed fwd / bwd == the tensor-op formula of A2/models/transformer.py:474-494 (fp64)."""
     import math

@@ -14,6 +14,8 @@ GROUPS = os.environ.get("DL_SWEEP_GROUPS", "0") == "1"      # also time the inte
 CONFIGS = [(0, 2), (0, 3), (1, 2), (1, 3), (1, 4), (2, 3), (3, 3), (3, 4)]
 if os.environ.get("DL_SWEEP_SHALLOW") == "1":      # round 5: 2-deep rings on the small tiles (32 KB of LDS: 5 workgroups per CU instead of 3)
     CONFIGS = [(1, 2), (1, 3), (2, 2), (2, 3), (3, 2), (3, 3)]
+if os.environ.get("DL_SWEEP_SPLIT") == "1":        # round 5: split reductions (stages code 200 + 10 * slices + ring depth) next to the unsplit tiles
+    CONFIGS = [(0, 3), (2, 3), (3, 3), (3, 223), (3, 233), (3, 243), (3, 222), (3, 242), (2, 223), (2, 233), (0, 223), (0, 233)]
 if os.environ.get("DL_SWEEP_ONLY"):                # comma-separated indices into FWD
     _only = [int(x) for x in os.environ["DL_SWEEP_ONLY"].split(",")]
 # (M rows, N, K, taps, conv geometry (H, W, stride, pad, dil) or None, epilogue with residual)
@@ -84,6 +86,8 @@ def run(shape, precision, mult=1):
                          B_split=sp, B16=w16 if precision == 3 else None, precision=precision, A16=Ah[i], A16lo=Al[i] if precision == 1 else None, C16=C16[i],
                          C16lo=C16l[i] if C16l else None, dl=(tile, stages))
         if precision == 3 and K % 64:
+            continue
+        if stages >= 200 and ((stages - 200) // 10 > K * taps // (64 if precision == 3 else 32) or M * N > (1 << 22)):
             continue
         row[(tile, stages)] = bench(new, nsets)
     return row, 2.0 * M * N * K * taps

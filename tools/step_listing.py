@@ -1,5 +1,6 @@
 """Kernel-by-kernel listing of the last captured step between two marker kernels, from a rocprofv3 --kernel-trace CSV.
-    python tools/step_listing.py kernel_trace.csv START_MARKER END_MARKER"""
+    python tools/step_listing.py kernel_trace.csv START_MARKER END_MARKER [STEPS_BACK]
+STEPS_BACK = 0 (default): the last step of the run (a pipelined replay prefetches nothing there); 1: the step before it (steady state)."""
 import csv, sys, re
 rows = []
 with open(sys.argv[1]) as f:
@@ -7,7 +8,8 @@ with open(sys.argv[1]) as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size_X", r.get("Grid_Size", "")), r.get("Workgroup_Size_X", r.get("Workgroup_Size", ""))))
 rows.sort()
 ends = [i for i, r in enumerate(rows) if "adamw_finish" in r[2]]
-step = rows[ends[-2] + 1:ends[-1] + 1]
+back = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+step = rows[ends[-2 - back] + 1:ends[-1 - back] + 1]
 a = next(i for i, r in enumerate(step) if sys.argv[2] in r[2])
 b = next(i for i, r in enumerate(step) if sys.argv[3] in r[2] and i > a)
 prev = step[a][0]
