@@ -881,6 +881,8 @@ class AggrProjFn(torch.autograd.Function):
         z = torch.zeros(B * d * Cc + B * Cc, device=x.device, dtype=torch.float32)      # dW_eff and dpf: one fill
         dWeff, dpf = z[:B * d * Cc].view(B, d, Cc), z[B * d * Cc:].view(B, Cc)
         gb = grad_buffer(bparam) if bparam.requires_grad else None
+        # (in line on the main chain: the exemplar gradient below needs it.  More, shorter pixel slices -- cdetr_wgrad_desc.wg_target -- make it
+        # SLOWER: 33.9 -> 42.6 us at 1536 workgroups, the 4 MB of dW_eff are written once per slice)
         wgrad_raw(dy, d, x, Cc, dWeff, Cc, h * w, d, Cc, batch=B, sY=h * w * d, sX=h * w * Cc, sW=d * Cc, dbias=gb)
         W2d = wparam.detach().reshape(d, -1)
         gw = grad_buffer(wparam).reshape(d, -1) if wparam.requires_grad else None

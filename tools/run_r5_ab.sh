@@ -6,5 +6,5 @@ mkdir -p $(dirname $out)
 F="--no-cpu-baseline --no-alt --no-extra --no-inference --no-real-data"
 for r in $(seq 1 $rounds); do for v in "$@"; do
   e="$v"; [ "$v" = "-" ] && e="CDETR_NOTHING=1"
-  echo -n "round $r [$v]: "; env $e timeout 300 python bench.py --mode graph --steps 30 --warmup 5 $F 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), 'median', round(d['step_ms']['median'],3))"
+  echo -n "round $r [$v]: "; env $e timeout 300 python bench.py --mode graph --steps ${STEPS:-30} --warmup 5 $F 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), 'median', round(d['step_ms']['median'],3))"
 done; done | tee $out
