@@ -6,6 +6,7 @@ one piece REMOVED at a time (results are wrong on purpose -- this prices optimis
   mirror     the data-gradient weight images are not rewritten
   lsap       the assignment solve returns at once (identity assignment)
   adamw      no optimizer pass
+  wgrad_dec / wgrad_enc / wgrad_tr   no parameter gradient of the decoder stack / the encoder stack / both (they run beside layer4's data gradients)
 usage: python tools/ablate.py [variant ...]      (default: all; each in its own trainer, same process)"""
 import os
 import sys
@@ -42,6 +43,20 @@ def run(variant):
     elif variant == "wgrad_bb":
         orig = ops.conv_wgrad_
         patch(ops, "conv_wgrad_", lambda *a, **k: None)
+    elif variant in ("wgrad_dec", "wgrad_enc", "wgrad_tr"):      # the decoder's / the encoder's / both stacks' parameter gradients only
+        def without_wg(fn):
+            def run_(ctx, *a, **k):
+                w = ops._wg
+                ops._wg = lambda *aa, **kk: None
+                try:
+                    return fn(ctx, *a, **k)
+                finally:
+                    ops._wg = w
+            return staticmethod(run_)
+        if variant in ("wgrad_dec", "wgrad_tr"):
+            patch(ops.DecoderStackFn, "_backward", without_wg(ops.DecoderStackFn._backward))
+        if variant in ("wgrad_enc", "wgrad_tr"):
+            patch(ops.EncoderLayerFn, "_backward", without_wg(ops.EncoderLayerFn._backward))
     elif variant == "lsap":
         def fake(cost, plan):
             idx = torch.zeros((2, plan.B, plan.Mmax), dtype=torch.int64, device=cost.device)
