@@ -122,7 +122,10 @@ int cdetr_gemm(const cdetr_gemm_desc* d, void* stream);
  * whose operands are given pre-split (A16 [+ A16lo] and B_split); for tests and tile sweeps.  tile: 0 = 128x128, 1 = 128x64,
  * 2 = 64x128, 3 = 64x64 (rows x channels per workgroup); stages: LDS ring depth 2..4 (3 for tile 0), or 13 = the halo-resident form for
  * stride-1 3x3 rows with pad == dil over a same-size map (forward or data-gradient rows; the pixel rows around a tile are staged once per
- * channel chunk, the nine taps read them at row offsets; <= 448 halo rows, <= 160 KB of LDS).  CDETR_ERR_UNSUPPORTED when the
+ * channel chunk, the nine taps read them at row offsets; <= 448 halo rows, <= 160 KB of LDS), or 200 + 10 * slices + ring depth (2 | 3) =
+ * the reduction of every output tile cut into 2..8 slices (grid.y): each slice parks its partial tile in cdetr_gemm_desc.splitk_ws
+ * (4096 arrival counters + tiles * slices * tile bytes), the slice that arrives last adds the partials in slice order and runs the
+ * fused epilogue (bit-identical whichever slice that is; needs slices <= k-tiles).  CDETR_ERR_UNSUPPORTED when the
  * operand formats / alignment do not allow it (cdetr_last_error says why).                                                        */
 int cdetr_gemm_dl(const cdetr_gemm_desc* d, int32_t tile, int32_t stages, void* stream);
 /* n INDEPENDENT GEMMs submitted together (same results as n cdetr_gemm calls; no problem may read another's output).  Few-row
