@@ -249,6 +249,7 @@ class Trainer:
         # workgroups of the in-line tail launch (0 = the library's default, 384): 8.82 / 8.73 / 8.70 / 8.67 ms at 384 / 768 / 2048 / 4096, flat to
         # 8192, +0.04 at 16384 (profiles/r5_ab_tail_wgrad.txt)
         self._tail_wg_target = int(os.environ.get("CDETR_TAIL_WG_TARGET", "6144"))
+        self._zero_arena_on = os.environ.get("CDETR_ZERO_ARENA", "1") != "0"      # A/B: 0 = the backward's accumulators are torch.zeros inside B
         self._tail_inline = float(os.environ.get("CDETR_TAIL_INLINE", getattr(args, "wgrad_tail_inline", 1.0)))   # share of layer2's weight gradients kept on the main stream
         self._frozen = {}                       # image shape -> frozen-stage buffers + graph (see "frozen-stage prefetch")
         self._pf_stream = self._pf_pool = self._wg_stream = None
@@ -475,6 +476,8 @@ class Trainer:
         """losses.backward().  `defer_trunk`: stop at the backbone (the gradient w.r.t. layer4's output is parked in
         `self._trunk_pending`, a backbone.TrunkBackward) -- the caller runs the three backbone segments itself (`_trunk_segment`)."""
         from . import ops
+        if ops.ZERO_ARENA is not None:
+            ops.ZERO_ARENA.reset()
         try:
             with ops.wgrad_queue():      # small parameter gradients outside the fused layer nodes (heads, positional MLPs): grouped
                 if defer_trunk:
@@ -910,10 +913,22 @@ class Trainer:
 
     def _capture_chain_pieces(self, st, world, warmup):
         from . import _ffi, ops
-        s, mode = self._capture_warmup(st, world, warmup)
+        # the backward's zeroed accumulators as slices of one buffer that Z fills beside the forward (ops.ZeroArena): measured by one
+        # stream-ordered forward + backward (the warm-up step when there is one), allocated OUTSIDE the graphs' pool -- Z runs beside F, whose
+        # temporaries share that pool
+        arena = ops.ZeroArena() if self._zero_arena_on else None
+        with ops.scope(ZERO_ARENA=arena):
+            s, mode = self._capture_warmup(st, world, warmup)
+            if arena is not None and arena.need == 0:
+                with torch.cuda.stream(s):
+                    self._fwd_bwd(st["images"], st["mask"], st["rects"], st["targets"], st["num_boxes"])
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+        if arena is not None:
+            arena.buf = torch.zeros(max(arena.need, 64), device=self.device, dtype=torch.float32)
         pf, wg = self._side_streams()
         G = torch.cuda.CUDAGraph
-        e = {"F": G()}
+        e = {"F": G(), "zarena": arena}
         sig2 = self._sig.data_ptr() + 8                  # "the backbone's forward is done": releases Z under the encoder / decoder
         after = (lambda: _ffi.check(_ffi.lib().cdetr_flag_signal(sig2, _ffi.stream_ptr()), "cdetr_flag_signal")) if self._z_late else None
         with ops.scope(AFTER_BACKBONE=after):
@@ -924,11 +939,13 @@ class Trainer:
         e["Z"] = G()
         with torch.cuda.graph(e["Z"], stream=pf, **mode):
             self._zero_and_mirror()
+            if arena is not None:
+                arena.buf.zero_()
         # every parameter gradient above the backbone (heads, decoder, encoder, projection) is collected instead of submitted inside B:
         # they become W0 on the weight-gradient stream, beside the backbone's data-gradient chain
         held = []                                       # operands of the side-stream weight gradients: alive until every main piece that may
         #                                                 run beside them has been captured (its tensors must not take their memory)
-        with ops.wgrad_queue(), ops.scope(WG_DEFER_NESTED=True):
+        with ops.wgrad_queue(), ops.scope(WG_DEFER_NESTED=True, ZERO_ARENA=arena):
             e["B"] = G()                                # solve + criterion + the backward down to the backbone
             with torch.cuda.graph(e["B"], stream=s, **mode):
                 # "the solve is next": releases the prefetch stream (cdetr_flag_wait)

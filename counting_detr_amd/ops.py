@@ -64,7 +64,7 @@ class scope:
     gradients fork to side streams, the release signal behind the backbone), set for the block and restored on exit whatever happens inside.
     The same contract as `arithmetic`: engines never leave a module-level switch changed behind their back; the module values stay the
     defaults of code that runs outside any engine.  Scopes nest."""
-    _KEYS = ("MIRROR", "BRANCH_BESIDE", "WGRAD_EVERY", "AFTER_BACKBONE", "WG_DEFER_NESTED")
+    _KEYS = ("MIRROR", "BRANCH_BESIDE", "WGRAD_EVERY", "AFTER_BACKBONE", "WG_DEFER_NESTED", "ZERO_ARENA")
 
     def __init__(self, **kw):
         assert all(k in self._KEYS for k in kw), kw
@@ -79,6 +79,39 @@ class scope:
     def __exit__(self, *exc):
         globals().update(self.saved)
         return False
+
+
+class ZeroArena:
+    """The backward's zeroed accumulators (the RCDA key / value gradients of both stacks, the decoder's query-position sums, the projection's
+    per-image weight gradient) as slices of ONE buffer an engine owns and zero-fills on its side stream, beside the forward, together with the
+    gradient arena -- instead of three tensor-library fills on the backward's critical path (7-17 + 7 + 5 us, tools/step_listing.py).
+    `buf is None`: a measuring pass -- requests are served by torch.zeros and their total recorded in `need`.  `reset()` opens a backward."""
+
+    def __init__(self):
+        self.buf, self.need, self.off = None, 0, 0
+
+    def reset(self):
+        self.off = 0
+
+    def take(self, n, device):
+        n_al = (n + 63) & ~63                      # 256-byte slices
+        if self.buf is None:
+            self.off += n_al
+            self.need = max(self.need, self.off)
+            return torch.zeros(n, device=device, dtype=torch.float32)
+        if self.off + n_al > self.buf.numel():     # (a backward that asks for more than the measured one did: never silently alias)
+            raise RuntimeError(f"ZeroArena: {self.off + n_al} elements requested, {self.buf.numel()} measured")
+        t = self.buf[self.off:self.off + n]
+        self.off += n_al
+        return t
+
+
+ZERO_ARENA = None
+
+
+def zeros_flat(n, device):
+    """n zeroed fp32 elements: a slice of the engine's pre-zeroed arena (ops.scope(ZERO_ARENA=...)) or a fresh torch.zeros."""
+    return ZERO_ARENA.take(n, device) if ZERO_ARENA is not None else torch.zeros(n, device=device, dtype=torch.float32)
 
 
 class _Timed:
@@ -878,7 +911,7 @@ class AggrProjFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         gemm_raw(dy, d, WeffT, d, dx, Cc, h * w, Cc, d, batch=B, sA=h * w * d, sB=Cc * d, sC=h * w * Cc, precision=bwd_precision())
-        z = torch.zeros(B * d * Cc + B * Cc, device=x.device, dtype=torch.float32)      # dW_eff and dpf: one fill
+        z = zeros_flat(B * d * Cc + B * Cc, x.device)      # dW_eff and dpf: one fill (or none: ops.ZeroArena)
         dWeff, dpf = z[:B * d * Cc].view(B, d, Cc), z[B * d * Cc:].view(B, Cc)
         gb = grad_buffer(bparam) if bparam.requires_grad else None
         # (in line on the main chain: the exemplar gradient below needs it.  More, shorter pixel slices -- cdetr_wgrad_desc.wg_target -- make it
@@ -1518,7 +1551,7 @@ class EncoderStackFn(torch.autograd.Function):
         c0 = ctx.ctxs[0]
         N, H, W, Cc, E, nh = c0.dims
         zn = N * H * W * E + N * W * E + N * H * E                  # per layer: dV + both key gradients (rcda_zero_numel)
-        zall = torch.zeros(len(ctx.ctxs) * zn, device=dX.device, dtype=torch.float32)      # ONE fill for the whole stack
+        zall = zeros_flat(len(ctx.ctxs) * zn, dX.device)      # ONE fill for the whole stack (or none: ops.ZeroArena)
         with wgrad_queue():
             for li in range(len(ctx.ctxs) - 1, -1, -1):
                 c = ctx.ctxs[li]
@@ -1641,7 +1674,7 @@ class DecoderStackFn(torch.autograd.Function):
         M = N * L
         dev = mem2.device
         zn = N * H * W * E + N * W * E + N * H * E                              # per layer: dV + both key gradients (rcda_zero_numel)
-        zall = torch.zeros(3 * M * E + len(layers) * zn, device=dev, dtype=torch.float32)     # ONE fill for the whole stack's accumulators
+        zall = zeros_flat(3 * M * E + len(layers) * zn, dev)     # ONE fill for the whole stack's accumulators (or none: ops.ZeroArena)
         acc = zall[:3 * M * E].view(3, M, E)                                    # d(query_pos), d(query_pos_x), d(query_pos_y)
         acc_p, acc_x, acc_y = acc[0], acc[1], acc[2]
         dMem = dKrm = dKcm = None

@@ -79,3 +79,28 @@ def test_product_never_imports_oracle():
     for fn in os.listdir(pkg):
         if fn.endswith(".py"):
             assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(pkg, fn)).read(), flags=re.M), fn
+
+
+def test_zero_arena_host_logic():
+    """ops.ZeroArena (the backward's zeroed accumulators as slices of one engine-owned buffer): a measuring pass serves torch.zeros and
+    records the high-water mark of one backward; the serving pass hands out aligned, disjoint slices in the same order and refuses to
+    alias when a backward asks for more than was measured."""
+    import torch
+    from counting_detr_amd import ops
+    a = ops.ZeroArena()
+    with ops.scope(ZERO_ARENA=a):
+        for _ in range(2):                       # two backwards of the same shape: the need is a maximum, not a sum
+            a.reset()
+            t1, t2 = ops.zeros_flat(100, "cpu"), ops.zeros_flat(7, "cpu")
+            assert t1.numel() == 100 and t2.numel() == 7 and float(t1.abs().sum() + t2.abs().sum()) == 0.0
+    assert a.need == 128 + 64 and ops.ZERO_ARENA is None
+    a.buf = torch.zeros(a.need)
+    with ops.scope(ZERO_ARENA=a):
+        a.reset()
+        s1, s2 = ops.zeros_flat(100, "cpu"), ops.zeros_flat(7, "cpu")
+        assert s1.data_ptr() == a.buf.data_ptr() and s2.data_ptr() == a.buf.data_ptr() + 128 * 4
+        s1.fill_(1.0)
+        assert float(s2.sum()) == 0.0            # disjoint
+        with pytest.raises(RuntimeError):
+            ops.zeros_flat(1, "cpu")
+    assert ops.zeros_flat(5, "cpu").numel() == 5   # outside any engine: a plain fill
