@@ -66,7 +66,7 @@ class MirrorItem(C.Structure):
                 ("tile0", C.c_int32), ("transpose", C.c_int32), ("pad_", C.c_int32), ("dst_hi", _p)]
 
 
-EXPORTS = ["cdetr_gemm", "cdetr_gemm_dl", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_layernorm_bwd_merge", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_posadd2",
+EXPORTS = ["cdetr_gemm", "cdetr_gemm_dl", "cdetr_gemm_group", "cdetr_wgrad", "cdetr_wgrad_group", "cdetr_colsum", "cdetr_sumsq", "cdetr_adamw_step", "cdetr_adamw_step2", "cdetr_relu_mask", "cdetr_relu_mask2", "cdetr_layernorm_fwd", "cdetr_layernorm_fwd_add", "cdetr_layernorm_bwd", "cdetr_layernorm_bwd_merge", "cdetr_groupnorm_fwd", "cdetr_groupnorm_bwd", "cdetr_groupnorm_fwd_ws", "cdetr_groupnorm_bwd_ws", "cdetr_posadd2",
            "cdetr_hw_reduce", "cdetr_posadd2_hw_reduce", "cdetr_bcast_add2", "cdetr_bcast_add2_sum", "cdetr_add2", "cdetr_grad_merge", "cdetr_sine_embed", "cdetr_sine_embed_bwd", "cdetr_maxpool3x3s2", "cdetr_maxpool3x3s2_split", "cdetr_weight_mirror", "cdetr_weight_images", "cdetr_rcda_fwd", "cdetr_rcda_bwd", "cdetr_mha_fwd", "cdetr_mha_bwd",
            "cdetr_mask_prep", "cdetr_stem_pack", "cdetr_exemplar_fwd", "cdetr_exemplar_bwd", "cdetr_aggr_weight_fwd", "cdetr_aggr_weight_bwd",
            "cdetr_box_head_fwd", "cdetr_box_head_bwd", "cdetr_match_cost", "cdetr_lsap", "cdetr_criterion_fwd", "cdetr_criterion_bwd", "cdetr_last_error", "cdetr_abi_version", "cdetr_delay", "cdetr_flag_signal", "cdetr_flag_wait"]
@@ -123,6 +123,10 @@ def lib():
         L.cdetr_groupnorm_fwd.argtypes = [_p] * 6 + [C.c_int32] * 4 + [C.c_float, _p]
         L.cdetr_groupnorm_bwd.restype = C.c_int
         L.cdetr_groupnorm_bwd.argtypes = [_p] * 8 + [C.c_int32] * 4 + [_p]
+        L.cdetr_groupnorm_fwd_ws.restype = C.c_int
+        L.cdetr_groupnorm_fwd_ws.argtypes = [_p] * 6 + [C.c_int32] * 4 + [C.c_float, _p, C.c_int64, _p]
+        L.cdetr_groupnorm_bwd_ws.restype = C.c_int
+        L.cdetr_groupnorm_bwd_ws.argtypes = [_p] * 8 + [C.c_int32] * 4 + [_p, C.c_int64, _p]
         L.cdetr_posadd2.restype = C.c_int
         L.cdetr_posadd2.argtypes = [_p] * 5 + [C.c_int32] * 4 + [_p]
         L.cdetr_posadd2_hw_reduce.restype = C.c_int

@@ -369,6 +369,206 @@ __global__ __launch_bounds__(GN_NT_BWD) void gn_bwd_kernel(const float* __restri
     }
 }
 
+
+// ---- GroupNorm with the pixels of an image SPLIT over workgroups (C == 256: one wave = one full 1 KB pixel row) -------------------------
+// The one-workgroup-per-(image, group) kernels above read 32-byte runs at a 1 KB stride on 64 workgroups (18 / 36 us for the projection's
+// 2 x 2500 x 256 map, on the step's main chain).  Here a workgroup owns GN_CH consecutive pixels x all channels (coalesced rows, B * P / GN_CH
+// workgroups), and the group statistics cross workgroups through a small workspace: launch 1 leaves per-(image, chunk, group) partials
+// -- forward: (count, mean, centred second moment) of the chunk, merged with Chan's update in chunk order, so the variance stays a centred one;
+// backward: the two plain sums -- launch 2 merges them (every workgroup for itself, same order: same result everywhere) and applies.
+constexpr int GN_CH = 32;         // pixels per workgroup: 4 waves x 8 rows, all 8 row loads of a wave in flight together
+
+__device__ __forceinline__ float gn_group_total(float v, const int cgq, float (*red)[64], const int w, const int lane) {
+    for (int m = 1; m < cgq; m <<= 1) v += __shfl_xor(v, m);       // the lanes (channel quads) of one group
+    __syncthreads();
+    red[w][lane] = v;
+    __syncthreads();
+    const int l0 = lane & ~(cgq - 1);
+    return (red[0][l0] + red[1][l0]) + (red[2][l0] + red[3][l0]);   // the four waves (pixel rows), fixed order
+}
+
+__global__ __launch_bounds__(256) void gn_split_stats_kernel(const float* __restrict__ x, float* __restrict__ ws, int P, int G, int nchunk) {
+    constexpr int C = 256;
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int p0 = ch * GN_CH, pn = min(GN_CH, P - p0);
+    const int cgq = (C / G) >> 2;
+    const float* xb = x + ((long)b * P + p0) * C + lane * 4;
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(xb + (long)min(w + 4 * j, pn - 1) * C);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (w + 4 * j < pn) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float n = (float)pn * (float)(C / G);
+    const float mu = gn_group_total(s, cgq, red, w, lane) / n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (w + 4 * j < pn) {
+            const float a = v[j].x - mu, b2 = v[j].y - mu, c2 = v[j].z - mu, e2 = v[j].w - mu;
+            m2 += (a * a + b2 * b2) + (c2 * c2 + e2 * e2);
+        }
+    const float M2 = gn_group_total(m2, cgq, red, w, lane);
+    if (w == 0 && (lane & (cgq - 1)) == 0) {
+        float* o = ws + (((long)b * nchunk + ch) * G + lane / cgq) * 3;
+        o[0] = n; o[1] = mu; o[2] = M2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_split_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ ws, float* __restrict__ y, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int P, int G, int nchunk, float eps) {
+    constexpr int C = 256;
+    __shared__ float comb[8][64][3];
+    __shared__ float stat[64][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int p0 = ch * GN_CH, pn = min(GN_CH, P - p0);
+    const int cgq = (C / G) >> 2;
+    const float* xb = x + ((long)b * P + p0) * C + lane * 4;
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(xb + (long)min(w + 4 * j, pn - 1) * C);
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4), bt = *reinterpret_cast<const float4*>(beta + lane * 4);
+    // merge the chunks of this image: NS = 256 / G sub-sequences (chunk s, s + NS, ...), then the NS partial results in order
+    const int NS = 256 / G, g = threadIdx.x % G, sub = threadIdx.x / G;
+    float n = 0.f, mu = 0.f, M2 = 0.f;
+    for (int c = sub; c < nchunk; c += NS) {
+        const float* pw = ws + (((long)b * nchunk + c) * G + g) * 3;
+        const float nc = pw[0], mc = pw[1], Mc = pw[2];
+        const float nt = n + nc, d = mc - mu;
+        mu += d * (nc / nt);
+        M2 += Mc + d * d * (n * nc / nt);
+        n = nt;
+    }
+    comb[sub][g][0] = n; comb[sub][g][1] = mu; comb[sub][g][2] = M2;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float tn = 0.f, tm = 0.f, tM = 0.f;
+        for (int s2 = 0; s2 < NS; ++s2) {
+            const float nc = comb[s2][g][0], mc = comb[s2][g][1], Mc = comb[s2][g][2];
+            if (nc > 0.f) {
+                const float nt = tn + nc, d = mc - tm;
+                tm += d * (nc / nt);
+                tM += Mc + d * d * (tn * nc / nt);
+                tn = nt;
+            }
+        }
+        const float rs = rsqrtf(tM / tn + eps);
+        stat[g][0] = tm; stat[g][1] = rs;
+        if (ch == 0) { mean[b * G + g] = tm; rstd[b * G + g] = rs; }
+    }
+    __syncthreads();
+    const float m = stat[lane / cgq][0], rs = stat[lane / cgq][1];
+    float* yb = y + ((long)b * P + p0) * C + lane * 4;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (w + 4 * j < pn) {
+            float4 o;
+            o.x = (v[j].x - m) * rs * gm.x + bt.x; o.y = (v[j].y - m) * rs * gm.y + bt.y;
+            o.z = (v[j].z - m) * rs * gm.z + bt.z; o.w = (v[j].w - m) * rs * gm.w + bt.w;
+            *reinterpret_cast<float4*>(yb + (long)(w + 4 * j) * C) = o;
+        }
+}
+
+__global__ __launch_bounds__(256) void gn_split_bwd_stats_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma, float* __restrict__ ws,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta, int P, int G, int nchunk) {
+    constexpr int C = 256;
+    __shared__ float red[4][64];
+    __shared__ float cred[4][64][8];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int p0 = ch * GN_CH, pn = min(GN_CH, P - p0);
+    const int cgq = (C / G) >> 2;
+    const long base = ((long)b * P + p0) * C + lane * 4;
+    float4 xv[8], dv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long o = base + (long)min(w + 4 * j, pn - 1) * C;
+        xv[j] = *reinterpret_cast<const float4*>(x + o);
+        dv[j] = *reinterpret_cast<const float4*>(dy + o);
+    }
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4);
+    const float mu = mean[b * G + lane / cgq], rs = rstd[b * G + lane / cgq];
+    float s1 = 0.f, s2 = 0.f;
+    float4 ag = make_float4(0.f, 0.f, 0.f, 0.f), ab = ag;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (w + 4 * j < pn) {
+            const float4 xh = make_float4((xv[j].x - mu) * rs, (xv[j].y - mu) * rs, (xv[j].z - mu) * rs, (xv[j].w - mu) * rs);
+            const float4 dg = make_float4(dv[j].x * gm.x, dv[j].y * gm.y, dv[j].z * gm.z, dv[j].w * gm.w);
+            s1 += (dg.x + dg.y) + (dg.z + dg.w);
+            s2 += (dg.x * xh.x + dg.y * xh.y) + (dg.z * xh.z + dg.w * xh.w);
+            ag.x += dv[j].x * xh.x; ag.y += dv[j].y * xh.y; ag.z += dv[j].z * xh.z; ag.w += dv[j].w * xh.w;
+            ab.x += dv[j].x; ab.y += dv[j].y; ab.z += dv[j].z; ab.w += dv[j].w;
+        }
+    const float S1 = gn_group_total(s1, cgq, red, w, lane);
+    const float S2 = gn_group_total(s2, cgq, red, w, lane);
+    if (w == 0 && (lane & (cgq - 1)) == 0) {
+        float* o = ws + (((long)b * nchunk + ch) * G + lane / cgq) * 2;
+        o[0] = S1; o[1] = S2;
+    }
+    cred[w][lane][0] = ag.x; cred[w][lane][1] = ag.y; cred[w][lane][2] = ag.z; cred[w][lane][3] = ag.w;
+    cred[w][lane][4] = ab.x; cred[w][lane][5] = ab.y; cred[w][lane][6] = ab.z; cred[w][lane][7] = ab.w;
+    __syncthreads();
+    // 512 channel sums of the chunk: thread t adds the four waves' partials of (quad t / 8... ) -- two per thread
+    for (int e = threadIdx.x; e < 512; e += 256) {
+        const int qd = e >> 3, k = e & 7;
+        const float t = (cred[0][qd][k] + cred[1][qd][k]) + (cred[2][qd][k] + cred[3][qd][k]);
+        atomicAdd((k < 4 ? dgamma : dbeta) + qd * 4 + (k & 3), t);
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_split_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ ws,
+                                                                 float* __restrict__ dx, int P, int G, int nchunk) {
+    constexpr int C = 256;
+    __shared__ float comb[8][64][2];
+    __shared__ float stat[64][2];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int b = blockIdx.y, ch = blockIdx.x;
+    const int p0 = ch * GN_CH, pn = min(GN_CH, P - p0);
+    const int cgq = (C / G) >> 2;
+    const long base = ((long)b * P + p0) * C + lane * 4;
+    float4 xv[8], dv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const long o = base + (long)min(w + 4 * j, pn - 1) * C;
+        xv[j] = *reinterpret_cast<const float4*>(x + o);
+        dv[j] = *reinterpret_cast<const float4*>(dy + o);
+    }
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4);
+    const int NS = 256 / G, g = threadIdx.x % G, sub = threadIdx.x / G;
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = sub; c < nchunk; c += NS) {
+        const float* pw = ws + (((long)b * nchunk + c) * G + g) * 2;
+        a1 += pw[0]; a2 += pw[1];
+    }
+    comb[sub][g][0] = a1; comb[sub][g][1] = a2;
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int s2 = 0; s2 < NS; ++s2) { t1 += comb[s2][g][0]; t2 += comb[s2][g][1]; }
+        const float inv = 1.f / ((float)P * (float)(C / G));
+        stat[g][0] = t1 * inv; stat[g][1] = t2 * inv;
+    }
+    __syncthreads();
+    const float m1 = stat[lane / cgq][0], m2 = stat[lane / cgq][1];
+    const float mu = mean[b * G + lane / cgq], rs = rstd[b * G + lane / cgq];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        if (w + 4 * j < pn) {
+            float4 o;
+            o.x = rs * (dv[j].x * gm.x - m1 - (xv[j].x - mu) * rs * m2); o.y = rs * (dv[j].y * gm.y - m1 - (xv[j].y - mu) * rs * m2);
+            o.z = rs * (dv[j].z * gm.z - m1 - (xv[j].z - mu) * rs * m2); o.w = rs * (dv[j].w * gm.w - m1 - (xv[j].w - mu) * rs * m2);
+            *reinterpret_cast<float4*>(dx + base + (long)(w + 4 * j) * C) = o;
+        }
+}
+
 }  // namespace
 
 extern "C" int cdetr_sumsq(const float* g, int64_t n, float* out, float* workspace, void* stream) {
@@ -868,6 +1068,39 @@ extern "C" int cdetr_groupnorm_bwd(const float* dy, const float* x, const float*
     CDETR_CHECK_ARG(C % G == 0 && ((C / G) & 3) == 0 && C / G <= 64, "cdetr_groupnorm_bwd: channels per group must be a multiple of 4, <= 64 (got %d)", C / G);
     hipLaunchKernelGGL(gn_bwd_kernel, dim3(B * G), dim3(GN_NT_BWD), 0, reinterpret_cast<hipStream_t>(stream), dy, x, mean, rstd, gamma, dx, dgamma, dbeta, P, C, G);
     return cdetr_launch_status("cdetr_groupnorm_bwd");
+}
+
+// The split forms (pixels of an image spread over workgroups, statistics through `ws`): C == 256, G a divisor of 64 with C / G a multiple of 4 and
+// a power of two of channel quads per group; any other shape -- or a workspace that is too small -- runs the one-workgroup-per-(image, group) kernels.
+static bool gn_split_ok(int B, int P, int C, int G, const void* ws, long ws_bytes, int per) {
+    const int cg = C / G, cgq = cg >> 2;
+    const int nchunk = (P + GN_CH - 1) / GN_CH;
+    return C == 256 && G >= 32 && G <= 64 && (256 % G) == 0 && (cg & 3) == 0 && (cgq & (cgq - 1)) == 0 && P >= 4 * GN_CH && ws != nullptr &&
+           ws_bytes >= (long)B * nchunk * G * per * 4 && (reinterpret_cast<uintptr_t>(ws) & 3) == 0;
+}
+
+extern "C" int cdetr_groupnorm_fwd_ws(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                                      int32_t B, int32_t P, int32_t C, int32_t G, float eps, void* ws, int64_t ws_bytes, void* stream) {
+    if (!(x && B > 0 && P > 0 && C > 0 && G > 0 && C % G == 0) || !gn_split_ok(B, P, C, G, ws, ws_bytes, 3))
+        return cdetr_groupnorm_fwd(x, gamma, beta, y, mean, rstd, B, P, C, G, eps, stream);
+    CDETR_CHECK_ARG(gamma && beta && y && mean && rstd, "cdetr_groupnorm_fwd_ws: null pointer");
+    const int nchunk = (P + GN_CH - 1) / GN_CH;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gn_split_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, x, reinterpret_cast<float*>(ws), P, G, nchunk);
+    hipLaunchKernelGGL(gn_split_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, x, gamma, beta, reinterpret_cast<const float*>(ws), y, mean, rstd, P, G, nchunk, eps);
+    return cdetr_launch_status("cdetr_groupnorm_fwd_ws");
+}
+
+extern "C" int cdetr_groupnorm_bwd_ws(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                                      float* dgamma, float* dbeta, int32_t B, int32_t P, int32_t C, int32_t G, void* ws, int64_t ws_bytes, void* stream) {
+    if (!(x && B > 0 && P > 0 && C > 0 && G > 0 && C % G == 0) || !gn_split_ok(B, P, C, G, ws, ws_bytes, 2))
+        return cdetr_groupnorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, B, P, C, G, stream);
+    CDETR_CHECK_ARG(dy && mean && rstd && gamma && dx && dgamma && dbeta, "cdetr_groupnorm_bwd_ws: null pointer");
+    const int nchunk = (P + GN_CH - 1) / GN_CH;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gn_split_bwd_stats_kernel, dim3(nchunk, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, reinterpret_cast<float*>(ws), dgamma, dbeta, P, G, nchunk);
+    hipLaunchKernelGGL(gn_split_bwd_apply_kernel, dim3(nchunk, B), dim3(256), 0, st, dy, x, mean, rstd, gamma, reinterpret_cast<const float*>(ws), dx, P, G, nchunk);
+    return cdetr_launch_status("cdetr_groupnorm_bwd_ws");
 }
 
 extern "C" int cdetr_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,

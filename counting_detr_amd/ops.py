@@ -1268,6 +1268,9 @@ def mha_core(qk, v, nh):
 
 
 # ----------------------------------------------------------------------------------------------------- layer norm & glue
+GN_SPLIT = os.environ.get("CDETR_GN_SPLIT", "1") != "0"      # A/B: 0 = one workgroup per (image, group)
+
+
 class GroupNormNHWCFn(torch.autograd.Function):
     """nn.GroupNorm(G, C) on an NHWC activation [B,h,w,C] (A2/models/anchor_detr.py:86-92) -- fwd / bwd are one kernel each, no layout
     round trip; dgamma / dbeta accumulate straight into the parameters' gradient buffers."""
@@ -1279,8 +1282,9 @@ class GroupNormNHWCFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(B * G, device=x.device, dtype=torch.float32)
         rstd = torch.empty(B * G, device=x.device, dtype=torch.float32)
-        check(lib().cdetr_groupnorm_fwd(ptr(x), ptr(wparam.detach()), ptr(bparam.detach()), ptr(y), ptr(mean), ptr(rstd), B, h * w, Cc, G,
-                                        eps, stream_ptr()), "cdetr_groupnorm_fwd")
+        ws = torch.empty(B * ((h * w + 31) // 32) * G * 3, device=x.device, dtype=torch.float32) if GN_SPLIT else None      # per-chunk statistics of the split form
+        check(lib().cdetr_groupnorm_fwd_ws(ptr(x), ptr(wparam.detach()), ptr(bparam.detach()), ptr(y), ptr(mean), ptr(rstd), B, h * w, Cc, G,
+                                           eps, ptr(ws), ws.numel() * 4 if ws is not None else 0, stream_ptr()), "cdetr_groupnorm_fwd_ws")
         ctx.save_for_backward(x, mean, rstd)
         ctx.wparam, ctx.bparam, ctx.G = wparam, bparam, G
         return y
@@ -1294,8 +1298,9 @@ class GroupNormNHWCFn(torch.autograd.Function):
         wparam, bparam = ctx.wparam, ctx.bparam
         gw = grad_buffer(wparam) if wparam.requires_grad else torch.zeros_like(wparam)
         gb = grad_buffer(bparam) if bparam.requires_grad else torch.zeros_like(bparam)
-        check(lib().cdetr_groupnorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(wparam.detach()), ptr(dx), ptr(gw), ptr(gb), B, h * w,
-                                        Cc, ctx.G, stream_ptr()), "cdetr_groupnorm_bwd")
+        ws = torch.empty(B * ((h * w + 31) // 32) * ctx.G * 2, device=x.device, dtype=torch.float32) if GN_SPLIT else None
+        check(lib().cdetr_groupnorm_bwd_ws(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(wparam.detach()), ptr(dx), ptr(gw), ptr(gb), B, h * w,
+                                           Cc, ctx.G, ptr(ws), ws.numel() * 4 if ws is not None else 0, stream_ptr()), "cdetr_groupnorm_bwd_ws")
         return dx, None, None, None, None
 
 

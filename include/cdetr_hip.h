@@ -215,6 +215,14 @@ int cdetr_groupnorm_fwd(const float* x, const float* gamma, const float* beta, f
                         int32_t B, int32_t P, int32_t C, int32_t G, float eps, void* stream);
 int cdetr_groupnorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
                         float* dgamma, float* dbeta, int32_t B, int32_t P, int32_t C, int32_t G, void* stream);
+/* The same two calls with the pixels of an image spread over workgroups (C == 256: coalesced 1 KB rows, B * P / 32 workgroups instead of B * G) and the
+ * group statistics crossing them through `ws` (>= B * ceil(P / 32) * G * 12 bytes forward, * 8 backward; contents undefined before and after): two
+ * launches each -- per-chunk partials (forward: count / mean / centred second moment, merged with Chan's update in chunk order), then merge + apply.
+ * Shapes the split form does not cover (C != 256, fewer than 128 pixels, ws too small / NULL) run cdetr_groupnorm_fwd / _bwd.                       */
+int cdetr_groupnorm_fwd_ws(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                           int32_t B, int32_t P, int32_t C, int32_t G, float eps, void* ws, int64_t ws_bytes, void* stream);
+int cdetr_groupnorm_bwd_ws(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma, float* dx,
+                           float* dgamma, float* dbeta, int32_t B, int32_t P, int32_t C, int32_t G, void* ws, int64_t ws_bytes, void* stream);
 
 int cdetr_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int32_t rows, int32_t C, float eps, void* stream);

@@ -720,11 +720,16 @@ def test_stem_row_packed_equals_per_tap_form(H, W, precision):
     close(y_rows.permute(0, 3, 1, 2), ref, msg="row-packed stem", **tol(precision))
 
 
-@pytest.mark.parametrize("B,h,w,C,G", [(2, 50, 50, 256, 32), (1, 7, 9, 64, 16), (3, 13, 5, 256, 4), (2, 20, 30, 96, 8)])
-def test_groupnorm_nhwc(B, h, w, C, G):
-    """cdetr_groupnorm_fwd / bwd on NHWC == F.group_norm on the channels-first view (fp64), incl. dgamma / dbeta accumulation."""
+@pytest.mark.parametrize("split", [True, False], ids=["split", "per-group"])
+@pytest.mark.parametrize("B,h,w,C,G", [(2, 50, 50, 256, 32), (1, 7, 9, 64, 16), (3, 13, 5, 256, 4), (2, 20, 30, 96, 8), (3, 37, 29, 256, 64), (1, 16, 8, 256, 32),
+                                       (2, 24, 36, 256, 32)])
+def test_groupnorm_nhwc(B, h, w, C, G, split, monkeypatch):
+    """cdetr_groupnorm_fwd_ws / bwd_ws on NHWC == F.group_norm on the channels-first view (fp64), incl. dgamma / dbeta accumulation: the
+    split form (C == 256, G = 32 / 64, >= 128 pixels: pixels spread over workgroups, ragged last chunk, a mean far from zero for the merged
+    centred moments) and the one-workgroup-per-(image, group) kernels every other shape -- and `split = False` -- runs."""
     from counting_detr_amd import ops
-    x = torch.randn(B, h, w, C, generator=g(1)) * 2 + 0.5
+    monkeypatch.setattr(ops, "GN_SPLIT", split)
+    x = torch.randn(B, h, w, C, generator=g(1)) * 2 + (30.0 if (h, w) == (24, 36) else 0.5)
     gm, bt = torch.randn(C, generator=g(2)), torch.randn(C, generator=g(3))
     dy = torch.randn(B, h, w, C, generator=g(4))
     xd = x.to(DEV).requires_grad_(True)
