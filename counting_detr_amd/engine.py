@@ -250,6 +250,7 @@ class Trainer:
         # 8192, +0.04 at 16384 (profiles/r5_ab_tail_wgrad.txt)
         self._tail_wg_target = int(os.environ.get("CDETR_TAIL_WG_TARGET", "6144"))
         self._zero_arena_on = os.environ.get("CDETR_ZERO_ARENA", "1") != "0"      # A/B: 0 = the backward's accumulators are torch.zeros inside B
+        self._arena_bufs = []                      # ops.ZeroArena buffers of the cached steps (shared by every step they are large enough for)
         self._tail_inline = float(os.environ.get("CDETR_TAIL_INLINE", getattr(args, "wgrad_tail_inline", 1.0)))   # share of layer2's weight gradients kept on the main stream
         self._frozen = {}                       # image shape -> frozen-stage buffers + graph (see "frozen-stage prefetch")
         self._pf_stream = self._pf_pool = self._wg_stream = None
@@ -626,6 +627,7 @@ class Trainer:
                 torch.cuda.synchronize()
             self._cache.clear()
             self._entry = None
+            self._arena_bufs = []
             self._frozen.clear()            # (the stem + layer1 graphs read the same folds / stem images: stale after an invalidation)
         self._mirror_stale = True           # the weight images are keyed on the folds' addresses (property `mirror`)
 
@@ -925,7 +927,13 @@ class Trainer:
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
         if arena is not None:
-            arena.buf = torch.zeros(max(arena.need, 64), device=self.device, dtype=torch.float32)
+            # one buffer serves every cached step it is large enough for (steps replay one after the other; its contents live inside a step only)
+            fit = [b for b in self._arena_bufs if b.numel() >= arena.need]
+            if fit:
+                arena.buf = min(fit, key=lambda b: b.numel())
+            else:
+                arena.buf = torch.zeros(max(arena.need, 64), device=self.device, dtype=torch.float32)
+                self._arena_bufs = [arena.buf]         # (the smaller ones stay alive with the entries that captured their address, and go with them)
         pf, wg = self._side_streams()
         G = torch.cuda.CUDAGraph
         e = {"F": G(), "zarena": arena}

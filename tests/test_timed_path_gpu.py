@@ -136,9 +136,12 @@ def test_probe_failure_switches_flags_and_prefetch_off(monkeypatch):
     tr2 = Trainer(ref_model, crit2, args, device=DEV)
     r0 = {k: float(v) for k, v in tr2.train_step(b0[0], b0[1], b0[2]).items()}
     r1 = {k: float(v) for k, v in tr2.train_step(b1[0], b1[1], b1[2]).items()}
-    for o, r in ((o0, r0), (o1, r1)):
-        for k in ("loss", "grad_norm"):
-            np.testing.assert_allclose(o[k], r[k], rtol=2e-4, err_msg=k)
+    # the first step agrees to rounding (1e-5...1e-6 measured).  The second step starts from parameters AdamW's first update moved by lr * sign(g): where a
+    # gradient is rounding noise (fp32 atomics accumulate in arrival order) the sign is a coin toss, so the two runs' second gradients differ by 2e-5...4e-4
+    # of the norm from run to run (tools/flaky_probe.py) -- the golden-vector bar for a gradient norm (2e-3, _check_step) applies there
+    for (o, r), tol_g in (((o0, r0), 2e-4), ((o1, r1), 2e-3)):
+        np.testing.assert_allclose(o["loss"], r["loss"], rtol=2e-4, err_msg="loss")
+        np.testing.assert_allclose(o["grad_norm"], r["grad_norm"], rtol=tol_g, err_msg="grad_norm")
     tr2.capture(b1[0], b1[1], b1[2])
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
     for _ in range(2):

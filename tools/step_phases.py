@@ -29,11 +29,13 @@ for r in allq:
     if r[3] != mainq:
         side.setdefault(r[3], []).append(r)
 first = "stem_pack" if any("stem_pack" in r[2] for r in step) else step[0][2][:40]
-markers = [("backbone fwd", first), ("proj + encoder fwd", "gn_fwd"), ("decoder fwd + heads", "flash::fwd"), ("matcher + criterion", "match_cost"),
-           ("heads + decoder bwd", "criterion_bwd"), ("encoder bwd", "rcda_bwd_kernel<2, 5"), ("proj + backbone bwd", "gn_bwd"), ("clip + AdamW", "sumsq")]
+# (GroupNorm: gn_fwd_kernel / gn_bwd_kernel until round 5, gn_split_stats_kernel / gn_split_bwd_stats_kernel since)
+markers = [("backbone fwd", (first,)), ("proj + encoder fwd", ("gn_fwd", "gn_split_stats")), ("decoder fwd + heads", ("flash::fwd",)), ("matcher + criterion", ("match_cost",)),
+           ("heads + decoder bwd", ("criterion_bwd",)), ("encoder bwd", ("rcda_bwd_kernel<2, 5",)), ("proj + backbone bwd", ("gn_bwd", "gn_split_bwd_stats")),
+           ("clip + AdamW", ("sumsq",))]
 idx = []
-for name, key in markers:
-    i = next((k for k, r in enumerate(step) if key in r[2] and (not idx or k > idx[-1][1])), None)
+for name, keys in markers:
+    i = next((k for k, r in enumerate(step) if any(key in r[2] for key in keys) and (not idx or k > idx[-1][1])), None)
     if i is not None:
         idx.append((name, i))
 out = []
