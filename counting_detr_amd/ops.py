@@ -1548,11 +1548,15 @@ class EncoderStackFn(torch.autograd.Function):
             if taps is not None:
                 taps[f"enc{li}"] = x.detach()
         ctx.ctxs = ctxs
-        return x
+        ctx.set_materialize_grads(False)      # (an embedding output nobody consumed brings None, not a zero tensor + its fill)
+        # the two positional embeddings leave the node again (aliases): the decoder takes THESE, so its gradients with respect to them arrive here
+        # as output gradients and seed the accumulation below -- autograd's two accumulation adds of d(posemb) disappear from the main chain
+        return x, posemb_row.view_as(posemb_row), posemb_col.view_as(posemb_col)
 
     @staticmethod
-    def backward(ctx, dX):
-        accR = accC = None
+    def backward(ctx, dX, dPR=None, dPC=None):
+        accR = dPR.contiguous() if dPR is not None else None
+        accC = dPC.contiguous() if dPC is not None else None
         c0 = ctx.ctxs[0]
         N, H, W, Cc, E, nh = c0.dims
         zn = N * H * W * E + N * W * E + N * H * E                  # per layer: dV + both key gradients (rcda_zero_numel)

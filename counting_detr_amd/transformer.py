@@ -322,7 +322,8 @@ class Transformer(nn.Module):
         enc = list(self.encoder_layers)
         if enc and enc[0].fused and src.is_cuda:
             if grad:
-                memory = ops.EncoderStackFn.apply(src, posemb_row, posemb_col, mask_row, mask_col, enc, enc[0].norm1.weight, self.taps)
+                # (the embeddings the decoder sees are the node's own outputs: see EncoderStackFn.forward)
+                memory, posemb_row, posemb_col = ops.EncoderStackFn.apply(src, posemb_row, posemb_col, mask_row, mask_col, enc, enc[0].norm1.weight, self.taps)
             else:       # inference: the same fused forward bodies, nothing saved
                 memory = src
                 for li, layer in enumerate(enc):
