@@ -193,7 +193,7 @@ def test_exchange_stream_runs_beside_the_backbone_backward():
     t1 = time_steps()
     tr.exchange.dummy_us = 0
     nb = sum(1 for i in range(4) if tr.seg_bounds[i + 1] > tr.seg_bounds[i])
-    # serial execution adds >= nb * us (+ the event / launch slack: >= 0.44 ms measured with the streams forced onto one queue); overlapped, the last
+    # serial execution adds >= nb * us = 0.4 ms by construction (+ the event / launch slack); overlapped, the last
     # bucket (+ ~30 us of slack per bucket) is exposed: 0.235 ms when the test was written, 0.30 ms since round 5 shortened this small model's backbone
     # backward (the last weight gradients on the whole chip: less backward to hide behind) -- the bar sits between the two regimes
     assert t1 - t0 < 0.9 * nb * us * 1e-3, f"{nb} dummy buckets of {us} us cost {t1 - t0:.3f} ms per step: the exchange stream does not overlap ({tr.side_stream_probe})"
