@@ -37,7 +37,7 @@ def step_gflop_per_image(H, W, Q):
     """algorithmic work of one train step per image, reduced form (mean-before-project keys):
     616 GFLOP at 800x800 / Q=300, 643 at Q=576, 212 at 384x576 / Q=300."""
     C, nh, d, dff = 256, 8, 32, 1024
-    px, h, w = H * W, H // 16, W // 16
+    px, h, w = H * W, (H + 15) // 16, (W + 15) // 16      # three stride-2 stages + the max-pool, each rounding up
     n = h * w
     backbone = 123697.0 * px
     proj = 4096.0 * 256 * n
@@ -186,6 +186,60 @@ def timed_steps(step, n, barrier):
     barrier()
     dt = time.perf_counter() - t0
     return dt, [evs[i].elapsed_time(evs[i + 1]) for i in range(n)], out
+
+
+def exchange_variants(trainer, step, barrier, dev, share, rank, n=5):
+    """First N > 1 contact, self-diagnosing: time `n` steps of each form of the gradient exchange -- {host-issued
+    all-reduce, captured bucket graphs} x {exchange stream of its own, buckets issued from the weight-gradient stream
+    (FlatGradExchange.on_side)} -- and keep the fastest for the contract's timed run.  Every rank takes the same decision (MAX over ranks
+    per variant); a line per variant goes to stderr AS IT COMPLETES, so a variant that hangs names itself.  The default form is timed
+    first.  Captured buckets need RCCL (gloo rehearsals skip them).  CDETR_BENCH_EXCHANGE_AB=0 skips all of this."""
+    ex = trainer.exchange
+    have_graphs = False
+    if not share:
+        ok = 1.0
+        try:
+            if ex.graphs is None:
+                ex.capture_buckets()
+        except Exception as e_:                                # noqa: BLE001 -- a capture problem must not cost the run
+            print(f"[bench] rank {rank}: capturing the bucket all-reduces failed ({type(e_).__name__}: {e_}); captured variants skipped", file=sys.stderr, flush=True)
+            ex.graphs = None
+            ok = 0.0
+        okt = torch.tensor([ok if ex.graphs is not None else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        have_graphs = float(okt[0]) > 0
+        if not have_graphs:
+            ex.graphs = None
+    variants = [("host_issued/own_stream", False, False)]
+    if have_graphs:
+        variants.append(("captured/own_stream", True, False))
+    variants.append(("host_issued/side_stream", False, True))
+    if have_graphs:
+        variants.append(("captured/side_stream", True, True))
+    res = {}
+    for name, graphs, side in variants:
+        ex.use_graphs, ex.on_side = graphs, side
+        for _ in range(2):
+            step()
+        barrier()
+        ex.probe = []
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        barrier()
+        dt = (time.perf_counter() - t0) / n * 1e3
+        exposed = ex.exposed_ms() or []
+        ex.probe = None
+        t = torch.tensor([dt, sum(exposed) / max(len(exposed), 1)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        res[name] = {"ms_per_step": float(t[0]), "allreduce_exposed_ms": float(t[1])}
+        if rank == 0:
+            print(f"[bench] exchange variant {name}: {float(t[0]):.3f} ms/step, exposed {float(t[1]):.3f} ms", file=sys.stderr, flush=True)
+    best = min(res, key=lambda k: res[k]["ms_per_step"])
+    _, graphs, side = next(v for v in variants if v[0] == best)
+    ex.use_graphs, ex.on_side = graphs, side
+    return {"variants": res, "kept": best, "steps_each": n, "probe": getattr(trainer, "side_stream_probe", None),
+            "note": "ms_per_step = MAX over ranks of the mean of %d captured steps; the timed run uses `kept`" % n}
 
 
 def build_trainer(dev, queries, prior, precision):
@@ -462,6 +516,9 @@ def main(argv=None):
     pipelined = mode == "graph" and trainer._entry is not None and trainer._entry.get("fs") is not None
     graph_step = (lambda: trainer.replay(pipelined=True)) if pipelined else trainer.replay
     step = eager_step if mode == "eager" else graph_step
+    exchange_ab = None
+    if world > 1 and mode == "graph" and os.environ.get("CDETR_BENCH_EXCHANGE_AB", "1") != "0":
+        exchange_ab = exchange_variants(trainer, graph_step, barrier, dev, share, rank)
     for _ in range(a.warmup):
         out = step()
     if world > 1:
@@ -636,6 +693,7 @@ def main(argv=None):
     if world > 1:
         ex = torch.tensor([sum(exposed) / max(len(exposed), 1) if exposed else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(ex, op=dist.ReduceOp.MAX)
+        res["exchange_variants"] = exchange_ab
         res["allreduce_exposed_ms"] = {"mean_max_over_ranks": float(ex[0]), "rank0": percentiles(exposed or []),
                                        "bytes_per_step": int(trainer.flat_g.numel() * 4),
                                        "buckets_bytes": [int((trainer.seg_bounds[i + 1] - trainer.seg_bounds[i]) * 4) for i in range(4)],
@@ -674,7 +732,10 @@ def main(argv=None):
             # crowded images (FSC-147 holds up to 3731 objects per image, A2/data/fsc147.py:80-84): target-capacity classes 2048 and 3800, where the
             # assignment is one LDS-resident workgroup per image (A2/models/matcher.py:229-247 calls scipy there: 17 ms at 900 x 3000)
             extra_shape(dev, 384, 576, 300, "learned", (37, 2100), a.batch, a.precision),
-            extra_shape(dev, 384, 576, 300, "learned", (3000, 3731), a.batch, a.precision)]
+            extra_shape(dev, 384, 576, 300, "learned", (3000, 3731), a.batch, a.precision),
+            # BASELINE configs[3] (FSCD-LVIS 2nd stage) at the largest image its reader feeds (L2/data/fscd_lvis.py:66-91: floor-32 of the image,
+            # longest side up to 1333): feature map 50 x 84 -- wider than one 64-key tile (round 6: rcda_fwd2_kernel<4, 6>, dV key-column chunks)
+            extra_shape(dev, 800, 1333, 300, "learned", Ts, a.batch, a.precision)]
     if world == 1 and not a.no_inference:
         res["inference"] = inference_leg(dev, [(800, 800), (384, 576), (800, 800, 8), (384, 576, 16)], a.batch, a.precision)
         res["stage1_pseudo_labels"] = stage1_leg(dev, a.precision)

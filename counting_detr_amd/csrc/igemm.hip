@@ -2392,7 +2392,9 @@ extern "C" int cdetr_wgrad(const cdetr_wgrad_desc* dp, void* stream) {
             // ~3 workgroups per CU; weights of <= 16 tiles pay slices x (atomic epilogue + pipeline fill) for little parallelism
             // gained: half as many slices measured 10-15 % faster there (5000x256x256, 20000x512x128)
             // (round 5: 384 for every problem -- beside the data-gradient chain fewer, longer workgroups disturb it less: profiles/r5_ab_wgrad.txt)
-            const long target = d.wg_target > 0 ? d.wg_target : (target_env ? target_env : 384);      // (wg_target: the caller knows better -- a launch alone on the chip)
+            // round 6: wg_target == 0 is again the rule for a launch that has the chip to itself (768; 384 for weights of <= 16
+            // tiles); a caller that runs the launch BESIDE a data-gradient chain asks for 384 itself (engine.Trainer: ops.wgrad_flush(wg_target=))
+            const long target = d.wg_target > 0 ? d.wg_target : (target_env ? target_env : (base <= 16 ? 384 : 768));
             long slices = (target + base - 1) / base;
             const long max_slices = (nktf + 3) / 4;                 // >= 4 k-tiles (128 pixels) per slice
             if (slices > max_slices) slices = max_slices;
@@ -2547,7 +2549,8 @@ extern "C" int cdetr_wgrad_group(const cdetr_wgrad_desc* descs, int32_t n, void*
             const cdetr_wgrad_desc& d = descs[tr64[c0 + k]];
             work += (long)((d.Nout + 63) / 64) * ((d.Cin + 63) / 64) * d.taps * d.batch * ((d.P + 31) / 32);
         }
-        static const long gtarget = getenv("CDETR_WGRAD_GROUP_TARGET") ? atol(getenv("CDETR_WGRAD_GROUP_TARGET")) : 384;      // (round 5: was 768, profiles/r5_ab_wgrad.txt)
+        // 768 for a launch alone on the chip; launches beside the data-gradient chain ask for 384 through wg_target (profiles/r5_ab_wgrad.txt)
+        static const long gtarget = getenv("CDETR_WGRAD_GROUP_TARGET") ? atol(getenv("CDETR_WGRAD_GROUP_TARGET")) : 768;
         long want = 0;                                    // cdetr_wgrad_desc.wg_target: the largest request of the members (a launch alone on the chip)
         for (int k = 0; k < m; ++k) want = std::max<long>(want, descs[tr64[c0 + k]].wg_target);
         const long gt = want > 0 ? want : gtarget;

@@ -379,6 +379,7 @@ __global__ __launch_bounds__(256) void igemm_dl_kernel(const cdetr_gemm_desc d, 
     if constexpr (SPLIT) {
         // Coherence across the 8 XCDs without fences (a device-scope fence writes back / invalidates a whole L2): the partials travel as
         // relaxed device-scope atomic stores / loads (sc1), s_waitcnt orders them before the arrival count, a device-scope RMW.
+        // (gfx950-specific ordering, not a HIP memory-model guarantee: include/cdetr_hip.h, cdetr_gemm_desc.splitk_ws; tools/splitk_stress.py)
         constexpr int FR = FM * FN * 16;
         int* cnt = reinterpret_cast<int*>(d.splitk_ws);
         float* wsp = reinterpret_cast<float*>(cnt + SPLITK_COUNTERS);

@@ -830,6 +830,14 @@ extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int3
     } else if (nc_max <= 4096 && cdetr_tune_env("CDETR_LSAP_GENERIC") == nullptr) {
         // crowded images: the register-resident solver over the 16 waves of one workgroup (rows <= Mmax, columns <= nc_max)
         const size_t wb = 2 * 16 * sizeof(WgSlot) + (size_t)Mmax * 12 + (size_t)nc_max * 12 + 64;
+        if (wb > 64 * 1024) {        // (Q ~ 1500 queries at 3800 targets; lsap_kernel<256> used to take such shapes)
+            const void* fn = nc_max <= 2048 ? reinterpret_cast<const void*>(lsap_wg_kernel<2>) : reinterpret_cast<const void*>(lsap_wg_kernel<4>);
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wb) != hipSuccess) {
+                (void)hipGetLastError();
+                cdetr_set_error("cdetr_lsap: %zu bytes of LDS for %d x %d problems exceed the device limit", wb, Mmax, nc_max);
+                return CDETR_ERR_UNSUPPORTED;
+            }
+        }
         if (nc_max <= 2048) hipLaunchKernelGGL(lsap_wg_kernel<2>, dim3(B), dim3(1024), wb, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status);
         else hipLaunchKernelGGL(lsap_wg_kernel<4>, dim3(B), dim3(1024), wb, st, cost, cost_off, tgt_off, Q, Mmax, idx_i, idx_j, status);
     } else {

@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
 }
 
 // ------------------------------------------------------------------------------------------------ forward, two-step form
-// split-bf16 only, W <= 64.  The contraction is evaluated as the reference factorises it
+// split-bf16 only, W <= 96 (KS <= 6 steps of 16 key columns).  The contraction is evaluated as the reference factorises it
 //     T_h[q,c] = sum_w A_row[q,w] V[h,w,c]          out[q,c] = sum_h A_col[q,h] T_h[q,c]
 // but transposed, so that everything that is constant over h stays in registers:
 //   * T_h^T[c,q] = sum_w V_h^T[c,w] A_row^T[w,q] is one short MFMA chain per h (KS = ceil(W/16) k-steps of 3 bf16 MFMAs).  Its
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
 constexpr int RCDA_WS_COUNTERS = 4096;   // int32 arrival counters at the head of cdetr_rcda_fwd_desc.ws (= SPLITK_COUNTERS of igemm.hip: one scratch serves both)
 constexpr int KSTR = 36;      // LDS row stride (floats) of the projected keys in rcda_scores_mfma: 36 / 4 odd -> conflict-free ds_read_b128
 
-// Score phase on the matrix pipe (split-bf16, H <= 64, W <= 64): S^T = K Q^T per 32-key tile -- A = the projected keys (row = key,
+// Score phase on the matrix pipe (split-bf16, H <= 32 TH, W <= 32 TW; TW, TH <= 3): S^T = K Q^T per 32-key tile -- A = the projected keys (row = key,
 // k-slot j of step s <-> channel 16s + 8g + j, read from LDS), B = this wave's 32 projected queries (column = query i32, same channel
 // slots, straight from global).  The accumulator of a tile holds, for query i32, the logits of keys 32t + (r&3) + 8(r>>2) + 4g: the
 // softmax over keys is an in-lane reduction over registers plus one exchange between the two lane halves.  Replaces the VALU loop of
@@ -373,12 +373,14 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
         }
     }
     // key-padding masks as bit sets (one ballot per 64 keys)
-    unsigned long long mrow = 0ull, mcol0 = 0ull;
+    unsigned long long mrow[2] = {0ull, 0ull}, mcol[2] = {0ull, 0ull};      // word 1: keys 64..127 (TW / TH == 3: maps wider than 64)
     if (d.mask_row) {
         const uint8_t* mr = d.mask_row + (long)n * W;
         const uint8_t* mc = d.mask_col + (long)n * H;
-        mrow = __ballot(lane < W && mr[min(lane, W - 1)] != 0);
-        mcol0 = __ballot(lane < H && mc[min(lane, H - 1)] != 0);
+        mrow[0] = __ballot(lane < W && mr[min(lane, W - 1)] != 0);
+        mcol[0] = __ballot(lane < H && mc[min(lane, H - 1)] != 0);
+        if (TW > 2) mrow[1] = __ballot(lane + 64 < W && mr[min(lane + 64, W - 1)] != 0);
+        if (TH > 2) mcol[1] = __ballot(lane + 64 < H && mc[min(lane + 64, H - 1)] != 0);
     }
     __syncthreads();
 
@@ -388,7 +390,7 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
         const int nt = side == 0 ? TW : TH;
         const int nkeys = side == 0 ? W : H, npad = side == 0 ? Wp : Hp;
         const float* Ks = side == 0 ? Krow : Kcol;
-        const unsigned long long mbits = side == 0 ? mrow : mcol0;
+        const unsigned long long* mbits = side == 0 ? mrow : mcol;
         float* S = side == 0 ? Srow + i32 * sm.sw : Scol + i32 * sm.sh;
         float sv[TMAX][16];
         float mx = -INFINITY;
@@ -411,7 +413,7 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
                 float v = acc[r] * d.scale;
-                if (key >= nkeys || ((mbits >> (key & 63)) & 1ull)) v = -INFINITY;
+                if (key >= nkeys || ((mbits[t >> 1] >> (key & 63)) & 1ull)) v = -INFINITY;
                 sv[t][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -462,7 +464,7 @@ __host__ __device__ inline Fwd2Smem fwd2_smem(const FwdSmem& sm, int H, int W, i
     return s;
 }
 
-template <int NW, int KS>
+template <int NW, int KS, int TH = 2>   // KS = 16-column steps of the key axis W (W <= 16 KS <= 96); TH = 32-row tiles of H in the MFMA score phase
 __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd_desc d) {
     constexpr int NT = 64 * NW, QB = QW * NW;
     constexpr int PD = 4;                                  // V tiles in flight
@@ -534,7 +536,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
         }
     };
 
-    if (H <= 64) rcda_scores_mfma<NT, (KS + 1) / 2, 2>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid, hz == 0);
+    if (H <= 32 * TH) rcda_scores_mfma<NT, (KS + 1) / 2, TH>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid, hz == 0);
     else rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
 
     // ---- hoisted B operand: this lane's A_row row, k-slot j of step s <-> w = 16s + 8g + j
@@ -1132,7 +1134,7 @@ __global__ __launch_bounds__(256) void rcda_dv_kernel(const cdetr_rcda_bwd_desc 
 }
 
 // ------------------------------------------------------------------------------------------------ backward (dV), two-step form
-// split-bf16 only, W <= 64.   dV[h,w,c] = sum_q A_row[q,w] * (A_col[q,h] dOut[q,c])
+// split-bf16 only, any W: chunks of <= 64 key columns.   dV[h,w,c] = sum_q A_row[q,w] * (A_col[q,h] dOut[q,c])
 // Workgroup = 8 waves = 8 key rows h (one per wave) of one (n, head) over a slice of the queries; the reduction runs over q:
 //   A operand  A_row^T[w, q]  (rows w: two 32-row fragments) -- the same for every h: transposed and split into bf16 hi/lo
 //              ONCE per workgroup while the q-tile is staged (4q x 4w register blocks -> ds_write_b64);
@@ -1162,14 +1164,22 @@ __device__ __forceinline__ void rcda_dv2_body(const cdetr_rcda_bwd_desc& d, cons
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int i32 = lane & 31, g = lane >> 5;
     const int n = by / d.nh, head = by % d.nh;
-    const int h0 = bx * 8, h = h0 + wid;
+    // bx = (key-column chunk, key-row group): maps wider than 64 columns (round 6: FSCD-LVIS images up to 1333 wide -> W = 84) are cut
+    // into ceil(Wp / 64) chunks of equal width (a multiple of 4 columns), one workgroup each; a chunk is the 64-row A_row^T tile below
+    const int nhg = (H + 7) >> 3;
+    const int wchunk = bx / nhg;
+    const int nwc = (Wp + 63) >> 6;
+    const int wper = (((Wp + nwc - 1) / nwc) + 3) & ~3;
+    const int wbase = wchunk * wper;
+    const int Wc = min(wper, Wp - wbase);               // columns of this chunk (<= 64, % 4 == 0)
+    const int h0 = (bx - wchunk * nhg) * 8, h = h0 + wid;
     const int qs = bz * q_per_slice;
     const int qe = min(L, qs + q_per_slice);
     const int ntile = (qe - qs + QT - 1) / QT;
     if (ntile <= 0) return;
 
     // ---- staging roles
-    const int nrb = 16 * (Wp >> 2);                     // a_row blocks: 16 q-groups x Wp/4 w-quads (<= 256)
+    const int nrb = 16 * (Wc >> 2);                     // a_row blocks: 16 q-groups x Wc/4 w-quads (<= 256)
     int role, q4, x4;                                   // q4 = q-group (4 queries), x4 = w-quad / c-quad / h-quad
     if (tid < nrb) { role = 0; q4 = tid & 15; x4 = tid >> 4; }
     else if (tid >= 256 && tid < 384) { role = 1; q4 = (tid - 256) & 15; x4 = (tid - 256) >> 4; }
@@ -1177,7 +1187,7 @@ __device__ __forceinline__ void rcda_dv2_body(const cdetr_rcda_bwd_desc& d, cons
     else { role = 3; q4 = 0; x4 = 0; }
     const float* src;                                   // row (qs + 4 q4), this thread's quad; advanced by one tile per fetch
     long rstride;
-    if (role == 0) { src = d.a_row + (((long)n * d.nh + head) * L) * Wp + x4 * 4; rstride = Wp; }
+    if (role == 0) { src = d.a_row + (((long)n * d.nh + head) * L) * Wp + wbase + x4 * 4; rstride = Wp; }
     else if (role == 1) { src = d.d_out + (long)n * L * E + head * D + x4 * 4; rstride = E; }
     else { src = d.a_col + (((long)n * d.nh + head) * L) * Hp + min(h0 + x4 * 4, Hp - 4); rstride = Hp; }
     float4 rs[2][4];
@@ -1213,10 +1223,10 @@ __device__ __forceinline__ void rcda_dv2_body(const cdetr_rcda_bwd_desc& d, cons
             *reinterpret_cast<float4*>(dst + 3 * 68) = make_float4(r[0].w, r[1].w, r[2].w, r[3].w);
         }
     };
-    // rows w >= Wp of A_row^T are never written: zero them once in both buffers
-    for (int idx = tid; idx < 2 * (64 - Wp) * (ARS / 2); idx += 512) {
-        const int b = idx / ((64 - Wp) * (ARS / 2)), r = idx - b * (64 - Wp) * (ARS / 2);
-        smem[b * sm.tile + sm.art + Wp * (ARS / 2) + r] = 0.f;
+    // rows w >= Wc of A_row^T are never written: zero them once in both buffers
+    for (int idx = tid; idx < 2 * (64 - Wc) * (ARS / 2); idx += 512) {
+        const int b = idx / ((64 - Wc) * (ARS / 2)), r = idx - b * (64 - Wc) * (ARS / 2);
+        smem[b * sm.tile + sm.art + Wc * (ARS / 2) + r] = 0.f;
     }
 
     f32x16 acc[2];
@@ -1270,8 +1280,8 @@ __device__ __forceinline__ void rcda_dv2_body(const cdetr_rcda_bwd_desc& d, cons
     for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int w = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (w < W) atomicAdd(d.d_v + (((long)n * H + h) * W + w) * E + head * D + i32, acc[f][r]);
+            const int wl = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g, w = wbase + wl;
+            if (wl < Wc && w < W) atomicAdd(d.d_v + (((long)n * H + h) * W + w) * E + head * D + i32, acc[f][r]);
         }
 }
 
@@ -1400,11 +1410,12 @@ extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nw = pick_nw(d.L, d.N * d.nh);
     static const int use_v2 = getenv("CDETR_RCDA_FWD2") ? atoi(getenv("CDETR_RCDA_FWD2")) : 1;
-    if (use_v2 && d.precision == 1 && d.W <= 64) {      // two-step form (see rcda_fwd2_kernel)
+    static const int wide = getenv("CDETR_RCDA_WIDE") ? atoi(getenv("CDETR_RCDA_WIDE")) : 1;       // 0: rounds 1-5 (W <= 64 only), for A/B
+    if (use_v2 && d.precision == 1 && d.W <= (wide ? 96 : 64)) {      // two-step form (see rcda_fwd2_kernel); W <= 96 = an 800 x 1333 image (FSCD-LVIS) at stride 16
         const int ks = (d.W + 15) / 16;
-        auto go = [&](auto kern, int NWv) -> int {
+        auto go = [&](auto kern, int NWv, int KSv = 0) -> int {     // KSv: the kernel's KS when it is not ceil(W / 16)
             const FwdSmem sm = fwd_smem(d.H, d.W, NWv);
-            const int bytes = fwd2_smem(sm, d.H, d.W, ks).total * 4;
+            const int bytes = fwd2_smem(sm, d.H, d.W, KSv ? KSv : ks).total * 4;
             int rc;
             if ((rc = set_smem(kern, bytes, "cdetr_rcda_fwd"))) return rc;
             dim3 grid((d.L + QW * NWv - 1) / (QW * NWv), d.N * d.nh), block(64 * NWv);
@@ -1419,6 +1430,11 @@ extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
         const int nw5 = nw5_t ? atoi(nw5_t) : nw5_env;
         const long wg4 = (long)((d.L + QW * 4 - 1) / (QW * 4)) * d.N * d.nh, wg5 = (long)((d.L + QW * 5 - 1) / (QW * 5)) * d.N * d.nh;
         if (nw5 && nw == 4 && ks == 4 && wg4 > 256 && wg4 <= 512 && wg5 <= 256) return go(rcda_fwd2_kernel<5, 4>, 5);
+        if (ks > 4 || (wide && d.H > 64)) {         // wide / tall maps (round 6): a third 32-key tile in the score phase
+            if (d.H > 64 && d.H <= 96) return ks <= 4 ? go(rcda_fwd2_kernel<4, 4, 3>, 4, 4) : go(rcda_fwd2_kernel<4, 6, 3>, 4, 6);
+            if (ks <= 4) return go(rcda_fwd2_kernel<4, 4>, 4, 4);        // H > 96: VALU score phase
+            return ks == 5 ? go(rcda_fwd2_kernel<4, 5>, 4) : go(rcda_fwd2_kernel<4, 6>, 4);
+        }
         if (nw == 4) {
             if (ks == 1) return go(rcda_fwd2_kernel<4, 1>, 4);
             if (ks == 2) return go(rcda_fwd2_kernel<4, 2>, 4);
@@ -1454,10 +1470,11 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     // the two-step dV (rcda_dv2_kernel) rides in the dS launch (rcda_bwd_all_kernel) unless CDETR_RCDA_MERGE=0
     static const int use_dv2 = getenv("CDETR_RCDA_DV2") ? atoi(getenv("CDETR_RCDA_DV2")) : 1;
     static const int merge = getenv("CDETR_RCDA_MERGE") ? atoi(getenv("CDETR_RCDA_MERGE")) : 1;
-    const bool dv2 = use_dv2 && d.precision >= 1 && d.W <= 64;
+    static const int wide = getenv("CDETR_RCDA_WIDE") ? atoi(getenv("CDETR_RCDA_WIDE")) : 1;
+    const bool dv2 = use_dv2 && d.precision >= 1 && (wide || d.W <= 64);
     int hgroups = 0, slices = 0, per = 0;
     if (dv2) {
-        hgroups = (d.H + 7) / 8;
+        hgroups = ((d.H + 7) / 8) * ((Wp + 63) / 64);                // (key-row groups) x (chunks of <= 64 key columns), see rcda_dv2_body
         const long base = (long)hgroups * d.N * d.nh;
         static const int dv2_target = getenv("CDETR_RCDA_DV2_TARGET") ? atoi(getenv("CDETR_RCDA_DV2_TARGET")) : 448;
         slices = (int)((dv2_target + base - 1) / base);              // < 2 workgroups of 8 waves per CU (measured: 448 -> 46 us, 512 -> 54 us at the encoder shape)

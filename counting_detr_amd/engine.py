@@ -47,7 +47,18 @@ class FlatGradExchange:
         self.dummy_us = 0       # rehearsal / tests: an idle kernel of this many microseconds per bucket stands in for the collective (world 1)
         self.launched = []
         self.graphs = None      # capture_buckets(): the bucket all-reduces as captured graphs
+        self.use_graphs = True  # replay them when they exist (bench.py's N > 1 A/B flips this between its variants)
         self.probe = None       # a list: finish() appends (compute-side event, comm-side event) per step -> exposed_ms()
+        # CDETR_EXCHANGE_ON_SIDE=1 (round 6; "fewer active hardware queues is faster"): no exchange stream of its own.  A
+        # bucket is issued from the stream that carries the weight gradients (`also`), asynchronously: the process group's internal stream --
+        # which runs RCCL's kernels whatever stream the call is made from -- takes its dependency from that stream's position (= the segment's
+        # data AND weight gradients), the issuing stream is not blocked, and finish() makes the compute stream wait for the work handles.  One
+        # active queue less than the default (own stream, blocked behind the collective until it completes).  Never run on N > 1 GPUs yet:
+        # selectable, covered by the dummy-collective test and bench.py's N > 1 A/B.
+        self.on_side = os.environ.get("CDETR_EXCHANGE_ON_SIDE", "0") == "1"
+        self.works = []         # on_side: async work handles of this step's buckets
+        self._pg_stream = None  # on_side rehearsal (world 1, dummy_us): stands in for the process group's internal stream
+        self.trace = None       # a dict {"buckets": [], "main": []}: per-bucket (seg, start, end) events + the trainer's per-piece events (tests)
 
     def capture_buckets(self, pool=None):
         """The four bucket all-reduces as captured graphs on the exchange stream (RCCL collectives are capturable): `segment_done` then
@@ -83,28 +94,61 @@ class FlatGradExchange:
         self.launched.append(seg)
         if hi <= lo:
             return
+        side = self.on_side and also is not None and self.stream is not None
+
+        def mark(stream):
+            if self.trace is None:
+                return None
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(stream)
+            return e
         if get_world_size() < 2:
             if self.dummy_us > 0 and self.stream is not None:       # same ordering as a real bucket, an idle kernel instead of the collective
                 from . import _ffi
-                self.stream.wait_stream(torch.cuda.current_stream())
-                if also is not None:
-                    self.stream.wait_stream(also)
-                with torch.cuda.stream(self.stream):
+                if side:                                            # issued from `also`; the idle kernel runs on the stand-in for RCCL's own stream
+                    if self._pg_stream is None:
+                        self._pg_stream = self.stream
+                    also.wait_stream(torch.cuda.current_stream())
+                    run_on = self._pg_stream
+                    run_on.wait_stream(also)
+                else:
+                    run_on = self.stream
+                    run_on.wait_stream(torch.cuda.current_stream())
+                    if also is not None:
+                        run_on.wait_stream(also)
+                with torch.cuda.stream(run_on):
+                    b0 = mark(run_on)
                     _ffi.check(_ffi.lib().cdetr_delay(int(self.dummy_us), _ffi.stream_ptr()), "cdetr_delay")
+                    b1 = mark(run_on)
+                if self.trace is not None:
+                    self.trace["buckets"].append((seg, b0, b1))
             return
         buf = self.flat_g[lo:hi]
-        if self.stream is not None:
+        g = self.graphs[seg] if (self.graphs and self.use_graphs) else None
+        if side:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            also.wait_event(ev)
+            with torch.cuda.stream(also):
+                if g is not None:
+                    g.replay()                   # (a captured bucket joins back into the stream that replays it: `also` is blocked behind it)
+                else:
+                    self.works.append(dist.all_reduce(buf, async_op=True))
+        elif self.stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.stream.wait_event(ev)
             if also is not None:
                 self.stream.wait_stream(also)
             with torch.cuda.stream(self.stream):
-                g = self.graphs[seg] if self.graphs else None
+                b0 = mark(self.stream)
                 if g is not None:
                     g.replay()
                 else:
                     dist.all_reduce(buf)
+                b1 = mark(self.stream)
+            if self.trace is not None:
+                self.trace["buckets"].append((seg, b0, b1))
         else:
             dist.all_reduce(buf)
 
@@ -116,12 +160,27 @@ class FlatGradExchange:
                 self.segment_done(seg)
         self.launched = []
         if self.stream is not None:
-            if self.probe is not None:      # how long the compute stream has to wait for the last bucket = exposed communication
+            cur = torch.cuda.current_stream()
+            if self.works or (self._pg_stream is not None and self.on_side):
+                # on_side: the compute stream waits for the asynchronous buckets themselves; exposed = how long that wait lasts
+                ea = eb = None
+                if self.probe is not None:
+                    ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ea.record(cur)
+                for w in self.works:
+                    w.wait()
+                self.works = []
+                if self._pg_stream is not None:
+                    cur.wait_stream(self._pg_stream)
+                if ea is not None:
+                    eb.record(cur)
+                    self.probe.append((ea, eb))
+            if self.probe is not None and not self.on_side:      # how long the compute stream has to wait for the last bucket = exposed communication
                 ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ea.record(torch.cuda.current_stream())
+                ea.record(cur)
                 eb.record(self.stream)
                 self.probe.append((ea, eb))
-            torch.cuda.current_stream().wait_stream(self.stream)
+            cur.wait_stream(self.stream)
 
     def exposed_ms(self):
         """Per-step time the compute stream waited on the gradient exchange (0 = fully hidden behind backward); call after a
@@ -621,7 +680,11 @@ class Trainer:
     def clear_graph_cache(self):
         """Drop every captured step AND every frozen-stage graph.  Captured graphs hold the ADDRESSES of value-derived device tables (FrozenBN
         folds, padded stem images): anything that rebuilds them (checkpoint.invalidate_caches: checkpoint loads, replica broadcast, an
-        InferenceEngine built on the same model) calls this."""
+        InferenceEngine built on the same model) calls this.
+        Cost: a device synchronisation now, then one re-capture (~0.1 s) per (shape, capacity) key the loop meets again and a
+        rebuilt weight mirror.  Building or refreshing an InferenceEngine on the model BEING TRAINED (a periodic evaluation) therefore costs
+        the trainer its whole cache once per evaluation: correct, ~0.1 s x the number of keys -- evaluate at epoch boundaries (main.py does),
+        not every few steps."""
         if self._cache or self._entry is not None or self._frozen:
             if self.flat_g.is_cuda:
                 torch.cuda.synchronize()
@@ -682,8 +745,9 @@ class Trainer:
         """Static buffers + captured graph of the frozen stage for one padded image shape."""
         from . import ops
         shape = tuple(shape)
-        fs = self._frozen.get(shape)
+        fs = self._frozen.pop(shape, None)
         if fs is not None:
+            self._frozen[shape] = fs               # most recently announced / used last: _trim_frozen keeps the NEWEST idle entries
             return fs
         _ = self.mirror                            # (re)built outside the capture below
         body = self.model.backbone.body
@@ -966,7 +1030,7 @@ class Trainer:
                 e["W0"] = G()
                 with ops.scope(WG_DEFER_NESTED=False):      # (this flush SUBMITS: the outer queue closes empty)
                     with torch.cuda.graph(e["W0"], stream=wg, **mode):
-                        ops.wgrad_flush()
+                        ops.wgrad_flush(wg_target=ops.WGRAD_BESIDE_TARGET)      # beside layer4's data-gradient chain
         out = {k: v.detach() for k, v in loss_dict.items()}
         out["loss"] = losses.detach()
         e["S"], e["W"] = [], []
@@ -999,7 +1063,7 @@ class Trainer:
                     held.append([x[2] for x in ops._WG_QUEUE])
                     gw = G()
                     with torch.cuda.graph(gw, stream=wg, **mode):
-                        ops.wgrad_flush()
+                        ops.wgrad_flush(wg_target=ops.WGRAD_BESIDE_TARGET)      # beside the next piece's data-gradient chain
             e["S"].append(g)
             e["W"].append(gw)
         ops.MIRROR = None
@@ -1076,8 +1140,16 @@ class Trainer:
             if tok is not None:
                 announce = (next_samples.tensors if hasattr(next_samples, "tensors") else next_samples, tok)
                 # a shape announced for the first time: its frozen-stage graph is captured HERE, before anything of this step is launched
-                # (the capture synchronises the device and runs an eager frozen stage -- never between two pieces of a step)
-                self._frozen_for(announce[0].shape)
+                # (the capture synchronises the device and runs an eager frozen stage -- never between two pieces of a step).  A capture
+                # that does not fit (this call sits outside step()'s eviction loop) drops the announce: the next batch then runs
+                # its frozen stage in line, or step() evicts and captures it when the batch arrives
+                try:
+                    self._frozen_for(announce[0].shape)
+                except torch.OutOfMemoryError:
+                    torch.cuda.synchronize()
+                    self._trim_frozen(limit=0)
+                    torch.cuda.empty_cache()
+                    announce = None
         if e["fs"] is not None:
             self._frozen_ready(e, token)
         return self._run_entry(e, announce)
@@ -1142,8 +1214,16 @@ class Trainer:
                 e["W0"].replay()
         if dp:
             self.exchange.segment_done(0, also=wg if e["W0"] is not None else None)      # first bucket: everything above the backbone
+        tr_ = self.exchange.trace
         for segs, g, gw in zip(e["pieces"], e["S"], e["W"]):
+            if tr_ is not None:
+                m0 = torch.cuda.Event(enable_timing=True)
+                m0.record(main)
             g.replay()
+            if tr_ is not None:
+                m1 = torch.cuda.Event(enable_timing=True)
+                m1.record(main)
+                tr_["main"].append((tuple(segs), m0, m1))
             if gw is not None:
                 evs = torch.cuda.Event()
                 evs.record(main)
@@ -1410,8 +1490,9 @@ class InferenceEngine:
     def _frozen_for(self, shape):
         from . import ops
         shape = tuple(shape)
-        fs = self._frozen.get(shape)
+        fs = self._frozen.pop(shape, None)
         if fs is not None:
+            self._frozen[shape] = fs               # most recently announced / used last: _trim_frozen keeps the NEWEST idle entries
             return fs
         _ = self.mirror                            # (re)built outside the capture below
         body = self.model.backbone.body

@@ -324,11 +324,23 @@ def wgrad_side_stream():
     return s
 
 
-def wgrad_flush(overlap=False):
+WGRAD_BESIDE_TARGET = int(_os.environ.get("CDETR_WGRAD_BESIDE_TARGET", "384"))
+
+
+def wgrad_flush(overlap=False, wg_target=None):
     """Submit whatever the innermost wgrad_queue() holds (the gradient exchange calls this before it ships a bucket).
-    overlap: on the side stream, ordered after everything issued so far on the current one; wgrad_join() is the matching join."""
+    overlap: on the side stream, ordered after everything issued so far on the current one; wgrad_join() is the matching join.
+    wg_target: cdetr_wgrad_desc.wg_target for the queued problems that carry none -- launches that run BESIDE the data-gradient chain
+    (overlap=True, or a side-stream graph of the chain layout) ask for WGRAD_BESIDE_TARGET = 384 workgroups: fewer, longer workgroups
+    disturb the chain less (profiles/r5_ab_wgrad.txt); the library's own default (768) is for a launch that has the chip to itself."""
     q = _WG_QUEUE
     if q:
+        if wg_target is None and overlap and WGRAD_ASYNC:
+            wg_target = WGRAD_BESIDE_TARGET
+        if wg_target:
+            for e in q:
+                if e[0].wg_target == 0:
+                    e[0].wg_target = int(wg_target)
         arr = (WgradDesc * len(q))(*[e[0] for e in q])
         if overlap and WGRAD_ASYNC:
             side = wgrad_side_stream()
@@ -916,7 +928,7 @@ class AggrProjFn(torch.autograd.Function):
         gb = grad_buffer(bparam) if bparam.requires_grad else None
         # (in line on the main chain: the exemplar gradient below needs it.  More, shorter pixel slices -- cdetr_wgrad_desc.wg_target -- make it
         # SLOWER: 33.9 -> 42.6 us at 1536 workgroups, the 4 MB of dW_eff are written once per slice)
-        wgrad_raw(dy, d, x, Cc, dWeff, Cc, h * w, d, Cc, batch=B, sY=h * w * d, sX=h * w * Cc, sW=d * Cc, dbias=gb)
+        wgrad_raw(dy, d, x, Cc, dWeff, Cc, h * w, d, Cc, batch=B, sY=h * w * d, sX=h * w * Cc, sW=d * Cc, dbias=gb, wg_target=WGRAD_BESIDE_TARGET)
         W2d = wparam.detach().reshape(d, -1)
         gw = grad_buffer(wparam).reshape(d, -1) if wparam.requires_grad else None
         check(lib().cdetr_aggr_weight_bwd(ptr(dWeff), ptr(pf), ptr(W2d), ptr(gw), ptr(dpf), B, d, Cc, stream_ptr()), "cdetr_aggr_weight_bwd")

@@ -85,7 +85,14 @@ typedef struct {
                           * 2-4 workgroups per tile; the partial tiles meet here and the last workgroup to arrive adds them IN SLICE ORDER
                           * (deterministic) and runs the fused epilogue.  Layout: [4096 int32 arrival counters | partial tiles]; the caller
                           * zeroes the counters ONCE (every call leaves them zero) and must not share one scratch between streams that
-                          * may run cdetr_gemm concurrently.  16-byte aligned.                                                       */
+                          * may run cdetr_gemm concurrently.  16-byte aligned.
+                          * ORDERING IS gfx950-SPECIFIC, not a HIP memory-model guarantee: the partial tiles travel as RELAXED agent-scope
+                          * atomic stores / loads (sc1: they bypass the XCD-private L2s), `s_waitcnt vmcnt(0)` + the workgroup barrier put
+                          * them before the relaxed agent-scope counter RMW.  An acquire / release pair would be the portable form and costs
+                          * a write-back + invalidate of a whole 4 MiB L2 per workgroup (+80 us per launch when measured); the same
+                          * protocol serves cdetr_gemm_dl's split form and cdetr_rcda_fwd_desc.ws.  tools/splitk_stress.py (4000 launches,
+                          * bit-identical results, counters back at zero) is the regression check to re-run after a compiler / runtime
+                          * update.                                                                                                  */
     int64_t splitk_ws_bytes; /* size of splitk_ws in bytes (>= 16 KiB + partial tiles; too small = fewer slices or none)            */
     const void* A16lo;   /* optional: the LO plane of A's split-bf16 form, lo = bf16(A - float(A16)) (same shape / strides as A16).  With
                           * A16 + A16lo + B_split the split-bf16 x3 product (precision 1) needs no conversion at all: the direct-to-LDS
@@ -150,9 +157,10 @@ typedef struct {
     cdetr_conv_geom g; /* mode DENSE or CONV_FWD (p = output pixel) */
     int32_t batch_inner; /* two-level batch, as in cdetr_gemm_desc */
     int32_t wg_target;   /* 0 = default.  > 0: the number of workgroups the launch (for cdetr_wgrad_group: the grouped launch this problem   */
-                         /* becomes part of -- the largest request of its members) should spread its pixel slices over.  The default (384 =    */
-                         /* 1.5 per CU) suits a launch that runs BESIDE another stream's chain; a caller that knows the launch has the chip to  */
-                         /* itself (the last weight gradients of a step) asks for more.  Results do not depend on it beyond fp32 summation order. */
+                         /* becomes part of -- the largest request of its members) should spread its pixel slices over.  The default (768 = 3  */
+                         /* per CU; 384 for a single weight of <= 16 tiles) suits a launch that has the chip to itself; a caller that runs the  */
+                         /* launch BESIDE another stream's chain asks for 384 (fewer, longer workgroups disturb the chain less), the step's     */
+                         /* last weight gradients for several thousand.  Results do not depend on it beyond fp32 summation order.               */
     int64_t sY2, sX2, sW2;
     const void* dY16;  /* optional bf16 TWINS of dY / X (same shapes, leading dimensions and batch strides, in elements): with        */
     const void* X16;   /* precision 3 (plain bf16) the kernel reads these instead -- half the operand bytes, no conversion at staging. */

@@ -23,7 +23,7 @@ REF = "/root/reference/src/CountDETR_147_2nd_stage"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
-def install_stubs():
+def install_stubs(ref=None):
     tv = types.ModuleType("torchvision")
     tv.__version__ = "0.9.0"
     mods = {n: types.ModuleType(n) for n in ("torchvision.models", "torchvision.models._utils",
@@ -63,7 +63,7 @@ def install_stubs():
         setattr(m, fn, lambda args: None)
         sys.modules[n] = m
     torch.Tensor.cuda = lambda self, *a, **k: self
-    sys.path.insert(0, REF)
+    sys.path.insert(0, ref or REF)
     import models.backbone as mb
     mb.is_main_process = lambda: False
 

@@ -212,7 +212,9 @@ def rcda_core_ref(qr, qc, kr, kc, v, mr, mc, nh):
 
 @pytest.mark.parametrize("N,L,H,W,masked", [(2, 300, 50, 50, False), (1, 600, 20, 30, True), (2, 77, 7, 5, True),
                                             (1, 130, 70, 40, True), (2, 2500, 50, 50, True), (1, 33, 24, 36, False),
-                                            (1, 200, 40, 84, True), (1, 100, 84, 70, False), (1, 64, 16, 64, True)])   # W > 64: the wide-map kernels
+                                            (1, 200, 40, 84, True), (1, 100, 84, 70, False), (1, 64, 16, 64, True),   # W > 64: the wide-map kernels
+                                            (2, 4200, 50, 84, True), (2, 300, 50, 84, True),      # FSCD-LVIS 800 x 1333: encoder / decoder shapes (round 6)
+                                            (1, 150, 33, 65, True), (1, 96, 96, 96, True), (1, 70, 84, 50, True), (1, 60, 100, 20, False)])
 def test_rcda_core(N, L, H, W, masked, precision):
     from counting_detr_amd import ops
     nh, E = 8, 256

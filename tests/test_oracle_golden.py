@@ -223,7 +223,7 @@ def test_g7_stage1(golden, name):
 
 
 # ------------------------------------------------------------------------------------------------ full-size vectors (G10, G11)
-@pytest.mark.parametrize("name", ["small_b2", "aux", "shipped576", "cfg2"])
+@pytest.mark.parametrize("name", ["small_b2", "aux", "shipped576", "cfg2", "lvis_wide"])
 def test_g10_full_size_reference_runs(golden, name):
     """The oracle vs the real reference at BASELINE's sizes (cfg2 = B=2 800x800 Q=300 T=(37,120), bench.py's batch), the shipped
     script's grid-576 shape, a padded batch and aux_loss=True: outputs, Hungarian indices (incl. every aux layer's), losses, total
