@@ -192,7 +192,7 @@ __device__ __forceinline__ void rcda_scores(const cdetr_rcda_fwd_desc& d, const 
     // ---- save A_row / A_col for the backward pass (coalesced copy of the wave's contiguous block)
     {
         const int nq = min(QW, L - qbase);   // may be <= 0 for tail waves
-        if (nq > 0) {
+        if (nq > 0 && d.a_row != nullptr) {      // (a_row == a_col == NULL: inference, nothing saved for a backward pass)
             save_rows(Srow, sm.sw, d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
             save_rows(Scol, sm.sh, d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
         }
@@ -323,6 +323,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd_kernel(const cdetr_rcda_fwd_
 //     per-lane scalar (the form with A_col*A_row as the MFMA operand needs a multiply + bf16 split per element per h);
 //   * V tiles are prefetched PD = 4 iterations ahead (8 registers per tile per thread): an iteration is never bound by
 //     the global-load latency, which is what limited the one-tile-ahead pipeline of rcda_fwd_kernel.
+constexpr int RCDA_RG_DEFAULT = 1;       // key rows per barrier of the two-step forward (see rcda_fwd2_kernel, RG)
 constexpr int RCDA_WS_COUNTERS = 4096;   // int32 arrival counters at the head of cdetr_rcda_fwd_desc.ws (= SPLITK_COUNTERS of igemm.hip: one scratch serves both)
 constexpr int KSTR = 36;      // LDS row stride (floats) of the projected keys in rcda_scores_mfma: 36 / 4 odd -> conflict-free ds_read_b128
 
@@ -446,7 +447,7 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
 
     {
         const int nq = min(QW, L - qbase);   // may be <= 0 for tail waves
-        if (nq > 0 && save) {
+        if (nq > 0 && save && d.a_row != nullptr) {
             save_rows(Srow, sm.sw, d.a_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
             save_rows(Scol, sm.sh, d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
         }
@@ -454,18 +455,31 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
 }
 
 struct Fwd2Smem { int off_v, vts, total; };
-__host__ __device__ inline Fwd2Smem fwd2_smem(const FwdSmem& sm, int H, int W, int KS) {
+__host__ __device__ inline Fwd2Smem fwd2_smem(const FwdSmem& sm, int H, int W, int KS, int RG = 1) {
     Fwd2Smem s;
     s.off_v = sm.off_k;
     s.vts = 32 * KS + 8;                                   // bf16 per V^T row: [hi 16KS | lo 16KS | pad 8] -> odd multiple of 16 bytes
-    const int vfloats = 2 * 32 * s.vts / 2;                // two buffers of 32 channel rows
+    const int vfloats = 2 * RG * 32 * s.vts / 2;           // two buffers (RG = 2: two PAIRS of buffers) of 32 channel rows
     const int kfloats = (W + H) * KSTR;                    // key tiles of the score phase, padded rows (see rcda_scores_mfma)
     s.total = sm.off_k + (kfloats > vfloats ? kfloats : vfloats);
     return s;
 }
 
-template <int NW, int KS, int TH = 2>   // KS = 16-column steps of the key axis W (W <= 16 KS <= 96); TH = 32-row tiles of H in the MFMA score phase
+// PROBE (tools/rcda_probe.py, CDETR_RCDA_PROBE=1; never dispatched otherwise): every wave writes 8 x uint64 of s_memtime readings into
+// cdetr_rcda_fwd_desc.ws -- [kernel start, score phase done, main loop start, main loop end, output stored, cycles spent waiting at the
+// per-key-row barrier, cycles in the MFMA + accumulate section, cycles in fetch + stash] -- so that "barrier cadence" is a number.
+// RG = 2 (round 6): TWO key rows per workgroup barrier -- four LDS tile buffers (two pairs), the rows' MFMA chains T_h and T_h+1 are
+// independent and interleave, half as many barriers.  The phase probe of the RG = 1 loop at the encoder shape (profiles/r6_rcda_probe.txt):
+// per key row ~650 cycles in the MFMA + accumulate section (12 dependent MFMAs = 384 cycles of issue), ~390 in fetch + stash, ~370 waiting
+// at the barrier.
+template <int NW, int KS, int TH = 2, bool PROBE = false, int RG = 1>   // KS = 16-column steps of the key axis W (W <= 16 KS <= 96); TH = 32-row tiles of H in the MFMA score phase
 __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd_desc d) {
+    unsigned long long pt[5] = {0, 0, 0, 0, 0}, pacc[3] = {0, 0, 0};
+    auto now = [&]() __attribute__((always_inline)) -> unsigned long long {
+        if constexpr (PROBE) { const unsigned long long t = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); return t; }
+        return 0ull;
+    };
+    pt[0] = now();
     constexpr int NT = 64 * NW, QB = QW * NW;
     constexpr int PD = 4;                                  // V tiles in flight
     constexpr int NBLK = 16 * 4 * KS;                      // 4w x 2c blocks of one tile: (4 KS w-groups) x 16 channel pairs
@@ -538,6 +552,7 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
 
     if (H <= 32 * TH) rcda_scores_mfma<NT, (KS + 1) / 2, TH>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid, hz == 0);
     else rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
+    pt[1] = now();
 
     // ---- hoisted B operand: this lane's A_row row, k-slot j of step s <-> w = 16s + 8g + j
     bf16x8 bh[KS], bl[KS];
@@ -559,11 +574,15 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
 
     vfetch(rv[0]); vfetch(rv[1]); vfetch(rv[2]); vfetch(rv[3]);
     vstash(rv[0], 0);          // the K tiles this overlays are dead: rcda_scores ended with a barrier
+    if constexpr (RG == 2) vstash(rv[1], 1);
     __syncthreads();
     // one iteration; U = h mod PD is a compile-time constant so the register ring is statically indexed
+    pt[2] = now();
     auto step = [&](auto U, int h) __attribute__((always_inline)) {
         constexpr int u = decltype(U)::value;
+        const unsigned long long s0 = now();
         vfetch(rv[u]);                                                   // tile h + PD; set u was stashed one iteration ago
+        const unsigned long long s1 = now();
         const float acolh = (h < he) ? Scol[i32 * sm.sh + h] : 0.f;
         const __bf16* vt = VT + (u & 1) * 32 * VTS + i32 * VTS + 8 * g;
         f32x16 T = zero;
@@ -575,15 +594,64 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) outT[r] = fmaf(acolh, T[r], outT[r]);
+        unsigned long long s2 = 0;
+        if constexpr (PROBE) { asm volatile("" :: "v"(outT[0]), "v"(outT[15])); s2 = now(); }
         vstash(rv[(u + 1) % PD], (u + 1) & 1);                          // tile h+1 -> the buffer tile h-1 used
+        const unsigned long long s3 = now();
         __syncthreads();
+        if constexpr (PROBE) {
+            const unsigned long long s4 = now();
+            pacc[0] += s4 - s3; pacc[1] += s2 - s1; pacc[2] += (s1 - s0) + (s3 - s2);
+        }
     };
-    for (int h0 = hb; h0 < he; h0 += PD) {
-        step(std::integral_constant<int, 0>{}, h0);
-        step(std::integral_constant<int, 1>{}, h0 + 1);
-        step(std::integral_constant<int, 2>{}, h0 + 2);
-        step(std::integral_constant<int, 3>{}, h0 + 3);
+    // RG == 2: pair P = (h / 2) mod 2 owns LDS buffers 2P, 2P + 1 and register sets 2P, 2P + 1
+    auto step2 = [&](auto P_, int h) __attribute__((always_inline)) {
+        constexpr int P = decltype(P_)::value, Q = 1 - P;
+        const unsigned long long s0 = now();
+        vfetch(rv[2 * P]);                                               // tiles h + 4, h + 5; the sets were stashed one iteration ago
+        vfetch(rv[2 * P + 1]);
+        const unsigned long long s1 = now();
+        const float acol0 = (h < he) ? Scol[i32 * sm.sh + h] : 0.f;
+        const float acol1 = (h + 1 < he) ? Scol[i32 * sm.sh + h + 1] : 0.f;
+        const __bf16* vt0 = VT + (2 * P) * 32 * VTS + i32 * VTS + 8 * g;
+        const __bf16* vt1 = vt0 + 32 * VTS;
+        f32x16 T0 = zero, T1 = zero;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const bf16x8 ah0 = *reinterpret_cast<const bf16x8*>(vt0 + 16 * s);
+            const bf16x8 al0 = *reinterpret_cast<const bf16x8*>(vt0 + 16 * KS + 16 * s);
+            const bf16x8 ah1 = *reinterpret_cast<const bf16x8*>(vt1 + 16 * s);
+            const bf16x8 al1 = *reinterpret_cast<const bf16x8*>(vt1 + 16 * KS + 16 * s);
+            T0 = mfma_bf16x3(ah0, al0, bh[s], bl[s], T0);
+            T1 = mfma_bf16x3(ah1, al1, bh[s], bl[s], T1);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) outT[r] = fmaf(acol1, T1[r], fmaf(acol0, T0[r], outT[r]));
+        unsigned long long s2 = 0;
+        if constexpr (PROBE) { asm volatile("" :: "v"(outT[0]), "v"(outT[15])); s2 = now(); }
+        vstash(rv[2 * Q], 2 * Q);                                        // tiles h + 2, h + 3 -> the pair tiles h - 2, h - 1 used
+        vstash(rv[2 * Q + 1], 2 * Q + 1);
+        const unsigned long long s3 = now();
+        __syncthreads();
+        if constexpr (PROBE) {
+            const unsigned long long s4 = now();
+            pacc[0] += s4 - s3; pacc[1] += s2 - s1; pacc[2] += (s1 - s0) + (s3 - s2);
+        }
+    };
+    if constexpr (RG == 2) {
+        for (int h0 = hb; h0 < he; h0 += 4) {
+            step2(std::integral_constant<int, 0>{}, h0);
+            step2(std::integral_constant<int, 1>{}, h0 + 2);
+        }
+    } else {
+        for (int h0 = hb; h0 < he; h0 += PD) {
+            step(std::integral_constant<int, 0>{}, h0);
+            step(std::integral_constant<int, 1>{}, h0 + 1);
+            step(std::integral_constant<int, 2>{}, h0 + 2);
+            step(std::integral_constant<int, 3>{}, h0 + 3);
+        }
     }
+    pt[3] = now();
     if (hs > 1) {
         // The slices' partial sums meet in the scratch the split-reduction GEMMs use (same layout: arrival counters, then partials; same
         // protocol, igemm.hip): park, count in, and the slice that arrives last adds all of them IN SLICE ORDER -- the same sum whichever
@@ -630,6 +698,14 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             *reinterpret_cast<float4*>(op + 8 * j) = make_float4(outT[4 * j], outT[4 * j + 1], outT[4 * j + 2], outT[4 * j + 3]);
+    }
+    if constexpr (PROBE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pt[4] = now();
+        if (lane == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(d.ws) + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wid) * 8;
+            o[0] = pt[0]; o[1] = pt[1]; o[2] = pt[2]; o[3] = pt[3]; o[4] = pt[4]; o[5] = pacc[0]; o[6] = pacc[1]; o[7] = pacc[2];
+        }
     }
 }
 
@@ -1406,16 +1482,21 @@ extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
     const cdetr_rcda_fwd_desc d = *dp;
     CDETR_CHECK_ARG(d.N > 0 && d.L > 0 && d.H > 0 && d.W > 0 && d.nh > 0, "cdetr_rcda_fwd: bad sizes");
     CDETR_CHECK_ARG(d.H <= 128 && d.W <= 1024, "cdetr_rcda_fwd: H must be <= 128 (got %d)", d.H);
-    CDETR_CHECK_ARG(d.q_row && d.q_col && d.k_row && d.k_col && d.v && d.out && d.a_row && d.a_col, "cdetr_rcda_fwd: null pointer");
+    CDETR_CHECK_ARG(d.q_row && d.q_col && d.k_row && d.k_col && d.v && d.out, "cdetr_rcda_fwd: null pointer");
+    CDETR_CHECK_ARG((d.a_row != nullptr) == (d.a_col != nullptr), "cdetr_rcda_fwd: a_row and a_col are saved together or not at all (both NULL: inference)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int nw = pick_nw(d.L, d.N * d.nh);
     static const int use_v2 = getenv("CDETR_RCDA_FWD2") ? atoi(getenv("CDETR_RCDA_FWD2")) : 1;
     static const int wide = getenv("CDETR_RCDA_WIDE") ? atoi(getenv("CDETR_RCDA_WIDE")) : 1;       // 0: rounds 1-5 (W <= 64 only), for A/B
     if (use_v2 && d.precision == 1 && d.W <= (wide ? 96 : 64)) {      // two-step form (see rcda_fwd2_kernel); W <= 96 = an 800 x 1333 image (FSCD-LVIS) at stride 16
         const int ks = (d.W + 15) / 16;
-        auto go = [&](auto kern, int NWv, int KSv = 0) -> int {     // KSv: the kernel's KS when it is not ceil(W / 16)
+        // key rows per barrier (rcda_fwd2_kernel<..., RG>): CDETR_RCDA_RG = 1 | 2
+        static const int rg_env = getenv("CDETR_RCDA_RG") ? atoi(getenv("CDETR_RCDA_RG")) : RCDA_RG_DEFAULT;
+        const char* rg_t = cdetr_tune_env("CDETR_RCDA_RG");
+        const int rg = ((rg_t ? atoi(rg_t) : rg_env) == 2 && ks == 4 && d.H <= 64) ? 2 : 1;
+        auto go = [&](auto kern, int NWv, int KSv = 0, int RGv = 1) -> int {     // KSv: the kernel's KS when it is not ceil(W / 16)
             const FwdSmem sm = fwd_smem(d.H, d.W, NWv);
-            const int bytes = fwd2_smem(sm, d.H, d.W, KSv ? KSv : ks).total * 4;
+            const int bytes = fwd2_smem(sm, d.H, d.W, KSv ? KSv : ks, RGv).total * 4;
             int rc;
             if ((rc = set_smem(kern, bytes, "cdetr_rcda_fwd"))) return rc;
             dim3 grid((d.L + QW * NWv - 1) / (QW * NWv), d.N * d.nh), block(64 * NWv);
@@ -1425,11 +1506,29 @@ extern "C" int cdetr_rcda_fwd(const cdetr_rcda_fwd_desc* dp, void* stream) {
         };
         // 5-wave workgroups (160 queries) when that lands the grid on <= one workgroup per CU and 4 waves do not: the encoder's
         // 2 x 8 x 2500 queries are 320 workgroups of 128 (64 CUs get two) but exactly 256 of 160
+        static const int probe = getenv("CDETR_RCDA_PROBE") ? atoi(getenv("CDETR_RCDA_PROBE")) : 0;
+        if (probe && d.ws && ks == 4 && d.H <= 64) {     // tools/rcda_probe.py: unsliced launch, stamps into d.ws
+            auto gop = [&](auto kern, int NWv) -> int {
+                const FwdSmem sm = fwd_smem(d.H, d.W, NWv);
+                const int bytes = fwd2_smem(sm, d.H, d.W, ks, rg).total * 4;
+                int rc;
+                if ((rc = set_smem(kern, bytes, "cdetr_rcda_fwd"))) return rc;
+                dim3 grid((d.L + QW * NWv - 1) / (QW * NWv), d.N * d.nh), block(64 * NWv);
+                hipLaunchKernelGGL(kern, grid, block, bytes, st, d);
+                return cdetr_launch_status("cdetr_rcda_fwd(probe)");
+            };
+            if (rg == 2) return probe == 5 ? gop(rcda_fwd2_kernel<5, 4, 2, true, 2>, 5) : gop(rcda_fwd2_kernel<4, 4, 2, true, 2>, 4);
+            return probe == 5 ? gop(rcda_fwd2_kernel<5, 4, 2, true>, 5) : gop(rcda_fwd2_kernel<4, 4, 2, true>, 4);
+        }
         static const int nw5_env = getenv("CDETR_RCDA_NW5") ? atoi(getenv("CDETR_RCDA_NW5")) : 1;
         const char* nw5_t = cdetr_tune_env("CDETR_RCDA_NW5");
         const int nw5 = nw5_t ? atoi(nw5_t) : nw5_env;
         const long wg4 = (long)((d.L + QW * 4 - 1) / (QW * 4)) * d.N * d.nh, wg5 = (long)((d.L + QW * 5 - 1) / (QW * 5)) * d.N * d.nh;
-        if (nw5 && nw == 4 && ks == 4 && wg4 > 256 && wg4 <= 512 && wg5 <= 256) return go(rcda_fwd2_kernel<5, 4>, 5);
+        // (round 6, measured and dropped: 6 / 7 / 8 waves per workgroup at the encoder shape -- two waves per SIMD so that one wave's MFMAs overlap the
+        // other's VALU / LDS work, fewer busy CUs: 51.6 / 53.0 / 54.5 us against 49.5 for the 5-wave form; profiles/r6_rcda_probe.txt)
+        if (nw5 && nw == 4 && ks == 4 && wg4 > 256 && wg4 <= 512 && wg5 <= 256)
+            return rg == 2 ? go(rcda_fwd2_kernel<5, 4, 2, false, 2>, 5, 0, 2) : go(rcda_fwd2_kernel<5, 4>, 5);
+        if (rg == 2 && nw == 4) return go(rcda_fwd2_kernel<4, 4, 2, false, 2>, 4, 0, 2);
         if (ks > 4 || (wide && d.H > 64)) {         // wide / tall maps (round 6): a third 32-key tile in the score phase
             if (d.H > 64 && d.H <= 96) return ks <= 4 ? go(rcda_fwd2_kernel<4, 4, 3>, 4, 4) : go(rcda_fwd2_kernel<4, 6, 3>, 4, 6);
             if (ks <= 4) return go(rcda_fwd2_kernel<4, 4>, 4, 4);        // H > 96: VALU score phase

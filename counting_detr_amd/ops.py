@@ -64,7 +64,7 @@ class scope:
     gradients fork to side streams, the release signal behind the backbone), set for the block and restored on exit whatever happens inside.
     The same contract as `arithmetic`: engines never leave a module-level switch changed behind their back; the module values stay the
     defaults of code that runs outside any engine.  Scopes nest."""
-    _KEYS = ("MIRROR", "BRANCH_BESIDE", "WGRAD_EVERY", "AFTER_BACKBONE", "WG_DEFER_NESTED", "ZERO_ARENA")
+    _KEYS = ("MIRROR", "BRANCH_BESIDE", "WGRAD_EVERY", "AFTER_BACKBONE", "WG_DEFER_NESTED", "ZERO_ARENA", "RCDA_SAVE")
 
     def __init__(self, **kw):
         assert all(k in self._KEYS for k in kw), kw
@@ -1126,6 +1126,8 @@ def maxpool3x3s2(x, split=False):
 
 
 # ----------------------------------------------------------------------------------------------------- RCDA core
+RCDA_SKIP_SAVE = os.environ.get("CDETR_RCDA_SKIP_SAVE", "1") != "0"    # inference: no attention maps written (A/B knob)
+RCDA_SAVE = True                                                        # ops.scope(RCDA_SAVE=False): the forward bodies run for inference
 RCDA_SLICES = os.environ.get("CDETR_RCDA_SLICES", "1") != "0"        # key-row slices of the two-step forward (cdetr_rcda_fwd_desc.ws; A/B knob)
 FUSE_RCDA_DQ = os.environ.get("CDETR_RCDA_FUSE_DQ", "1") != "0"     # query gradients inside the dS launch (A/B knob)
 FUSE_RCDA_DK = os.environ.get("CDETR_RCDA_FUSE_DK", "1") != "0"     # key gradients too (split-bf16 mode)
@@ -1135,15 +1137,21 @@ def rcda_pads(H, W):
     return (H + 7) & ~7, (W + 3) & ~3
 
 
-def rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh):
-    """-> (out [N,L,E], a_row [N,nh,L,Wp], a_col [N,nh,L,Hp]); inputs contiguous fp32."""
+def rcda_fwd_raw(q_row, q_col, k_row, k_col, v, mask_row, mask_col, nh, save=None):
+    """-> (out [N,L,E], a_row [N,nh,L,Wp], a_col [N,nh,L,Hp]); inputs contiguous fp32.
+    save: keep the two attention maps for the backward pass (default: ops.RCDA_SAVE -- True unless the caller runs the forward bodies for
+    inference, `with ops.scope(RCDA_SAVE=False)`: transformer.py's no-grad branch; torch.is_grad_enabled() cannot tell, it is False inside
+    every autograd.Function.forward).  Without it the kernels get NULL and skip the 2 x 8 MB of stores per encoder call (round 6)
+    -> (out, None, None)."""
     N, L, E = q_row.shape
     H, W = v.shape[1:3]
     assert E == nh * 32, "the RCDA kernels are specialised for head_dim 32"
     Hp, Wp = rcda_pads(H, W)
+    if save is None:
+        save = RCDA_SAVE or not RCDA_SKIP_SAVE
     out = torch.empty((N, L, E), device=v.device, dtype=torch.float32)
-    a_row = torch.empty((N, nh, L, Wp), device=v.device, dtype=torch.float32)
-    a_col = torch.empty((N, nh, L, Hp), device=v.device, dtype=torch.float32)
+    a_row = torch.empty((N, nh, L, Wp), device=v.device, dtype=torch.float32) if save else None
+    a_col = torch.empty((N, nh, L, Hp), device=v.device, dtype=torch.float32) if save else None
     d = RcdaFwdDesc()
     d.N, d.L, d.H, d.W, d.nh, d.scale = N, L, H, W, nh, 32 ** -0.5
     d.precision = PRECISION

@@ -326,10 +326,11 @@ class Transformer(nn.Module):
                 memory, posemb_row, posemb_col = ops.EncoderStackFn.apply(src, posemb_row, posemb_col, mask_row, mask_col, enc, enc[0].norm1.weight, self.taps)
             else:       # inference: the same fused forward bodies, nothing saved
                 memory = src
-                for li, layer in enumerate(enc):
-                    memory = ops.EncoderLayerFn.forward(ops._Ctx(), memory, posemb_row, posemb_col, mask_row, mask_col, layer, None)
-                    if self.taps is not None:
-                        self.taps[f"enc{li}"] = memory
+                with ops.scope(RCDA_SAVE=False):      # no backward: the attention maps are not written
+                    for li, layer in enumerate(enc):
+                        memory = ops.EncoderLayerFn.forward(ops._Ctx(), memory, posemb_row, posemb_col, mask_row, mask_col, layer, None)
+                        if self.taps is not None:
+                            self.taps[f"enc{li}"] = memory
         else:
             memory = src
             for li, layer in enumerate(enc):
@@ -343,7 +344,11 @@ class Transformer(nn.Module):
         if self.fused_decoder and src.is_cuda:
             args = (tgt, query_pos, query_pos_x, query_pos_y, memory, None, None, mask_row, mask_col, list(self.decoder_layers),
                     pattern.weight, posemb_row, posemb_col)
-            layer_outs = ops.DecoderStackFn.apply(*args) if grad else ops.DecoderStackFn.forward(ops._Ctx(), *args)
+            if grad:
+                layer_outs = ops.DecoderStackFn.apply(*args)
+            else:
+                with ops.scope(RCDA_SAVE=False):
+                    layer_outs = ops.DecoderStackFn.forward(ops._Ctx(), *args)
         else:
             k_row_mean = memory.mean(1) + posemb_row                      # shared by the 6 decoder layers
             k_col_mean = memory.mean(2) + posemb_col

@@ -311,7 +311,8 @@ int cdetr_maxpool3x3s2_split(const float* X, float* Y, void* Y16, void* Y16lo, i
  * or NULL.  Computes, per (n, head):  A_row = softmax_W(scale*q_row.k_row^T), A_col = softmax_H(scale*q_col.k_col^T),
  * out[n][q][head*32+c] = sum_h sum_w A_col[q][h] A_row[q][w] v[n][h][w][head*32+c].
  * a_row [N][nh][L][Wp], a_col [N][nh][L][Hp] (Wp = W rounded up to 4, Hp = H rounded up to 8; pad = 0) are written
- * for the backward pass.                                                                                      */
+ * for the backward pass; both NULL = inference: nothing is saved (2 x 8 MB of stores per encoder call at 800 x 800).  Feature maps up to
+ * 128 x 1024 keys; the MFMA two-step kernels cover W <= 96 (an 800 x 1333 FSCD-LVIS image at stride 16), wider maps the generic kernel.  */
 typedef struct {
     int32_t N, L, H, W, nh; /* head dim fixed at 32 */
     int32_t precision;      /* 0 = fp32 MFMA, 1 = split-bf16 x3 (as in cdetr_gemm_desc) */

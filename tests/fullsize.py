@@ -83,7 +83,8 @@ def check_param_samples(z, name, model, grads=True, grad_rtol=3e-2, what=""):
     params = dict(model.named_parameters())
     pidx, fidx = z[f"{name}/sample_pidx"], z[f"{name}/sample_fidx"]
     g_ref, after = z[f"{name}/sample_grad"], z[f"{name}/sample_after"]
-    worst_g, worst_p = 0.0, 0.0
+    worst_g, worst_p, n_rel = 0.0, 0.0, 0
+    tn = float(z[f"{name}/grad_total_norm"])
     by_param = {}
     for k in range(len(pidx)):
         by_param.setdefault(int(pidx[k]), []).append(k)
@@ -99,7 +100,17 @@ def check_param_samples(z, name, model, grads=True, grad_rtol=3e-2, what=""):
         if grads and grads_well_posed(z, name):
             g = p.grad.reshape(-1)[fi].double().cpu().numpy()
             gr = g_ref[ks].astype(np.float64)
-            err_g = np.abs(g - gr) / np.maximum(np.abs(gr), 1e-30)
-            assert err_g.max() <= grad_rtol, f"{what}{n}: gradient element {int(fidx[ks][err_g.argmax()])}: {g[err_g.argmax()]:.6e} vs {gr[err_g.argmax()]:.6e}"
-            worst_g = max(worst_g, float(err_g.max()))
+            # relative bar for the elements that matter to the step (|g| >= 1e-5 of the total gradient norm); below that a parameter's whole
+            # gradient is a sum that nearly cancels (adapt_pos2d.2.bias in lvis_wide: 3e-6 against a total norm of 428 -- the plain-bf16
+            # backward's 2^-9 per term shows as 6 % there): those get the absolute floor the per-parameter norm bar uses (1e-6 of the total norm)
+            big = np.abs(gr) >= 1e-5 * tn
+            err_abs = np.abs(g - gr)
+            assert (err_abs[~big] <= 1e-6 * tn).all(), f"{what}{n}: small gradient element off by {err_abs[~big].max():.3e} (total norm {tn:.3e})"
+            if big.any():
+                err_g = err_abs[big] / np.abs(gr[big])
+                k = int(np.flatnonzero(big)[err_g.argmax()])
+                assert err_g.max() <= grad_rtol, f"{what}{n}: gradient element {int(fidx[ks][k])}: {g[k]:.6e} vs {gr[k]:.6e}"
+                worst_g = max(worst_g, float(err_g.max()))
+                n_rel += int(big.sum())
+    check_param_samples.last_counts = (n_rel, len(pidx))      # (elements under the relative gradient bar, elements sampled)
     return worst_g, worst_p
