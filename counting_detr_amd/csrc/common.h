@@ -87,6 +87,19 @@ __device__ __forceinline__ void split_bf16_pk(float x0, float x1, unsigned& hi, 
     lo = __builtin_bit_cast(unsigned, l);
 }
 // four consecutive-k fp32 values -> hi (8 bytes) at dst, lo (8 bytes) at dst + lo_off (both in bf16 elements)
+// Sum / maximum of a value over the two halves of a wave (lane l and lane l ^ 32), the same result in both lanes.  gfx950's
+// v_permlane32_swap exchanges the upper half of one register with the lower half of another in ONE VALU instruction; __shfl_xor(x, 32)
+// is a ds_bpermute -- an LDS-pipe round trip of ~100 cycles, which sat once per key column in the RCDA dS loop and once or twice per key
+// tile in the flash-attention loops (round 6).  a + b is commutative, so the results are bit-identical to the shuffle forms.
+__device__ __forceinline__ float xhalf_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);     // r[0] = [lo, lo], r[1] = [hi, hi]
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xhalf_max(float x) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 __device__ __forceinline__ void stash_split4(__bf16* dst, int lo_off, float x0, float x1, float x2, float x3) {
     uint2 h, l;
     split_bf16_pk(x0, x1, h.x, l.x);

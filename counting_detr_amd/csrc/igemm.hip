@@ -1824,7 +1824,7 @@ __device__ __forceinline__ void wgrad_direct_body(const cdetr_wgrad_desc& d, con
     }
     if (dbias != nullptr && tj == 0) {
         bsum += __shfl_xor(bsum, 16, 64);
-        bsum += __shfl_xor(bsum, 32, 64);
+        bsum = xhalf_sum(bsum);
         if (g4 == 0 && iv) atomicAdd(dbias + ci, bsum);
     }
 }

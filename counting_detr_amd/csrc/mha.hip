@@ -113,17 +113,17 @@ __global__ __launch_bounds__(256) void mha_fwd_kernel(const float* __restrict__ 
     }
     // combine the four key-subset partials of each query
     float mn = fmaxf(m, __shfl_xor(m, 16, 64));
-    mn = fmaxf(mn, __shfl_xor(mn, 32, 64));
+    mn = xhalf_max(mn);
     const float cs = (m > -INFINITY) ? expf(m - mn) : 0.f;
     l *= cs;
     l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = xhalf_sum(l);
     const float inv = 1.f / l;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         float a = acc[c] * cs;
         a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
+        a = xhalf_sum(a);
         acc[c] = a * inv;
     }
     if (qv) {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void mha_bwd_q_kernel(const float* __restrict_
     for (int c = 0; c < D; ++c) {
         float a = dq[c];
         a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
+        a = xhalf_sum(a);
         dq[c] = a * scale;
     }
     if (qv) {
@@ -249,9 +249,9 @@ __global__ __launch_bounds__(256) void mha_bwd_kv_kernel(const float* __restrict
     for (int c = 0; c < D; ++c) {
         float a = dk[c], b = dvv[c];
         a += __shfl_xor(a, 16, 64);
-        a += __shfl_xor(a, 32, 64);
+        a = xhalf_sum(a);
         b += __shfl_xor(b, 16, 64);
-        b += __shfl_xor(b, 32, 64);
+        b = xhalf_sum(b);
         dk[c] = a * scale;
         dvv[c] = b;
     }
@@ -393,13 +393,13 @@ __global__ __launch_bounds__(NTF) void fwd_kernel(const float* __restrict__ qk, 
                 if (t * 32 + reg_row(r, g) >= L) S[r] = -INFINITY;
                 mx = fmaxf(mx, S[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xhalf_max(mx);
             const float mn = fmaxf(m, mx);
             const float corr = __expf(m - mn);
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { S[r] = __expf(S[r] - mn); ls += S[r]; }
-            ls += __shfl_xor(ls, 32, 64);
+            ls = xhalf_sum(ls);
             l = l * corr + ls;
             m = mn;
 #pragma unroll
@@ -468,13 +468,13 @@ __global__ __launch_bounds__(2 * NTF) void fwd_ks_kernel(const float* __restrict
                 if ((tbase + t) * 32 + reg_row(r, g) >= L) S[r] = -INFINITY;
                 mx = fmaxf(mx, S[r]);
             }
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = xhalf_max(mx);
             const float mn = fmaxf(m, mx);
             const float corr = __expf(m - mn);
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { S[r] = __expf(S[r] - mn); ls += S[r]; }
-            ls += __shfl_xor(ls, 32, 64);
+            ls = xhalf_sum(ls);
             l = l * corr + ls;
             m = mn;
 #pragma unroll

@@ -90,6 +90,42 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ gsrc, int r
     }
 }
 
+// Two tensors staged together (the dS kernel's A_row and A_col rows): when each fits one batch, ALL loads of both are issued before the first LDS
+// store -- one global round trip instead of two (round-6 probe: 5.2 us of a 55 us workgroup went into the two stage_rows calls) -- and the
+// (row, column) of a slot advances incrementally instead of by a division per slot.
+template <int CH>
+__device__ __forceinline__ void stage_rows_pair(const float* __restrict__ g0, int cols0, float* lds0, int stride0,
+                                                const float* __restrict__ g1, int cols1, float* lds1, int stride1, int rows_valid, int lane) {
+    const int c40 = cols0 >> 2, c41 = cols1 >> 2;
+    if (QW * c40 > 64 * CH || QW * c41 > 64 * CH) {
+        stage_rows<CH>(g0, rows_valid, cols0, lds0, stride0, lane);
+        stage_rows<CH>(g1, rows_valid, cols1, lds1, stride1, lane);
+        return;
+    }
+    float4 t0[CH], t1[CH];
+    const int last0 = max(rows_valid * c40 - 1, 0), last1 = max(rows_valid * c41 - 1, 0);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) t0[u] = ld4(g0 + 4 * (long)min(lane + 64 * u, last0));
+#pragma unroll
+    for (int u = 0; u < CH; ++u) t1[u] = ld4(g1 + 4 * (long)min(lane + 64 * u, last1));
+    auto put = [&](const float4 (&t)[CH], int cols4, float* lds, int stride) __attribute__((always_inline)) {
+        const int dr = 64 / cols4, dc = 64 - dr * cols4;
+        int r = lane / cols4, c4 = lane - r * cols4;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (r < QW) {
+                const bool ok = r < rows_valid;
+                float* dst = lds + r * stride + 4 * c4;
+                dst[0] = ok ? t[u].x : 0.f; dst[1] = ok ? t[u].y : 0.f; dst[2] = ok ? t[u].z : 0.f; dst[3] = ok ? t[u].w : 0.f;
+            }
+            r += dr; c4 += dc;
+            if (c4 >= cols4) { c4 -= cols4; ++r; }
+        }
+    };
+    put(t0, c40, lds0, stride0);
+    put(t1, c41, lds1, stride1);
+}
+
 // The reverse of stage_rows: `rows` x `cols` (cols % 4 == 0) from an LDS tile (row stride lds_stride, any parity) to a contiguous, 16-byte
 // aligned global block, 16-byte stores, (row, column) advanced incrementally -- the per-element `idx / cols` of a flat loop costs ~40
 // instructions each and was a third of the score phase.
@@ -333,10 +369,14 @@ constexpr int KSTR = 36;      // LDS row stride (floats) of the projected keys i
 // softmax over keys is an in-lane reduction over registers plus one exchange between the two lane halves.  Replaces the VALU loop of
 // rcda_scores (50 keys x (8 LDS reads + 32 FMAs) per lane: 9 of the forward kernel's 43 us at the decoder shape).
 // Leaves A_row / A_col in the wave's LDS tiles and saves them, like rcda_scores; ends with the key tiles dead.
-template <int NT, int TW, int TH>
+template <int NT, int TW, int TH, bool PROBE = false>
 __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, const FwdSmem& sm, float* smem, float* Srow, float* Scol,
                                                  int tid, int lane, int i32, int g, int n, int head, int qbase, int q, bool qvalid,
-                                                 bool save = true) {
+                                                 bool save = true, unsigned long long* stamps = nullptr) {
+    // PROBE: stamps[0..5] = keys + queries landed (before the barrier) | barrier passed | row side done | column side done | barrier passed | maps saved
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if constexpr (PROBE) { stamps[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    };
     const int H = d.H, W = d.W, L = d.L, E = d.nh * D;
     const int Wp = (W + 3) & ~3, Hp = (H + 7) & ~7;
     float* Krow = smem + sm.off_k;             // [W][KSTR]
@@ -383,7 +423,10 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
         if (TW > 2) mrow[1] = __ballot(lane + 64 < W && mr[min(lane + 64, W - 1)] != 0);
         if (TH > 2) mcol[1] = __ballot(lane + 64 < H && mc[min(lane + 64, H - 1)] != 0);
     }
+    if constexpr (PROBE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    stamp(0);
     __syncthreads();
+    stamp(1);
 
 #pragma unroll
     for (int side = 0; side < 2; ++side) {
@@ -410,16 +453,23 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
                 acc = mfma_bf16x3(ah, al, qh[side][st], ql[side][st], acc);
             }
             mfma_drain(acc);
+            // "this key does not count" as ONE 32-bit set per lane and tile: bit p <-> key 32t + 4g + p (p = (r&3) + 8(r>>2) is a compile-time
+            // constant per register), = the padding-mask bits of the tile shifted by 4g, OR every key >= nkeys.  The per-element form
+            // `key >= nkeys || (mask >> key) & 1` compiled to a 64-bit shift and two exec-mask regions per logit (round-6 probe: 3.4 us per
+            // side of the score phase, 7000 cycles for 32 logits per lane); with the set it is an AND, a compare and a select.
+            const unsigned chunk = (unsigned)(mbits[t >> 1] >> (32 * (t & 1)));       // wave-uniform
+            const int lim = nkeys - 32 * t - 4 * g;                                  // keys of this lane with p >= lim are out of range
+            const unsigned dead = (chunk >> (4 * g)) | (lim >= 32 ? 0u : (lim <= 0 ? 0xffffffffu : (0xffffffffu << lim)));
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
-                float v = acc[r] * d.scale;
-                if (key >= nkeys || ((mbits[t >> 1] >> (key & 63)) & 1ull)) v = -INFINITY;
+                constexpr unsigned one = 1u;
+                const unsigned bit = one << ((r & 3) + 8 * (r >> 2));
+                const float v = (dead & bit) ? -INFINITY : acc[r] * d.scale;
                 sv[t][r] = v;
                 mx = fmaxf(mx, v);
             }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xhalf_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
@@ -431,7 +481,7 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
                 sum += e;
             }
         }
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xhalf_sum(sum);
         const float inv = 1.f / sum;
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
@@ -439,11 +489,15 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * g;
-                if (key < npad) S[key] = sv[t][r] * inv;          // keys in [nkeys, npad) carry exp(-inf) = 0
+                // keys in [nkeys, npad) carry exp(-inf) = 0; keys >= npad go to the row's spare slot (the strides sw = Wp + 1 / sh = Hp + 4
+                // leave index npad unused): an unconditional store instead of one exec-mask region per logit
+                S[min(key, npad)] = sv[t][r] * inv;
             }
         }
+        stamp(2 + side);
     }
     __syncthreads();   // all waves done with the key tiles (the V buffers overlay them); the LDS rows are visible to the whole wave
+    stamp(4);
 
     {
         const int nq = min(QW, L - qbase);   // may be <= 0 for tail waves
@@ -452,6 +506,7 @@ __device__ __forceinline__ void rcda_scores_mfma(const cdetr_rcda_fwd_desc& d, c
             save_rows(Scol, sm.sh, d.a_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
         }
     }
+    stamp(5);
 }
 
 struct Fwd2Smem { int off_v, vts, total; };
@@ -465,7 +520,7 @@ __host__ __device__ inline Fwd2Smem fwd2_smem(const FwdSmem& sm, int H, int W, i
     return s;
 }
 
-// PROBE (tools/rcda_probe.py, CDETR_RCDA_PROBE=1; never dispatched otherwise): every wave writes 8 x uint64 of s_memtime readings into
+// PROBE (tools/rcda_probe.py, CDETR_RCDA_PROBE=1; never dispatched otherwise): every wave writes 16 x uint64 of s_memtime readings into
 // cdetr_rcda_fwd_desc.ws -- [kernel start, score phase done, main loop start, main loop end, output stored, cycles spent waiting at the
 // per-key-row barrier, cycles in the MFMA + accumulate section, cycles in fetch + stash] -- so that "barrier cadence" is a number.
 // RG = 2 (round 6): TWO key rows per workgroup barrier -- four LDS tile buffers (two pairs), the rows' MFMA chains T_h and T_h+1 are
@@ -550,7 +605,8 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
         }
     };
 
-    if (H <= 32 * TH) rcda_scores_mfma<NT, (KS + 1) / 2, TH>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid, hz == 0);
+    unsigned long long sst[6] = {0, 0, 0, 0, 0, 0};
+    if (H <= 32 * TH) rcda_scores_mfma<NT, (KS + 1) / 2, TH, PROBE>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid, hz == 0, sst);
     else rcda_scores<NT>(d, sm, smem, Srow, Scol, tid, lane, i32, g, n, head, qbase, q, qvalid);
     pt[1] = now();
 
@@ -703,8 +759,10 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         pt[4] = now();
         if (lane == 0) {
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(d.ws) + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wid) * 8;
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(d.ws) + ((long)(blockIdx.y * gridDim.x + blockIdx.x) * NW + wid) * 16;
             o[0] = pt[0]; o[1] = pt[1]; o[2] = pt[2]; o[3] = pt[3]; o[4] = pt[4]; o[5] = pacc[0]; o[6] = pacc[1]; o[7] = pacc[2];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[8 + i] = sst[i];
         }
     }
 }
@@ -714,6 +772,9 @@ __global__ __launch_bounds__(64 * NW) void rcda_fwd2_kernel(const cdetr_rcda_fwd
 //   U: per-wave [32][su] slices holding A_col at the start and the ds_col / A_row staging at the end; while the main loop
 //      runs (A_col lives in registers) the same memory is the double-buffered V tile shared by the workgroup;
 //   R: per-wave [32][sw] A_row; element (q, w) is overwritten by dA_row[q, w] as soon as column w has been consumed.
+// A/B knob of the fused key gradients (rcda_bwd_body): 1 = every wave adds its partial tiles to global itself (rounds 3-5)
+__device__ __constant__ int g_rcda_dk_per_wave = 0;
+__device__ __forceinline__ bool rcda_dk_per_wave() { return g_rcda_dk_per_wave != 0; }
 constexpr int BWD_CG = 2;     // key columns staged and consumed per workgroup barrier of the dS kernel
 struct BwdSmem {
     int sw, sh, su, off_u, off_r, off_kk, total;
@@ -736,8 +797,26 @@ __host__ __device__ inline BwdSmem bwd_smem(int H, int W, int NF, int NW, bool w
 }
 
 // TERMS: bf16 MFMAs per product in the split-bf16 paths (3, or 1 = plain bf16: cdetr_rcda_bwd_desc.precision 3)
-template <int NF, int NW, int PREC, int TERMS = 3>
+// PROBE (tools/rcda_probe.py bwd, CDETR_RCDA_PROBE; never dispatched otherwise): cdetr_rcda_bwd_desc.ds_row is the stamp buffer (16 x uint64 per
+// wave of s_memtime readings: start | attention rows staged, A_col in registers | main loop over the key columns done | both softmax backward
+// passes | keys in LDS | query gradients stored | key gradients added), nothing is saved through ds_row / ds_col.
+template <int NF, int NW, int PREC, int TERMS = 3, bool PROBE = false>
 __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, const int bx, const int by) {
+    unsigned long long pst[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if constexpr (PROBE) { pst[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+    };
+    auto flush_probe = [&]() __attribute__((always_inline)) {
+        if constexpr (PROBE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((threadIdx.x & 63) == 0) {
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(d.ds_row) + ((long)(by * gridDim.x + bx) * NW + (threadIdx.x >> 6)) * 16;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) o[i] = pst[i];
+            }
+        }
+    };
+    stamp(0);
     constexpr int NT = 64 * NW, QB = QW * NW;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int VS = 36;                 // V tile row stride (floats): 36/4 odd -> conflict-free ds_read_b128
@@ -777,22 +856,34 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
     float* dArow = Arow;
     float* Vs = smem + sm.off_u;                             // [2][CG][HR][36], overlays U during the main loop
 
-    // ---- load the saved attention rows of this wave (coalesced), zero for tail queries
-    {
-        const int qb = min(qbase, L - 1), nqv = max(nq, 0);      // tail waves (qbase >= L) stage zeros from an in-bounds address
-        stage_rows<8>(d.a_row + (((long)n * d.nh + head) * L + qb) * Wp, nqv, Wp, Arow, sm.sw, lane);
-        stage_rows<8>(d.a_col + (((long)n * d.nh + head) * L + qb) * Hp, nqv, Hp, Acol, sm.sh, lane);
-    }
-    // dOut^T fragment (B operand, loop invariant): lane (j = query, g) holds dOut[q][8kk + 4g + s]
+    // dOut^T fragment (B operand, loop invariant): lane (j = query, g) holds dOut[q][8kk + 4g + s]; requested before the attention rows so that
+    // the two fetches share one round trip
     float dob[4][4];
+    float4 dobt[4];
     {
         const float* dp = d.d_out + ((long)n * L + (qvalid ? q : 0)) * E + head * D;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            float4 t = ld4(dp + kk * 8 + g * 4);
-            if (!qvalid) t = make_float4(0.f, 0.f, 0.f, 0.f);
-            dob[kk][0] = t.x; dob[kk][1] = t.y; dob[kk][2] = t.z; dob[kk][3] = t.w;
-        }
+        for (int kk = 0; kk < 4; ++kk) dobt[kk] = ld4(dp + kk * 8 + g * 4);
+    }
+    // ---- load the saved attention rows of this wave (coalesced), zero for tail queries
+    // A_col goes straight into the transposed register layout it is used in (element (f, r) <-> key row h = 32f + (r&3) + 8(r>>2) + 4g of query
+    // i32: four consecutive h = one 16-byte load); rounds 1-5 staged it through LDS (64 scalar stores + 32 scalar reads per lane + two barriers)
+    float4 act[NF][4];
+    {
+        const float* ac = d.a_col + (((long)n * d.nh + head) * L + (qvalid ? q : 0)) * Hp;
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) act[f][j] = ld4(ac + min(32 * f + 8 * j + 4 * g, Hp - 4));
+    }
+    {
+        const int qb = min(qbase, L - 1), nqv = max(nq, 0);      // tail waves (qbase >= L) stage zeros from an in-bounds address
+        stage_rows<8>(d.a_row + (((long)n * d.nh + head) * L + qb) * Wp, nqv, Wp, Arow, sm.sw, lane);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        if (!qvalid) dobt[kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+        dob[kk][0] = dobt[kk].x; dob[kk][1] = dobt[kk].y; dob[kk][2] = dobt[kk].z; dob[kk][3] = dobt[kk].w;
     }
     bf16x8 dobh[2], dobl[2];      // loop-invariant split of the dOut^T fragment (split-bf16 mode)
 #pragma unroll
@@ -801,18 +892,23 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
                             dob[2 * kp + 1][0], dob[2 * kp + 1][1], dob[2 * kp + 1][2], dob[2 * kp + 1][3]};
         split_bf16x8(x, dobh[kp], dobl[kp]);
     }
-    __syncthreads();
     // A_col in the transposed accumulator layout: element (f, r) <-> key row h = 32f + (r&3) + 8(r>>2) + 4g, query i32
     float acolT[NF][16], dacolT[NF][16];
 #pragma unroll
     for (int f = 0; f < NF; ++f)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int h = 32 * f + (r & 3) + 8 * (r >> 2) + 4 * g;
-            acolT[f][r] = (h < Hp) ? Acol[i32 * sm.sh + h] : 0.f;
-            dacolT[f][r] = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const bool ok = qvalid && (32 * f + 8 * j + 4 * g < Hp);
+            acolT[f][4 * j + 0] = ok ? act[f][j].x : 0.f;
+            acolT[f][4 * j + 1] = ok ? act[f][j].y : 0.f;
+            acolT[f][4 * j + 2] = ok ? act[f][j].z : 0.f;
+            acolT[f][4 * j + 3] = ok ? act[f][j].w : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dacolT[f][4 * j + k] = 0.f;
         }
-    __syncthreads();           // every wave holds its A_col rows in registers: U becomes the V tile buffers
+    // (no workgroup barrier here: the A_row slices are private to their waves, nobody reads the U region before the first V tile is staged,
+    // and the barrier that follows that staging orders the rest)
+    stamp(1);
 
     // ---- main loop over key columns w.  V[:, w, :] tiles run through a ring of PD register sets (unconditional loads: rows
     // h >= H re-read row H-1 -- A_col is zero there -- and columns w >= W re-read column W-1, weighted by A_row = 0) and are
@@ -868,12 +964,16 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
         constexpr int u = decltype(U)::value;
         const int buf = u & 1;
         vfetch(rv[u]);                                                   // the set after next; set u was staged one step ago
+#if CDETR_RCDA_UNROLL_CC
+#pragma unroll
+#else
 #pragma clang loop unroll(disable)
+#endif
       for (int cc = 0; cc < CG; ++cc) {       // rolled on purpose: unrolled, the compiler keeps CG accumulator sets live (380 VGPRs)
         const int w = w0s + cc;
         const float* tile = Vs + (buf * CG + cc) * HR * VS;
         const float arow = Arow[i32 * sm.sw + w];                        // zero for W <= w < Wp
-        float part = 0.f;
+        float part4[4] = {0.f, 0.f, 0.f, 0.f};      // four partial sums: one accumulator is a chain of 16 NF dependent FMAs per key column
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             f32x16 gt = zero16;
@@ -898,11 +998,12 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                part = fmaf(acolT[f][r], gt[r], part);
+                part4[r & 3] = fmaf(acolT[f][r], gt[r], part4[r & 3]);
                 dacolT[f][r] = fmaf(arow, gt[r], dacolT[f][r]);
             }
         }
-        part += __shfl_xor(part, 32, 64);
+        float part = (part4[0] + part4[1]) + (part4[2] + part4[3]);
+        part = xhalf_sum(part);
         if (g == 0) dArow[i32 * sm.sw + w] = part;
       }
         vstash(rv[(u + 1) % PD], buf ^ 1);
@@ -913,6 +1014,7 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
         step(std::integral_constant<int, 1>{}, w0 + CG);
     }
 
+    stamp(2);
     // The loop ended with a barrier: the V buffers are dead and every wave owns its U slice again.
     auto wave_sync = [&]() {     // same-wave LDS hand-off: order the writes above before the reads below
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -925,12 +1027,25 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
         stage_rows<8>(d.a_row + (((long)n * d.nh + head) * L + min(qbase, L - 1)) * Wp, max(nq, 0), Wp, Ar, sm.sw, lane);
         wave_sync();
         float dot = 0.f;
-        for (int w = g; w < W; w += 2) dot = fmaf(Ar[i32 * sm.sw + w], dArow[i32 * sm.sw + w], dot);
-        dot += __shfl_xor(dot, 32, 64);
-        for (int w = g; w < Wp; w += 2)
-            dArow[i32 * sm.sw + w] = (w < W) ? d.scale * Ar[i32 * sm.sw + w] * (dArow[i32 * sm.sw + w] - dot) : 0.f;
+#pragma unroll 8
+        for (int w = g; w < W; w += 2) dot = fmaf(Ar[i32 * sm.sw + w], dArow[i32 * sm.sw + w], dot);      // (unrolled: the LDS reads of 8 steps fly together)
+        dot = xhalf_sum(dot);
+        for (int w0 = g; w0 < Wp; w0 += 16) {        // batches of 8: all reads of a batch before its writes (the two tiles may alias as far as the compiler knows)
+            float a8[8], b8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int wc = min(w0 + 2 * j, Wp - 1);
+                a8[j] = Ar[i32 * sm.sw + wc];
+                b8[j] = dArow[i32 * sm.sw + wc];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int w = w0 + 2 * j;
+                dArow[i32 * sm.sw + min(w, Wp)] = (w < W) ? d.scale * a8[j] * (b8[j] - dot) : 0.f;      // w >= Wp: the row's spare slot (sw = Wp + 1)
+            }
+        }
         wave_sync();
-        if (nq > 0 && d.ds_row) save_rows(dArow, sm.sw, d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
+        if (!PROBE && nq > 0 && d.ds_row) save_rows(dArow, sm.sw, d.ds_row + (((long)n * d.nh + head) * L + qbase) * Wp, nq, Wp, lane);
         wave_sync();               // the slice is rewritten below
     }
     // ---- softmax backward, column attention (registers), staged through the U slice for a coalesced store
@@ -940,7 +1055,7 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
         for (int f = 0; f < NF; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) dot = fmaf(acolT[f][r], dacolT[f][r], dot);
-        dot += __shfl_xor(dot, 32, 64);
+        dot = xhalf_sum(dot);
 #pragma unroll
         for (int f = 0; f < NF; ++f)
 #pragma unroll
@@ -949,10 +1064,25 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
                 if (h < Hp) Acol[i32 * sm.sh + h] = d.scale * acolT[f][r] * (dacolT[f][r] - dot);
             }
         wave_sync();
-        if (nq > 0 && d.ds_col) save_rows(Acol, sm.sh, d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
+        if (!PROBE && nq > 0 && d.ds_col) save_rows(Acol, sm.sh, d.ds_col + (((long)n * d.nh + head) * L + qbase) * Hp, nq, Hp, lane);
     }
+    stamp(3);
     // ---- fused query gradients: dq_row[q][:] = sum_w dS_row[q][w] k_row[w][:], dq_col likewise.  dS_row / dS_col are still in this
     // wave's LDS tiles; the projected keys of (n, head) are staged once per workgroup.  Lane (query i32, half g) owns channels 16g..16g+15.
+    // the projected queries of the fused key gradients (used after the query gradients below): requested now, so that their round trip hides
+    // behind the key staging and the dq products
+    float qv[2][2][8];                                    // [side][step][j]: q[qbase + 16 step + 8g + j][head*32 + i32]
+    if (PREC == 1 && d.dq_row && d.dk_row) {
+#pragma unroll
+        for (int side = 0; side < 2; ++side)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int qq = qbase + 16 * st + 8 * g + j;
+                    qv[side][st][j] = (side == 0 ? d.q_row : d.q_col)[((long)n * L + min(max(qq, 0), L - 1)) * E + head * D + i32];
+                }
+    }
     if (d.dq_row) {
         float* Kk = smem + sm.off_kk;
         if (kpre_ok) {
@@ -979,6 +1109,7 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
             }
         }
         __syncthreads();
+        stamp(4);
         if constexpr (PREC == 1) {
             // dq^T[c][q] = sum_w k^T[c][w] dS^T[w][q] on the matrix pipe: A = k^T (row = channel i32, k-slot j of step s <-> key 16s + 8g + j),
             // B = dS^T (column = query i32, same key slots, read from this lane's own LDS row); keys past the end are masked to zero
@@ -1012,26 +1143,23 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
                         *reinterpret_cast<float4*>(dst + 8 * j) = make_float4(acc[4 * j], acc[4 * j + 1], acc[4 * j + 2], acc[4 * j + 3]);
                 }
             }
+            stamp(5);
             if (d.dk_row) {
                 // ---- fused key gradients: dk[w][c] += sum_q dS[q][w] q[q][c] over this workgroup's queries.  Per wave: A = dS^T (row = key,
                 // k-slot j of step s <-> query 16s + 8g + j, column reads of the wave's LDS tile), B = the projected queries straight from
-                // global (lane = channel i32: 128-byte coalesced rows); every wave adds its partial [keys][32] tile to global atomically
-                // (summing the waves' tiles in LDS first cost more: ds_add_f32 runs at a few hundred cycles per wave instruction).
-                float qv[2][2][8];                                    // [side][step][j]: q[qbase + 16 step + 8g + j][head*32 + i32]
-#pragma unroll
-                for (int side = 0; side < 2; ++side)
-#pragma unroll
-                    for (int st = 0; st < 2; ++st)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const int qq = qbase + 16 * st + 8 * g + j;
-                            const float t = (side == 0 ? d.q_row : d.q_col)[((long)n * L + min(max(qq, 0), L - 1)) * E + head * D + i32];
-                            qv[side][st][j] = t;
-                        }
+                // global (lane = channel i32: 128-byte coalesced rows); the waves' partial [keys][32] tiles are summed through LDS (plain stores + one
+                // pass of reads: ds_add_f32 ran at a few hundred cycles per wave instruction when that was tried) and added to global once per workgroup.
+                // Round 6: the waves' partial [keys][32] tiles meet in LDS (each wave parks its two tiles in its own, by then dead, dS slices) and
+                // the workgroup adds ONE tile per side to global: NW x fewer atomics (the probe put 11 us of the encoder-shape workgroup's 55 us
+                // into this phase: 80 waves per (image, head) adding to the same 6400 addresses).  Maps with more than 128 keys per side keep the
+                // per-wave atomics.
+                const bool wg_reduce = (W <= 128 && H <= 128) && !rcda_dk_per_wave();
+                constexpr int NTL = 4;
 #pragma unroll
                 for (int side = 0; side < 2; ++side) {
                     const int nkeys = side == 0 ? W : H;
                     const float* S = side == 0 ? dArow : Acol;        // [32 queries][stride]
+                    float* Sw = side == 0 ? dArow : Acol;
                     const int sstr = side == 0 ? sm.sw : sm.sh;
                     float* acc_g = (side == 0 ? d.dk_row + (long)n * W * E : d.dk_col + (long)n * H * E) + head * D + i32;
                     bf16x8 bh[2], bl[2];
@@ -1043,7 +1171,7 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
                         split_bf16x8(b, bh[st], bl[st]);
                     }
                     const int ntile = (nkeys + 31) >> 5;
-                    for (int tl = 0; tl < ntile; ++tl) {
+                    auto tile = [&](int tl) __attribute__((always_inline)) -> f32x16 {
                         const int wkey = 32 * tl + i32, wc = min(wkey, nkeys - 1);
                         f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1059,15 +1187,54 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
                             acc = mfma_bf16_terms<TERMS>(ah, al, bh[st], bl[st], acc);
                         }
                         mfma_drain(acc);
-                        // accumulator: row = key 32 tl + (r & 3) + 8 (r >> 2) + 4 g, column = channel i32
+                        return acc;
+                    };
+                    if (wg_reduce) {
+                        f32x16 accs[NTL];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int wk = 32 * tl + (r & 3) + 8 * (r >> 2) + 4 * g;
-                            if (wk < nkeys) atomicAdd(acc_g + (long)wk * E, acc[r]);     // 128-byte rows per half-wave
+                        for (int tl = 0; tl < NTL; ++tl)
+                            if (tl < ntile) accs[tl] = tile(tl);
+                        wave_sync();                                   // every read of this wave's dS slice is done: it becomes the partial tile [key][32]
+#pragma unroll
+                        for (int tl = 0; tl < NTL; ++tl)
+                            if (tl < ntile) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int wk = 32 * tl + (r & 3) + 8 * (r >> 2) + 4 * g;
+                                    Sw[min(wk, nkeys) * D + i32] = accs[tl][r];      // keys past the end: row `nkeys` of the slice (never read; QW (stride) >= (nkeys + 1) 32)
+                                }
+                            }
+                    } else {
+                        for (int tl = 0; tl < ntile; ++tl) {
+                            const f32x16 acc = tile(tl);
+                            // accumulator: row = key 32 tl + (r & 3) + 8 (r >> 2) + 4 g, column = channel i32
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int wk = 32 * tl + (r & 3) + 8 * (r >> 2) + 4 * g;
+                                if (wk < nkeys) atomicAdd(acc_g + (long)wk * E, acc[r]);     // 128-byte rows per half-wave
+                            }
                         }
                     }
                 }
+                if (wg_reduce) {
+                    __syncthreads();
+                    const int nrow = W * D, ntot = (W + H) * D;
+                    for (int e = tid; e < ntot; e += NT) {
+                        const bool rowside = e < nrow;
+                        const int idx = rowside ? e : e - nrow;
+                        const float* base = rowside ? smem + sm.off_r + idx : smem + sm.off_u + idx;
+                        const int wstr = rowside ? QW * sm.sw : QW * sm.su;
+                        float sum = 0.f;
+#pragma unroll
+                        for (int wv = 0; wv < NW; ++wv) sum += base[wv * wstr];
+                        const int key = idx >> 5, ch = idx & 31;
+                        float* dst = rowside ? d.dk_row + ((long)n * W + key) * E + head * D + ch : d.dk_col + ((long)n * H + key) * E + head * D + ch;
+                        atomicAdd(dst, sum);
+                    }
+                }
             }
+            stamp(6);
+            flush_probe();
             return;
         }
 #pragma unroll
@@ -1100,11 +1267,11 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
     }
 }
 
-template <int NF, int NW, int PREC, int TERMS = 3>
+template <int NF, int NW, int PREC, int TERMS = 3, bool PROBE = false>
 __global__ __launch_bounds__(64 * NW) void rcda_bwd_kernel(const cdetr_rcda_bwd_desc d) {
     int bx_ = blockIdx.x, by_ = blockIdx.y;
     xcd_slab(bx_, by_);
-    rcda_bwd_body<NF, NW, PREC, TERMS>(d, bx_, by_);
+    rcda_bwd_body<NF, NW, PREC, TERMS, PROBE>(d, bx_, by_);
 }
 
 // ------------------------------------------------------------------------------------------------ backward (dV)
@@ -1590,6 +1757,27 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     // 256 registers a 512-thread block leaves a wave: never merged.)
     const long ds_wgs = (long)((d.L + QW * nw - 1) / (QW * nw)) * d.N * d.nh;
     const int mh = (dv2 && NF < 4 && (merge == 2 || (merge == 1 && ds_wgs <= 128))) ? hgroups : 0;
+    static const int dk_per_wave = getenv("CDETR_RCDA_DK_PER_WAVE") ? atoi(getenv("CDETR_RCDA_DK_PER_WAVE")) : 0;      // A/B only
+    static bool dk_pushed = false;
+    if (dk_per_wave && !dk_pushed) {
+        const int one = 1;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_rcda_dk_per_wave), &one, sizeof(int));
+        dk_pushed = true;
+    }
+    static const int probe = getenv("CDETR_RCDA_PROBE") ? atoi(getenv("CDETR_RCDA_PROBE")) : 0;
+    if (probe && NF == 2 && d.precision == 3 && d.ds_row && d.dk_row) {      // tools/rcda_probe.py: the dS kernel alone, stamps into ds_row
+        const int NWp = probe == 5 ? 5 : 4;
+        const BwdSmem sm = bwd_smem(d.H, d.W, 2, NWp, true);
+        dim3 grid((d.L + QW * NWp - 1) / (QW * NWp), d.N * d.nh), block(64 * NWp);
+        if (NWp == 5) {
+            if ((rc = set_smem(rcda_bwd_kernel<2, 5, 1, 1, true>, sm.total * 4, "cdetr_rcda_bwd"))) return rc;
+            hipLaunchKernelGGL((rcda_bwd_kernel<2, 5, 1, 1, true>), grid, block, sm.total * 4, st, d);
+        } else {
+            if ((rc = set_smem(rcda_bwd_kernel<2, 4, 1, 1, true>, sm.total * 4, "cdetr_rcda_bwd"))) return rc;
+            hipLaunchKernelGGL((rcda_bwd_kernel<2, 4, 1, 1, true>), grid, block, sm.total * 4, st, d);
+        }
+        return cdetr_launch_status("cdetr_rcda_bwd(probe)");
+    }
     if (NF == 1) rc = nw == 4 ? launch_rcda_bwd<1, 4>(d, st, mh, slices, per) : launch_rcda_bwd<1, 2>(d, st, mh, slices, per);
     else if (NF == 2) {
         // 5-wave workgroups when they put the grid on <= one workgroup per CU and 4-wave ones do not (see cdetr_rcda_fwd)
