@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 PEAK_BF16_MFMA_TFLOPS = 2500.0       # dense bf16 MFMA; the split-bf16 mode spends 3 bf16 MFMAs per algorithmic product
 PRECISIONS = {"bf16x3": 1, "fp32": 0}
-TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (5, 4, 3, 2)) if os.path.exists(p)), "")
+TRAFFIC_JSON = next((p for p in (os.path.join(ROOT, "profiles", f"r{r}_traffic.json") for r in (6, 5, 4, 3, 2)) if os.path.exists(p)), "")
 
 
 def step_gflop_per_image(H, W, Q):
