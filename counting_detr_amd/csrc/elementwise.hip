@@ -643,6 +643,30 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
                                                      float* __restrict__ o1, float* __restrict__ o2) {
     const int lane = threadIdx.x & 63;
     const int nv = C >> 8;   // float4 per lane (C multiple of 256) -- checked on the host
+    if (nv == 1) {
+        // C == 256 (every LayerNorm of this model; round 6): the row, gamma, beta and the optional addends are ALL requested before the first
+        // reduction -- one memory round trip per row.  The general form below fetches gamma / beta / addends after the two reductions: a second
+        // (and third) trip in a kernel that is nothing but a chain of them (~5 us per launch, 30 launches per step).  Absent addends read the
+        // row itself (a valid address, result unused), so there is no branch around a load.
+        const float4 g4 = reinterpret_cast<const float4*>(gamma)[lane];
+        const float4 b4 = reinterpret_cast<const float4*>(beta)[lane];
+        for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
+            const float4 v = reinterpret_cast<const float4*>(x + (long)row * C)[lane];
+            const float4 p1 = reinterpret_cast<const float4*>((a1 ? a1 : x) + (long)row * C)[lane];
+            const float4 p2 = reinterpret_cast<const float4*>((a2 ? a2 : x) + (long)row * C)[lane];
+            const float mu = wave_sum((v.x + v.y) + (v.z + v.w)) / C;
+            const float a = v.x - mu, b = v.y - mu, c = v.z - mu, dd = v.w - mu;
+            const float rs = rsqrtf(wave_sum((a * a + b * b) + (c * c + dd * dd)) / C + eps);
+            if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+            float4 o;
+            o.x = (v.x - mu) * rs * g4.x + b4.x; o.y = (v.y - mu) * rs * g4.y + b4.y;
+            o.z = (v.z - mu) * rs * g4.z + b4.z; o.w = (v.w - mu) * rs * g4.w + b4.w;
+            reinterpret_cast<float4*>(y + (long)row * C)[lane] = o;
+            if (a1) reinterpret_cast<float4*>(o1 + (long)row * C)[lane] = make_float4(o.x + p1.x, o.y + p1.y, o.z + p1.z, o.w + p1.w);
+            if (a2) reinterpret_cast<float4*>(o2 + (long)row * C)[lane] = make_float4(o.x + p2.x, o.y + p2.y, o.z + p2.z, o.w + p2.w);
+        }
+        return;
+    }
     for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += gridDim.x * 4) {
         const float4* xr = reinterpret_cast<const float4*>(x + (long)row * C);
         float4 v[LN_MAXV];

@@ -1662,45 +1662,56 @@ __device__ __forceinline__ void igemm_direct_body(const cdetr_gemm_desc& d, cons
         }
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // The operand forms (16-byte loads or four scalars) are decided ONCE, outside the batch loop (round 6): with `if (vecA)` / `if (vecB)`
+    // inside it every chunk's load sat in its own basic block followed by `s_waitcnt vmcnt(0)` -- 2 UB serialised round trips per batch in a
+    // kernel whose whole life is ~7 us (found in the ISA; the comment below states what the loop was always meant to do).
+    auto run = [&](auto VA_, auto VB_) __attribute__((always_inline)) {
+    constexpr bool VA = decltype(VA_)::value, VB = decltype(VB_)::value;
     for (int k0 = kbeg; k0 < kend; k0 += 16 * UB) {
         float a[UB][4], b[UB][4];
+        float bw[BL == 0 ? 1 : UB][4];                               // b_layout 1: the per-k weight scales
+        const float* wsp = wsc ? wsc : arow;
+        // phase 1: every load of the batch, raw (branch-free, clamped addresses); phase 2: masks / scales + the MFMA chain.  The scheduling
+        // barrier between them keeps the compiler from sinking each load to its first use (it did: two loads in flight, `s_waitcnt vmcnt(0)`
+        // before every second MFMA -- the register-pressure heuristic of a 256-thread kernel)
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {       // branch-free, clamped addresses: all loads of the batch are in flight together
+        for (int u = 0; u < UB; ++u) {
             const int k = k0 + u * 16 + g4 * 4;
-            if (vecA) {
-                const bool ok = k < kend;
-                const float4 t = ld4(arow + (ok ? k : 0));
-                const float f = ok ? am : 0.f;
-                a[u][0] = t.x * f; a[u][1] = t.y * f; a[u][2] = t.z * f; a[u][3] = t.w * f;
+            if constexpr (VA) {
+                const float4 t = ld4(arow + (k < kend ? k : 0));
+                a[u][0] = t.x; a[u][1] = t.y; a[u][2] = t.z; a[u][3] = t.w;
             } else {
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const bool ok = k + s < kend;
-                    a[u][s] = arow[ok ? k + s : 0] * (ok ? am : 0.f);
-                }
+                for (int s = 0; s < 4; ++s) a[u][s] = arow[k + s < kend ? k + s : 0];
             }
             if (BL == 0) {
-                if (vecB) {
-                    const bool ok = k < kend;
-                    const float4 t = ld4(brow + (ok ? k : 0));
-                    const float f = ok ? bm : 0.f;
-                    b[u][0] = t.x * f; b[u][1] = t.y * f; b[u][2] = t.z * f; b[u][3] = t.w * f;
+                if constexpr (VB) {
+                    const float4 t = ld4(brow + (k < kend ? k : 0));
+                    b[u][0] = t.x; b[u][1] = t.y; b[u][2] = t.z; b[u][3] = t.w;
                 } else {
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const bool ok = k + s < kend;
-                        b[u][s] = brow[ok ? k + s : 0] * (ok ? bm : 0.f);
-                    }
+                    for (int s = 0; s < 4; ++s) b[u][s] = brow[k + s < kend ? k + s : 0];
                 }
             } else {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    const bool ok = k + s < kend;
-                    const int kk = ok ? k + s : 0;
-                    float v = brow[(long)kk * d.ldb];
-                    if (wsc) v *= wsc[kk];
-                    b[u][s] = (ok && nv) ? v : 0.f;
+                    const int kk = k + s < kend ? k + s : 0;
+                    b[u][s] = brow[(long)kk * d.ldb];
+                    bw[u][s] = wsp[wsc ? kk : 0];                    // (no branch around the load: absent scales read one valid float and are ignored)
                 }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int k = k0 + u * 16 + g4 * 4;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bool oka = VA ? (k < kend) : (k + s < kend);
+                const bool okb = (BL == 0 && VB) ? (k < kend) : (k + s < kend);
+                a[u][s] *= oka ? am : 0.f;
+                if (BL == 0) b[u][s] *= okb ? bm : 0.f;
+                else b[u][s] = (okb && nv) ? (wsc ? b[u][s] * bw[BL == 0 ? 0 : u][s] : b[u][s]) : 0.f;
             }
         }
 #pragma unroll
@@ -1708,6 +1719,11 @@ __device__ __forceinline__ void igemm_direct_body(const cdetr_gemm_desc& d, cons
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][s], b[u][s], acc, 0, 0, 0);
     }
+    };
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    if (vecA) { if (vecB || BL != 0) run(T_{}, T_{}); else run(T_{}, F_{}); }
+    else { if (vecB || BL != 0) run(F_{}, T_{}); else run(F_{}, F_{}); }
     mfma_drain(acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wid][r * 64 + lane] = acc[r];
