@@ -248,13 +248,12 @@ def build_trainer(dev, queries, prior, precision):
     from counting_detr_amd.args import default_args
     from counting_detr_amd.engine import Trainer
     from counting_detr_amd.init import seeded_init_
-    ops.PRECISION = PRECISIONS[precision]
     args = default_args(device=str(dev), num_query_position=queries, spatial_prior=prior)
     model, crit, _ = counting_detr_amd.build_model(args)
     seeded_init_(model)          # deterministic name-seeded random weights (no checkpoints in this environment)
     model.to(dev).train()
     crit.train()
-    return Trainer(model, crit, args, device=dev)
+    return Trainer(model, crit, args, device=dev, precision=PRECISIONS[precision])      # the trainer owns its arithmetic: no module global is flipped
 
 
 def extra_shape(dev, H, W, queries, prior, Ts, batch, precision, steps=10):
@@ -284,7 +283,6 @@ def inference_leg(dev, shapes, batch0, precision, steps=20):
     from counting_detr_amd.args import default_args
     from counting_detr_amd.engine import InferenceEngine
     from counting_detr_amd.init import seeded_init_
-    ops.PRECISION = PRECISIONS[precision]
     args = default_args(device=str(dev))
     model, _, _ = counting_detr_amd.build_model(args)
     seeded_init_(model)
@@ -295,7 +293,7 @@ def inference_leg(dev, shapes, batch0, precision, steps=20):
         images, rects, _ = synthetic_batch(batch, H, W, (1,), seed=7, device=dev)
         row = {"image": [H, W], "images_per_gpu": batch, "queries": 300}
         for tag, graphs in (("graph", True), ("eager", False)):
-            eng = InferenceEngine(model, graphs=graphs)
+            eng = InferenceEngine(model, graphs=graphs, precision=PRECISIONS[precision])
             # (graph mode, one batch of look-ahead like infer.py's loop: the next batch's frozen stage runs beside this batch's encoder / decoder)
             for _ in range(3):
                 counts = eng(images, rects, next_samples=images)[0]
@@ -315,7 +313,6 @@ def stage1_leg(dev, precision, points=900, H=800, W=800, steps=20):
     from counting_detr_amd.args import default_args
     from counting_detr_amd.engine import build_weight_mirror
     from counting_detr_amd.init import seeded_init_
-    ops.PRECISION = PRECISIONS[precision]
     args = default_args(device=str(dev), spatial_prior="defined")
     model, _, _ = stage1.build(args)
     seeded_init_(model)
@@ -325,8 +322,7 @@ def stage1_leg(dev, precision, points=900, H=800, W=800, steps=20):
     g0 = torch.Generator().manual_seed(5)
     image = torch.randn(1, 3, H, W, generator=g0).to(dev)
     pts = (torch.rand(1, points, 2, generator=g0) * 0.9 + 0.05).to(dev)
-    prev, ops.MIRROR = ops.MIRROR, mirror
-    try:
+    with ops.arithmetic(PRECISIONS[precision]), ops.scope(MIRROR=mirror):
         with torch.no_grad():
             run = lambda: stage1.generate_pseudo_boxes(model, image, pts)      # noqa: E731
             for _ in range(3):
@@ -343,8 +339,6 @@ def stage1_leg(dev, precision, points=900, H=800, W=800, steps=20):
                 gr.replay()
             torch.cuda.synchronize()
             dt_g, per_g, _ = timed_steps(gr.replay, steps, torch.cuda.synchronize)
-    finally:
-        ops.MIRROR = prev
     return {"what": f"stage-1 forward (point -> box): {points} anchor points, one {H}x{W} image, pseudo boxes out", "steps": steps,
             "graph": {"value": steps / dt_g, "unit": "images/s", "ms_per_image": dt_g / steps * 1e3, "step_ms": percentiles(per_g)},
             "eager": {"value": steps / dt_e, "unit": "images/s", "ms_per_image": dt_e / steps * 1e3},
@@ -356,8 +350,6 @@ def real_data_leg(dev, precision, batch=2, reps=4):
     class) on batches shaped like FSC-147 after the reference's resize rule (384 high, widths multiples of 32, A2/data/fsc147.py:75-77)
     with target counts that change every step; ms/step of the steady state per image size next to the fixed-shape replay of the same
     size (Trainer.capture / replay, what `value` times).  In-memory batches: the reader / PIL decode is not part of the step."""
-    from counting_detr_amd import ops
-    ops.PRECISION = PRECISIONS[precision]
     tr = build_trainer(dev, 300, "learned", precision)
     sizes = [(384, 576), (384, 512), (384, 640)]
     counts = [(37, 120), (7, 64), (101, 3), (56, 0), (12, 128), (90, 77)]
@@ -544,18 +536,18 @@ def main(argv=None):
     import counting_detr_amd.backbone as bb
     hook = bb._BACKWARD_HOOK
     bb.set_backward_hook(None)
-    ops.PROFILE = []
     nb = float(sum(len(t_["boxes"]) for t_ in targets))
     from counting_detr_amd.misc import nested_tensor_from_tensor_list
     im, mk = nested_tensor_from_tensor_list(images).decompose()
     reps = 2
-    with ops.arithmetic(*trainer.arith):
+    prof = []
+    with ops.arithmetic(*trainer.arith), ops.scope(PROFILE=prof):      # (ops.scope: the switch is set for the block and restored whatever happens inside)
         for _ in range(reps):
             trainer._fwd_bwd(im, mk, rects, targets, nb)
     torch.cuda.synchronize()
     fam = {}
     shapes = {}
-    for family, flops, e0, e1, tag, nbytes, issued in ops.PROFILE:
+    for family, flops, e0, e1, tag, nbytes, issued in prof:
         if tag is not None:
             sh = shapes.setdefault((family,) + tuple(tag), [0.0, 0.0, 0])
             sh[0] += flops; sh[1] += e0.elapsed_time(e1) * 1e-3; sh[2] += 1
@@ -569,18 +561,15 @@ def main(argv=None):
     # times of kernels that do not share the chip with another stream (the product runs the overlapped form: ops.WGRAD_EVERY)
     unoverlapped = None
     if ops.WGRAD_EVERY or ops.BRANCH_BESIDE:
-        every, ops.WGRAD_EVERY = ops.WGRAD_EVERY, 0
-        beside, ops.BRANCH_BESIDE = ops.BRANCH_BESIDE, 0
-        ops.PROFILE = []
-        with ops.arithmetic(*trainer.arith):
+        prof2 = []
+        with ops.arithmetic(*trainer.arith), ops.scope(PROFILE=prof2, WGRAD_EVERY=0, BRANCH_BESIDE=0):
             for _ in range(reps):
                 trainer._fwd_bwd(im, mk, rects, targets, nb)
         torch.cuda.synchronize()
         f2 = {}
-        for family, flops, e0, e1, tag, nbytes, issued in ops.PROFILE:
+        for family, flops, e0, e1, tag, nbytes, issued in prof2:
             f = f2.setdefault(family, [0.0, 0.0, 0])
             f[0] += flops; f[1] += e0.elapsed_time(e1) * 1e-3; f[2] += 1
-        ops.WGRAD_EVERY, ops.BRANCH_BESIDE = every, beside
         dense_ = PEAK_FP32_MFMA_TFLOPS if a.precision == "fp32" else PEAK_BF16_MFMA_TFLOPS
         unoverlapped = {k: {"tflops": v[0] / v[1] / 1e12, "frac": v[0] / v[1] / 1e12 / dense_, "ms_per_step": v[1] / reps * 1e3,
                             "avg_launch_us": v[1] / max(v[2], 1) * 1e6} for k, v in f2.items() if v[1] > 0}
@@ -589,7 +578,6 @@ def main(argv=None):
                                 "the step is 0.2-0.3 ms slower that way.  roofline.achieved / frac / families are the launches AS THEY RUN in the product "
                                 "(two streams share the chip during the backbone's backward and at its three shortcut convolutions: every kernel there "
                                 "takes longer, their sum takes less)")
-    ops.PROFILE = None
     if os.environ.get("CDETR_BENCH_SHAPES") and rank == 0:
         rows = sorted(shapes.items(), key=lambda kv: -kv[1][1])
         with open(os.environ["CDETR_BENCH_SHAPES"], "w") as f:
@@ -703,7 +691,6 @@ def main(argv=None):
     if world == 1 and not a.no_alt:
         # the same step in the other arithmetic mode (short run, same launch mode), for transparency
         alt = "fp32" if a.precision != "fp32" else "bf16x3"
-        ops.PRECISION = PRECISIONS[alt]
         own, trainer.arith = trainer.arith, (PRECISIONS[alt], trainer.arith[1])      # (the trainer computes in ITS arithmetic, not the module default)
         if a.no_graph:
             alt_step = eager_step
@@ -719,7 +706,6 @@ def main(argv=None):
         torch.cuda.synchronize()
         dta = (time.perf_counter() - t1) / 5
         res["alt_precision"] = {"precision": alt, "value": a.batch / dta, "unit": "images/s", "ms_per_step": dta * 1e3, "steps": 5}
-        ops.PRECISION = PRECISIONS[a.precision]
         trainer.arith = own
     if world == 1 and not a.no_extra:
         del trainer

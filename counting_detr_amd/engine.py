@@ -503,17 +503,31 @@ class Trainer:
             return torch.clamp(t / get_world_size(), min=1)[0]
         return max(nb, 1.0)
 
+    def _arm_mirror(self):
+        """ops.MIRROR (which weight images the GEMMs read) is armed by the forward and disarmed by the LAST piece of the backward -- a span that
+        crosses method (and captured-graph) boundaries, so it is an ops.scope held by the trainer instead of a `with` block; leaving it restores
+        whatever was in force before (never a bare assignment to the module)."""
+        from . import ops
+        self._disarm_mirror()
+        self._mscope = ops.scope(MIRROR=self.mirror)
+        self._mscope.__enter__()
+
+    def _disarm_mirror(self):
+        sc, self._mscope = getattr(self, "_mscope", None), None
+        if sc is not None:
+            sc.__exit__(None, None, None)
+
     def _forward(self, images, mask, rects):
         """Forward weight images + model forward.  Leaves ops.MIRROR armed: `_loss_backward` (or `_trunk_segment(last=True)`) disarms it."""
         from .misc import NestedTensor
         from . import ops
         if self.mirror is not None:
             self.mirror.refresh("fwd")
-        ops.MIRROR = self.mirror
+        self._arm_mirror()
         try:
             outputs, _ = self.model(NestedTensor(images, mask), rects=rects)
         except BaseException:
-            ops.MIRROR = None
+            self._disarm_mirror()
             raise
         return outputs
 
@@ -548,7 +562,7 @@ class Trainer:
                     losses.backward(self._one)
         finally:
             if not defer_trunk:
-                ops.MIRROR = None
+                self._disarm_mirror()
         ops.wgrad_join()             # parameter gradients that ran beside the backward (ops.wgrad_flush(overlap=True))
 
     def _loss_backward(self, outputs, targets, num_boxes, defer_trunk=False):
@@ -570,7 +584,7 @@ class Trainer:
             if main is not None:
                 main.wait_stream(self._side)
         except BaseException:
-            ops.MIRROR = None
+            self._disarm_mirror()
             raise
         self._backward(losses, defer_trunk)
         # detached: a returned loss that still references the autograd graph keeps its AccumulateGrad nodes (and their stream) alive
@@ -593,7 +607,7 @@ class Trainer:
                 ops.wgrad_join()
         finally:
             if last:
-                ops.MIRROR = None
+                self._disarm_mirror()
                 self._trunk_pending = None
 
     def _step_impl(self, images, mask, rects, targets, num_boxes):
@@ -974,7 +988,7 @@ class Trainer:
             with ops.scope(BRANCH_BESIDE=0, WGRAD_EVERY=0):      # no fork inside a capture: every graph is one chain
                 return self._capture_chain_pieces(st, world, warmup)
         finally:
-            ops.MIRROR = None                                    # (armed by _forward; a failed capture must not leave it armed)
+            self._disarm_mirror()                                    # (armed by _forward; a failed capture must not leave it armed)
             self._trunk_pending = None
 
     def _capture_chain_pieces(self, st, world, warmup):
@@ -1066,7 +1080,7 @@ class Trainer:
                         ops.wgrad_flush(wg_target=ops.WGRAD_BESIDE_TARGET)      # beside the next piece's data-gradient chain
             e["S"].append(g)
             e["W"].append(gw)
-        ops.MIRROR = None
+        self._disarm_mirror()
         self._trunk_pending = None
         e["O"] = G()
         with torch.cuda.graph(e["O"], stream=s, **mode):

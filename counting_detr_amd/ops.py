@@ -64,7 +64,7 @@ class scope:
     gradients fork to side streams, the release signal behind the backbone), set for the block and restored on exit whatever happens inside.
     The same contract as `arithmetic`: engines never leave a module-level switch changed behind their back; the module values stay the
     defaults of code that runs outside any engine.  Scopes nest."""
-    _KEYS = ("MIRROR", "BRANCH_BESIDE", "WGRAD_EVERY", "AFTER_BACKBONE", "WG_DEFER_NESTED", "ZERO_ARENA", "RCDA_SAVE")
+    _KEYS = ("MIRROR", "BRANCH_BESIDE", "WGRAD_EVERY", "AFTER_BACKBONE", "WG_DEFER_NESTED", "ZERO_ARENA", "RCDA_SAVE", "PROFILE")
 
     def __init__(self, **kw):
         assert all(k in self._KEYS for k in kw), kw

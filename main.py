@@ -61,9 +61,8 @@ def main(args):
     # every rank builds the SAME initial weights (the init draws from the global RNG); only the data order is rank-specific.
     # Trainer additionally broadcasts rank 0's parameters and buffers (what DistributedDataParallel does at construction).
     torch.manual_seed(args.seed)
-    if getattr(args, "bwd_precision", None):                            # arithmetic of the backward contractions
-        from counting_detr_amd import ops
-        ops.PRECISION_BWD = {"bf16": 3, "bf16x2": 2, "bf16x3": 1}[args.bwd_precision]
+    # arithmetic of the backward contractions: handed to the trainer, which owns its arithmetic (ops.arithmetic) -- no module global is flipped
+    bwd_precision = {"bf16": 3, "bf16x2": 2, "bf16x3": 1}[args.bwd_precision] if getattr(args, "bwd_precision", None) else None
     model, criterion, _ = counting_detr_amd.build_model(args)
     model.to(device)
     if args.pretrained_backbone:                                        # A2/models/backbone.py:153-155 -> resnet.py:292-297
@@ -78,7 +77,7 @@ def main(args):
     if args.resume:                                                     # A2/main.py:195-209
         checkpoint, _, _ = ckpt_io.resume_model(model, args.resume, skip_mismatch=args.resume_skip_mismatch)
 
-    trainer = Trainer(model, criterion, args, device=device)           # 3 lr groups + flat AdamW (A2/main.py:157-189); syncs replicas; owns its arithmetic
+    trainer = Trainer(model, criterion, args, device=device, precision_bwd=bwd_precision)           # 3 lr groups + flat AdamW (A2/main.py:157-189); syncs replicas; owns its arithmetic
     if checkpoint is not None and (args.resume_optimizer or args.auto_resume) and checkpoint.get("optimizer"):
         # opt-in (the reference loads weights only and starts at --start_epoch, A2/main.py:195-209): continue an interrupted run
         trainer.load_state_dict(checkpoint["optimizer"], checkpoint.get("lr_scheduler"))

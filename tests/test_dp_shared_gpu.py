@@ -76,8 +76,8 @@ def test_two_ranks_match_single_process_on_the_concatenated_batch(use_graph, pre
     # The fp32 cases pin the exchange mechanics to 1e-4: that needs the FORWARD of an image to be bit-identical in a batch of two and
     # of four, which holds as long as a GEMM's summation order does not depend on its row count.  The split reductions
     # (cdetr_gemm_desc.splitk_ws) choose their slice count from the grid size, i.e. from the batch: activations then differ in the
-    # last bits (measured 2e-6, tools/sk_check3.py) and this random-init network turns that into ~1e-3 on the gradient (the same
-    # ~500x it shows for the 1.5e-5 of the bf16x3 rounding, matching unchanged -- tools/sk_check.py).  So: split off where the
+    # last bits (measured 2e-6 in round 2: tools/sk_check3.py, in the git history since the round-6 pruning) and this random-init network turns that into ~1e-3 on the gradient (the same
+    # ~500x it shows for the 1.5e-5 of the bf16x3 rounding, matching unchanged -- round 2, tools/sk_check.py, git history).  So: split off where the
     # tolerance is the fp32 one, on (the default) in the bf16x3 cases.
     if precision == 0:
         monkeypatch.setenv("CDETR_SPLITK", "0")          # the spawned ranks read it at import

@@ -1,4 +1,4 @@
-# generic same-lease A/B of environment settings: [STEPS=n] [BENCH_ARGS="--size 384 576"] bash tools/run_r5_ab.sh OUTFILE ROUNDS "ENV1=a ENV2=b" "ENV3=c" ...   ("-" = defaults)
+# generic same-lease A/B of environment settings: [STEPS=n] [BENCH_ARGS="--size 384 576"] bash tools/run_ab_env.sh OUTFILE ROUNDS "ENV1=a ENV2=b" "ENV3=c" ...   ("-" = defaults)
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=$1; rounds=$2; shift 2
