@@ -65,7 +65,7 @@ def _worker(rank, world, port, use_graph, precision, ret):
             out = tr.train_step(*shard)
         torch.cuda.synchronize()
         ret[rank] = {"g": tr.flat_g.detach().cpu(), "p": tr.flat_p.detach().cpu(), "loss": float(out["loss"]),
-                     "gn": float(out["grad_norm"])}
+                     "gn": float(out["grad_norm"]), "on_side": bool(tr.exchange.on_side)}
     finally:
         dist.destroy_process_group()
 
@@ -86,6 +86,23 @@ def test_two_ranks_match_single_process_on_the_concatenated_batch(use_graph, pre
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, _free_port(), use_graph, precision, ret), nprocs=2, join=True)
     old, ops.PRECISION = ops.PRECISION, precision
+    try:
+        _compare(ret)
+    finally:
+        ops.PRECISION = old
+
+
+def test_two_ranks_with_the_buckets_issued_from_the_side_stream(monkeypatch):
+    """FlatGradExchange.on_side (CDETR_EXCHANGE_ON_SIDE=1, round 6): the buckets are issued asynchronously from the weight-gradient stream and
+    the compute stream waits for the work handles in finish() -- the captured chain replay must give the same reduced gradient, the same
+    parameters on both ranks and the same agreement with the single-process step as the default form."""
+    from counting_detr_amd import ops
+    monkeypatch.setenv("CDETR_EXCHANGE_ON_SIDE", "1")        # the spawned ranks read it when their FlatGradExchange is built
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, _free_port(), True, 1, ret), nprocs=2, join=True)
+    assert all(ret[r].get("on_side") for r in (0, 1)), "the ranks did not run the on-side form"
+    old, ops.PRECISION = ops.PRECISION, 1
     try:
         _compare(ret)
     finally:
