@@ -270,6 +270,27 @@ def test_g10_full_size_reference_runs(golden, name):
     total.backward()
     gn = torch.norm(torch.stack([sd[n].grad.norm() for n in names if sd[n].grad is not None]))
     np.testing.assert_allclose(gn.item(), z[f"{name}/grad_total_norm"], rtol=2e-3)
+    # conditioning diagnostics the generator stored (round 6): the oracle's own outputs give the same distances from a tie / from the L1 kink
+    i_, j_ = idx[0][0].numpy(), idx[0][1].numpy()
+    if len(i_):
+        marg = float((out["pred_boxes"][0][i_].detach() - c["targets"][0]["boxes"][j_]).abs().min())
+        np.testing.assert_allclose(marg, z[f"{name}/min_l1_margin"][0], atol=5e-6, rtol=1e-2)
+    # ... and, where the gradient is a well-posed demand (fullsize.grads_well_posed: no matched coordinate on the kink), the oracle's gradient
+    # agrees with the reference's ELEMENT by element on the stored sample (the 4 largest-|gradient| elements of every parameter)
+    from fullsize import grads_well_posed
+    if grads_well_posed(z, name) and not c["aux"]:
+        pnames = [str(n) for n in z[f"{name}/param_names"]]
+        pidx, fidx, gref = z[f"{name}/sample_pidx"], z[f"{name}/sample_fidx"], z[f"{name}/sample_grad"].astype(np.float64)
+        tn = float(z[f"{name}/grad_total_norm"])
+        worst = 0.0
+        for k in range(len(pidx)):
+            g = sd[pnames[int(pidx[k])]].grad.reshape(-1)[int(fidx[k])].item()
+            if abs(gref[k]) >= 1e-5 * tn:
+                worst = max(worst, abs(g - gref[k]) / abs(gref[k]))
+            else:
+                assert abs(g - gref[k]) <= 1e-6 * tn
+        assert worst <= 5e-3, f"{name}: oracle gradient element off by {worst:.2e}"
+        print(f"{name}: oracle vs reference, worst sampled gradient element {worst:.2e}")
 
 
 def test_g11_stage1_900_points(golden):
