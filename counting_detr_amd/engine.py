@@ -161,8 +161,9 @@ class FlatGradExchange:
         self.launched = []
         if self.stream is not None:
             cur = torch.cuda.current_stream()
-            if self.works or (self._pg_stream is not None and self.on_side):
-                # on_side: the compute stream waits for the asynchronous buckets themselves; exposed = how long that wait lasts
+            if self.on_side:
+                # the compute stream waits for the asynchronous buckets themselves (and for the exchange stream, which carries the buckets of
+                # segments that had no weight-gradient stream to ride on); exposed = how long all of that lasts
                 ea = eb = None
                 if self.probe is not None:
                     ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -172,10 +173,12 @@ class FlatGradExchange:
                 self.works = []
                 if self._pg_stream is not None:
                     cur.wait_stream(self._pg_stream)
+                cur.wait_stream(self.stream)
                 if ea is not None:
                     eb.record(cur)
                     self.probe.append((ea, eb))
-            if self.probe is not None and not self.on_side:      # how long the compute stream has to wait for the last bucket = exposed communication
+                return
+            if self.probe is not None:      # how long the compute stream has to wait for the last bucket = exposed communication
                 ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ea.record(cur)
                 eb.record(self.stream)
