@@ -969,7 +969,8 @@ __device__ __forceinline__ void rcda_bwd_body(const cdetr_rcda_bwd_desc& d, cons
 #else
 #pragma clang loop unroll(disable)
 #endif
-      for (int cc = 0; cc < CG; ++cc) {       // rolled on purpose: unrolled, the compiler keeps CG accumulator sets live (380 VGPRs)
+      for (int cc = 0; cc < CG; ++cc) {       // rolled on purpose: unrolled, the compiler keeps CG accumulator sets live (380 VGPRs in round 2; round 6, -DCDETR_RCDA_UNROLL_CC=1:
+                                              // 256 VGPRs + 136 bytes of scratch in the 5-wave kernel, 84 bytes without the parked keys -- two waves share a SIMD there)
         const int w = w0s + cc;
         const float* tile = Vs + (buf * CG + cc) * HR * VS;
         const float arow = Arow[i32 * sm.sw + w];                        // zero for W <= w < Wp
