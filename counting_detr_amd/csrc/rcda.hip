@@ -1628,7 +1628,8 @@ inline int fwd2_slices(const cdetr_rcda_fwd_desc& d, int base, int nt, int lds_b
     else {
         const int per_cu = lds_bytes > 0 ? std::max(1, std::min(4, (160 * 1024) / lds_bytes)) : 1;
         (void)per_cu;
-        hs = (200 + base / 2) / base;            // ~200 workgroups (tools/rcda_slices.py: 48 -> 4, 80 -> 3, 112 -> 2 slices are the fastest)
+        hs = 256 / base;                         // as many slices as keep the grid on one workgroup per CU (round 6, after the score phase got cheaper:
+                                                 // 48 workgroups -> 5 slices 18.9 us, 4: 20.2, 6: 22.2; 80 -> 3 and 112 -> 2 as before, tools/rcda_slices.py)
     }
     hs = std::min(std::min(hs, 8), d.H / 8);
     const long avail = (long)d.ws_bytes - (long)RCDA_WS_COUNTERS * 4;
