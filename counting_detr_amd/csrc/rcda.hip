@@ -1744,8 +1744,13 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
     if (dv2) {
         hgroups = ((d.H + 7) / 8) * ((Wp + 63) / 64);                // (key-row groups) x (chunks of <= 64 key columns), see rcda_dv2_body
         const long base = (long)hgroups * d.N * d.nh;
-        static const int dv2_target = getenv("CDETR_RCDA_DV2_TARGET") ? atoi(getenv("CDETR_RCDA_DV2_TARGET")) : 448;
-        slices = (int)((dv2_target + base - 1) / base);              // < 2 workgroups of 8 waves per CU (measured: 448 -> 46 us, 512 -> 54 us at the encoder shape)
+        // query slices of the dV workgroups.  Round 6 (after the dS kernel got shorter): 2 slices at the encoder shape (224 workgroups: dS + dV 82-83 us;
+        // 4 slices, the rounds 2-5 rule: 85-87; 1 slice: 94-96) and 1 slice when the launch is shared with a short dS grid (decoder: 37.8-38.5 us
+        // against 40.0); CDETR_RCDA_DV2_TARGET overrides
+        static const int dv2_target_env = getenv("CDETR_RCDA_DV2_TARGET") ? atoi(getenv("CDETR_RCDA_DV2_TARGET")) : 0;
+        const long ds_wgs0 = (long)((d.L + QW * nw - 1) / (QW * nw)) * d.N * d.nh;
+        const int dv2_target = dv2_target_env ? dv2_target_env : (ds_wgs0 <= 128 ? 112 : 224);
+        slices = (int)((dv2_target + base - 1) / base);
         const int max_slices = (d.L + 255) / 256;                    // >= 4 q-tiles per slice
         if (slices > max_slices) slices = max_slices;
         if (slices < 1) slices = 1;
