@@ -1758,12 +1758,14 @@ extern "C" int cdetr_rcda_bwd(const cdetr_rcda_bwd_desc* dp, void* stream) {
         per = ((per + 63) / 64) * 64;
         slices = (d.L + per - 1) / per;
     }
-    // ... when the dS grid leaves most CUs free (decoder: 48 workgroups; 51 + 14 us as two launches -> 52 us as one).  At the encoder shape the
-    // dS kernel already puts one 5-wave workgroup on every CU and the dV workgroups cannot move in beside them (8 waves at the merged kernel's
-    // 200 registers fill a CU): 61 + 33 us became 117 us -- measured, so the rule looks at the grid.  (The H > 64 kernels need more than the
-    // 256 registers a 512-thread block leaves a wave: never merged.)
+    // (Rounds 2-5 merged only when the dS grid left most CUs free -- decoder: 48 workgroups --, because at the encoder shape 61 + 33 us became
+    // 117 us with the kernels of that time.  The H > 64 kernels need more than the 256 registers a 512-thread block leaves a wave: never merged.)
     const long ds_wgs = (long)((d.L + QW * nw - 1) / (QW * nw)) * d.N * d.nh;
-    const int mh = (dv2 && NF < 4 && (merge == 2 || (merge == 1 && ds_wgs <= 128))) ? hgroups : 0;
+    // Round 6: merged at EVERY shape the two-step dV covers.  With the dS body 13 % shorter and the dV workgroups on two query slices the shared
+    // launch now wins at the encoder shape too (dS + dV 82 -> 76.4-77.1 us; 50 x 84 keys, L = 4200: 275 -> 176 us; step -0.02...-0.09 ms in three
+    // same-lease pairs, profiles/r6_ab_rcda_slices.txt) -- the 117 us of round 2 was measured with the round-2 kernels.  CDETR_RCDA_MERGE=3: the old
+    // rule (merge only when the dS grid is <= 128 workgroups), 0: never.
+    const int mh = (dv2 && NF < 4 && (merge == 1 || merge == 2 || (merge == 3 && ds_wgs <= 128))) ? hgroups : 0;
     static const int dk_per_wave = getenv("CDETR_RCDA_DK_PER_WAVE") ? atoi(getenv("CDETR_RCDA_DK_PER_WAVE")) : 0;      // A/B only
     static bool dk_pushed = false;
     if (dk_per_wave && !dk_pushed) {
