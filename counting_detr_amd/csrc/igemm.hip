@@ -2037,7 +2037,8 @@ int gemm_vec_b(const cdetr_gemm_desc& d) {
 }
 // the kernel classes of the default dispatch (shared by cdetr_gemm and cdetr_gemm_group)
 bool gemm_is_direct(const cdetr_gemm_desc& d, int vecA, int vecB) {
-    return d.g.mode == CDETR_ROWS_DENSE && (gemm_blocks(d, 64, 64) <= 48 || !(vecA && vecB && (d.K % 32) == 0)) && gemm_blocks(d, 64, 64) < 192;
+    static const long direct_max = getenv("CDETR_DIRECT_MAX_BLOCKS") ? atol(getenv("CDETR_DIRECT_MAX_BLOCKS")) : 48;      // A/B knob
+    return d.g.mode == CDETR_ROWS_DENSE && (gemm_blocks(d, 64, 64) <= direct_max || !(vecA && vecB && (d.K % 32) == 0)) && gemm_blocks(d, 64, 64) < 192;
 }
 bool gemm_is_fewrow_split(const cdetr_gemm_desc& d, int vecA, int vecB) {
     const char* e = cdetr_tune_env("CDETR_GEMM_FEWROW_SPLIT");      // A/B knob (tests)
