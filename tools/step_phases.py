@@ -1,5 +1,5 @@
 """Phases of ONE captured train step from a rocprofv3 --kernel-trace CSV: kernel time and idle gaps between the phase markers
-(stem_pack -> gn_fwd -> first flash::fwd -> match_cost -> criterion_bwd -> first rcda_bwd<2,5 (encoder) -> gn_bwd -> sumsq -> adamw).
+(stem_pack -> gn_fwd -> first flash::fwd -> match_cost -> criterion_bwd -> first rcda_bwd<2,5 or rcda_bwd_all<2,5 (encoder) -> gn_bwd -> sumsq -> adamw).
 
     python tools/step_phases.py kernel_trace.csv [out.txt]"""
 import csv
@@ -31,7 +31,7 @@ for r in allq:
 first = "stem_pack" if any("stem_pack" in r[2] for r in step) else step[0][2][:40]
 # (GroupNorm: gn_fwd_kernel / gn_bwd_kernel until round 5, gn_split_stats_kernel / gn_split_bwd_stats_kernel since)
 markers = [("backbone fwd", (first,)), ("proj + encoder fwd", ("gn_fwd", "gn_split_stats")), ("decoder fwd + heads", ("flash::fwd",)), ("matcher + criterion", ("match_cost",)),
-           ("heads + decoder bwd", ("criterion_bwd",)), ("encoder bwd", ("rcda_bwd_kernel<2, 5",)), ("proj + backbone bwd", ("gn_bwd", "gn_split_bwd_stats")),
+           ("heads + decoder bwd", ("criterion_bwd",)), ("encoder bwd", ("rcda_bwd_kernel<2, 5", "rcda_bwd_all_kernel<2, 5")), ("proj + backbone bwd", ("gn_bwd", "gn_split_bwd_stats")),
            ("clip + AdamW", ("sumsq",))]
 idx = []
 for name, keys in markers:
