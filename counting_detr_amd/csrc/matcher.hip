@@ -804,7 +804,8 @@ extern "C" int cdetr_lsap(const float* cost, const int64_t* cost_off, const int3
         // single-wave register-resident solver; nr <= Mmax rows, nc <= nc_max columns
         const size_t state = (size_t)Mmax * 12 + (size_t)nc_max * 12 + 64;
         const size_t with_cost = state + (size_t)Mmax * nc_max * 4;
-        const bool cost_lds = with_cost <= 156 * 1024;
+        static const int lds_env = getenv("CDETR_LSAP_COST_LDS") ? atoi(getenv("CDETR_LSAP_COST_LDS")) : 1;      // A/B: 0 = cost matrix read from L2 (small LDS footprint)
+        const bool cost_lds = lds_env && with_cost <= 156 * 1024;
         const size_t wb = cost_lds ? with_cost : state;
         auto go = [&](auto kern) {
             if (wb > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wb);

@@ -308,6 +308,7 @@ class Trainer:
         self._pf_post_us = int(os.environ.get("CDETR_PF_POST_US", 30))          # head start of the solve over the prefetched stage's workgroups
         self._pf_delay_us = int(os.environ.get("CDETR_PF_DELAY_US", 0))        # "single" layout only: fixed delay in front of the prefetched stage
         self._pf_eager = os.environ.get("CDETR_PF_EAGER", "0") == "1"
+        self._b_first = os.environ.get("CDETR_B_FIRST", "0") == "1"           # A/B: submit B before the prefetch stream's flag wait (see _run_entry: it loses)
         # workgroups of the in-line tail launch (0 = the library's default, 384): 8.82 / 8.73 / 8.70 / 8.67 ms at 384 / 768 / 2048 / 4096, flat to
         # 8192, +0.04 at 16384 (profiles/r5_ab_tail_wgrad.txt)
         self._tail_wg_target = int(os.environ.get("CDETR_TAIL_WG_TARGET", "6144"))
@@ -1209,19 +1210,30 @@ class Trainer:
             evz = torch.cuda.Event()
             evz.record(pf)
         e["F"].replay()
-        if announce is not None:
+
+        def release_prefetch():
             # the next batch's frozen stage: behind F (event) AND behind the signal kernel that opens B -- the solve keeps its cost matrix in
             # LDS (a whole compute unit's worth) and must be resident before the stem / layer1 workgroups take every CU
-            evf = torch.cuda.Event()
-            evf.record(main)
-            pf.wait_event(evf)
             with torch.cuda.stream(pf):
                 _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr(), self._sig.data_ptr() + 4, self._pf_timeout_us, self._pf_post_us, _ffi.stream_ptr()),
                            "cdetr_flag_wait")
             self._prefetch(announce[0], announce[1], announce[0], ordered=True)
+        if announce is not None:
+            evf = torch.cuda.Event()
+            evf.record(main)
+            pf.wait_event(evf)          # issued HERE in both orders: the wait makes the runtime submit the event's marker now -- left pending, the
+            if not self._b_first:       # marker completes with the batch of commands that follows it (B: measured, the frozen stage then started 2.3 ms late)
+                release_prefetch()
         main.wait_event(evz)
         idle("before_B")
         e["B"].replay()
+        if announce is not None and self._b_first:
+            # CDETR_B_FIRST=1 (round 6 A/B, off): B SUBMITTED before the prefetch stream's flag wait + frozen-stage graph (same device-side ordering:
+            # the event and the flag carry it).  tools/step_gaps.py shows the main queue idle for 75 us between F's last kernel and B's first and for
+            # another 55 us in front of the solve in pipelined steps (8 us / 0 in line).  Submitting B first removes both (the solve then runs 262 us
+            # instead of 326-364) -- but whatever is submitted to the prefetch stream AFTER B's launch does not start before B has finished: the frozen
+            # stage lands 2.3 ms late, under the backbone's backward (a 200 us hole there), and the step is 0.02-0.05 ms slower.  profiles/r6_step_gaps.txt
+            release_prefetch()
         if e["W0"] is not None:                        # the parameter gradients above the backbone: beside the backbone's data-gradient chain
             evb = torch.cuda.Event()
             evb.record(main)
