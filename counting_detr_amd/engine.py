@@ -226,6 +226,72 @@ def build_weight_mirror(model, named, dgrad=True):
     return ops.WeightMirror(entries, fwd) if (entries or fwd) else None
 
 
+class _DeviceEvents:
+    """Cross-stream ordering of the chain replay with DEVICE-scope events (round 6).  torch.cuda.Event() is a default HIP event: recording it
+    performs a SYSTEM-scope release (the chip's caches are written back so that host-coherent memory is consistent) -- right for an event the
+    host synchronises on, waste for one that only orders two streams of the same GPU: hipEventCreateWithFlags(hipEventDisableTiming |
+    hipEventReleaseToDevice) through the HIP runtime torch itself is linked to.  A ring of events, re-recorded round robin (a wait captures the
+    record that is current when it is issued).  A/B (CDETR_DEVICE_EVENTS=1; default off): the chain's boundaries cost the same 14-16 us of idle
+    with either kind and the step is neutral in three same-lease pairs (profiles/r6_step_gaps.txt) -- the system-scope release is not what a boundary costs."""
+    DISABLE_TIMING, RELEASE_TO_DEVICE = 0x2, 0x40000000
+
+    def __init__(self, n=64):
+        import ctypes
+        self._c = ctypes
+        self._hip = ctypes.CDLL("libamdhip64.so")
+        self._hip.hipEventCreateWithFlags.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint]
+        self._hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self._hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        self._hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self._ring = []
+        for _ in range(n):
+            h = ctypes.c_void_p()
+            rc = self._hip.hipEventCreateWithFlags(ctypes.byref(h), self.DISABLE_TIMING | self.RELEASE_TO_DEVICE)
+            if rc != 0:
+                raise RuntimeError(f"hipEventCreateWithFlags failed ({rc})")
+            self._ring.append(h)
+        self._i = 0
+
+    def record(self, stream):
+        h = self._ring[self._i]
+        self._i = (self._i + 1) % len(self._ring)
+        rc = self._hip.hipEventRecord(h, self._c.c_void_p(stream.cuda_stream))
+        if rc != 0:
+            raise RuntimeError(f"hipEventRecord failed ({rc})")
+        return h
+
+    def wait(self, stream, h):
+        rc = self._hip.hipStreamWaitEvent(self._c.c_void_p(stream.cuda_stream), h, 0)
+        if rc != 0:
+            raise RuntimeError(f"hipStreamWaitEvent failed ({rc})")
+
+    def order(self, later, earlier):
+        """`later` waits for everything issued so far on `earlier` (Stream.wait_stream with a device-scope event)."""
+        self.wait(later, self.record(earlier))
+
+    def __del__(self):
+        try:
+            for h in self._ring:
+                self._hip.hipEventDestroy(h)
+        except Exception:
+            pass
+
+
+class _TorchEvents:
+    """The same interface on torch.cuda.Event (default flags): CDETR_DEVICE_EVENTS=0."""
+
+    def record(self, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        return ev
+
+    def wait(self, stream, ev):
+        stream.wait_event(ev)
+
+    def order(self, later, earlier):
+        later.wait_stream(earlier)
+
+
 def _scoped(fn):
     """Run a Trainer / InferenceEngine method under the engine's own arithmetic (ops.arithmetic)."""
     import functools
@@ -506,6 +572,12 @@ class Trainer:
             dist.all_reduce(t)
             return torch.clamp(t / get_world_size(), min=1)[0]
         return max(nb, 1.0)
+
+    def _events(self):
+        ev = getattr(self, "_evs", None)
+        if ev is None:
+            ev = self._evs = _DeviceEvents() if (self.flat_g.is_cuda and os.environ.get("CDETR_DEVICE_EVENTS", "0") == "1") else _TorchEvents()
+        return ev
 
     def _arm_mirror(self):
         """ops.MIRROR (which weight images the GEMMs read) is armed by the forward and disarmed by the LAST piece of the backward -- a span that
@@ -810,7 +882,7 @@ class Trainer:
         """Make the frozen stage's output for the entry's current images available in fs['x'] / fs['x16'] (main stream)."""
         fs = e["fs"]
         main = torch.cuda.current_stream()
-        main.wait_stream(self._pf_stream)                       # whatever was prefetched has landed
+        self._events().order(main, self._pf_stream)             # whatever was prefetched has landed
         if token is None or fs["token"] != token:               # not announced (or another batch than the announced one): in line
             fs["images"].copy_(e["st"]["images"])
             fs["graph"].replay()
@@ -1199,16 +1271,14 @@ class Trainer:
         main = torch.cuda.current_stream()
         pf, wg = self._side_streams()
         # Z needs the optimizer step of the previous call to be done and nothing else: behind everything issued so far, beside F
-        ev0 = torch.cuda.Event()
-        ev0.record(main)
-        pf.wait_event(ev0)
+        evs_ = self._events()
+        evs_.wait(pf, evs_.record(main))
         with torch.cuda.stream(pf):
             idle("before_Z")
             if e.get("z_late"):                        # (zero-fill + weight images are floods: beside the latency-bound encoder / decoder, not the backbone)
                 _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr() + 8, self._sig.data_ptr() + 12, self._z_timeout_us, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
             e["Z"].replay()
-            evz = torch.cuda.Event()
-            evz.record(pf)
+            evz = evs_.record(pf)
         e["F"].replay()
 
         def release_prefetch():
@@ -1219,12 +1289,11 @@ class Trainer:
                            "cdetr_flag_wait")
             self._prefetch(announce[0], announce[1], announce[0], ordered=True)
         if announce is not None:
-            evf = torch.cuda.Event()
-            evf.record(main)
-            pf.wait_event(evf)          # issued HERE in both orders: the wait makes the runtime submit the event's marker now -- left pending, the
+            evf = evs_.record(main)
+            evs_.wait(pf, evf)          # issued HERE in both orders: the wait makes the runtime submit the event's marker now -- left pending, the
             if not self._b_first:       # marker completes with the batch of commands that follows it (B: measured, the frozen stage then started 2.3 ms late)
                 release_prefetch()
-        main.wait_event(evz)
+        evs_.wait(main, evz)
         idle("before_B")
         e["B"].replay()
         if announce is not None and self._b_first:
@@ -1235,9 +1304,7 @@ class Trainer:
             # stage lands 2.3 ms late, under the backbone's backward (a 200 us hole there), and the step is 0.02-0.05 ms slower.  profiles/r6_step_gaps.txt
             release_prefetch()
         if e["W0"] is not None:                        # the parameter gradients above the backbone: beside the backbone's data-gradient chain
-            evb = torch.cuda.Event()
-            evb.record(main)
-            wg.wait_event(evb)
+            evs_.wait(wg, evs_.record(main))
             with torch.cuda.stream(wg):
                 idle("before_W0")
                 e["W0"].replay()
@@ -1254,15 +1321,13 @@ class Trainer:
                 m1.record(main)
                 tr_["main"].append((tuple(segs), m0, m1))
             if gw is not None:
-                evs = torch.cuda.Event()
-                evs.record(main)
-                wg.wait_event(evs)
+                evs_.wait(wg, evs_.record(main))
                 with torch.cuda.stream(wg):
                     gw.replay()
             if dp:
                 for seg in segs:
                     self.exchange.segment_done(seg, also=wg if gw is not None else None)
-        main.wait_stream(wg)
+        evs_.order(main, wg)
         if dp:
             self.exchange.finish()
         e["O"].replay()
