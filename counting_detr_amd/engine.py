@@ -374,6 +374,10 @@ class Trainer:
         self._pf_post_us = int(os.environ.get("CDETR_PF_POST_US", 30))          # head start of the solve over the prefetched stage's workgroups
         self._pf_delay_us = int(os.environ.get("CDETR_PF_DELAY_US", 0))        # "single" layout only: fixed delay in front of the prefetched stage
         self._pf_eager = os.environ.get("CDETR_PF_EAGER", "0") == "1"
+        self._fs_stage_x = os.environ.get("CDETR_FS_STAGE_X", "1") != "0"      # the frozen stage's fp32 output through a staging buffer (no event between F and B)
+        if self._fs_stage_x and "CDETR_PF_TIMEOUT_US" not in os.environ and not hasattr(args, "frozen_prefetch_timeout_us"):
+            self._pf_timeout_us = 4000        # the prefetch stream reaches its flag wait as soon as Z is done (~1.9 ms into the step), not at the forward's end
+        self._fs_copy_on_side = os.environ.get("CDETR_FS_COPY_ON_SIDE", "0") == "1"      # xs -> x on the side stream behind W0 instead of at the next step's head
         self._b_first = os.environ.get("CDETR_B_FIRST", "0") == "1"           # A/B: submit B before the prefetch stream's flag wait (see _run_entry: it loses)
         # workgroups of the in-line tail launch (0 = the library's default, 384): 8.82 / 8.73 / 8.70 / 8.67 ms at 384 / 768 / 2048 / 4096, flat to
         # 8192, +0.04 at 16384 (profiles/r5_ab_tail_wgrad.txt)
@@ -847,6 +851,10 @@ class Trainer:
         fs = {"images": torch.zeros(shape, device=dev), "x": torch.empty((B, h, w, 256), device=dev),
               "x16": torch.empty((B, h, w, 256), device=dev, dtype=torch.bfloat16),
               "x16s": torch.empty((B, h, w, 256), device=dev, dtype=torch.bfloat16), "token": None, "keep": None}
+        # Round 6: the fp32 output is staged like the twin (the stage writes `xs`, the step's head copies xs -> x), so the prefetched stage never
+        # writes what a running forward reads and needs NO event between the forward graph and the solve's graph: that event's marker cost the
+        # main queue ~0.09 ms per step (the graph launched behind it started 30-160 us late; profiles/r6_step_gaps.txt); the copy costs ~35 us
+        fs["xs"] = torch.empty((B, h, w, 256), device=dev) if self._fs_stage_x else fs["x"]
         # (a HIP CU-masked stream -- hipExtStreamCreateWithCUMask, leaving 16-64 CUs to the step's own latency-bound chain -- was tried:
         # with such a queue alive EVERY launch of the process slowed down, 9.3 -> 19 ms per step, in-line replays included:
         # profiles/r4_prefetch_ab_cumask.txt; an ordinary stream it is)
@@ -856,13 +864,13 @@ class Trainer:
                 self.mirror.refresh("fwd")                      # the frozen layers' pre-split images (rewritten, unchanged, by every step)
             ps.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(ps):
-                body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))       # lazily cached tables exist before the capture
+                body.frozen_stage(fs["images"], True, out_to=(fs["xs"], fs["x16s"]))       # lazily cached tables exist before the capture
             torch.cuda.current_stream().wait_stream(ps)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             mode = {"capture_error_mode": "thread_local"} if get_world_size() > 1 else {}
             with torch.cuda.graph(g, pool=self._pf_pool, stream=ps, **mode):
-                body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))
+                body.frozen_stage(fs["images"], True, out_to=(fs["xs"], fs["x16s"]))
         fs["graph"] = g
         self._frozen[shape] = fs
         self._trim_frozen()
@@ -883,14 +891,18 @@ class Trainer:
         fs = e["fs"]
         main = torch.cuda.current_stream()
         self._events().order(main, self._pf_stream)             # whatever was prefetched has landed
-        if token is None or fs["token"] != token:               # not announced (or another batch than the announced one): in line
+        hit = not (token is None or fs["token"] != token)
+        if not hit:                                             # not announced (or another batch than the announced one): in line
             fs["images"].copy_(e["st"]["images"])
             fs["graph"].replay()
             self.prefetch_stats["inline"] += 1
         else:
             self.prefetch_stats["hits"] += 1
-        fs["token"] = fs["keep"] = None
+        x_done = fs.get("x_done") is not None and fs.get("x_done") == token and hit
+        fs["token"] = fs["keep"] = fs["x_done"] = None
         fs["x16"].copy_(fs["x16s"])
+        if fs["xs"] is not fs["x"] and not x_done:             # (x_done: the prefetch stream moved xs -> x itself at the end of the previous step)
+            fs["x"].copy_(fs["xs"])
 
     def _prefetch(self, images, token, keep, ordered=False):
         """Release the frozen stage of the announced next batch behind everything issued so far on the current stream (`ordered`: the
@@ -911,7 +923,7 @@ class Trainer:
             if self._pf_eager:                 # stream-ordered launches instead of the graph (A/B: CDETR_PF_EAGER)
                 from . import ops
                 with ops.scope(MIRROR=self.mirror, BRANCH_BESIDE=0):
-                    self.model.backbone.body.frozen_stage(fs["images"], True, out_to=(fs["x"], fs["x16s"]))
+                    self.model.backbone.body.frozen_stage(fs["images"], True, out_to=(fs["xs"], fs["x16s"]))
             else:
                 fs["graph"].replay()
         fs["token"], fs["keep"] = token, keep                   # (`keep`: the announced object stays alive, so its id cannot be re-used)
@@ -944,6 +956,8 @@ class Trainer:
                 fs["images"].copy_(st["images"])
                 fs["graph"].replay()
                 fs["x16"].copy_(fs["x16s"])
+                if fs["xs"] is not fs["x"]:
+                    fs["x"].copy_(fs["xs"])
                 fs["token"] = fs["keep"] = None
                 body.frozen_input = (fs["x"], fs["x16"])
             if layout == "chain":
@@ -1272,6 +1286,8 @@ class Trainer:
         pf, wg = self._side_streams()
         # Z needs the optimizer step of the previous call to be done and nothing else: behind everything issued so far, beside F
         evs_ = self._events()
+        # (this event's marker costs the forward graph behind it ~0.03 ms as well -- measured by leaving it out, which only the flag's timing would then
+        # make safe: kept.  profiles/r6_step_gaps.txt)
         evs_.wait(pf, evs_.record(main))
         with torch.cuda.stream(pf):
             idle("before_Z")
@@ -1289,8 +1305,9 @@ class Trainer:
                            "cdetr_flag_wait")
             self._prefetch(announce[0], announce[1], announce[0], ordered=True)
         if announce is not None:
-            evf = evs_.record(main)
-            evs_.wait(pf, evf)          # issued HERE in both orders: the wait makes the runtime submit the event's marker now -- left pending, the
+            if not self._fs_stage_x:      # (staged output: the stage writes nothing a running forward reads; ev0 + stream order cover the staging buffers)
+                evf = evs_.record(main)
+                evs_.wait(pf, evf)      # issued HERE in both orders: the wait makes the runtime submit the event's marker now -- left pending, the
             if not self._b_first:       # marker completes with the batch of commands that follows it (B: measured, the frozen stage then started 2.3 ms late)
                 release_prefetch()
         evs_.wait(main, evz)
@@ -1308,6 +1325,13 @@ class Trainer:
             with torch.cuda.stream(wg):
                 idle("before_W0")
                 e["W0"].replay()
+                if announce is not None and self._fs_stage_x and wg is pf and self._fs_copy_on_side:
+                    # the staged fp32 output of the NEXT batch's frozen stage moves into place HERE, on the side stream: behind the stage (stream
+                    # order) and behind B (W0 waits for it: this step's forward is done with `x`) -- the next step's head then copies the twin only
+                    fsn = self._frozen.get(tuple(announce[0].shape))
+                    if fsn is not None and fsn["token"] == announce[1] and fsn["xs"] is not fsn["x"]:
+                        fsn["x"].copy_(fsn["xs"])
+                        fsn["x_done"] = announce[1]
         if dp:
             self.exchange.segment_done(0, also=wg if e["W0"] is not None else None)      # first bucket: everything above the backbone
         tr_ = self.exchange.trace
