@@ -1295,6 +1295,12 @@ class Trainer:
                 _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr() + 8, self._sig.data_ptr() + 12, self._z_timeout_us, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
             e["Z"].replay()
             evz = evs_.record(pf)
+            if announce is None:
+                # B signals "the solve is next" in EVERY replay, and nothing waits for it in a step that announces no next batch: the
+                # counter must not run ahead of `consumed`, or every later wait finds last step's signal and passes at once (the frozen
+                # stage then floods the chip under the forward: +0.28 ms per step, found as bench.py --mode auto losing to --mode graph).
+                # A wait with timeout 0 advances `consumed` by exactly one, whichever side of the signal it lands on.
+                _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr(), self._sig.data_ptr() + 4, 0, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
         e["F"].replay()
 
         def release_prefetch():
@@ -1669,6 +1675,9 @@ class InferenceEngine:
                 # a LINEAR graph (no in-graph forks): hipGraphLaunch enqueues it in ~0.1 ms of host time (2.7 ms with forks)
                 with ops.scope(BRANCH_BESIDE=0, AFTER_BACKBONE=after):
                     self._run(*st)                     # lazily cached tables of this shape exist before the capture
+                    if after is not None:              # (that run signalled too: keep `consumed` level with the counter)
+                        with torch.cuda.stream(self._pf_stream):
+                            _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr(), self._sig.data_ptr() + 4, 0, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
                     self._stream.wait_stream(torch.cuda.current_stream())
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
@@ -1712,6 +1721,9 @@ class InferenceEngine:
                     f2["images"].copy_(nxt, non_blocking=True)
                     f2["graph"].replay()
                 f2["token"], f2["keep"] = tok, nxt
+            elif self._sig is not None:
+                with torch.cuda.stream(self._pf_stream):      # the captured forward signals in every replay: consume the one nobody waits for
+                    _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr(), self._sig.data_ptr() + 4, 0, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
         e[0].replay()
         return e[2]
 
