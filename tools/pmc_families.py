@@ -72,7 +72,7 @@ def main():
     out = {"workload": "B=2 800x800 Q=300 bf16x3 fwd / bf16 bwd, one eager step (bench.py --no-graph --steps 1 --warmup 1)",
            "step_equivalents_in_the_profiled_process": nstep, "families_bytes_per_step": fams, "families_bytes_per_kernel_launch": per_launch,
            "detail": detail, "pmc": pmc, "total_bytes_per_step": sum(fams.values()),
-           "source": "profiles/r5_pmc_* summaries (tools/run_meas_r5.sh): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* in separate passes with "
+           "source": "profiles/r6_pmc_* summaries (tools/run_meas_r6.sh): rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_* in separate passes with "
                      "--kernel-trace only; FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section), KiB -> bytes; "
                      "tools/pmc_families.py"}
     json.dump(out, open(sys.argv[4], "w"), indent=1)
