@@ -378,6 +378,7 @@ class Trainer:
         if self._fs_stage_x and "CDETR_PF_TIMEOUT_US" not in os.environ and not hasattr(args, "frozen_prefetch_timeout_us"):
             self._pf_timeout_us = 4000        # the prefetch stream reaches its flag wait as soon as Z is done (~1.9 ms into the step), not at the forward's end
         self._fs_copy_on_side = os.environ.get("CDETR_FS_COPY_ON_SIDE", "0") == "1"      # xs -> x on the side stream behind W0 instead of at the next step's head
+        self._fs_twin_on_side = os.environ.get("CDETR_FS_TWIN_ON_SIDE", "1") == "1"      # x16s -> x16 on the prefetch stream beside the forward instead of at the step's head
         self._b_first = os.environ.get("CDETR_B_FIRST", "0") == "1"           # A/B: submit B before the prefetch stream's flag wait (see _run_entry: it loses)
         # workgroups of the in-line tail launch (0 = the library's default, 384): 8.82 / 8.73 / 8.70 / 8.67 ms at 384 / 768 / 2048 / 4096, flat to
         # 8192, +0.04 at 16384 (profiles/r5_ab_tail_wgrad.txt)
@@ -900,7 +901,10 @@ class Trainer:
             self.prefetch_stats["hits"] += 1
         x_done = fs.get("x_done") is not None and fs.get("x_done") == token and hit
         fs["token"] = fs["keep"] = fs["x_done"] = None
-        fs["x16"].copy_(fs["x16s"])
+        if self._fs_twin_on_side and e.get("layout") == "chain":
+            e["twin_pending"] = fs       # only the backward reads the twin (layer2's weight gradients, behind Z's event): _run_entry copies it on the prefetch stream
+        else:
+            fs["x16"].copy_(fs["x16s"])
         if fs["xs"] is not fs["x"] and not x_done:             # (x_done: the prefetch stream moved xs -> x itself at the end of the previous step)
             fs["x"].copy_(fs["xs"])
 
@@ -1290,6 +1294,9 @@ class Trainer:
         # make safe: kept.  profiles/r6_step_gaps.txt)
         evs_.wait(pf, evs_.record(main))
         with torch.cuda.stream(pf):
+            fsp = e.pop("twin_pending", None)
+            if fsp is not None:                        # the frozen stage's bf16 twin moves into place beside the forward (41 MB; 23 us less at the step's head)
+                fsp["x16"].copy_(fsp["x16s"])
             idle("before_Z")
             if e.get("z_late"):                        # (zero-fill + weight images are floods: beside the latency-bound encoder / decoder, not the backbone)
                 _ffi.check(_ffi.lib().cdetr_flag_wait(self._sig.data_ptr() + 8, self._sig.data_ptr() + 12, self._z_timeout_us, 0, _ffi.stream_ptr()), "cdetr_flag_wait")
