@@ -417,6 +417,10 @@ int cdetr_abi_version(void);
  * cdetr_flag_signal / cdetr_flag_wait: ordering between two streams from INSIDE captured graphs, where no event can be recorded: the signal
  *   (one thread) adds 1 to *flag; the wait (one thread, at the head of the other stream's work) sleeps until *flag has passed *seen -- its own
  *   count of consumed signals, updated by the kernel -- or `timeout_us` has gone by (a missing signal costs a delay, never a hang).
+ *   Every signal needs exactly one wait: a wait advances *seen by one (to the flag's value when it was satisfied, by one when it timed out
+ *   and the signal arrives later), so a signal nobody waited for leaves the flag one ahead and every later wait passes at once.  A replay
+ *   whose signal has no waiter CONSUMES it with timeout_us = 0 (advances *seen by one, whichever side of the signal it lands on).
+ *   The flags are a SCHEDULING hint only: whatever must hold for correctness is ordered by events / stream order as well.
  *   engine.Trainer releases the next batch's frozen stage (A2/models/backbone.py:93-95) the moment the Hungarian solve of the current step
  *   (A2/models/matcher.py:243-247) is about to start: the solve needs one whole compute unit's LDS for its cost matrix.                   */
 int cdetr_delay(int32_t us, void* stream);
