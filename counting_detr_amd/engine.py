@@ -377,7 +377,7 @@ class Trainer:
         self._fs_stage_x = os.environ.get("CDETR_FS_STAGE_X", "1") != "0"      # the frozen stage's fp32 output through a staging buffer (no event between F and B)
         if self._fs_stage_x and "CDETR_PF_TIMEOUT_US" not in os.environ and not hasattr(args, "frozen_prefetch_timeout_us"):
             self._pf_timeout_us = 4000        # the prefetch stream reaches its flag wait as soon as Z is done (~1.9 ms into the step), not at the forward's end
-        self._fs_copy_on_side = os.environ.get("CDETR_FS_COPY_ON_SIDE", "0") == "1"      # xs -> x on the side stream behind W0 instead of at the next step's head
+        self._fs_copy_on_side = int(os.environ.get("CDETR_FS_COPY_ON_SIDE", "0"))      # xs -> x on the side stream behind W0 instead of at the next step's head
         self._fs_twin_on_side = os.environ.get("CDETR_FS_TWIN_ON_SIDE", "1") == "1"      # x16s -> x16 on the prefetch stream beside the forward instead of at the step's head
         self._b_first = os.environ.get("CDETR_B_FIRST", "0") == "1"           # A/B: submit B before the prefetch stream's flag wait (see _run_entry: it loses)
         # workgroups of the in-line tail launch (0 = the library's default, 384): 8.82 / 8.73 / 8.70 / 8.67 ms at 384 / 768 / 2048 / 4096, flat to
@@ -1333,18 +1333,22 @@ class Trainer:
             # instead of 326-364) -- but whatever is submitted to the prefetch stream AFTER B's launch does not start before B has finished: the frozen
             # stage lands 2.3 ms late, under the backbone's backward (a 200 us hole there), and the step is 0.02-0.05 ms slower.  profiles/r6_step_gaps.txt
             release_prefetch()
+        def stage_into_place():
+            # (CDETR_FS_COPY_ON_SIDE, A/B) the staged fp32 output of the NEXT batch's frozen stage moves into place on the side stream: behind the stage
+            # (stream order) and behind B (W0 waits for it: this step's forward is done with `x`) -- the next step's head then copies nothing.
+            # 1 = right behind W0 (beside the backbone's data gradients), 2 = behind the last weight-gradient graph (beside the tail of layer2's)
+            if announce is not None and self._fs_stage_x and wg is pf:
+                fsn = self._frozen.get(tuple(announce[0].shape))
+                if fsn is not None and fsn["token"] == announce[1] and fsn["xs"] is not fsn["x"]:
+                    fsn["x"].copy_(fsn["xs"])
+                    fsn["x_done"] = announce[1]
         if e["W0"] is not None:                        # the parameter gradients above the backbone: beside the backbone's data-gradient chain
             evs_.wait(wg, evs_.record(main))
             with torch.cuda.stream(wg):
                 idle("before_W0")
                 e["W0"].replay()
-                if announce is not None and self._fs_stage_x and wg is pf and self._fs_copy_on_side:
-                    # the staged fp32 output of the NEXT batch's frozen stage moves into place HERE, on the side stream: behind the stage (stream
-                    # order) and behind B (W0 waits for it: this step's forward is done with `x`) -- the next step's head then copies the twin only
-                    fsn = self._frozen.get(tuple(announce[0].shape))
-                    if fsn is not None and fsn["token"] == announce[1] and fsn["xs"] is not fsn["x"]:
-                        fsn["x"].copy_(fsn["xs"])
-                        fsn["x_done"] = announce[1]
+                if self._fs_copy_on_side == 1:
+                    stage_into_place()
         if dp:
             self.exchange.segment_done(0, also=wg if e["W0"] is not None else None)      # first bucket: everything above the backbone
         tr_ = self.exchange.trace
@@ -1364,6 +1368,9 @@ class Trainer:
             if dp:
                 for seg in segs:
                     self.exchange.segment_done(seg, also=wg if gw is not None else None)
+        if self._fs_copy_on_side == 2 and e["W0"] is not None:
+            with torch.cuda.stream(wg):
+                stage_into_place()
         evs_.order(main, wg)
         if dp:
             self.exchange.finish()
