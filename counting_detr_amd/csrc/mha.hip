@@ -318,14 +318,19 @@ __device__ __forceinline__ void tr_stash(const TrRegs& r, __bf16* tile, int t) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) stash_split4(dst + c * TS, 32, r.t[c], r.t[4 + c], r.t[8 + c], r.t[12 + c]);
 }
-// acc += A(tile rows, this lane's row i32) * B (hi/lo fragments of the two k-steps)
+// acc += A(tile rows, this lane's row i32) * B (hi/lo fragments of the two k-steps); TERMS = 1: hi * hi only (the lo halves are not read)
+template <int TERMS = 3>
 __device__ __forceinline__ f32x16 mma_tile(f32x16 acc, const __bf16* tile, int i32, int g, const bf16x8 (&bh)[2], const bf16x8 (&bl)[2]) {
     const __bf16* a = tile + i32 * TS + 8 * g;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a + 16 * s);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + 32 + 16 * s);
-        acc = mfma_bf16x3(ah, al, bh[s], bl[s], acc);
+        if constexpr (TERMS == 1) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[s], acc, 0, 0, 0);
+        } else {
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(a + 32 + 16 * s);
+            acc = mfma_bf16x3(ah, al, bh[s], bl[s], acc);
+        }
     }
     return acc;
 }
@@ -517,6 +522,10 @@ __global__ __launch_bounds__(2 * NTF) void fwd_ks_kernel(const float* __restrict
 // The backward is ONE launch: workgroups with blockIdx.z == 0 own queries (dq), those with blockIdx.z == 1 own keys (dk, dv).  The two
 // halves are independent -- the key half forms D = rowsum(dO * O) of each query tile itself while it stages the tile (it used to read the
 // query half's result, which serialised two 17 us launches of 80 workgroups each) -- so they share the chip instead of following each other.
+// TB = bf16 MFMAs per product of the four GRADIENT contractions (dP = dO V^T, dQ, dK, dV): 3 = split-bf16 like the forward, 1 = plain bf16 (the
+// backward's default arithmetic, ops.PRECISION_BWD 3).  The recomputed scores S = Q K^T keep all three terms in both: p = exp(S - lse) against the
+// FORWARD's log-sum-exp turns an error of S into a relative error of every probability of the row.
+template <int TB>
 __device__ __forceinline__ void bwd_q_body(__bf16* lds, const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ o,
                                            const float* __restrict__ dO, const float* __restrict__ lse, float* __restrict__ dqk,
                                            int N, int L, int nh, float scale) {
@@ -567,7 +576,7 @@ __device__ __forceinline__ void bwd_q_body(__bf16* lds, const float* __restrict_
         const __bf16* base = lds + buf * 3 * TILE;
         if (t < ntile) {           // workgroup-uniform: surplus steps of the last ring turn only stage and synchronise
             f32x16 S = mma_tile(zero16(), base, i32, g, qh, ql);
-            const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, dh, dl);
+            const f32x16 dP = mma_tile<TB>(zero16(), base + TILE, i32, g, dh, dl);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float p = (t * 32 + reg_row(r, g) < L) ? __expf(S[r] - li) : 0.f;
@@ -575,7 +584,7 @@ __device__ __forceinline__ void bwd_q_body(__bf16* lds, const float* __restrict_
             }
             bf16x8 sh[2], sl[2];
             reg_frag(S, sh, sl);
-            dQT = mma_tile(dQT, base + 2 * TILE, i32, g, sh, sl);
+            dQT = mma_tile<TB>(dQT, base + 2 * TILE, i32, g, sh, sl);
         }
         stash(nxt.k, nxt.v, nxt.kt, buf ^ 1);
         __syncthreads();
@@ -590,6 +599,7 @@ __device__ __forceinline__ void bwd_q_body(__bf16* lds, const float* __restrict_
     }
 }
 
+template <int TB>
 __device__ __forceinline__ void bwd_kv_body(__bf16* lds, float (*stat)[2][32], const float* __restrict__ qk, const float* __restrict__ v,
                                             const float* __restrict__ o, const float* __restrict__ dO, const float* __restrict__ lse,
                                             float* __restrict__ dqk, float* __restrict__ dv, int N, int L, int nh, float scale) {
@@ -648,7 +658,7 @@ __device__ __forceinline__ void bwd_kv_body(__bf16* lds, float (*stat)[2][32], c
         const __bf16* base = lds + buf * 4 * TILE;
         if (t < ntile) {           // workgroup-uniform: surplus steps of the last ring turn only stage and synchronise
         f32x16 S = mma_tile(zero16(), base, i32, g, kh, kl);                   // S^T[q, key]
-        const f32x16 dP = mma_tile(zero16(), base + TILE, i32, g, vh, vl);     // dP^T[q, key]
+        const f32x16 dP = mma_tile<TB>(zero16(), base + TILE, i32, g, vh, vl);     // dP^T[q, key]
         f32x16 P;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -664,9 +674,9 @@ __device__ __forceinline__ void bwd_kv_body(__bf16* lds, float (*stat)[2][32], c
         }
         bf16x8 ph[2], pl[2], sh[2], sl[2];
         reg_frag(P, ph, pl);
-        dVT = mma_tile(dVT, base + 3 * TILE, i32, g, ph, pl);                  // dV^T[c, key] += dO^T[c, q] P[q, key]
+        dVT = mma_tile<TB>(dVT, base + 3 * TILE, i32, g, ph, pl);              // dV^T[c, key] += dO^T[c, q] P[q, key]
         reg_frag(S, sh, sl);
-        dKT = mma_tile(dKT, base + 2 * TILE, i32, g, sh, sl);                  // dK^T[c, key] += Q^T[c, q] dS[q, key]
+        dKT = mma_tile<TB>(dKT, base + 2 * TILE, i32, g, sh, sl);              // dK^T[c, key] += Q^T[c, q] dS[q, key]
         }
         stash(nxt, buf ^ 1);
         __syncthreads();
@@ -682,13 +692,14 @@ __device__ __forceinline__ void bwd_kv_body(__bf16* lds, float (*stat)[2][32], c
     }
 }
 
+template <int TB>
 __global__ __launch_bounds__(NTF) void bwd_kernel(const float* __restrict__ qk, const float* __restrict__ v, const float* __restrict__ o,
                                                   const float* __restrict__ dO, const float* __restrict__ lse, float* __restrict__ dqk,
                                                   float* __restrict__ dv, int N, int L, int nh, float scale) {
     __shared__ __attribute__((aligned(16))) __bf16 lds[2 * 4 * TILE];
     __shared__ __attribute__((aligned(16))) float stat[2][2][32];
-    if (blockIdx.z == 0) bwd_q_body(lds, qk, v, o, dO, lse, dqk, N, L, nh, scale);
-    else bwd_kv_body(lds, stat, qk, v, o, dO, lse, dqk, dv, N, L, nh, scale);
+    if (blockIdx.z == 0) bwd_q_body<TB>(lds, qk, v, o, dO, lse, dqk, N, L, nh, scale);
+    else bwd_kv_body<TB>(lds, stat, qk, v, o, dO, lse, dqk, dv, N, L, nh, scale);
 }
 }  // namespace flash
 
@@ -713,8 +724,12 @@ extern "C" int cdetr_mha_bwd(const float* qk, const float* v, const float* o, co
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     dim3 grid((L + 63) / 64, N * nh);
     static const int use_mfma = getenv("CDETR_MHA_MFMA") ? atoi(getenv("CDETR_MHA_MFMA")) : 1;
+    if (use_mfma && precision == 3) {      // split-bf16 scores, plain-bf16 gradient contractions (flash::bwd_q_body)
+        hipLaunchKernelGGL(flash::bwd_kernel<1>, dim3(grid.x, grid.y, 2), dim3(flash::NTF), 0, st, qk, v, o, d_o, lse, d_qk, d_v, N, L, nh, scale);
+        return cdetr_launch_status("cdetr_mha_bwd");
+    }
     if (use_mfma && precision == 1) {
-        hipLaunchKernelGGL(flash::bwd_kernel, dim3(grid.x, grid.y, 2), dim3(flash::NTF), 0, st, qk, v, o, d_o, lse, d_qk, d_v, N, L, nh, scale);
+        hipLaunchKernelGGL(flash::bwd_kernel<3>, dim3(grid.x, grid.y, 2), dim3(flash::NTF), 0, st, qk, v, o, d_o, lse, d_qk, d_v, N, L, nh, scale);
         return cdetr_launch_status("cdetr_mha_bwd");
     }
     hipLaunchKernelGGL(mha_bwd_q_kernel, grid, dim3(256), 0, st, qk, v, o, d_o, lse, d_qk, work, N, L, nh, scale);

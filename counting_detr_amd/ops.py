@@ -30,6 +30,11 @@ PRECISION = int(_os.environ.get("CDETR_PRECISION", "1"))
 # 3 = plain bf16 (1 MFMA).  The forward always runs bf16x3: its 1e-3 / bit-exact-assignment contract has no room for a bf16
 # rounding per product (~1e-2 end to end), gradients have (per-parameter norms within 1e-2 of the reference).  DESIGN.md section 3.
 PRECISION_BWD = int(_os.environ.get("CDETR_PRECISION_BWD", "3"))
+# The decoder self-attention's backward in the backward's default arithmetic (scores recomputed in split-bf16, the four gradient contractions in
+# plain bf16: cdetr_mha_bwd precision 3).  Measured -0.02 ms per step (21 -> 17 us per call) -- and OFF: the gradient of `adapt_pos2d.2.bias` reaches
+# it only through this kernel's d_q / d_k, is ~3e-6 of the step's norm (a key-side bias cancels in the softmax) and its post-AdamW SIGNS are then
+# decided by the bf16 noise: the full-size step's parameter-sum bar on it fails (3.5 sign flips of 256 where 2.5 are allowed).  profiles/r6_ab_mha_bwd.txt
+MHA_BWD_BF16 = _os.environ.get("CDETR_MHA_BWD_BF16", "0") == "1"
 
 
 def bwd_precision():
@@ -1259,8 +1264,9 @@ def mha_bwd_raw(qk, v, o, d_o, lse, nh):
     d_qk = torch.empty_like(qk)
     d_v = torch.empty_like(v)
     work = torch.empty((N, nh, L), device=qk.device, dtype=torch.float32)
+    prec = bwd_precision() if MHA_BWD_BF16 else PRECISION      # 3: split-bf16 scores, plain-bf16 gradient contractions (A/B: CDETR_MHA_BWD_BF16=0)
     check(lib().cdetr_mha_bwd(ptr(qk), ptr(v), ptr(o), ptr(d_o), ptr(lse), ptr(d_qk), ptr(d_v), ptr(work), N, L, nh,
-                              (E // nh) ** -0.5, PRECISION, stream_ptr()), "cdetr_mha_bwd")
+                              (E // nh) ** -0.5, prec, stream_ptr()), "cdetr_mha_bwd")
     return d_qk, d_v
 
 

@@ -351,7 +351,9 @@ static inline int32_t cdetr_rcda_hp(int32_t H) { return (H + 7) & ~7; }
 /* ---- decoder self-attention core (nn.MultiheadAttention(256, 8) at A2/models/transformer.py:337,369-370) ---------
  * qk [N][L][2E] = projected queries | keys, v [N][L][E], E = nh*32; o = softmax(scale * q k^T) v per head, lse [N][nh][L]
  * saved for backward.  cdetr_mha_bwd writes d_qk [N][L][2E], d_v [N][L][E]; work: N*nh*L floats of scratch (the row sums D of the
- * fp32 mode's two launches; the split-bf16 mode is ONE launch whose key half forms D itself and leaves `work` untouched).           */
+ * fp32 mode's two launches; the split-bf16 mode is ONE launch whose key half forms D itself and leaves `work` untouched).
+ * cdetr_mha_bwd precision: 0 = fp32, 1 = split-bf16 x3 throughout, 3 = the scores recomputed in split-bf16 x3 (p = exp(s - lse) against the
+ * forward's lse) and the four gradient contractions (dP, dQ, dK, dV) in plain bf16, one MFMA per product.                           */
 int cdetr_mha_fwd(const float* qk, const float* v, float* o, float* lse, int32_t N, int32_t L, int32_t nh, float scale,
                   int32_t precision, void* stream);
 int cdetr_mha_bwd(const float* qk, const float* v, const float* o, const float* d_o, const float* lse, float* d_qk, float* d_v,

@@ -528,7 +528,12 @@ def test_mha_core(N, L, precision):
     go = torch.randn(N, L, E, generator=g(3))
     qkd, vd = qk.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
     o = ops.mha_core(qkd, vd, nh)
-    o.backward(go.to(DEV))
+    old = ops.MHA_BWD_BF16
+    ops.MHA_BWD_BF16 = _BWD_MODE == 3                   # (opt-in in the product: cdetr_mha_bwd precision 3 is exercised here)
+    try:
+        o.backward(go.to(DEV))
+    finally:
+        ops.MHA_BWD_BF16 = old
     qk64, v64 = qk.double().requires_grad_(True), v.double().requires_grad_(True)
     hs = lambda t: t.reshape(N, L, nh, 32).permute(0, 2, 1, 3)   # noqa: E731
     a = ((hs(qk64[..., :E]) * 32 ** -0.5) @ hs(qk64[..., E:]).transpose(-1, -2)).softmax(-1)
